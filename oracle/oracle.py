@@ -1,0 +1,192 @@
+"""ctypes loader for the CPU oracle (oracle/spfe_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product (sp_orb_slam_amd/) never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libspfe_oracle.so")
+_lib = None
+
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    """Compile oracle/libspfe_oracle.so with gcc (seconds)."""
+    src = os.path.join(_HERE, "spfe_oracle.c")
+    hdr = os.path.join(_HERE, "..", "include", "spfe_exact_math.h")
+    if (not force and os.path.exists(_SO)
+            and os.path.getmtime(_SO) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        return _SO
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libspfe_oracle.so"],
+                          stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.oracle_num_params.restype = C.c_size_t
+        L.oracle_weight_offset.restype = C.c_size_t
+        L.oracle_weight_offset.argtypes = [C.c_int]
+        L.oracle_bias_offset.restype = C.c_size_t
+        L.oracle_bias_offset.argtypes = [C.c_int]
+        L.oracle_network.restype = C.c_int
+        L.oracle_network.argtypes = [f32p, u8p, C.c_int, C.c_int, f32p, f32p, C.c_void_p]
+        L.oracle_tail.restype = C.c_int
+        L.oracle_tail.argtypes = [f32p, C.c_int, C.c_int, f32p, f32p, f32p, f32p, f32p, f32p, i32p]
+        L.oracle_sample_desc.restype = None
+        L.oracle_sample_desc.argtypes = [f32p, C.c_int, C.c_int, f32p, f32p, C.c_int, f32p]
+        L.oracle_heat.restype = None
+        L.oracle_heat.argtypes = [f32p, C.c_int, C.c_int, f32p, f32p, C.c_void_p]
+        L.oracle_sort.restype = None
+        L.oracle_sort.argtypes = [f32p, C.c_int, i32p]
+        L.oracle_nms.restype = C.c_int
+        L.oracle_nms.argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 f32p, f32p, i32p, i16p]
+        L.oracle_covariance.restype = None
+        L.oracle_covariance.argtypes = [f32p, C.c_int, C.c_int, f32p, f32p, C.c_int, f32p, f32p,
+                                        f32p]
+        L.oracle_postprocess.restype = C.c_int
+        L.oracle_postprocess.argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p,
+                                         f32p, f32p, f32p, i16p, f32p, f32p, f32p, f32p,
+                                         C.POINTER(C.c_int)]
+        L.oracle_expf.restype = C.c_float
+        L.oracle_expf.argtypes = [C.c_float]
+        L.oracle_logf.restype = C.c_float
+        L.oracle_logf.argtypes = [C.c_float]
+        L.oracle_sum256.restype = C.c_float
+        L.oracle_sum256.argtypes = [f32p]
+        _lib = L
+    return _lib
+
+
+def num_params():
+    return int(lib().oracle_num_params())
+
+
+def network(blob, img):
+    """u8 image [H,W] -> (semi [hc,wc,65], coarse [hc,wc,256], feat [hc,wc,128])."""
+    H, W = img.shape
+    hc, wc = H // 8, W // 8
+    semi = np.empty((hc, wc, 65), np.float32)
+    coarse = np.empty((hc, wc, 256), np.float32)
+    feat = np.empty((hc, wc, 128), np.float32)
+    rc = lib().oracle_network(np.ascontiguousarray(blob, np.float32),
+                              np.ascontiguousarray(img, np.uint8), H, W, semi, coarse,
+                              feat.ctypes.data)
+    if rc:
+        raise ValueError("oracle_network rc=%d" % rc)
+    return semi, coarse, feat
+
+
+def tail(semi, H, W):
+    hc, wc = H // 8, W // 8
+    dd = np.empty((hc, wc), np.float32)
+    sd = np.empty((hc, wc), np.float32)
+    hl = np.empty((H, W), np.float32)
+    cx = np.empty(hc * wc, np.float32)
+    cy = np.empty(hc * wc, np.float32)
+    cs = np.empty(hc * wc, np.float32)
+    cc = np.empty(hc * wc, np.int32)
+    n = lib().oracle_tail(np.ascontiguousarray(semi, np.float32), H, W, dd, sd, hl, cx, cy, cs, cc)
+    return dict(dense_dust=dd, semi_dust=sd, heat_log=hl, x=cx[:n].copy(), y=cy[:n].copy(),
+                score=cs[:n].copy(), cell=cc[:n].copy())
+
+
+def sample_desc(coarse, H, W, xs, ys):
+    n = len(xs)
+    out = np.empty((n, 256), np.float32)
+    if n:
+        lib().oracle_sample_desc(np.ascontiguousarray(coarse, np.float32), H, W,
+                                 np.ascontiguousarray(xs, np.float32),
+                                 np.ascontiguousarray(ys, np.float32), n, out)
+    return out
+
+
+def heat(heat_log):
+    H, W = heat_log.shape
+    h = np.empty((H, W), np.float32)
+    hi = np.empty((H, W), np.float32)
+    mm = np.zeros(2, np.float64)
+    lib().oracle_heat(np.ascontiguousarray(heat_log, np.float32), H, W, h, hi, mm.ctypes.data)
+    return h, hi, mm
+
+
+def sort(score):
+    n = len(score)
+    order = np.empty(n, np.int32)
+    lib().oracle_sort(np.ascontiguousarray(score, np.float32), n, order)
+    return order
+
+
+def nms(px, py, num_features, W, H, border=8, dist=4):
+    n = len(px)
+    cap = max(num_features + 2, 1)
+    kx = np.empty(cap, np.float32)
+    ky = np.empty(cap, np.float32)
+    src = np.empty(cap, np.int32)
+    occ = np.empty((H // 8, W // 8), np.int16)
+    k = lib().oracle_nms(np.ascontiguousarray(px, np.float32), np.ascontiguousarray(py, np.float32),
+                         n, num_features, border, dist, W, H, kx, ky, src, occ)
+    return kx[:k].copy(), ky[:k].copy(), src[:k].copy(), occ
+
+
+def covariance(heat_inv, kx, ky):
+    H, W = heat_inv.shape
+    k = len(kx)
+    cov = np.empty((max(k, 1), 2), np.float32)
+    cinv = np.empty((max(k, 1), 2), np.float32)
+    resp = np.empty(max(k, 1), np.float32)
+    lib().oracle_covariance(np.ascontiguousarray(heat_inv, np.float32), H, W,
+                            np.ascontiguousarray(kx, np.float32),
+                            np.ascontiguousarray(ky, np.float32), k, cov, cinv, resp)
+    return cov[:k], cinv[:k], resp[:k]
+
+
+def postprocess(semi, coarse, H, W, num_features):
+    """SPExtractor::operator() after the network.  Returns a dict of all outputs."""
+    hc, wc = H // 8, W // 8
+    cap = num_features + 2
+    kx = np.empty(cap, np.float32)
+    ky = np.empty(cap, np.float32)
+    resp = np.empty(cap, np.float32)
+    desc = np.empty((cap, 256), np.float32)
+    cov = np.empty((cap, 2), np.float32)
+    cinv = np.empty((cap, 2), np.float32)
+    occ = np.empty((hc, wc), np.int16)
+    dd = np.empty((hc, wc), np.float32)
+    sd = np.empty((hc, wc), np.float32)
+    h = np.empty((H, W), np.float32)
+    hi = np.empty((H, W), np.float32)
+    ncand = C.c_int(0)
+    k = lib().oracle_postprocess(np.ascontiguousarray(semi, np.float32),
+                                 np.ascontiguousarray(coarse, np.float32), H, W, num_features, kx,
+                                 ky, resp, desc, cov, cinv, occ, dd, sd, h, hi, C.byref(ncand))
+    if k < 0:
+        raise ValueError("oracle_postprocess rc=%d" % k)
+    return dict(K=k, kp_xy=np.stack([kx[:k], ky[:k]], 1), response=resp[:k].copy(),
+                desc=desc[:k].copy(), cov2=cov[:k].copy(), cov2_inv=cinv[:k].copy(), occ_grid=occ,
+                dense_dust=dd, semi_dust=sd, heat=h, heat_inv=hi, n_candidates=ncand.value)
+
+
+def extract(blob, img, num_features):
+    """Full SPExtractor::operator(): u8 image -> dict of outputs (+ semi/coarse)."""
+    if img is None or img.size == 0:
+        raise RuntimeError("input image is empty")  # sp_extractor.cpp:364-365
+    H, W = img.shape
+    semi, coarse, _ = network(blob, img)
+    out = postprocess(semi, coarse, H, W, num_features)
+    out["semi"] = semi
+    out["coarse"] = coarse
+    return out

@@ -1,0 +1,499 @@
+/*
+ * spfe_oracle.c — CPU ORACLE for the SuperPoint extraction path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under sp_orb_slam_amd/ or include/ links,
+ * imports or calls this file; only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg do, and there only as the checker.
+ *
+ * PARITY UNPINNED: the reference (HyHuang1995/sp_orb_slam) ships no tests,
+ * golden vectors or weights for this path and cannot be built or run here
+ * (libtorch-CUDA hard-wired, OpenCV/Eigen/ROS absent — SURVEY.md §8c).  This
+ * file is a plain-C restatement of the reference algorithm, function by
+ * function, each citing the reference lines it follows; it is cross-checked in
+ * the build container against the same ATen op sequence executed by PyTorch-CPU
+ * (tests/golden/make_golden.py -> tests/golden/*.npz).
+ *
+ * All citations are to /root/reference/orb_slam2/src/cv/sp_extractor.cpp
+ * unless stated otherwise.  Arithmetic order for every float step is the one
+ * fixed in include/spfe_exact_math.h (the reference leaves it to
+ * libtorch/cuDNN/OpenCV).
+ *
+ * Data layouts (ours, not the reference's NCHW): activations are NHWC float,
+ * i.e. [y][x][c]; `semi` is [hc][wc][65]; `coarse` is [hc][wc][256].
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#include "../include/spfe_exact_math.h"
+
+#define EXPORT __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* weight blob: for each layer in SPFE_LAYERS order: weight OIHW, then bias —  */
+/* the register_module order of sp_extractor.cpp:46-62.                        */
+/* ------------------------------------------------------------------------- */
+static size_t layer_weight_count(int l) {
+  const spfe_layer_t *L = &SPFE_LAYERS[l];
+  return (size_t)L->cout * L->cin * L->ksize * L->ksize;
+}
+EXPORT size_t oracle_weight_offset(int l) {
+  size_t off = 0;
+  for (int i = 0; i < l; ++i) off += layer_weight_count(i) + SPFE_LAYERS[i].cout;
+  return off;
+}
+EXPORT size_t oracle_bias_offset(int l) { return oracle_weight_offset(l) + layer_weight_count(l); }
+EXPORT size_t oracle_num_params(void) { return oracle_weight_offset(SPFE_NUM_LAYERS); }
+
+/* ------------------------------------------------------------------------- */
+/* One conv layer (+bias, +ReLU): torch::nn::Conv2d cross-correlation, stride 1,*/
+/* zero padding ksize/2 (:27-43), relu(:81-99).  in: [H][W][cin], out:          */
+/* [H][W][cout].  Accumulation order = spfe_exact_math.h layer plan.            */
+/* ------------------------------------------------------------------------- */
+static void conv_layer(int l, const float *blob, const float *in, int H, int W, float *out) {
+  const spfe_layer_t *L = &SPFE_LAYERS[l];
+  const int cin = L->cin, cout = L->cout, ks = L->ksize, pad = ks / 2, taps = ks * ks;
+  const int kc = L->kc < cin ? L->kc : cin;
+  const int nchunk = cin / kc;
+  const float *w = blob + oracle_weight_offset(l); /* [cout][cin][ky][kx] */
+  const float *b = blob + oracle_bias_offset(l);
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+  const int coutp = (cout + 63) & ~63; /* pad to 64 for the vector loop */
+
+  /* zero-padded input copy */
+  float *inp = (float *)calloc((size_t)Hp * Wp * cin, sizeof(float));
+  for (int y = 0; y < H; ++y)
+    memcpy(inp + ((size_t)(y + pad) * Wp + pad) * cin, in + (size_t)y * W * cin,
+           (size_t)W * cin * sizeof(float));
+  /* weights in K order: wt[chunk][tap][c][coutp] */
+  float *wt = (float *)calloc((size_t)nchunk * taps * kc * coutp, sizeof(float));
+  for (int ch = 0; ch < nchunk; ++ch)
+    for (int t = 0; t < taps; ++t)
+      for (int c = 0; c < kc; ++c)
+        for (int co = 0; co < cout; ++co)
+          wt[(((size_t)ch * taps + t) * kc + c) * coutp + co] =
+              w[((size_t)co * cin + ch * kc + c) * taps + t];
+
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int y = 0; y < H; ++y) {
+    float acc[64];
+    for (int x = 0; x < W; ++x) {
+      for (int cb = 0; cb < coutp; cb += 64) {
+        for (int i = 0; i < 64; ++i) acc[i] = 0.0f;
+        for (int ch = 0; ch < nchunk; ++ch)
+          for (int t = 0; t < taps; ++t) {
+            const int ky = t / ks, kx = t % ks;
+            const float *px = inp + ((size_t)(y + ky) * Wp + (x + kx)) * cin + ch * kc;
+            const float *wrow = wt + (((size_t)ch * taps + t) * kc) * coutp + cb;
+            for (int c = 0; c < kc; ++c) {
+              const float xv = px[c];
+              const float *wr = wrow + (size_t)c * coutp;
+              for (int i = 0; i < 64; ++i) acc[i] = __builtin_fmaf(xv, wr[i], acc[i]);
+            }
+          }
+        const int nco = (cout - cb) < 64 ? (cout - cb) : 64;
+        float *o = out + ((size_t)y * W + x) * cout + cb;
+        for (int i = 0; i < nco; ++i) {
+          float v = acc[i] + b[cb + i];
+          if (L->relu) v = v > 0.0f ? v : 0.0f;
+          o[i] = v;
+        }
+      }
+    }
+  }
+  free(inp);
+  free(wt);
+}
+
+/* torch::max_pool2d(x, 2, 2)  (:83,87,91).  in [H][W][c] -> out [H/2][W/2][c] */
+static void maxpool2(const float *in, int H, int W, int c, float *out) {
+  const int Ho = H / 2, Wo = W / 2;
+  for (int y = 0; y < Ho; ++y)
+    for (int x = 0; x < Wo; ++x)
+      for (int k = 0; k < c; ++k) {
+        float a = in[((size_t)(2 * y) * W + 2 * x) * c + k];
+        float b = in[((size_t)(2 * y) * W + 2 * x + 1) * c + k];
+        float d = in[((size_t)(2 * y + 1) * W + 2 * x) * c + k];
+        float e = in[((size_t)(2 * y + 1) * W + 2 * x + 1) * c + k];
+        float m = a > b ? a : b;
+        float n = d > e ? d : e;
+        out[((size_t)y * Wo + x) * c + k] = m > n ? m : n;
+      }
+}
+
+/*
+ * SPFrontend::forward, network part (:81-100) + input conversion (:388).
+ * img: u8 [H][W]; outputs semi [hc][wc][65], coarse [hc][wc][256] (raw, not yet
+ * normalised).  `feat` (optional) receives conv4b output [hc][wc][128].
+ */
+EXPORT int oracle_network(const float *blob, const uint8_t *img, int H, int W, float *semi,
+                          float *coarse, float *feat) {
+  if (H % 8 || W % 8 || H <= 0 || W <= 0) return -1;
+  size_t maxel = (size_t)H * W * 64;
+  float *a = (float *)malloc(maxel * sizeof(float));
+  float *b = (float *)malloc(maxel * sizeof(float));
+  float *x0 = (float *)malloc((size_t)H * W * sizeof(float));
+  for (size_t i = 0; i < (size_t)H * W; ++i) x0[i] = spfe_pixel_to_float(img[i]);
+  int h = H, w = W;
+  conv_layer(0, blob, x0, h, w, a); /* conv1a */
+  conv_layer(1, blob, a, h, w, b);  /* conv1b */
+  maxpool2(b, h, w, 64, a);
+  h /= 2, w /= 2;
+  conv_layer(2, blob, a, h, w, b); /* conv2a */
+  conv_layer(3, blob, b, h, w, a); /* conv2b */
+  maxpool2(a, h, w, 64, b);
+  h /= 2, w /= 2;
+  conv_layer(4, blob, b, h, w, a); /* conv3a */
+  conv_layer(5, blob, a, h, w, b); /* conv3b */
+  maxpool2(b, h, w, 128, a);
+  h /= 2, w /= 2;
+  conv_layer(6, blob, a, h, w, b); /* conv4a */
+  conv_layer(7, blob, b, h, w, a); /* conv4b -> a */
+  if (feat) memcpy(feat, a, (size_t)h * w * 128 * sizeof(float));
+  float *cPa = (float *)malloc((size_t)h * w * 256 * sizeof(float));
+  conv_layer(8, blob, a, h, w, cPa);     /* convPa + relu (:96) */
+  conv_layer(9, blob, cPa, h, w, semi);  /* convPb (:97) */
+  conv_layer(10, blob, a, h, w, cPa);    /* convDa + relu (:99) */
+  conv_layer(11, blob, cPa, h, w, coarse); /* convDb (:100) */
+  free(cPa);
+  free(a);
+  free(b);
+  free(x0);
+  return 0;
+}
+
+/*
+ * Detector tail (:105-131): channel softmax over 65 logits per cell, dustbin
+ * slices, per-cell max/arg-max over the 64 non-dust channels (lowest index on
+ * ties, ATen semantics), pixel coordinates through the `grid` convention of
+ * :64-73 (channel k <-> dy=k/8, dx=k%8), threshold >= 0.007, row-major
+ * compaction, and the log-heat map with pixel_shuffle(8).
+ *
+ * cand_*: capacity hc*wc.  Returns N (number of candidates).
+ * heat_log: [H][W].  dense_dust / semi_dust: [hc][wc].
+ */
+EXPORT int oracle_tail(const float *semi, int H, int W, float *dense_dust, float *semi_dust,
+                       float *heat_log, float *cand_x, float *cand_y, float *cand_score,
+                       int *cand_cell) {
+  const int hc = H / 8, wc = W / 8;
+  int n = 0;
+  for (int cy = 0; cy < hc; ++cy)
+    for (int cx = 0; cx < wc; ++cx) {
+      const float *s = semi + ((size_t)cy * wc + cx) * SPFE_SEMI_CH;
+      float m = s[0];
+      for (int k = 1; k < SPFE_SEMI_CH; ++k) m = s[k] > m ? s[k] : m;
+      float e[64];
+      for (int k = 0; k < 64; ++k) e[k] = spfe_expf(s[k] - m);
+      const float ed = spfe_expf(s[64] - m);
+      const float total = spfe_sum64_host(e) + ed;
+      semi_dust[cy * wc + cx] = s[64];       /* :106 */
+      dense_dust[cy * wc + cx] = ed / total; /* :107 */
+      float best = -1.0f;
+      int bi = 0;
+      for (int k = 0; k < 64; ++k) {
+        const float p = e[k] / total; /* :105 */
+        if (p > best) { best = p; bi = k; } /* strict > : lowest index wins ties (:112) */
+        const float pc = p < SPFE_HEAT_FLOOR ? SPFE_HEAT_FLOOR : p; /* :129 */
+        heat_log[(size_t)(cy * 8 + k / 8) * W + cx * 8 + k % 8] = spfe_logf(pc); /* :130-131 */
+      }
+      if (best >= SPFE_SCORE_THRESH) { /* :122 */
+        cand_x[n] = (float)(cx * 8 + bi % 8); /* :64-73,118 */
+        cand_y[n] = (float)(cy * 8 + bi / 8);
+        cand_score[n] = best;
+        cand_cell[n] = cy * wc + cx;
+        ++n;
+      }
+    }
+  return n;
+}
+
+/*
+ * Descriptor sampling (:102-103, :134-148).  coarse [hc][wc][256] RAW; each tap
+ * is first divided by its cell's L2 norm (:102-103, no epsilon), then bilinear
+ * grid_sample with align_corners=true and zero padding, then the sampled
+ * 256-vector is L2-normalised (:148).  Coordinates follow the literal steps
+ * c = x / (w/2) - 1 (:137-138), ix = ((c + 1) / 2) * (wc - 1) (ATen
+ * grid_sampler_unnormalize, align_corners).
+ * out desc [n][256].
+ */
+static float cell_norm(const float *v) {
+  float sq[256];
+  for (int i = 0; i < 256; ++i) sq[i] = v[i] * v[i];
+  return sqrtf(spfe_sum256_host(sq));
+}
+EXPORT void oracle_sample_desc(const float *coarse, int H, int W, const float *xs, const float *ys,
+                               int n, float *desc) {
+  const int hc = H / 8, wc = W / 8;
+  /* x_s.div(w / 2.0) - 1.0 (:137-138).  ATen-CUDA (the only device the reference
+   * runs on, :348-351) evaluates tensor / scalar as tensor * float(1.0 / scalar). */
+  const float inv_hw = (float)(1.0 / (double)(float)(W / 2.0));
+  const float inv_hh = (float)(1.0 / (double)(float)(H / 2.0));
+  for (int i = 0; i < n; ++i) {
+    const float gx = xs[i] * inv_hw - 1.0f;
+    const float gy = ys[i] * inv_hh - 1.0f;
+    const float ix = ((gx + 1.0f) / 2.0f) * (float)(wc - 1);
+    const float iy = ((gy + 1.0f) / 2.0f) * (float)(hc - 1);
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - fx0, wy1 = iy - fy0; /* weight of the +1 neighbours */
+    const float wx0 = (fx0 + 1.0f) - ix, wy0 = (fy0 + 1.0f) - iy;
+    const float w_nw = wx0 * wy0, w_ne = wx1 * wy0, w_sw = wx0 * wy1, w_se = wx1 * wy1;
+    const int tx[4] = {x0, x1, x0, x1}, ty[4] = {y0, y0, y1, y1};
+    const float tw[4] = {w_nw, w_ne, w_sw, w_se};
+    float acc[256];
+    for (int c = 0; c < 256; ++c) acc[c] = 0.0f;
+    for (int t = 0; t < 4; ++t) {
+      if (tx[t] < 0 || tx[t] >= wc || ty[t] < 0 || ty[t] >= hc) continue; /* zeros padding */
+      const float *v = coarse + ((size_t)ty[t] * wc + tx[t]) * 256;
+      const float nrm = cell_norm(v);
+      for (int c = 0; c < 256; ++c) acc[c] = acc[c] + (v[c] / nrm) * tw[t];
+    }
+    float sq[256];
+    for (int c = 0; c < 256; ++c) sq[c] = acc[c] * acc[c];
+    const float nrm = sqrtf(spfe_sum256_host(sq));
+    for (int c = 0; c < 256; ++c) desc[(size_t)i * 256 + c] = acc[c] / nrm;
+  }
+}
+
+/*
+ * to_heat (:461-474): img = -heat_log; (min,max) by minMaxLoc (doubles); the two
+ * cv::MatExpr results evaluate as ONE affine map per pixel:
+ *   heat     = L * (-1/(max-min)) + (-min/(max-min))
+ *   heat_inv = L * ( 1/(max-min)) + ( max/(max-min))
+ * with the scale/shift formed in double ( x * (1.0/d) ) and rounded to float,
+ * then a float multiply followed by a float add.
+ */
+EXPORT void oracle_heat(const float *heat_log, int H, int W, float *heat, float *heat_inv,
+                        double *minmax_out) {
+  const size_t n = (size_t)H * W;
+  float mn = -heat_log[0], mx = -heat_log[0];
+  for (size_t i = 1; i < n; ++i) {
+    const float m = -heat_log[i];
+    mn = m < mn ? m : mn;
+    mx = m > mx ? m : mx;
+  }
+  const double dmin = (double)mn, dmax = (double)mx;
+  const double inv = 1.0 / (dmax - dmin);
+  const float a_h = (float)(-inv), b_h = (float)(-dmin * inv);
+  const float a_i = (float)(inv), b_i = (float)(dmax * inv);
+  for (size_t i = 0; i < n; ++i) {
+    const float L = heat_log[i];
+    if (heat) heat[i] = L * a_h + b_h;
+    if (heat_inv) heat_inv[i] = L * a_i + b_i;
+  }
+  if (minmax_out) { minmax_out[0] = dmin; minmax_out[1] = dmax; }
+}
+
+/*
+ * Descending score sort (:489-498), tie rule of spfe_ranks_before.
+ * order[i] = index (into the candidate arrays) of the i-th best candidate.
+ */
+static const float *g_sort_score;
+static int cmp_rank(const void *pa, const void *pb) {
+  const int a = *(const int *)pa, b = *(const int *)pb;
+  if (spfe_ranks_before(g_sort_score[a], a, g_sort_score[b], b)) return -1;
+  if (spfe_ranks_before(g_sort_score[b], b, g_sort_score[a], a)) return 1;
+  return 0;
+}
+EXPORT void oracle_sort(const float *score, int n, int *order) {
+  for (int i = 0; i < n; ++i) order[i] = i;
+  g_sort_score = score;
+  qsort(order, n, sizeof(int), cmp_rank); /* keys are unique (index tie-break): order is total */
+}
+
+/*
+ * nms() (:161-250), literal: byte grid W x H padded by dist_thresh, greedy 9x9
+ * suppression in sorted order over ALL candidates, stop after the
+ * (num_features+1)-th survivor, border reject, raster scan output, occ_grid.
+ * px,py: candidate coordinates ALREADY in sorted order (n entries).
+ * Outputs: kp_x, kp_y (integer valued), kp_src (index into the sorted list),
+ * occ_grid int16 [H/8][W/8] (-1 = empty).  Returns K.
+ */
+EXPORT int oracle_nms(const float *px, const float *py, int n, int num_features, int border,
+                      int dist, int W, int H, float *kp_x, float *kp_y, int *kp_src,
+                      int16_t *occ_grid) {
+  const int GW = W + 2 * dist, GH = H + 2 * dist;
+  unsigned char *grid = (unsigned char *)calloc((size_t)GW * GH, 1);
+  unsigned short *inds = (unsigned short *)calloc((size_t)W * H, sizeof(unsigned short));
+  for (int i = 0; i < (H / 8) * (W / 8); ++i) occ_grid[i] = -1; /* :178 */
+  for (int i = 0; i < n; ++i) { /* :183-189 */
+    const int uu = (int)px[i], vv = (int)py[i];
+    grid[(size_t)(vv + dist) * GW + uu + dist] = 1;
+    inds[(size_t)vv * W + uu] = (unsigned short)i;
+  }
+  int n_feature = 0;
+  for (int i = 0; i < n; ++i) { /* :195-214 */
+    const int uu = (int)px[i] + dist, vv = (int)py[i] + dist;
+    if (grid[(size_t)vv * GW + uu] != 1) continue;
+    for (int k = -dist; k < dist + 1; ++k)
+      for (int j = -dist; j < dist + 1; ++j) {
+        if (j == 0 && k == 0) continue;
+        grid[(size_t)(vv + k) * GW + uu + j] = 0;
+      }
+    grid[(size_t)vv * GW + uu] = 2;
+    n_feature++;
+    if (n_feature > num_features) break;
+  }
+  int n_pts = 0;
+  for (int v = 0; v < H + dist; ++v) /* :220-238 */
+    for (int u = 0; u < W + dist; ++u) {
+      if (u - dist >= W - border || u - dist < border || v - dist >= H - border ||
+          v - dist < border)
+        continue;
+      if (grid[(size_t)v * GW + u] == 2) {
+        occ_grid[((v - dist) / 8) * (W / 8) + (u - dist) / 8] = (int16_t)n_pts;
+        const int sel = inds[(size_t)(v - dist) * W + (u - dist)];
+        kp_x[n_pts] = (float)(int)px[sel];
+        kp_y[n_pts] = (float)(int)py[sel];
+        kp_src[n_pts] = sel;
+        n_pts++;
+      }
+    }
+  free(grid);
+  free(inds);
+  return n_pts;
+}
+
+/*
+ * computeCovariance() (:252-340), literal: FIFO BFS per keypoint in emitted
+ * order down the heat_inv hill, ONE visited mask shared by all keypoints,
+ * visited set at pop, neighbour order left/up/right/down with bounds
+ * xx>0, yy>0, xx<w, yy<h, accept iff unvisited && value>0 && value<current.
+ * cov = sum (s_i / sum s) * delta_i^2, clamp >= 1, cov_inv = 1/cov.
+ * response[i] = heat_inv(y,x) (:271).
+ */
+EXPORT void oracle_covariance(const float *heat_inv, int H, int W, const float *kp_x,
+                              const float *kp_y, int K, float *cov2, float *cov2_inv,
+                              float *response) {
+  unsigned char *fresh = (unsigned char *)malloc((size_t)H * W);
+  memset(fresh, 1, (size_t)H * W);
+  size_t cap = 1024, qcap = 1024;
+  float *dx2 = (float *)malloc(cap * sizeof(float));
+  float *dy2 = (float *)malloc(cap * sizeof(float));
+  float *sc = (float *)malloc(cap * sizeof(float));
+  int *q = (int *)malloc(qcap * sizeof(int));
+  for (int i = 0; i < K; ++i) {
+    const int uu = (int)kp_x[i], vv = (int)kp_y[i];
+    response[i] = heat_inv[(size_t)vv * W + uu];
+    size_t cnt = 0, qh = 0, qt = 0;
+    q[qt++] = vv * W + uu;
+    while (qh < qt) {
+      const int cur = q[qh++];
+      const int u = cur % W, v = cur / W;
+      fresh[cur] = 0;
+      if (cnt == cap) {
+        cap *= 2;
+        dx2 = (float *)realloc(dx2, cap * sizeof(float));
+        dy2 = (float *)realloc(dy2, cap * sizeof(float));
+        sc = (float *)realloc(sc, cap * sizeof(float));
+      }
+      const float fdx = (float)u - (float)uu, fdy = (float)v - (float)vv;
+      dx2[cnt] = fdx * fdx;
+      dy2[cnt] = fdy * fdy;
+      const float centroid = heat_inv[cur];
+      sc[cnt] = centroid;
+      cnt++;
+      if (qt + 4 > qcap) {
+        qcap *= 2;
+        q = (int *)realloc(q, qcap * sizeof(int));
+      }
+#define CHECK_UV(u_, v_)                                                      \
+  do {                                                                        \
+    const int id_ = (v_) * W + (u_);                                          \
+    const float hv_ = heat_inv[id_];                                          \
+    if (fresh[id_] && hv_ > 0.0f && hv_ < centroid) q[qt++] = id_;            \
+  } while (0)
+      if (u - 1 > 0) CHECK_UV(u - 1, v);
+      if (v - 1 > 0) CHECK_UV(u, v - 1);
+      if (u + 1 < W) CHECK_UV(u + 1, v);
+      if (v + 1 < H) CHECK_UV(u, v + 1);
+#undef CHECK_UV
+    }
+    float sum = 0.0f;
+    for (size_t j = 0; j < cnt; ++j) sum += sc[j];
+    float cx = 0.0f, cy = 0.0f;
+    for (size_t j = 0; j < cnt; ++j) {
+      const float wgt = sc[j] / sum;
+      cx += wgt * dx2[j];
+      cy += wgt * dy2[j];
+    }
+    if (cx < 1.0f) cx = 1.0f;
+    if (cy < 1.0f) cy = 1.0f;
+    cov2[2 * i] = cx;
+    cov2[2 * i + 1] = cy;
+    cov2_inv[2 * i] = 1.0f / cx;
+    cov2_inv[2 * i + 1] = 1.0f / cy;
+  }
+  free(fresh);
+  free(dx2);
+  free(dy2);
+  free(sc);
+  free(q);
+}
+
+/*
+ * SPExtractor::operator() (:361-514) end to end, given semi/coarse.
+ * Buffers sized by the caller: kp_* and cov* and response >= num_features+1,
+ * desc >= (num_features+1)*256, occ_grid hc*wc, dense_dust/semi_dust hc*wc,
+ * heat/heat_inv H*W.  Returns K (>=0) or <0 on error.
+ */
+EXPORT int oracle_postprocess(const float *semi, const float *coarse, int H, int W,
+                              int num_features, float *kp_x, float *kp_y, float *response,
+                              float *desc, float *cov2, float *cov2_inv, int16_t *occ_grid,
+                              float *dense_dust, float *semi_dust, float *heat, float *heat_inv,
+                              int *n_candidates) {
+  const int C = (H / 8) * (W / 8);
+  float *heat_log = (float *)malloc((size_t)H * W * sizeof(float));
+  float *cx = (float *)malloc(C * sizeof(float)), *cy = (float *)malloc(C * sizeof(float));
+  float *cs = (float *)malloc(C * sizeof(float));
+  int *cc = (int *)malloc(C * sizeof(int));
+  const int N = oracle_tail(semi, H, W, dense_dust, semi_dust, heat_log, cx, cy, cs, cc);
+  if (n_candidates) *n_candidates = N;
+  /* forward() samples descriptors for ALL candidates (:134-148) */
+  float *desc_all = (float *)malloc((size_t)(N > 0 ? N : 1) * 256 * sizeof(float));
+  oracle_sample_desc(coarse, H, W, cx, cy, N, desc_all);
+  float *hinv_local = heat_inv ? heat_inv : (float *)malloc((size_t)H * W * sizeof(float));
+  oracle_heat(heat_log, H, W, heat, hinv_local, NULL); /* :461-474 */
+  int *order = (int *)malloc((N > 0 ? N : 1) * sizeof(int));
+  oracle_sort(cs, N, order); /* :489-498 */
+  float *sx = (float *)malloc((N > 0 ? N : 1) * sizeof(float));
+  float *sy = (float *)malloc((N > 0 ? N : 1) * sizeof(float));
+  for (int i = 0; i < N; ++i) { sx[i] = cx[order[i]]; sy[i] = cy[order[i]]; }
+  int *src = (int *)malloc((size_t)(num_features + 2) * sizeof(int));
+  const int K = oracle_nms(sx, sy, N, num_features, SPFE_NMS_BORDER, SPFE_NMS_DIST, W, H, kp_x,
+                           kp_y, src, occ_grid); /* :502 */
+  for (int i = 0; i < K; ++i) /* :240-249 */
+    memcpy(desc + (size_t)i * 256, desc_all + (size_t)order[src[i]] * 256, 256 * sizeof(float));
+  oracle_covariance(hinv_local, H, W, kp_x, kp_y, K, cov2, cov2_inv, response); /* :508 */
+  if (!heat_inv) free(hinv_local);
+  free(heat_log); free(cx); free(cy); free(cs); free(cc);
+  free(desc_all); free(order); free(sx); free(sy); free(src);
+  return K;
+}
+
+/* Full path: u8 image -> everything (network + postprocess). */
+EXPORT int oracle_extract(const float *blob, const uint8_t *img, int H, int W, int num_features,
+                          float *kp_x, float *kp_y, float *response, float *desc, float *cov2,
+                          float *cov2_inv, int16_t *occ_grid, float *dense_dust,
+                          float *semi_dust, float *heat, float *heat_inv, int *n_candidates) {
+  if (!img) return -2;
+  if (H % 8 || W % 8 || H <= 0 || W <= 0) return -1;
+  const int C = (H / 8) * (W / 8);
+  float *semi = (float *)malloc((size_t)C * SPFE_SEMI_CH * sizeof(float));
+  float *coarse = (float *)malloc((size_t)C * 256 * sizeof(float));
+  int rc = oracle_network(blob, img, H, W, semi, coarse, NULL);
+  if (rc == 0)
+    rc = oracle_postprocess(semi, coarse, H, W, num_features, kp_x, kp_y, response, desc, cov2,
+                            cov2_inv, occ_grid, dense_dust, semi_dust, heat, heat_inv,
+                            n_candidates);
+  free(semi);
+  free(coarse);
+  return rc;
+}
+
+/* exact-math probes so GPU tests can compare device bits with host bits */
+EXPORT float oracle_expf(float x) { return spfe_expf(x); }
+EXPORT float oracle_logf(float x) { return spfe_logf(x); }
+EXPORT float oracle_sum256(const float *v) { return spfe_sum256_host(v); }
