@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py — frames/sec of the SuperPoint extraction path on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (for N > 1 launched by
+torch.distributed.run, one rank per GPU).  A step = one pass of the whole hot
+path (u8 frames resident in HBM -> fixed-stride keypoint/descriptor records in
+HBM, plus the RCCL all-gather of the records when N > 1) over a batch of
+FRAMES_PER_GPU frames per GPU.  Prints ONE JSON line on rank 0.
+
+Workload = BASELINE.json configs[1] scaled the way configs[2] shards it:
+752x480 frames, num_features = 1000, f32, 8 independent frames per GPU per step
+(64 frames on 8 GPUs); weak scaling.  The batch-1 latency of configs[1] is
+reported beside it as `latency_batch1_ms`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_FRAME = {(480, 752): 61221703680, (480, 640): 52103577600, (720, 1280): 156310732800}
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def conv1b_flop(H, W):
+    return 2 * H * W * 64 * 64 * 9
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames-per-gpu", type=int, default=8)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=752)
+    ap.add_argument("--num-features", type=int, default=1000)
+    ap.add_argument("--detector", default="dense", choices=["dense", "sparse"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    os.environ.setdefault("SPFE_STAGE_TIMING", "1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import numpy as np
+    import torch  # device memory, streams, torch.distributed (RCCL); imported before libspfe
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+
+    from sp_orb_slam_amd import synth, weights
+    from sp_orb_slam_amd.extractor import SPExtractor
+
+    H, W, nf, B = args.height, args.width, args.num_features, args.frames_per_gpu
+    blob = weights.synthetic(7, args.detector)
+    ext = SPExtractor(nf, H, W, blob, max_batch=B, device=local, with_heat=False)
+    rec_bytes = ext.record_bytes()
+    # synthetic frames: seeds 200.., distinct per rank
+    frames = synth.make_batch(200 + rank * B, B, H, W)
+    d_img = torch.from_numpy(frames).cuda()
+    d_rec = torch.zeros(B * rec_bytes, dtype=torch.uint8, device="cuda")
+    d_all = torch.zeros(world * B * rec_bytes, dtype=torch.uint8, device="cuda") if world > 1 else None
+    stream = torch.cuda.current_stream()
+
+    def step():
+        ext.extract_batch_device(d_img.data_ptr(), B, d_rec.data_ptr(), stream.cuda_stream)
+        if world > 1:
+            dist.all_gather_into_tensor(d_all, d_rec)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ext.stage_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    stages = ext.stage_times()
+
+    # sanity: the gathered records decode and carry the expected keypoint counts
+    rec0 = ext.view_record(d_rec[:rec_bytes].cpu().numpy())
+    if world > 1:
+        recl = ext.view_record(d_all[(world * B - 1) * rec_bytes:].cpu().numpy())
+        assert 0 < recl.K <= nf + 1
+    assert 0 < rec0.K <= nf + 1
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        fps = world * B * args.steps / dt
+        flop_frame = FLOP_PER_FRAME.get((H, W))
+        # dominant kernel: conv1b (43.5 % of the FLOPs), one launch covers B frames
+        t_conv1b = stages.get("conv1b", 0.0) * 1e-3
+        ach = (conv1b_flop(H, W) * B / t_conv1b / 1e12) if t_conv1b > 0 else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "conv1b_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "frames/sec SuperPoint extract (752x480, 1k kpts)",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%dx%d u8 frames, num_features=%d, f32 MFMA, %d frames/GPU/step, "
+                                   "%s synthetic detector weights; records all-gathered over RCCL when n_gpus>1"
+                                   % (W, H, nf, B, args.detector),
+                       "frames_per_gpu": B, "height": H, "width": W, "num_features": nf,
+                       "parallelism": "dp%d" % world},
+            "roofline": {"bound": "mfma", "kernel": "conv_f32_kernel<64,3,16,...,pool> (conv1b)",
+                         "achieved": round(ach, 2) if ach else None, "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4) if ach else None,
+                         "traffic": traffic},
+            "whole_path_tflops": round(fps * flop_frame / 1e12, 2) if flop_frame else None,
+            "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+        }
+        # batch-1 latency (configs[1] as written: one frame per call)
+        ext1 = SPExtractor(nf, H, W, blob, max_batch=1, device=local, with_heat=False)
+        d1 = d_img[:1].contiguous()
+        r1 = torch.zeros(rec_bytes, dtype=torch.uint8, device="cuda")
+        lat = []
+        for i in range(60):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ext1.extract_batch_device(d1.data_ptr(), 1, r1.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - t1) * 1e3)
+        lat = sorted(lat[10:])
+        out["latency_batch1_ms"] = {"p50": round(lat[len(lat) // 2], 4), "p99": round(lat[-1], 4)}
+        ext1.close()
+
+        if world == 1 and not args.no_cpu_baseline:
+            # CPU baseline: the C oracle (a port of the path; the reference has no CPU
+            # path and cannot be built here) on this host's cores, bounded sample.
+            from oracle import oracle
+            nthr = os.cpu_count() or 1
+            done, t1 = 0, time.perf_counter()
+            while True:
+                oracle.extract(blob, frames[done % B], nf)
+                done += 1
+                el = time.perf_counter() - t1
+                if el >= args.cpu_seconds or done >= 64:
+                    break
+            out["cpu_baseline"] = {"value": round(done / el, 3), "unit": "frames/s", "cores": nthr,
+                                   "kind": "port",
+                                   "sample": "%d frames of the same %dx%d workload through oracle/spfe_oracle.c "
+                                             "(OpenMP, %d threads), %.1f s" % (done, W, H, nthr, el)}
+        print(json.dumps(out), flush=True)
+    ext.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

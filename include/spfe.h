@@ -1,0 +1,154 @@
+/*
+ * spfe.h — C ABI of libspfe.so, the MI355X-native SuperPoint feature front-end.
+ *
+ * Drop-in boundary for ONE path of HyHuang1995/sp_orb_slam: the extractor call
+ *     (*mpORBextractorLeft)(im, cv::Mat(), mvKeys, mDescriptors)
+ * (orb_slam2/src/type/frame.cpp:296-314), i.e. SPExtractor::operator()
+ * (orb_slam2/src/cv/sp_extractor.cpp:361-514) and everything below it
+ * (SPFrontend::forward :79-159, nms :161-250, computeCovariance :252-340).
+ * Plain pointers and sizes only: no torch, OpenCV or Eigen types.  The C++
+ * adaptor that restores the BaseExtractor signature
+ * (include/orb_slam/cv/base_extractor.h:54-56) is include/spfe_extractor.hpp;
+ * INTEGRATION.md shows the reference-side change.
+ *
+ * All functions return SPFE_OK (0) or a negative SPFE_E* code; the message for
+ * the last failure on the calling thread is spfe_last_error().
+ */
+#ifndef SPFE_H
+#define SPFE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define SPFE_API __attribute__((visibility("default")))
+#else
+#define SPFE_API
+#endif
+
+#define SPFE_OK 0
+#define SPFE_EINVAL (-1)   /* bad argument / size not a multiple of 8 / wrong batch */
+#define SPFE_EEMPTY (-2)   /* null or empty image: sp_extractor.cpp:364-365 throws here */
+#define SPFE_EHIP (-3)     /* HIP runtime error (no GPU, OOM, launch failure) */
+#define SPFE_EWEIGHTS (-4) /* weight blob/file missing or malformed */
+
+/* spfe_config.precision */
+#define SPFE_PRECISION_F32 0 /* exact f32 on v_mfma_f32_32x32x2_f32; bit-reproducible */
+
+/* spfe_config.flags */
+#define SPFE_FLAG_HEAT 1u /* also produce heat / heat_inv (H*W floats each), sp_extractor.cpp:461-474 */
+
+#define SPFE_DESC_DIM 256
+#define SPFE_NUM_PARAMS 1300865 /* sp_extractor.cpp:16-43; order = register_module order :46-62 */
+
+typedef struct spfe_handle_s *spfe_handle;
+
+/*
+ * Replaces the SPExtractor constructor (sp_extractor.cpp:342-359), which reads
+ * tracking::num_features (tracker.cpp:131), camera::height/width and
+ * common::model_path (:354-355) from globals.
+ */
+typedef struct {
+  int height;               /* camera::height, multiple of 8 (:70) */
+  int width;                /* camera::width, multiple of 8 */
+  int num_features;         /* tracking::num_features; up to num_features+1 keypoints (:211-213) */
+  int max_batch;            /* frames per spfe_extract_batch* call (>=1) */
+  int device;               /* HIP device ordinal */
+  int precision;            /* SPFE_PRECISION_* */
+  unsigned flags;           /* SPFE_FLAG_* */
+  const float *weights;     /* flat fp32 blob, SPFE_NUM_PARAMS floats, or NULL */
+  const char *weights_path; /* "SPFW" file (sp_orb_slam_amd/weights.py), used if weights==NULL */
+} spfe_config;
+
+/*
+ * Everything the caller reads after operator() (frame.cpp:296-314): keypoints,
+ * descriptors and the SPExtractor side outputs (sp_extractor.h:61-73).
+ * Pointers are library-owned host buffers, valid until the next call on the
+ * same handle (the reference hands out cv::Mat headers over freed tensor
+ * storage, sp_extractor.cpp:432-433,448-451; this does not).
+ */
+typedef struct {
+  int K;                    /* keypoints emitted, raster order (:220-238) */
+  int n_candidates;         /* cells with score >= 0.007 (:122) */
+  const float *kp_xy;       /* [K][2] pt.x, pt.y (integer valued); size=1, octave=0, angle=-1 (:231-232) */
+  const float *kp_response; /* [K] heat_inv at the keypoint (:271) */
+  const float *desc;        /* [K][256] unit-L2 rows, CV_32FC1 (:512-513) */
+  const float *cov2;        /* [K][2] (:332) */
+  const float *cov2_inv;    /* [K][2] getCov2Inv() (sp_extractor.h:67) */
+  const int16_t *occ_grid;  /* [H/8][W/8] CV_16SC1, -1 = empty (:178,227-228) */
+  const float *dense_dust;  /* [H/8][W/8] softmax dustbin (:107,450) */
+  const float *semi_dust;   /* [H/8][W/8] raw dustbin logit (:106,448) */
+  const float *heat;        /* [H][W] or NULL without SPFE_FLAG_HEAT (:467) */
+  const float *heat_inv;    /* [H][W] or NULL without SPFE_FLAG_HEAT (:468) */
+} spfe_result;
+
+SPFE_API int spfe_create(const spfe_config *cfg, spfe_handle *out);
+SPFE_API void spfe_destroy(spfe_handle h);
+
+/* SPExtractor::operator() for one CV_8UC1 frame of the configured size.
+ * `stride` = bytes between rows (cv::Mat::step). */
+SPFE_API int spfe_extract(spfe_handle h, const uint8_t *image, int stride, spfe_result *out);
+
+/* n independent frames (n <= max_batch); outs[i] valid until the next call. */
+SPFE_API int spfe_extract_batch(spfe_handle h, const uint8_t *const *images, int stride, int n,
+                       spfe_result *outs);
+
+/*
+ * Device-resident batch path (multi-GPU pipeline): d_images is a DEVICE pointer
+ * to n contiguous u8 frames [n][H][W]; d_records is a DEVICE buffer of
+ * n * spfe_record_bytes(h) bytes that receives one fixed-stride record per
+ * frame (layout: spfe_record_layout).  Work is enqueued on `stream`
+ * (hipStream_t, NULL = the handle's own stream) and NOT synchronised: the caller
+ * may all-gather d_records with RCCL on the same stream.
+ */
+typedef struct {
+  size_t bytes;    /* record stride, multiple of 256 */
+  int kmax;        /* num_features + 1 */
+  size_t off_hdr;  /* int32 K, int32 n_candidates, int32 status, int32 reserved */
+  size_t off_xy;   /* float [kmax][2] */
+  size_t off_resp; /* float [kmax] */
+  size_t off_cov;  /* float [kmax][2] */
+  size_t off_cinv; /* float [kmax][2] */
+  size_t off_desc; /* float [kmax][256] */
+  size_t off_occ;  /* int16 [H/8][W/8] */
+  size_t off_dd;   /* float [H/8][W/8] dense_dust */
+  size_t off_sd;   /* float [H/8][W/8] semi_dust */
+} spfe_record_layout;
+
+SPFE_API int spfe_get_record_layout(spfe_handle h, spfe_record_layout *out);
+SPFE_API size_t spfe_record_bytes(spfe_handle h);
+SPFE_API int spfe_extract_batch_device(spfe_handle h, const void *d_images, int n, void *d_records,
+                              void *stream);
+/* Host view of ONE record that the caller copied to host memory. */
+SPFE_API int spfe_view_record(spfe_handle h, const void *host_record, spfe_result *out);
+
+/* Test/diagnostic tap: copy an intermediate device buffer of frame `frame` of
+ * the last call to host. Names: "semi" [hc][wc][65], "coarse" [hc][wc][256],
+ * "heat_log" [H][W], "feat" [hc][wc][128], "act<i>" layer outputs.
+ * Returns the number of bytes copied or a negative error. */
+SPFE_API long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size_t cap);
+
+/* Per-stage GPU time (ms, HIP events recorded on the launch stream around every
+ * kernel), averaged over the calls since spfe_stage_reset (the library keeps the
+ * last 128 calls).  Enabled by SPFE_STAGE_TIMING=1 in the environment at
+ * spfe_create; returns the number of stages written (names: spfe_stage_name). */
+SPFE_API int spfe_stage_times(spfe_handle h, float *ms, int cap);
+SPFE_API int spfe_stage_reset(spfe_handle h);
+SPFE_API const char *spfe_stage_name(int i);
+
+/* Test hook: evaluates the device forms of spfe_expf(x) and spfe_logf(|x|)
+ * (include/spfe_exact_math.h) on n host floats, so tests can compare GPU bits
+ * with host bits. */
+SPFE_API int spfe_math_probe(const float *in, float *out_exp, float *out_log, int n);
+
+SPFE_API const char *spfe_last_error(void);
+SPFE_API const char *spfe_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPFE_H */

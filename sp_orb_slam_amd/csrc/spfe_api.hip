@@ -1,0 +1,565 @@
+// spfe_api.hip — host side of libspfe.so: handle, weight packing, the per-batch
+// launch sequence and the C ABI of include/spfe.h.
+//
+// One handle = one GPU, one stream, one set of buffers (SURVEY.md §8b
+// "Threading"): the object SPExtractor's constructor builds
+// (/root/reference/orb_slam2/src/cv/sp_extractor.cpp:342-359) and whose
+// operator() (:361-514) the extract calls replace.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/spfe.h"
+#include "../../include/spfe_exact_math.h"
+#include "spfe_kernels.h"
+
+namespace spfe {
+void covariance_host(const float *heat_inv, int H, int W, const float *kp_xy, int K, float *cov2,
+                     float *cov2_inv);
+}
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      return fail(SPFE_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                  __LINE__);                                                            \
+  } while (0)
+
+constexpr int NSTAGE = 16;
+const char *kStageNames[NSTAGE] = {"conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b",
+                                   "conv4a", "conv4b", "convPaDa", "convPb", "convDb", "tail",
+                                   "heat_norm", "select", "desc", "total"};
+
+struct ConvLayer {
+  int cin, cout_real, nblk, ks;
+  bool pool, relu, small_tile;
+  float *d_w = nullptr, *d_b = nullptr;
+  const float *in = nullptr;
+  int in_stride = 0, in_choff = 0;
+  float *out = nullptr;
+  int out_stride = 0, out_choff = 0;
+  int H = 0, W = 0;  // input resolution of this layer
+};
+
+}  // namespace
+
+struct spfe_handle_s {
+  spfe_config cfg{};
+  int H = 0, W = 0, hc = 0, wc = 0, C = 0, kmax = 0, B = 0;
+  hipStream_t stream = nullptr;
+  std::vector<void *> dev_allocs;
+  std::vector<void *> host_allocs;
+  uint8_t *d_img = nullptr;
+  float *d_w1a = nullptr, *d_b1a = nullptr;
+  float *act[8] = {};
+  float *d_head = nullptr, *d_semi = nullptr, *d_coarse = nullptr;
+  float *d_heat_log = nullptr, *d_heat = nullptr, *d_heat_inv = nullptr;
+  float *d_minmax = nullptr, *d_cell_score = nullptr, *d_heat_consts = nullptr;
+  uint8_t *d_cell_k = nullptr;
+  int *d_kp_cell = nullptr;
+  uint8_t *d_records = nullptr;
+  ConvLayer layers[10];
+  spfe::RecordLayout rl{};
+  // host side
+  uint8_t *h_img = nullptr, *h_records = nullptr;
+  float *h_heat = nullptr, *h_heat_inv = nullptr;
+  int last_n = 0;
+  // per-stage timing: a ring of event sets, one set per enqueue() call
+  bool timing = false;
+  static constexpr int EVSETS = 128;
+  std::vector<hipEvent_t> evpool;  // [EVSETS][NSTAGE + 1]
+  long calls = 0, calls_at_reset = 0;
+  hipEvent_t *ev = nullptr;        // set used by the current call
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(spfe_handle h, T **p, size_t count) {
+  void *q = nullptr;
+  HIP_TRY(hipMalloc(&q, count * sizeof(T) + 256));
+  h->dev_allocs.push_back(q);
+  *p = reinterpret_cast<T *>(q);
+  return SPFE_OK;
+}
+template <class T>
+int host_alloc(spfe_handle h, T **p, size_t count) {
+  void *q = nullptr;
+  HIP_TRY(hipHostMalloc(&q, count * sizeof(T) + 256, hipHostMallocDefault));
+  h->host_allocs.push_back(q);
+  *p = reinterpret_cast<T *>(q);
+  return SPFE_OK;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+void make_layout(int kmax, int C, spfe::RecordLayout *r) {
+  size_t o = 0;
+  r->kmax = kmax;
+  r->off_hdr = o; o += 16;
+  r->off_xy = o; o = align_up(o + (size_t)kmax * 2 * 4, 16);
+  r->off_resp = o; o = align_up(o + (size_t)kmax * 4, 16);
+  r->off_cov = o; o = align_up(o + (size_t)kmax * 2 * 4, 16);
+  r->off_cinv = o; o = align_up(o + (size_t)kmax * 2 * 4, 16);
+  r->off_desc = o; o = align_up(o + (size_t)kmax * SPFE_DESC_DIM * 4, 16);
+  r->off_occ = o; o = align_up(o + (size_t)C * 2, 16);
+  r->off_dd = o; o = align_up(o + (size_t)C * 4, 16);
+  r->off_sd = o; o = align_up(o + (size_t)C * 4, 16);
+  r->bytes = align_up(o, 256);
+}
+
+// offsets into the flat blob (register_module order, sp_extractor.cpp:46-62)
+size_t blob_weight_offset(int l) {
+  size_t off = 0;
+  for (int i = 0; i < l; ++i) {
+    const spfe_layer_t &L = SPFE_LAYERS[i];
+    off += (size_t)L.cout * L.cin * L.ksize * L.ksize + L.cout;
+  }
+  return off;
+}
+
+// pack OIHW weights of one or two layers (concatenated along cout) into
+// [nblk][chunk][tap][KC][64] (K order of spfe_exact_math.h) + padded bias
+int pack_layer(spfe_handle h, const float *blob, const int *lids, int nl, ConvLayer *out) {
+  const spfe_layer_t &L0 = SPFE_LAYERS[lids[0]];
+  const int cin = L0.cin, ks = L0.ksize, taps = ks * ks;
+  int cout = 0;
+  for (int i = 0; i < nl; ++i) cout += SPFE_LAYERS[lids[i]].cout;
+  const int kc = spfe::conv_kc(ks), nchunk = cin / kc, nblk = (cout + 63) / 64;
+  std::vector<float> w((size_t)nblk * nchunk * taps * kc * 64, 0.0f), bia((size_t)nblk * 64, 0.0f);
+  int co_base = 0;
+  for (int i = 0; i < nl; ++i) {
+    const spfe_layer_t &L = SPFE_LAYERS[lids[i]];
+    const float *W = blob + blob_weight_offset(lids[i]);
+    const float *Bv = W + (size_t)L.cout * L.cin * taps;
+    for (int co = 0; co < L.cout; ++co) {
+      const int g = co_base + co, nb = g / 64, j = g % 64;
+      bia[g] = Bv[co];
+      for (int ci = 0; ci < cin; ++ci) {
+        const int ch = ci / kc, c = ci % kc;
+        for (int t = 0; t < taps; ++t)
+          w[((((size_t)nb * nchunk + ch) * taps + t) * kc + c) * 64 + j] =
+              W[((size_t)co * cin + ci) * taps + t];
+      }
+    }
+    co_base += L.cout;
+  }
+  int rc;
+  if ((rc = dev_alloc(h, &out->d_w, w.size()))) return rc;
+  if ((rc = dev_alloc(h, &out->d_b, bia.size()))) return rc;
+  HIP_TRY(hipMemcpy(out->d_w, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(out->d_b, bia.data(), bia.size() * 4, hipMemcpyHostToDevice));
+  out->cin = cin;
+  out->cout_real = cout;
+  out->nblk = nblk;
+  out->ks = ks;
+  return SPFE_OK;
+}
+
+int load_blob(const spfe_config *cfg, std::vector<float> *blob) {
+  blob->resize(SPFE_NUM_PARAMS);
+  if (cfg->weights) {
+    memcpy(blob->data(), cfg->weights, (size_t)SPFE_NUM_PARAMS * 4);
+    return SPFE_OK;
+  }
+  if (!cfg->weights_path) return fail(SPFE_EWEIGHTS, "no weights: both weights and weights_path are NULL");
+  FILE *f = fopen(cfg->weights_path, "rb");
+  if (!f) return fail(SPFE_EWEIGHTS, "cannot open weight file %s", cfg->weights_path);
+  unsigned char head[16];
+  uint32_t ver = 0;
+  uint64_t n = 0;
+  bool ok = fread(head, 1, 16, f) == 16 && memcmp(head, "SPFW", 4) == 0;
+  if (ok) {
+    memcpy(&ver, head + 4, 4);
+    memcpy(&n, head + 8, 8);
+    ok = ver == 1 && n == SPFE_NUM_PARAMS && fread(blob->data(), 4, n, f) == n;
+  }
+  fclose(f);
+  if (!ok) return fail(SPFE_EWEIGHTS, "%s is not a valid SPFW v1 file with %d params", cfg->weights_path, SPFE_NUM_PARAMS);
+  return SPFE_OK;
+}
+
+int build(spfe_handle h, const spfe_config *cfg) {
+  h->cfg = *cfg;
+  h->H = cfg->height; h->W = cfg->width;
+  h->hc = h->H / 8; h->wc = h->W / 8; h->C = h->hc * h->wc;
+  h->kmax = cfg->num_features + 1;
+  h->B = cfg->max_batch;
+  const int H = h->H, W = h->W, B = h->B, C = h->C;
+  HIP_TRY(hipSetDevice(cfg->device));
+  HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  const char *tenv = getenv("SPFE_STAGE_TIMING");
+  h->timing = tenv && atoi(tenv) != 0;
+  if (h->timing) {
+    h->evpool.resize((size_t)spfe_handle_s::EVSETS * (NSTAGE + 1), nullptr);
+    for (auto &e : h->evpool) HIP_TRY(hipEventCreate(&e));
+  }
+
+  std::vector<float> blob;
+  int rc = load_blob(cfg, &blob);
+  if (rc) return rc;
+
+  // conv1a weights: [tap][64]
+  {
+    const float *Wt = blob.data() + blob_weight_offset(0);
+    std::vector<float> w(9 * 64), bv(64);
+    for (int co = 0; co < 64; ++co) {
+      for (int t = 0; t < 9; ++t) w[t * 64 + co] = Wt[co * 9 + t];
+      bv[co] = Wt[64 * 9 + co];
+    }
+    if ((rc = dev_alloc(h, &h->d_w1a, w.size()))) return rc;
+    if ((rc = dev_alloc(h, &h->d_b1a, bv.size()))) return rc;
+    HIP_TRY(hipMemcpy(h->d_w1a, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_b1a, bv.data(), bv.size() * 4, hipMemcpyHostToDevice));
+  }
+
+  // activations (NHWC f32).  act[0]=conv1a .. act[7]=conv4b
+  const int lh[8] = {H, H / 2, H / 2, H / 4, H / 4, H / 8, H / 8, H / 8};
+  const int lw[8] = {W, W / 2, W / 2, W / 4, W / 4, W / 8, W / 8, W / 8};
+  const int lc[8] = {64, 64, 64, 64, 128, 128, 128, 128};
+  for (int i = 0; i < 8; ++i)
+    if ((rc = dev_alloc(h, &h->act[i], (size_t)B * lh[i] * lw[i] * lc[i]))) return rc;
+  if ((rc = dev_alloc(h, &h->d_img, (size_t)B * H * W))) return rc;
+  if ((rc = dev_alloc(h, &h->d_head, (size_t)B * C * 512))) return rc;
+  if ((rc = dev_alloc(h, &h->d_semi, (size_t)B * C * SPFE_SEMI_CH))) return rc;
+  if ((rc = dev_alloc(h, &h->d_coarse, (size_t)B * C * SPFE_DESC_DIM))) return rc;
+  if ((rc = dev_alloc(h, &h->d_heat_log, (size_t)B * H * W))) return rc;
+  if ((rc = dev_alloc(h, &h->d_heat_inv, (size_t)B * H * W))) return rc;
+  if (cfg->flags & SPFE_FLAG_HEAT)
+    if ((rc = dev_alloc(h, &h->d_heat, (size_t)B * H * W))) return rc;
+  if ((rc = dev_alloc(h, &h->d_minmax, (size_t)B * 64 * 2))) return rc;
+  if ((rc = dev_alloc(h, &h->d_cell_score, (size_t)B * C))) return rc;
+  if ((rc = dev_alloc(h, &h->d_heat_consts, (size_t)B * 4))) return rc;
+  if ((rc = dev_alloc(h, &h->d_cell_k, (size_t)B * C))) return rc;
+  if ((rc = dev_alloc(h, &h->d_kp_cell, (size_t)B * h->kmax))) return rc;
+  make_layout(h->kmax, C, &h->rl);
+  if ((rc = dev_alloc(h, &h->d_records, (size_t)B * h->rl.bytes))) return rc;
+  HIP_TRY(hipMemset(h->d_records, 0, (size_t)B * h->rl.bytes));
+
+  // the MFMA conv chain
+  struct Spec { int nl, l0, l1, src, dst; bool pool; };
+  // src/dst index into act[]; -1 = head buffer
+  const Spec specs[8] = {{1, 1, 0, 0, 1, true},  {1, 2, 0, 1, 2, false}, {1, 3, 0, 2, 3, true},
+                         {1, 4, 0, 3, 4, false}, {1, 5, 0, 4, 5, true},  {1, 6, 0, 5, 6, false},
+                         {1, 7, 0, 6, 7, false}, {2, 8, 10, 7, -1, false}};
+  const char *senv = getenv("SPFE_SMALL_TILE_MAXH");
+  const int small_maxh = senv ? atoi(senv) : H / 4;  // layers with input height <= this use 4-row tiles
+  for (int i = 0; i < 8; ++i) {
+    ConvLayer &L = h->layers[i];
+    const int lids[2] = {specs[i].l0, specs[i].l1};
+    if ((rc = pack_layer(h, blob.data(), lids, specs[i].nl, &L))) return rc;
+    L.pool = specs[i].pool;
+    L.relu = true;
+    L.H = lh[specs[i].src];
+    L.W = lw[specs[i].src];
+    L.small_tile = L.H <= small_maxh;
+    L.in = h->act[specs[i].src];
+    L.in_stride = lc[specs[i].src];
+    L.in_choff = 0;
+    if (specs[i].dst >= 0) { L.out = h->act[specs[i].dst]; L.out_stride = lc[specs[i].dst]; }
+    else { L.out = h->d_head; L.out_stride = 512; }
+    L.out_choff = 0;
+  }
+  {  // convPb: head[0:256] -> semi (65)
+    ConvLayer &L = h->layers[8];
+    const int lids[1] = {9};
+    if ((rc = pack_layer(h, blob.data(), lids, 1, &L))) return rc;
+    L.pool = false; L.relu = false; L.small_tile = true; L.H = H / 8; L.W = W / 8;
+    L.in = h->d_head; L.in_stride = 512; L.in_choff = 0;
+    L.out = h->d_semi; L.out_stride = SPFE_SEMI_CH; L.out_choff = 0;
+  }
+  {  // convDb: head[256:512] -> coarse (256)
+    ConvLayer &L = h->layers[9];
+    const int lids[1] = {11};
+    if ((rc = pack_layer(h, blob.data(), lids, 1, &L))) return rc;
+    L.pool = false; L.relu = false; L.small_tile = true; L.H = H / 8; L.W = W / 8;
+    L.in = h->d_head; L.in_stride = 512; L.in_choff = 256;
+    L.out = h->d_coarse; L.out_stride = SPFE_DESC_DIM; L.out_choff = 0;
+  }
+
+  // pinned host mirrors for the host-facing calls
+  if ((rc = host_alloc(h, &h->h_img, (size_t)B * H * W))) return rc;
+  if ((rc = host_alloc(h, &h->h_records, (size_t)B * h->rl.bytes))) return rc;
+  if ((rc = host_alloc(h, &h->h_heat_inv, (size_t)B * H * W))) return rc;
+  if (cfg->flags & SPFE_FLAG_HEAT)
+    if ((rc = host_alloc(h, &h->h_heat, (size_t)B * H * W))) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  return SPFE_OK;
+}
+
+#define STAGE_MARK(i) \
+  do { if (h->timing) HIP_TRY(hipEventRecord(h->ev[i], s)); } while (0)
+
+// Enqueue the whole path for n frames already in device memory.
+int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, hipStream_t s) {
+  const int H = h->H, W = h->W;
+  if (h->timing) h->ev = h->evpool.data() + (size_t)(h->calls % spfe_handle_s::EVSETS) * (NSTAGE + 1);
+  h->calls++;
+  STAGE_MARK(0);
+  HIP_TRY(spfe::launch_conv1a(d_images, h->d_w1a, h->d_b1a, h->act[0], n, H, W, s));
+  STAGE_MARK(1);
+  for (int i = 0; i < 10; ++i) {
+    const ConvLayer &L = h->layers[i];
+    spfe::ConvParams p;
+    p.in = L.in; p.in_stride = L.in_stride; p.in_choff = L.in_choff;
+    p.wpack = L.d_w; p.bias = L.d_b;
+    p.out = L.out; p.out_stride = L.out_stride; p.out_choff = L.out_choff; p.cout_real = L.cout_real;
+    p.B = n; p.H = L.H; p.W = L.W;
+    const int th = spfe::conv_tile_rows(L.small_tile);
+    p.tiles_x = (L.W + 31) / 32; p.tiles_y = (L.H + th - 1) / th; p.nblk = L.nblk;
+    HIP_TRY(spfe::launch_conv_f32(p, L.cin, L.ks, L.pool, L.relu, L.small_tile, s));
+    STAGE_MARK(2 + i);
+  }
+  spfe::FrameBufs f{};
+  f.semi = h->d_semi; f.coarse = h->d_coarse;
+  f.heat_log = h->d_heat_log; f.heat = h->d_heat; f.heat_inv = h->d_heat_inv;
+  f.minmax = reinterpret_cast<uint32_t *>(h->d_minmax);
+  f.cell_score = h->d_cell_score; f.cell_k = h->d_cell_k; f.kp_cell = h->d_kp_cell;
+  f.records = d_records; f.heat_consts = h->d_heat_consts;
+  HIP_TRY(spfe::launch_tail(f, h->rl, n, H, W, s));
+  STAGE_MARK(12);
+  HIP_TRY(spfe::launch_heat_norm(f, n, H, W, s));
+  STAGE_MARK(13);
+  HIP_TRY(spfe::launch_select(f, h->rl, n, H, W, h->cfg.num_features, s));
+  STAGE_MARK(14);
+  HIP_TRY(spfe::launch_desc(f, h->rl, n, H, W, s));
+  STAGE_MARK(15);
+  h->last_n = n;
+  return SPFE_OK;
+}
+
+void view_record(const spfe_handle h, const uint8_t *rec, const float *heat, const float *heat_inv,
+                 spfe_result *out) {
+  const spfe::RecordLayout &r = h->rl;
+  const int *hdr = reinterpret_cast<const int *>(rec + r.off_hdr);
+  out->K = hdr[0];
+  out->n_candidates = hdr[1];
+  out->kp_xy = reinterpret_cast<const float *>(rec + r.off_xy);
+  out->kp_response = reinterpret_cast<const float *>(rec + r.off_resp);
+  out->desc = reinterpret_cast<const float *>(rec + r.off_desc);
+  out->cov2 = reinterpret_cast<const float *>(rec + r.off_cov);
+  out->cov2_inv = reinterpret_cast<const float *>(rec + r.off_cinv);
+  out->occ_grid = reinterpret_cast<const int16_t *>(rec + r.off_occ);
+  out->dense_dust = reinterpret_cast<const float *>(rec + r.off_dd);
+  out->semi_dust = reinterpret_cast<const float *>(rec + r.off_sd);
+  out->heat = heat;
+  out->heat_inv = heat_inv;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *spfe_last_error(void) { return g_err.c_str(); }
+const char *spfe_version(void) { return "spfe 0.1 (gfx950, f32-mfma)"; }
+const char *spfe_stage_name(int i) { return (i >= 0 && i < NSTAGE) ? kStageNames[i] : ""; }
+
+int spfe_create(const spfe_config *cfg, spfe_handle *out) {
+  if (!cfg || !out) return fail(SPFE_EINVAL, "spfe_create: null argument");
+  *out = nullptr;
+  if (cfg->height <= 0 || cfg->width <= 0 || cfg->height % 8 || cfg->width % 8)
+    return fail(SPFE_EINVAL, "image size %dx%d must be positive multiples of 8 (sp_extractor.cpp:70)",
+                cfg->width, cfg->height);
+  if (cfg->height < 16 || cfg->width < 16)
+    return fail(SPFE_EINVAL, "image size %dx%d too small", cfg->width, cfg->height);
+  if (cfg->num_features < 1 || cfg->num_features > 32766)
+    return fail(SPFE_EINVAL, "num_features %d out of range (occ_grid is int16)", cfg->num_features);
+  if (cfg->max_batch < 1) return fail(SPFE_EINVAL, "max_batch must be >= 1");
+  if (cfg->precision != SPFE_PRECISION_F32) return fail(SPFE_EINVAL, "unsupported precision %d", cfg->precision);
+  if ((size_t)(cfg->height / 8) * (cfg->width / 8) > 65535 ||
+      spfe::select_lds_bytes(cfg->height, cfg->width) > 160 * 1024)
+    return fail(SPFE_EINVAL, "image %dx%d too large for the single-workgroup selection stage", cfg->width,
+                cfg->height);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(SPFE_EHIP, "no HIP device available (libspfe has no CPU path)");
+  if (cfg->device < 0 || cfg->device >= ndev)
+    return fail(SPFE_EINVAL, "device %d out of range (%d devices)", cfg->device, ndev);
+  spfe_handle h = new spfe_handle_s();
+  int rc = build(h, cfg);
+  if (rc) {
+    std::string keep = g_err;
+    spfe_destroy(h);
+    g_err = keep;
+    return rc;
+  }
+  *out = h;
+  return SPFE_OK;
+}
+
+void spfe_destroy(spfe_handle h) {
+  if (!h) return;
+  (void)hipSetDevice(h->cfg.device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void *p : h->dev_allocs) (void)hipFree(p);
+  for (void *p : h->host_allocs) (void)hipHostFree(p);
+  for (auto &e : h->evpool)
+    if (e) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int spfe_get_record_layout(spfe_handle h, spfe_record_layout *o) {
+  if (!h || !o) return fail(SPFE_EINVAL, "null argument");
+  const spfe::RecordLayout &r = h->rl;
+  o->bytes = r.bytes; o->kmax = r.kmax; o->off_hdr = r.off_hdr; o->off_xy = r.off_xy;
+  o->off_resp = r.off_resp; o->off_cov = r.off_cov; o->off_cinv = r.off_cinv;
+  o->off_desc = r.off_desc; o->off_occ = r.off_occ; o->off_dd = r.off_dd; o->off_sd = r.off_sd;
+  return SPFE_OK;
+}
+
+size_t spfe_record_bytes(spfe_handle h) { return h ? h->rl.bytes : 0; }
+
+int spfe_extract_batch_device(spfe_handle h, const void *d_images, int n, void *d_records, void *stream) {
+  if (!h) return fail(SPFE_EINVAL, "null handle");
+  if (!d_images) return fail(SPFE_EEMPTY, "input image is empty");
+  if (n < 1 || n > h->B) return fail(SPFE_EINVAL, "batch %d not in [1, %d]", n, h->B);
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
+  uint8_t *rec = d_records ? reinterpret_cast<uint8_t *>(d_records) : h->d_records;
+  return enqueue(h, reinterpret_cast<const uint8_t *>(d_images), n, rec, s);
+}
+
+int spfe_extract_batch(spfe_handle h, const uint8_t *const *images, int stride, int n, spfe_result *outs) {
+  if (!h || !outs) return fail(SPFE_EINVAL, "null argument");
+  if (!images) return fail(SPFE_EEMPTY, "input image is empty");
+  if (n < 1 || n > h->B) return fail(SPFE_EINVAL, "batch %d not in [1, %d]", n, h->B);
+  const int H = h->H, W = h->W;
+  if (stride < W) return fail(SPFE_EINVAL, "stride %d smaller than width %d", stride, W);
+  for (int i = 0; i < n; ++i) {
+    if (!images[i]) return fail(SPFE_EEMPTY, "input image is empty");  // sp_extractor.cpp:364-365
+    for (int y = 0; y < H; ++y)
+      memcpy(h->h_img + ((size_t)i * H + y) * W, images[i] + (size_t)y * stride, W);
+  }
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  hipStream_t s = h->stream;
+  HIP_TRY(hipMemcpyAsync(h->d_img, h->h_img, (size_t)n * H * W, hipMemcpyHostToDevice, s));
+  int rc = enqueue(h, h->d_img, n, h->d_records, s);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(h->h_records, h->d_records, (size_t)n * h->rl.bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h->h_heat_inv, h->d_heat_inv, (size_t)n * H * W * 4, hipMemcpyDeviceToHost, s));
+  if (h->d_heat)
+    HIP_TRY(hipMemcpyAsync(h->h_heat, h->d_heat, (size_t)n * H * W * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (int i = 0; i < n; ++i) {
+    uint8_t *rec = h->h_records + (size_t)i * h->rl.bytes;
+    const float *hinv = h->h_heat_inv + (size_t)i * H * W;
+    const int K = reinterpret_cast<const int *>(rec + h->rl.off_hdr)[0];
+    // computeCovariance (sp_extractor.cpp:252-340) — host stage, as in the reference
+    spfe::covariance_host(hinv, H, W, reinterpret_cast<const float *>(rec + h->rl.off_xy), K,
+                          reinterpret_cast<float *>(rec + h->rl.off_cov),
+                          reinterpret_cast<float *>(rec + h->rl.off_cinv));
+    const bool want = (h->cfg.flags & SPFE_FLAG_HEAT) != 0;
+    view_record(h, rec, want ? h->h_heat + (size_t)i * H * W : nullptr, want ? hinv : nullptr, &outs[i]);
+  }
+  return SPFE_OK;
+}
+
+int spfe_extract(spfe_handle h, const uint8_t *image, int stride, spfe_result *out) {
+  if (!image) return fail(SPFE_EEMPTY, "input image is empty");
+  const uint8_t *imgs[1] = {image};
+  return spfe_extract_batch(h, imgs, stride, 1, out);
+}
+
+int spfe_view_record(spfe_handle h, const void *host_record, spfe_result *out) {
+  if (!h || !host_record || !out) return fail(SPFE_EINVAL, "null argument");
+  view_record(h, reinterpret_cast<const uint8_t *>(host_record), nullptr, nullptr, out);
+  return SPFE_OK;
+}
+
+long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size_t cap) {
+  if (!h || !name || !dst) return fail(SPFE_EINVAL, "null argument");
+  if (frame < 0 || frame >= h->B) return fail(SPFE_EINVAL, "frame %d out of range", frame);
+  const size_t C = h->C, HW = (size_t)h->H * h->W;
+  const void *src = nullptr;
+  size_t bytes = 0;
+  std::string nm(name);
+  if (nm == "semi") { src = h->d_semi + frame * C * SPFE_SEMI_CH; bytes = C * SPFE_SEMI_CH * 4; }
+  else if (nm == "coarse") { src = h->d_coarse + frame * C * SPFE_DESC_DIM; bytes = C * SPFE_DESC_DIM * 4; }
+  else if (nm == "head") { src = h->d_head + frame * C * 512; bytes = C * 512 * 4; }
+  else if (nm == "heat_log") { src = h->d_heat_log + frame * HW; bytes = HW * 4; }
+  else if (nm == "heat_inv") { src = h->d_heat_inv + frame * HW; bytes = HW * 4; }
+  else if (nm == "heat" && h->d_heat) { src = h->d_heat + frame * HW; bytes = HW * 4; }
+  else if (nm == "cell_score") { src = h->d_cell_score + frame * C; bytes = C * 4; }
+  else if (nm == "feat") { src = h->act[7] + frame * C * 128; bytes = C * 128 * 4; }
+  else if (nm.size() == 4 && nm.compare(0, 3, "act") == 0 && nm[3] >= '0' && nm[3] <= '7') {
+    const int i = nm[3] - '0';
+    const int lh[8] = {1, 2, 2, 4, 4, 8, 8, 8};
+    const int lc[8] = {64, 64, 64, 64, 128, 128, 128, 128};
+    const size_t per = (size_t)(h->H / lh[i]) * (h->W / lh[i]) * lc[i];
+    src = h->act[i] + frame * per; bytes = per * 4;
+  } else return fail(SPFE_EINVAL, "unknown debug buffer '%s'", name);
+  if (bytes > cap) return fail(SPFE_EINVAL, "buffer '%s' needs %zu bytes, cap %zu", name, bytes, cap);
+  if (hipSetDevice(h->cfg.device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess ||
+      hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+    return fail(SPFE_EHIP, "debug read of '%s' failed", name);
+  return (long)bytes;
+}
+
+int spfe_stage_reset(spfe_handle h) {
+  if (!h) return fail(SPFE_EINVAL, "null handle");
+  h->calls_at_reset = h->calls;
+  return SPFE_OK;
+}
+
+// Average per-stage GPU time (ms) over the calls since spfe_stage_reset (at most
+// the last EVSETS calls).  Needs SPFE_STAGE_TIMING=1 at spfe_create.
+int spfe_stage_times(spfe_handle h, float *ms, int cap) {
+  if (!h || !ms) return fail(SPFE_EINVAL, "null argument");
+  if (!h->timing || h->calls == h->calls_at_reset) return 0;
+  if (hipSetDevice(h->cfg.device) != hipSuccess) return fail(SPFE_EHIP, "hipSetDevice failed");
+  long first = h->calls_at_reset;
+  if (h->calls - first > spfe_handle_s::EVSETS) first = h->calls - spfe_handle_s::EVSETS;
+  const int nst = cap < NSTAGE ? cap : NSTAGE;
+  std::vector<double> acc(NSTAGE, 0.0);
+  for (long c = first; c < h->calls; ++c) {
+    hipEvent_t *ev = h->evpool.data() + (size_t)(c % spfe_handle_s::EVSETS) * (NSTAGE + 1);
+    if (hipEventSynchronize(ev[15]) != hipSuccess) return fail(SPFE_EHIP, "event sync failed");
+    for (int i = 0; i < 15; ++i) {
+      float t = 0;
+      (void)hipEventElapsedTime(&t, ev[i], ev[i + 1]);
+      acc[i] += t;
+    }
+    float t = 0;
+    (void)hipEventElapsedTime(&t, ev[0], ev[15]);
+    acc[15] += t;
+  }
+  for (int i = 0; i < nst; ++i) ms[i] = (float)(acc[i] / (double)(h->calls - first));
+  return nst;
+}
+
+// test hook: run the exact-math device functions on n floats (host buffers)
+int spfe_math_probe(const float *in, float *out_exp, float *out_log, int n) {
+  float *d_in = nullptr, *d_e = nullptr, *d_l = nullptr;
+  HIP_TRY(hipMalloc(&d_in, n * 4));
+  HIP_TRY(hipMalloc(&d_e, n * 4));
+  HIP_TRY(hipMalloc(&d_l, n * 4));
+  HIP_TRY(hipMemcpy(d_in, in, n * 4, hipMemcpyHostToDevice));
+  HIP_TRY(spfe::launch_math_probe(d_in, d_e, d_l, n, nullptr));
+  HIP_TRY(hipMemcpy(out_exp, d_e, n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_log, d_l, n * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(d_in); (void)hipFree(d_e); (void)hipFree(d_l);
+  return SPFE_OK;
+}
+
+}  // extern "C"

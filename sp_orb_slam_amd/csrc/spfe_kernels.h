@@ -1,0 +1,70 @@
+// spfe_kernels.h — launch interface between the host pipeline (spfe_api.hip) and
+// the gfx950 kernels.  Everything here is internal to libspfe.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace spfe {
+
+// ---------------------------------------------------------------------------
+// f32 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 (conv_f32.hip)
+// Activations are NHWC f32: element (b,y,x,c) at ((b*H+y)*W+x)*stride + choff + c.
+// ---------------------------------------------------------------------------
+struct ConvParams {
+  const float *in;
+  int in_stride, in_choff;
+  const float *wpack;  // [nblk][chunk][tap][KC][64], K order of spfe_exact_math.h
+  const float *bias;   // [nblk*64]
+  float *out;
+  int out_stride, out_choff, cout_real;
+  int B, H, W;  // conv input == conv output size (before the optional 2x2 pool)
+  int tiles_x, tiles_y, nblk;
+};
+
+// cin: 64/128/256; ksize: 3 or 1; pool/relu: fused epilogue; small_tile: 4-row
+// tiles (more workgroups for the low-resolution layers).
+hipError_t launch_conv_f32(const ConvParams &p, int cin, int ksize, bool pool, bool relu,
+                           bool small_tile, hipStream_t s);
+int conv_kc(int ksize);        // K-chunk the kernel stages per barrier (16 for 3x3, 64 for 1x1)
+int conv_tile_rows(bool small_tile);
+
+// conv1a: u8 image -> (x * 1/255) -> 3x3 conv 1->64 + bias + relu, NHWC out.
+// w: [9][64] (tap-major), b: [64]
+hipError_t launch_conv1a(const uint8_t *img, const float *w9x64, const float *b64, float *out, int B,
+                         int H, int W, hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// detector tail, selection, descriptors (tail_select.hip)
+// ---------------------------------------------------------------------------
+struct FrameBufs {
+  // per-frame strides are implied by H, W; all arrays are [B][...]
+  const float *semi;    // [B][C][65]
+  const float *coarse;  // [B][C][256]
+  float *heat_log;      // [B][H][W]
+  float *heat;          // [B][H][W] or null
+  float *heat_inv;      // [B][H][W]
+  uint32_t *minmax;     // [B][2] ordered-uint keys of min/max of heat_log
+  float *cell_score;    // [B][C]  0 = no candidate
+  uint8_t *cell_k;      // [B][C]  arg-max channel
+  int *kp_cell;         // [B][kmax] cell index of emitted keypoint
+  uint8_t *records;     // [B][record_bytes]
+  float *heat_consts;   // [B][4] a_heat, b_heat, a_inv, b_inv
+};
+
+struct RecordLayout {
+  size_t bytes;
+  int kmax;
+  size_t off_hdr, off_xy, off_resp, off_cov, off_cinv, off_desc, off_occ, off_dd, off_sd;
+};
+
+hipError_t launch_tail(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s);
+hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H, int W,
+                         int num_features, hipStream_t s);
+hipError_t launch_heat_norm(const FrameBufs &f, int B, int H, int W, hipStream_t s);
+hipError_t launch_desc(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s);
+size_t select_lds_bytes(int H, int W);
+
+// exact-math probe kernels for tests (device bits vs host bits)
+hipError_t launch_math_probe(const float *in, float *out_exp, float *out_log, int n, hipStream_t s);
+
+}  // namespace spfe

@@ -1,0 +1,403 @@
+// tail_select.hip — detector tail, keypoint selection and descriptor sampling.
+//
+// Replaces, on the GPU, what the reference does with ~15 small ATen kernels plus
+// host loops (/root/reference/orb_slam2/src/cv/sp_extractor.cpp):
+//   tail_kernel       softmax / dustbin slices / per-cell arg-max / threshold /
+//                     log-heat + pixel_shuffle               (:105-131)
+//   heat_norm_kernel  to_heat affine normalisation            (:461-474)
+//   select_kernel     score sort + greedy NMS + border reject + raster order +
+//                     occ_grid                               (:489-498, :161-250)
+//   desc_kernel       coarse L2-normalise + bilinear grid_sample + L2-normalise
+//                     for the emitted keypoints only          (:102-103, :134-148)
+// Float steps follow include/spfe_exact_math.h so every integer decision is
+// bit-identical to the CPU oracle given identical logits.
+#include "spfe_kernels.h"
+#include "../../include/spfe_exact_math.h"
+
+namespace spfe {
+
+#define TAIL_BLOCKS_PER_FRAME 64
+
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max64(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_min64(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float o = __shfl_xor(v, off, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+// One wavefront per 8x8 cell: lane k owns position channel k, the dustbin logit
+// is a wave-uniform load.  grid = (TAIL_BLOCKS_PER_FRAME, B), 4 waves per block,
+// each wave strides over the frame's cells.  min/max of the log-heat are reduced
+// per block and written as partials (no atomics, no init).
+__global__ __launch_bounds__(256) void tail_kernel(FrameBufs f, RecordLayout rl, int H, int W) {
+  const int wc = W >> 3, hc = H >> 3, C = hc * wc;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const float *semi = f.semi + (size_t)b * C * SPFE_SEMI_CH;
+  float *heat_log = f.heat_log + (size_t)b * H * W;
+  uint8_t *rec = f.records + (size_t)b * rl.bytes;
+  float *dense_dust = reinterpret_cast<float *>(rec + rl.off_dd);
+  float *semi_dust = reinterpret_cast<float *>(rec + rl.off_sd);
+  float lmin = 0.0f, lmax = -1e30f;  // log-heat is <= 0
+  const int dy = lane >> 3, dx = lane & 7;
+  for (int cell = blockIdx.x * 4 + wave; cell < C; cell += gridDim.x * 4) {
+    const int cy = cell / wc, cx = cell - cy * wc;
+    const float *s = semi + (size_t)cell * SPFE_SEMI_CH;
+    const float v = s[lane];
+    const float vd = s[64];
+    float m = wave_max64(v);
+    m = vd > m ? vd : m;
+    const float e = spfe_expf(v - m);
+    const float ed = spfe_expf(vd - m);
+    const float total = wave_sum64(e) + ed;
+    const float p = e / total;
+    // arg-max over the 64 position channels, lowest index on ties (:112)
+    float bv = p;
+    int bi = lane;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float ov = __shfl_xor(bv, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    const float pc = p < SPFE_HEAT_FLOOR ? SPFE_HEAT_FLOOR : p;
+    const float L = spfe_logf(pc);
+    heat_log[(size_t)(cy * 8 + dy) * W + cx * 8 + dx] = L;
+    lmin = L < lmin ? L : lmin;
+    lmax = L > lmax ? L : lmax;
+    if (lane == 0) {
+      semi_dust[cell] = vd;
+      dense_dust[cell] = ed / total;
+      f.cell_score[(size_t)b * C + cell] = bv >= SPFE_SCORE_THRESH ? bv : 0.0f;
+      f.cell_k[(size_t)b * C + cell] = (uint8_t)bi;
+    }
+  }
+  __shared__ float smin[4], smax[4];
+  lmin = wave_min64(lmin);
+  lmax = wave_max64(lmax);
+  if (lane == 0) { smin[wave] = lmin; smax[wave] = lmax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = smin[0], c = smax[0];
+    for (int i = 1; i < 4; ++i) { a = smin[i] < a ? smin[i] : a; c = smax[i] > c ? smax[i] : c; }
+    float *part = reinterpret_cast<float *>(f.minmax) + ((size_t)b * TAIL_BLOCKS_PER_FRAME + blockIdx.x) * 2;
+    part[0] = a;
+    part[1] = c;
+  }
+}
+
+hipError_t launch_tail(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s) {
+  hipLaunchKernelGGL(tail_kernel, dim3(TAIL_BLOCKS_PER_FRAME, B), dim3(256), 0, s, f, r, H, W);
+  return hipGetLastError();
+}
+
+// to_heat (:461-474): img = -L, min/max as doubles, one affine map per pixel with
+// float scale/shift, float multiply then float add (oracle_heat has the rule).
+__global__ __launch_bounds__(256) void heat_norm_kernel(FrameBufs f, int H, int W) {
+  const int b = blockIdx.y;
+  __shared__ float sc[4];
+  if (threadIdx.x < 64) {
+    const float *part = reinterpret_cast<const float *>(f.minmax) + (size_t)b * TAIL_BLOCKS_PER_FRAME * 2;
+    float lo = part[threadIdx.x * 2], hi = part[threadIdx.x * 2 + 1];
+    lo = wave_min64(lo);
+    hi = wave_max64(hi);
+    if (threadIdx.x == 0) {
+      // m = -L : min(m) = -max(L), max(m) = -min(L)
+      const double dmin = (double)(-hi), dmax = (double)(-lo);
+      const double inv = 1.0 / (dmax - dmin);
+      sc[0] = (float)(-inv);
+      sc[1] = (float)(-dmin * inv);
+      sc[2] = (float)(inv);
+      sc[3] = (float)(dmax * inv);
+      if (blockIdx.x == 0) {
+        float *hc4 = f.heat_consts + (size_t)b * 4;
+        hc4[0] = sc[0]; hc4[1] = sc[1]; hc4[2] = sc[2]; hc4[3] = sc[3];
+      }
+    }
+  }
+  __syncthreads();
+  const float a_h = sc[0], b_h = sc[1], a_i = sc[2], b_i = sc[3];
+  const size_t n4 = (size_t)H * W / 4;
+  const float4 *L4 = reinterpret_cast<const float4 *>(f.heat_log + (size_t)b * H * W);
+  float4 *hi4 = reinterpret_cast<float4 *>(f.heat_inv + (size_t)b * H * W);
+  float4 *h4 = f.heat ? reinterpret_cast<float4 *>(f.heat + (size_t)b * H * W) : nullptr;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 L = L4[i];
+    float4 o;
+    o.x = L.x * a_i + b_i; o.y = L.y * a_i + b_i; o.z = L.z * a_i + b_i; o.w = L.w * a_i + b_i;
+    hi4[i] = o;
+    if (h4) {
+      o.x = L.x * a_h + b_h; o.y = L.y * a_h + b_h; o.z = L.z * a_h + b_h; o.w = L.w * a_h + b_h;
+      h4[i] = o;
+    }
+  }
+}
+
+hipError_t launch_heat_norm(const FrameBufs &f, int B, int H, int W, hipStream_t s) {
+  const int blocks = (int)(((size_t)H * W / 4 + 255) / 256);
+  hipLaunchKernelGGL(heat_norm_kernel, dim3(blocks < 128 ? blocks : 128, B), dim3(256), 0, s, f, H, W);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Selection: one 1024-thread workgroup per frame, all state in LDS.
+// The reference sorts candidates by score and runs a sequential greedy NMS on a
+// byte image (:489-502, :161-250).  There is at most one candidate per 8x8 cell
+// and the suppression window is Chebyshev radius 4 < 8, so a candidate interacts
+// only with its 8 neighbouring cells: the greedy result is the unique fixed point
+// of "alive iff no higher-ranked alive candidate within the window", reached by
+// parallel rounds (no sort needed).  The break after num_features+1 survivors
+// (:211-213) keeps the num_features+1 best-ranked survivors; border reject
+// (:222-224) and raster numbering (:226-236) follow.
+// ---------------------------------------------------------------------------
+enum : uint8_t { ST_NONE = 0, ST_UNDEC = 1, ST_ALIVE = 2, ST_DEAD = 3, ST_KEPT = 4 };
+
+size_t select_lds_bytes(int H, int W) {
+  const size_t C = (size_t)(H / 8) * (W / 8);
+  const size_t Cp = (C + 15) & ~(size_t)15;
+  return Cp * 4 + Cp * 2 + Cp + Cp + ((size_t)(H / 8) + 16) * 4 * 2 + 64;
+}
+
+__global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout rl, int H, int W,
+                                                      int num_features) {
+  const int wc = W >> 3, hc = H >> 3, C = hc * wc;
+  const int Cp = (C + 15) & ~15;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  float *sScore = reinterpret_cast<float *>(smem);
+  uint16_t *sList = reinterpret_cast<uint16_t *>(sScore + Cp);
+  uint8_t *sK = reinterpret_cast<uint8_t *>(sList + Cp);
+  uint8_t *sState = sK + Cp;
+  int *sRow = reinterpret_cast<int *>(sState + Cp);  // [hc+1] counts, then [hc+1] bases
+  int *sRowBase = sRow + (hc + 16);
+  int *sCnt = sRowBase + (hc + 16);  // [0] undecided flag, [1] survivors, [2] candidates, [3] K
+
+  const float *gscore = f.cell_score + (size_t)b * C;
+  const uint8_t *gk = f.cell_k + (size_t)b * C;
+  uint8_t *rec = f.records + (size_t)b * rl.bytes;
+  int *hdr = reinterpret_cast<int *>(rec + rl.off_hdr);
+  float *kp_xy = reinterpret_cast<float *>(rec + rl.off_xy);
+  int16_t *occ = reinterpret_cast<int16_t *>(rec + rl.off_occ);
+  int *kp_cell = f.kp_cell + (size_t)b * rl.kmax;
+
+  if (tid < 8) sCnt[tid] = 0;
+  for (int i = tid; i < hc + 1; i += 1024) sRow[i] = 0;
+  __syncthreads();
+  int ncand = 0;
+  for (int c = tid; c < C; c += 1024) {
+    const float s = gscore[c];
+    sScore[c] = s;
+    sK[c] = gk[c];
+    sState[c] = s > 0.0f ? ST_UNDEC : ST_NONE;
+    ncand += s > 0.0f;
+  }
+  if (ncand) atomicAdd(&sCnt[2], ncand);
+  __syncthreads();
+
+  // ---- NMS fixed point ----
+  for (int round = 0; round < 4096; ++round) {
+    if (tid == 0) sCnt[0] = 0;
+    __syncthreads();
+    int pending = 0;
+    for (int c = tid; c < C; c += 1024) {
+      if (sState[c] != ST_UNDEC) continue;
+      const int cy = c / wc, cx = c - cy * wc;
+      const int k = sK[c];
+      const int x = cx * 8 + (k & 7), y = cy * 8 + (k >> 3);
+      const float sc = sScore[c];
+      bool dead = false, blocked = false;
+      for (int ny = cy - 1; ny <= cy + 1; ++ny) {
+        if (ny < 0 || ny >= hc) continue;
+        for (int nx = cx - 1; nx <= cx + 1; ++nx) {
+          if (nx < 0 || nx >= wc) continue;
+          const int n = ny * wc + nx;
+          if (n == c) continue;
+          const uint8_t st = sState[n];
+          if (st == ST_NONE || st == ST_DEAD) continue;
+          const int kn = sK[n];
+          const int ddx = nx * 8 + (kn & 7) - x, ddy = ny * 8 + (kn >> 3) - y;
+          if (ddx > SPFE_NMS_DIST || ddx < -SPFE_NMS_DIST || ddy > SPFE_NMS_DIST || ddy < -SPFE_NMS_DIST)
+            continue;
+          if (!spfe_ranks_before(sScore[n], n, sc, c)) continue;
+          if (st == ST_ALIVE) dead = true; else blocked = true;
+        }
+      }
+      if (dead) sState[c] = ST_DEAD;
+      else if (!blocked) sState[c] = ST_ALIVE;
+      else pending = 1;
+    }
+    if (pending) sCnt[0] = 1;
+    __syncthreads();
+    if (sCnt[0] == 0) break;
+    __syncthreads();
+  }
+
+  // ---- compact survivors, rank them, keep the num_features+1 best (:211-213) ----
+  for (int c = tid; c < C; c += 1024)
+    if (sState[c] == ST_ALIVE) sList[atomicAdd(&sCnt[1], 1)] = (uint16_t)c;
+  __syncthreads();
+  const int S = sCnt[1];
+  for (int i = tid; i < S; i += 1024) {
+    const int c = sList[i];
+    const float sc = sScore[c];
+    int rank = 0;
+    for (int j = 0; j < S; ++j) {
+      const int cj = sList[j];
+      rank += spfe_ranks_before(sScore[cj], cj, sc, c);
+    }
+    if (rank <= num_features) {
+      const int cy = c / wc, cx = c - cy * wc;
+      const int k = sK[c];
+      const int x = cx * 8 + (k & 7), y = cy * 8 + (k >> 3);
+      // border reject (:222-224)
+      if (!(x < SPFE_NMS_BORDER || x >= W - SPFE_NMS_BORDER || y < SPFE_NMS_BORDER ||
+            y >= H - SPFE_NMS_BORDER)) {
+        sState[c] = ST_KEPT;
+        atomicAdd(&sRow[cy], 1);
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int r = 0; r < hc; ++r) { sRowBase[r] = acc; acc += sRow[r]; }
+    sCnt[3] = acc;
+    hdr[0] = acc;       // K
+    hdr[1] = sCnt[2];   // n_candidates
+    hdr[2] = 0;         // status
+    hdr[3] = S;         // NMS survivors before the cut (diagnostic)
+  }
+  __syncthreads();
+  // ---- raster order (y outer, x inner) (:220-238) and occ_grid (:227-228) ----
+  for (int c = tid; c < C; c += 1024) {
+    int16_t o = -1;
+    if (sState[c] == ST_KEPT) {
+      const int cy = c / wc, cx = c - cy * wc;
+      const int k = sK[c];
+      const int dyc = k >> 3;
+      int idx = sRowBase[cy];
+      for (int nx = 0; nx < wc; ++nx) {
+        const int n = cy * wc + nx;
+        if (sState[n] != ST_KEPT) continue;
+        const int dyn = sK[n] >> 3;
+        idx += (dyn < dyc) || (dyn == dyc && nx < cx);
+      }
+      o = (int16_t)idx;
+      kp_xy[2 * idx] = (float)(cx * 8 + (k & 7));
+      kp_xy[2 * idx + 1] = (float)(cy * 8 + dyc);
+      kp_cell[idx] = c;
+    }
+    occ[c] = o;
+  }
+}
+
+hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H, int W,
+                         int num_features, hipStream_t s) {
+  const size_t lds = select_lds_bytes(H, W);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(select_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(select_kernel, dim3(B), dim3(1024), lds, s, f, r, H, W, num_features);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Descriptors for the emitted keypoints: one wavefront per keypoint, lane l owns
+// channels 4l..4l+3 (one float4 of the NHWC coarse map per tap: 1 KiB coalesced).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float sum256_wave(float4 sq) {
+  float s = sq.x;
+  s = s + sq.y;
+  s = s + sq.z;
+  s = s + sq.w;
+  return wave_sum64(s);
+}
+
+__global__ __launch_bounds__(256) void desc_kernel(FrameBufs f, RecordLayout rl, int H, int W) {
+  const int wc = W >> 3, hc = H >> 3, C = hc * wc;
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  uint8_t *rec = f.records + (size_t)b * rl.bytes;
+  const int K = reinterpret_cast<const int *>(rec + rl.off_hdr)[0];
+  if (i >= K) return;
+  const float *kp_xy = reinterpret_cast<const float *>(rec + rl.off_xy);
+  const float x = kp_xy[2 * i], y = kp_xy[2 * i + 1];
+  // :137-138 with ATen-CUDA scalar division (x * float(1/(w/2))), then the
+  // align_corners un-normalisation of grid_sampler
+  const float inv_hw = (float)(1.0 / (double)(float)(W / 2.0));
+  const float inv_hh = (float)(1.0 / (double)(float)(H / 2.0));
+  const float gx = x * inv_hw - 1.0f;
+  const float gy = y * inv_hh - 1.0f;
+  const float ix = ((gx + 1.0f) / 2.0f) * (float)(wc - 1);
+  const float iy = ((gy + 1.0f) / 2.0f) * (float)(hc - 1);
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  const float wx1 = ix - fx0, wy1 = iy - fy0;
+  const float wx0 = (fx0 + 1.0f) - ix, wy0 = (fy0 + 1.0f) - iy;
+  const float tw[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+  const float *coarse = f.coarse + (size_t)b * C * SPFE_DESC_DIM;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int txx = x0 + (t & 1), tyy = y0 + (t >> 1);
+    if (txx < 0 || txx >= wc || tyy < 0 || tyy >= hc) continue;  // zeros padding
+    const float4 v = *reinterpret_cast<const float4 *>(coarse + ((size_t)tyy * wc + txx) * SPFE_DESC_DIM + lane * 4);
+    float4 sq;
+    sq.x = v.x * v.x; sq.y = v.y * v.y; sq.z = v.z * v.z; sq.w = v.w * v.w;
+    const float nrm = sqrtf(sum256_wave(sq));
+    acc.x = acc.x + (v.x / nrm) * tw[t];
+    acc.y = acc.y + (v.y / nrm) * tw[t];
+    acc.z = acc.z + (v.z / nrm) * tw[t];
+    acc.w = acc.w + (v.w / nrm) * tw[t];
+  }
+  float4 sq;
+  sq.x = acc.x * acc.x; sq.y = acc.y * acc.y; sq.z = acc.z * acc.z; sq.w = acc.w * acc.w;
+  const float nrm = sqrtf(sum256_wave(sq));
+  float4 o;
+  o.x = acc.x / nrm; o.y = acc.y / nrm; o.z = acc.z / nrm; o.w = acc.w / nrm;
+  float *desc = reinterpret_cast<float *>(rec + rl.off_desc);
+  *reinterpret_cast<float4 *>(desc + (size_t)i * SPFE_DESC_DIM + lane * 4) = o;
+  if (lane == 0) {
+    float *resp = reinterpret_cast<float *>(rec + rl.off_resp);
+    resp[i] = f.heat_inv[(size_t)b * H * W + (size_t)(int)y * W + (int)x];  // :271
+  }
+}
+
+hipError_t launch_desc(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s) {
+  hipLaunchKernelGGL(desc_kernel, dim3((r.kmax + 3) / 4, B), dim3(256), 0, s, f, r, H, W);
+  return hipGetLastError();
+}
+
+// exact-math probe: device spfe_expf / spfe_logf on arbitrary inputs
+__global__ void math_probe_kernel(const float *in, float *oe, float *ol, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    oe[i] = spfe_expf(in[i]);
+    ol[i] = spfe_logf(in[i] < 0.0f ? -in[i] : in[i]);
+  }
+}
+hipError_t launch_math_probe(const float *in, float *out_exp, float *out_log, int n, hipStream_t s) {
+  hipLaunchKernelGGL(math_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out_exp, out_log, n);
+  return hipGetLastError();
+}
+
+}  // namespace spfe

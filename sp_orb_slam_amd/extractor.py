@@ -1,0 +1,334 @@
+"""Host-side mirror of the reference extractor interface over the C ABI.
+
+`SPExtractor` keeps the call shape of the reference class
+(/root/reference/orb_slam2/include/orb_slam/cv/sp_extractor.h:49-88):
+construct once with the number of features, call it with a CV_8UC1 image and an
+(ignored) mask, get keypoints + a K x 256 float32 descriptor matrix, then read
+the side outputs the tracker copies right after the call
+(/root/reference/orb_slam2/src/type/frame.cpp:296-314): getCov2Inv(),
+dense_dust_, heat_, occ_grid_.  Everything is computed by libspfe.so
+(hand-written HIP for gfx950); there is NO CPU path: importing works anywhere,
+constructing an extractor without the library or without a GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libspfe.so")
+
+SPFE_FLAG_HEAT = 1
+SPFE_PRECISION_F32 = 0
+NUM_PARAMS = 1300865
+_ERRORS = {-1: "SPFE_EINVAL", -2: "SPFE_EEMPTY", -3: "SPFE_EHIP", -4: "SPFE_EWEIGHTS"}
+
+# every symbol include/spfe.h declares (tests check that the library exports all)
+ABI_SYMBOLS = [
+    "spfe_create", "spfe_destroy", "spfe_extract", "spfe_extract_batch",
+    "spfe_get_record_layout", "spfe_record_bytes", "spfe_extract_batch_device",
+    "spfe_view_record", "spfe_debug_read", "spfe_stage_times", "spfe_stage_reset",
+    "spfe_stage_name",
+    "spfe_math_probe", "spfe_last_error", "spfe_version",
+]
+
+
+class SpfeError(RuntimeError):
+    pass
+
+
+class _Config(C.Structure):
+    _fields_ = [("height", C.c_int), ("width", C.c_int), ("num_features", C.c_int),
+                ("max_batch", C.c_int), ("device", C.c_int), ("precision", C.c_int),
+                ("flags", C.c_uint), ("weights", C.c_void_p), ("weights_path", C.c_char_p)]
+
+
+class _Result(C.Structure):
+    _fields_ = [("K", C.c_int), ("n_candidates", C.c_int), ("kp_xy", C.c_void_p),
+                ("kp_response", C.c_void_p), ("desc", C.c_void_p), ("cov2", C.c_void_p),
+                ("cov2_inv", C.c_void_p), ("occ_grid", C.c_void_p), ("dense_dust", C.c_void_p),
+                ("semi_dust", C.c_void_p), ("heat", C.c_void_p), ("heat_inv", C.c_void_p)]
+
+
+class RecordLayout(C.Structure):
+    _fields_ = [("bytes", C.c_size_t), ("kmax", C.c_int), ("off_hdr", C.c_size_t),
+                ("off_xy", C.c_size_t), ("off_resp", C.c_size_t), ("off_cov", C.c_size_t),
+                ("off_cinv", C.c_size_t), ("off_desc", C.c_size_t), ("off_occ", C.c_size_t),
+                ("off_dd", C.c_size_t), ("off_sd", C.c_size_t)]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libspfe.so (built by __graft_entry__.build()).  Raises if missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SpfeError("libspfe.so not built at %s — run `python -c 'import __graft_entry__ as g; "
+                        "g.build()'` (there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.spfe_create.restype = C.c_int
+    L.spfe_create.argtypes = [C.POINTER(_Config), C.POINTER(C.c_void_p)]
+    L.spfe_destroy.restype = None
+    L.spfe_destroy.argtypes = [C.c_void_p]
+    L.spfe_extract.restype = C.c_int
+    L.spfe_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(_Result)]
+    L.spfe_extract_batch.restype = C.c_int
+    L.spfe_extract_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int,
+                                     C.POINTER(_Result)]
+    L.spfe_get_record_layout.restype = C.c_int
+    L.spfe_get_record_layout.argtypes = [C.c_void_p, C.POINTER(RecordLayout)]
+    L.spfe_record_bytes.restype = C.c_size_t
+    L.spfe_record_bytes.argtypes = [C.c_void_p]
+    L.spfe_extract_batch_device.restype = C.c_int
+    L.spfe_extract_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.spfe_view_record.restype = C.c_int
+    L.spfe_view_record.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Result)]
+    L.spfe_debug_read.restype = C.c_long
+    L.spfe_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.spfe_stage_times.restype = C.c_int
+    L.spfe_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
+    L.spfe_stage_reset.restype = C.c_int
+    L.spfe_stage_reset.argtypes = [C.c_void_p]
+    L.spfe_stage_name.restype = C.c_char_p
+    L.spfe_stage_name.argtypes = [C.c_int]
+    L.spfe_math_probe.restype = C.c_int
+    L.spfe_math_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.spfe_last_error.restype = C.c_char_p
+    L.spfe_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        msg = load_library().spfe_last_error().decode()
+        if rc == -2:
+            # the reference throws std::runtime_error("input image is empty")
+            # (sp_extractor.cpp:364-365)
+            raise RuntimeError("input image is empty")
+        raise SpfeError("%s: %s" % (_ERRORS.get(rc, rc), msg))
+
+
+KEYPOINT_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("size", np.float32),
+                           ("angle", np.float32), ("response", np.float32),
+                           ("octave", np.int32), ("class_id", np.int32)])
+
+
+def _as_np(ptr, shape, dtype):
+    n = int(np.prod(shape))
+    if n == 0 or not ptr:
+        return np.zeros(shape, dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape).copy()
+
+
+class FrameResult:
+    """Deep copies of everything one extractor call produced for one frame."""
+
+    def __init__(self, r, H, W, with_heat):
+        hc, wc = H // 8, W // 8
+        K = r.K
+        self.K = K
+        self.n_candidates = r.n_candidates
+        xy = _as_np(r.kp_xy, (K, 2), np.float32)
+        resp = _as_np(r.kp_response, (K,), np.float32)
+        kps = np.zeros(K, KEYPOINT_DTYPE)
+        # cv::KeyPoint(x, y, 1.0f): angle -1, octave 0, class_id -1 (sp_extractor.cpp:231-232)
+        kps["x"], kps["y"] = xy[:, 0], xy[:, 1]
+        kps["size"], kps["angle"], kps["octave"], kps["class_id"] = 1.0, -1.0, 0, -1
+        kps["response"] = resp  # :271
+        self.keypoints = kps
+        self.kp_xy = xy
+        self.response = resp
+        self.descriptors = _as_np(r.desc, (K, 256), np.float32)
+        self.cov2 = _as_np(r.cov2, (K, 2), np.float32)
+        self.cov2_inv = _as_np(r.cov2_inv, (K, 2), np.float32)
+        self.occ_grid = _as_np(r.occ_grid, (hc, wc), np.int16)
+        self.dense_dust = _as_np(r.dense_dust, (hc, wc), np.float32)
+        self.semi_dust = _as_np(r.semi_dust, (hc, wc), np.float32)
+        self.heat = _as_np(r.heat, (H, W), np.float32) if with_heat and r.heat else None
+        self.heat_inv = _as_np(r.heat_inv, (H, W), np.float32) if with_heat and r.heat_inv else None
+
+
+class SPExtractor:
+    """MI355X SuperPoint extractor with the reference's call signature.
+
+    Reference constructor: SPExtractor(int nfeatures) reading camera::height,
+    camera::width and common::model_path from globals (sp_extractor.cpp:342-359);
+    here they are explicit arguments.
+    """
+
+    def __init__(self, nfeatures, height, width, weights, max_batch=1, device=0, with_heat=True):
+        self._h = C.c_void_p()
+        self._lib = load_library()
+        self.nfeatures, self.height, self.width = int(nfeatures), int(height), int(width)
+        self.max_batch, self.with_heat = int(max_batch), bool(with_heat)
+        cfg = _Config()
+        cfg.height, cfg.width, cfg.num_features = self.height, self.width, self.nfeatures
+        cfg.max_batch, cfg.device, cfg.precision = self.max_batch, int(device), SPFE_PRECISION_F32
+        cfg.flags = SPFE_FLAG_HEAT if with_heat else 0
+        keep = None
+        if isinstance(weights, (str, bytes, os.PathLike)):
+            cfg.weights, cfg.weights_path = None, os.fsencode(weights)
+        else:
+            keep = np.ascontiguousarray(weights, np.float32)
+            if keep.size != NUM_PARAMS:
+                raise SpfeError("weight blob has %d params, expected %d" % (keep.size, NUM_PARAMS))
+            cfg.weights, cfg.weights_path = keep.ctypes.data, None
+        _check(self._lib.spfe_create(C.byref(cfg), C.byref(self._h)))
+        del keep
+        self.layout = RecordLayout()
+        _check(self._lib.spfe_get_record_layout(self._h, C.byref(self.layout)))
+        # BaseExtractor(n, 1.0, 1, 1, 1): one pyramid level (base_extractor.h:12-47)
+        self.nlevels, self.scaleFactor = 1, 1.0
+        self.semi_dust_ = self.dense_dust_ = self.heat_ = self.heat_inv_ = self.occ_grid_ = None
+        self.mask_ = None  # never written by the reference either
+        self._cov2 = self._cov2_inv = None
+        self.last = None
+
+    # -- BaseExtractor getters (base_extractor.h:58-72) --
+    def GetLevels(self):
+        return 1
+
+    def GetScaleFactor(self):
+        return 1.0
+
+    def GetScaleFactors(self):
+        return [1.0]
+
+    def GetInverseScaleFactors(self):
+        return [1.0]
+
+    def GetScaleSigmaSquares(self):
+        return [1.0]
+
+    def GetInverseScaleSigmaSquares(self):
+        return [1.0]
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.spfe_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check_image(self, image):
+        if image is None or getattr(image, "size", 0) == 0:
+            raise RuntimeError("input image is empty")  # sp_extractor.cpp:364-365
+        img = np.asarray(image)
+        if img.dtype != np.uint8 or img.ndim != 2:
+            raise SpfeError("image must be CV_8UC1 (2-D uint8)")  # assert at :368
+        if img.shape != (self.height, self.width):
+            raise SpfeError("image is %s, extractor was built for %s" %
+                            (img.shape, (self.height, self.width)))
+        if img.strides[1] != 1:
+            img = np.ascontiguousarray(img)
+        return img
+
+    def _publish(self, fr):
+        self.last = fr
+        self.semi_dust_, self.dense_dust_ = fr.semi_dust, fr.dense_dust
+        self.heat_, self.heat_inv_, self.occ_grid_ = fr.heat, fr.heat_inv, fr.occ_grid
+        self._cov2, self._cov2_inv = fr.cov2, fr.cov2_inv
+
+    def __call__(self, image, mask=None):
+        """operator()(image, mask, keypoints, descriptors) — mask is ignored (:361-363)."""
+        img = self._check_image(image)
+        r = _Result()
+        _check(self._lib.spfe_extract(self._h, img.ctypes.data, img.strides[0], C.byref(r)))
+        fr = FrameResult(r, self.height, self.width, self.with_heat)
+        self._publish(fr)
+        return fr.keypoints, fr.descriptors
+
+    def extract_batch(self, images):
+        """n independent frames in one call; returns a list of FrameResult."""
+        imgs = [self._check_image(im) for im in images]
+        n = len(imgs)
+        if n == 0:
+            raise RuntimeError("input image is empty")
+        strides = {im.strides[0] for im in imgs}
+        if len(strides) != 1:
+            imgs = [np.ascontiguousarray(im) for im in imgs]
+        ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+        res = (_Result * n)()
+        _check(self._lib.spfe_extract_batch(self._h, ptrs, imgs[0].strides[0], n, res))
+        out = [FrameResult(res[i], self.height, self.width, self.with_heat) for i in range(n)]
+        self._publish(out[-1])
+        return out
+
+    # -- side outputs (sp_extractor.h:61-73) --
+    def getCov(self):
+        return self._cov2
+
+    def getCov2Inv(self):
+        return self._cov2_inv
+
+    def getHeatMap(self):
+        return self.heat_
+
+    def getMask(self):
+        return self.mask_
+
+    # -- device-resident path --
+    def record_bytes(self):
+        return int(self._lib.spfe_record_bytes(self._h))
+
+    def extract_batch_device(self, d_images, n, d_records=None, stream=None):
+        """Enqueue n frames already in device memory (raw device pointers as ints)."""
+        if not d_images:
+            raise RuntimeError("input image is empty")
+        _check(self._lib.spfe_extract_batch_device(self._h, C.c_void_p(d_images), int(n),
+                                                   C.c_void_p(d_records or 0),
+                                                   C.c_void_p(stream or 0)))
+
+    def view_record(self, host_record):
+        """Decode ONE record (bytes-like / uint8 array copied from the device)."""
+        rec = np.ascontiguousarray(np.frombuffer(host_record, np.uint8)
+                                   if not isinstance(host_record, np.ndarray) else host_record)
+        r = _Result()
+        _check(self._lib.spfe_view_record(self._h, rec.ctypes.data, C.byref(r)))
+        return FrameResult(r, self.height, self.width, False)
+
+    def debug_read(self, name, frame=0):
+        shapes = {"semi": (self.height // 8, self.width // 8, 65),
+                  "coarse": (self.height // 8, self.width // 8, 256),
+                  "head": (self.height // 8, self.width // 8, 512),
+                  "feat": (self.height // 8, self.width // 8, 128),
+                  "heat_log": (self.height, self.width), "heat_inv": (self.height, self.width),
+                  "heat": (self.height, self.width),
+                  "cell_score": (self.height // 8, self.width // 8)}
+        div = [1, 2, 2, 4, 4, 8, 8, 8]
+        ch = [64, 64, 64, 64, 128, 128, 128, 128]
+        for i in range(8):
+            shapes["act%d" % i] = (self.height // div[i], self.width // div[i], ch[i])
+        out = np.empty(shapes[name], np.float32)
+        n = self._lib.spfe_debug_read(self._h, name.encode(), frame, out.ctypes.data, out.nbytes)
+        if n < 0:
+            _check(int(n))
+        return out
+
+    def stage_reset(self):
+        _check(self._lib.spfe_stage_reset(self._h))
+
+    def stage_times(self):
+        buf = (C.c_float * 32)()
+        n = self._lib.spfe_stage_times(self._h, buf, 32)
+        if n < 0:
+            _check(n)
+        return {self._lib.spfe_stage_name(i).decode(): buf[i] for i in range(n)}
+
+
+def math_probe(x):
+    """Device spfe_expf(x), spfe_logf(|x|) for a float32 array (test hook)."""
+    x = np.ascontiguousarray(x, np.float32)
+    e = np.empty_like(x)
+    l = np.empty_like(x)
+    _check(load_library().spfe_math_probe(x.ctypes.data, e.ctypes.data, l.ctypes.data, x.size))
+    return e, l

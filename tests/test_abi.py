@@ -1,0 +1,80 @@
+"""CPU: the C-ABI library loads and exports every symbol include/spfe.h declares;
+host-side argument checking; weight-file round trip.  No compute calls."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from sp_orb_slam_amd import extractor, weights
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported():
+    hdr = open(os.path.join(ROOT, "include", "spfe.h")).read()
+    declared = set(re.findall(r"SPFE_API[^;(]*?\b(spfe_\w+)\s*\(", hdr))
+    assert declared == set(extractor.ABI_SYMBOLS)
+    lib = ctypes.CDLL(extractor.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_library_reports_version_and_stage_names():
+    L = extractor.load_library()
+    assert b"gfx950" in L.spfe_version()
+    names = [L.spfe_stage_name(i).decode() for i in range(16)]
+    assert names[0] == "conv1a" and names[-1] == "total" and "select" in names
+
+
+def test_create_rejects_bad_config_without_gpu():
+    blob = np.zeros(weights.NUM_PARAMS, np.float32)
+    # size not a multiple of 8 is rejected before any HIP call (sp_extractor.cpp:70)
+    with pytest.raises(extractor.SpfeError, match="multiples of 8"):
+        extractor.SPExtractor(100, 100, 96, blob)
+    with pytest.raises(extractor.SpfeError, match="num_features"):
+        extractor.SPExtractor(0, 64, 96, blob)
+    with pytest.raises(extractor.SpfeError, match="params"):
+        extractor.SPExtractor(100, 64, 96, blob[:10])
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product must fail loudly, not compute on the host."""
+    import subprocess
+    import sys
+    code = ("import numpy as np, sys; sys.path.insert(0, %r);"
+            "from sp_orb_slam_amd import extractor, weights;"
+            "from sp_orb_slam_amd.extractor import SPExtractor\n"
+            "try:\n"
+            "    SPExtractor(10, 64, 96, np.zeros(weights.NUM_PARAMS, np.float32)); print('CREATED')\n"
+            "except extractor.SpfeError as e:\n"
+            "    print('ERR', e)\n" % ROOT)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env).stdout
+    assert "CREATED" not in out and "SPFE_EHIP" in out
+
+
+def test_weight_file_roundtrip(tmp_path):
+    blob = weights.synthetic(3, "sparse")
+    p = tmp_path / "w.spfw"
+    weights.save(p, blob)
+    assert np.array_equal(weights.load(p), blob)
+    named = weights.to_named_tensors(blob)
+    assert named["convPb.weight"].shape == (65, 256, 1, 1)
+    assert np.array_equal(weights.from_named_tensors(named), blob)
+    with open(p, "r+b") as f:
+        f.write(b"XXXX")
+    with pytest.raises(ValueError):
+        weights.load(p)
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under sp_orb_slam_amd/ or include/ may use it."""
+    for base in ("sp_orb_slam_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for fn in files:
+                if fn.endswith((".py", ".hip", ".cpp", ".h", ".hpp")):
+                    txt = open(os.path.join(dirpath, fn), errors="ignore").read()
+                    assert "oracle/" not in txt.replace("oracle/spfe_oracle.c);", "") or fn == "spfe_exact_math.h", fn
+                    assert "import oracle" not in txt and "from oracle" not in txt, fn

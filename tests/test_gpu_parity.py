@@ -1,0 +1,242 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through
+the C ABI (sp_orb_slam_amd.extractor -> libspfe.so), against the CPU oracle on
+the same seeded inputs, and against the committed ATen-CPU golden fixtures.
+
+Bars:
+  * keypoint positions / order, occ_grid, candidate count: bit-exact;
+  * descriptors: max-abs <= 2e-5 on unit vectors (f32);   DESC_TOL
+  * heat / heat_inv / response: abs <= 1e-5;               HEAT_TOL
+  * cov2 / cov2_inv: rel <= 1e-5.                          COV_RTOL
+The f32 MFMA path follows the same operation order as the oracle
+(include/spfe_exact_math.h), so the tests additionally report (and for the
+network outputs require) BITWISE equality.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from sp_orb_slam_amd import synth, weights
+from sp_orb_slam_amd.extractor import SPExtractor, SpfeError, math_probe
+
+pytestmark = pytest.mark.gpu
+
+DESC_TOL = 2e-5
+HEAT_TOL = 1e-5
+COV_RTOL = 1e-5
+
+
+def _compare(fr, ref, with_heat=True):
+    assert fr.n_candidates == ref["n_candidates"]
+    assert fr.K == ref["K"]
+    assert np.array_equal(fr.kp_xy, ref["kp_xy"])
+    assert np.array_equal(fr.occ_grid, ref["occ_grid"])
+    assert np.abs(fr.descriptors - ref["desc"]).max(initial=0) <= DESC_TOL
+    assert np.abs(fr.response - ref["response"]).max(initial=0) <= HEAT_TOL
+    assert np.allclose(fr.cov2, ref["cov2"], rtol=COV_RTOL, atol=0)
+    assert np.allclose(fr.cov2_inv, ref["cov2_inv"], rtol=COV_RTOL, atol=0)
+    assert np.abs(fr.dense_dust - ref["dense_dust"]).max() <= 1e-6
+    assert np.allclose(fr.semi_dust, ref["semi_dust"], rtol=1e-6, atol=1e-6)
+    if with_heat:
+        assert np.abs(fr.heat - ref["heat"]).max() <= HEAT_TOL
+        assert np.abs(fr.heat_inv - ref["heat_inv"]).max() <= HEAT_TOL
+
+
+def test_exact_math_device_bits_equal_host_bits():
+    rng = np.random.default_rng(0)
+    x = np.concatenate([-rng.random(4096).astype(np.float32) * 90.0,
+                        -np.float32(10.0) ** rng.uniform(-6, 1.9, 4096).astype(np.float32),
+                        np.array([0.0, -0.0, -86.0, -86.5, -1e-30], np.float32)])
+    e, _ = math_probe(x)
+    ref_e = np.array([oracle.lib().oracle_expf(float(v)) for v in x], np.float32)
+    assert np.array_equal(e.view(np.uint32), ref_e.view(np.uint32))
+    y = np.concatenate([rng.uniform(0.001, 1.0, 8192).astype(np.float32),
+                        np.array([0.001, 1.0, 0.5, 0.70710677, 0.0153846], np.float32)])
+    _, l = math_probe(y)
+    ref_l = np.array([oracle.lib().oracle_logf(float(v)) for v in y], np.float32)
+    assert np.array_equal(l.view(np.uint32), ref_l.view(np.uint32))
+    # and both are accurate
+    assert np.abs(ref_l - np.log(y.astype(np.float64))).max() < 3e-7
+    assert (np.abs(ref_e - np.exp(x.astype(np.float64))) / np.exp(x.astype(np.float64)))[x > -80].max() < 3e-7
+
+
+@pytest.mark.parametrize("H,W,iseed,wseed,det,nf", [
+    (64, 96, 1, 7, "dense", 20),
+    (64, 96, 2, 7, "sparse", 100),
+    (128, 160, 5, 11, "sparse", 200),
+    (72, 104, 9, 7, "dense", 1000),     # tiles partially outside the image at every level
+    (240, 320, 3, 7, "dense", 300),
+    (480, 640, 1, 7, "sparse", 1000),   # BASELINE configs[0] shape
+])
+def test_full_path_matches_oracle(H, W, iseed, wseed, det, nf):
+    img = synth.make_image(iseed, H, W)
+    blob = weights.synthetic(wseed, det)
+    ext = SPExtractor(nf, H, W, blob)
+    kps, desc = ext(img, None)
+    ref = oracle.extract(blob, img, nf)
+    semi = ext.debug_read("semi")
+    coarse = ext.debug_read("coarse")
+    # network: bitwise (same fma order as the oracle)
+    assert np.array_equal(semi.view(np.uint32), ref["semi"].view(np.uint32))
+    assert np.array_equal(coarse.view(np.uint32), ref["coarse"].view(np.uint32))
+    _compare(ext.last, ref)
+    assert np.array_equal(np.stack([kps["x"], kps["y"]], 1), ref["kp_xy"])
+    assert desc.shape == (ref["K"], 256) and desc.dtype == np.float32
+    assert np.all(kps["size"] == 1.0) and np.all(kps["angle"] == -1.0) and np.all(kps["octave"] == 0)
+    assert np.array_equal(kps["response"], ext.last.response)
+    ext.close()
+
+
+def test_layerwise_activations_bitwise():
+    """Every conv stage against the oracle's network on a size with ragged tiles."""
+    H, W = 88, 120
+    img = synth.make_image(4, H, W)
+    blob = weights.synthetic(7, "dense")
+    ext = SPExtractor(50, H, W, blob)
+    ext(img, None)
+    _, _, feat = oracle.network(blob, img)
+    got = ext.debug_read("feat")
+    assert np.array_equal(got.view(np.uint32), feat.view(np.uint32))
+    ext.close()
+
+
+def test_bench_config_752x480_1000_keypoints():
+    """BASELINE configs[1]: 752x480, 1000 keypoints, f32."""
+    H, W, nf = 480, 752, 1000
+    blob = weights.synthetic(7, "dense")
+    ext = SPExtractor(nf, H, W, blob)
+    for seed in (100, 101):
+        img = synth.make_image(seed, H, W)
+        ext(img, None)
+        ref = oracle.extract(blob, img, nf)
+        _compare(ext.last, ref)
+        assert ext.last.K <= nf + 1 and ext.last.K > 900
+    ext.close()
+
+
+@pytest.mark.parametrize("name", ["g64x96_dense", "g64x96_sparse", "g128x160_sparse",
+                                  "g480x752_dense", "g480x640_sparse"])
+def test_against_aten_golden(name, golden_dir):
+    """HIP path vs the fixtures generated by the ATen-CPU op sequence."""
+    g = np.load("%s/%s.npz" % (golden_dir, name))
+    H, W, nf = int(g["meta_H"]), int(g["meta_W"]), int(g["meta_num_features"])
+    img = g["image"] if "image" in g.files else synth.make_image(int(g["meta_image_seed"]), H, W)
+    blob = weights.synthetic(int(g["meta_weight_seed"]), str(g["meta_detector"]))
+    ext = SPExtractor(nf, H, W, blob)
+    ext(img, None)
+    fr = ext.last
+    assert fr.n_candidates == int(g["n_candidates"])
+    assert np.array_equal(fr.kp_xy.astype(np.int16), g["kp_xy"])
+    assert np.array_equal(fr.occ_grid, g["occ_grid"])
+    assert np.abs(fr.response - g["response"]).max() <= HEAT_TOL
+    assert np.allclose(fr.cov2_inv, g["cov2_inv"], rtol=COV_RTOL)
+    assert np.abs(fr.dense_dust - g["dense_dust"]).max() <= 1e-5
+    if "kp_desc" in g.files:
+        assert np.abs(fr.descriptors - g["kp_desc"]).max() <= DESC_TOL
+        assert np.abs(fr.heat - g["heat"]).max() <= HEAT_TOL
+    else:
+        assert np.abs(fr.descriptors[::16] - g["kp_desc_sub"]).max() <= DESC_TOL
+        assert np.abs(fr.heat[H // 2] - g["heat_row"]).max() <= HEAT_TOL
+    ext.close()
+
+
+def test_batch_equals_single_frames():
+    H, W, nf, n = 120, 160, 150, 5
+    blob = weights.synthetic(7, "dense")
+    imgs = [synth.make_image(30 + i, H, W) for i in range(n)]
+    ext1 = SPExtractor(nf, H, W, blob)
+    single = []
+    for im in imgs:
+        ext1(im, None)
+        single.append(ext1.last)
+    extb = SPExtractor(nf, H, W, blob, max_batch=8)
+    batch = extb.extract_batch(imgs)
+    for a, b in zip(single, batch):
+        assert a.K == b.K and np.array_equal(a.kp_xy, b.kp_xy)
+        assert np.array_equal(a.descriptors, b.descriptors)  # same kernels, same order: bitwise
+        assert np.array_equal(a.occ_grid, b.occ_grid)
+        assert np.array_equal(a.cov2_inv, b.cov2_inv)
+        assert np.array_equal(a.heat, b.heat)
+    ext1.close()
+    extb.close()
+
+
+def test_strided_input_and_repeat_calls():
+    H, W, nf = 64, 96, 50
+    blob = weights.synthetic(7, "dense")
+    big = np.zeros((H, W + 32), np.uint8)
+    img = synth.make_image(8, H, W)
+    big[:, :W] = img
+    ext = SPExtractor(nf, H, W, blob)
+    k1, d1 = ext(big[:, :W], None)   # row stride W+32 (cv::Mat::step)
+    k2, d2 = ext(img, None)
+    assert np.array_equal(k1, k2) and np.array_equal(d1, d2)
+    ext.close()
+
+
+def test_error_behaviour():
+    H, W = 64, 96
+    blob = weights.synthetic(7, "dense")
+    ext = SPExtractor(10, H, W, blob)
+    with pytest.raises(RuntimeError, match="input image is empty"):  # sp_extractor.cpp:364-365
+        ext(np.zeros((0, 0), np.uint8), None)
+    with pytest.raises(RuntimeError, match="input image is empty"):
+        ext(None, None)
+    with pytest.raises(SpfeError):
+        ext(np.zeros((H, W + 8), np.uint8), None)
+    with pytest.raises(SpfeError):
+        ext(np.zeros((H, W), np.float32), None)
+    with pytest.raises(SpfeError):
+        ext.extract_batch([np.zeros((H, W), np.uint8)] * 2)  # max_batch = 1
+    ext.close()
+
+
+def test_zero_and_one_candidate():
+    """N = 0 and N = 1 (the reference's squeeze() at :146 mis-shapes N = 1; here both are defined)."""
+    H, W = 64, 96
+    named = weights.to_named_tensors(weights.synthetic(7, "dense"))
+    named["convPb.weight"][:] = 0
+    named["convPb.bias"][:] = 0
+    named["convPb.bias"][64] = 30.0  # all mass on the dustbin: no cell reaches 0.007
+    blob0 = weights.from_named_tensors(named)
+    img = synth.make_image(1, H, W)
+    ext = SPExtractor(10, H, W, blob0)
+    kps, desc = ext(img, None)
+    ref = oracle.extract(blob0, img, 10)
+    assert ref["K"] == 0 and len(kps) == 0 and desc.shape == (0, 256)
+    assert np.all(ext.occ_grid_ == -1) and ext.last.n_candidates == 0
+    ext.close()
+    # one candidate: a single position logit at one cell pattern via a huge weight on one channel
+    named["convPb.bias"][64] = 3.0
+    named["convPb.bias"][27] = 0.0
+    blob1 = weights.from_named_tensors(named)
+    ref = oracle.extract(blob1, img, 10)
+    ext = SPExtractor(10, H, W, blob1)
+    ext(img, None)
+    _compare(ext.last, ref)
+    ext.close()
+
+
+def test_nms_cut_and_border_properties_720p():
+    """1280x720 (BASELINE configs[3] shape): size-independent properties of the selection."""
+    H, W, nf = 720, 1280, 1000
+    blob = weights.synthetic(7, "dense")
+    img = synth.make_image(300, H, W)
+    ext = SPExtractor(nf, H, W, blob, with_heat=False)
+    kps, desc = ext(img, None)
+    fr = ext.last
+    assert 0 < fr.K <= nf + 1
+    x, y = fr.kp_xy[:, 0].astype(int), fr.kp_xy[:, 1].astype(int)
+    assert np.all((x >= 8) & (x < W - 8) & (y >= 8) & (y < H - 8))          # border 8
+    key = y * W + x
+    assert np.all(np.diff(key) > 0)                                          # raster order
+    cells = (y // 8) * (W // 8) + x // 8
+    assert len(np.unique(cells)) == fr.K                                     # <= 1 kp per cell
+    occ = fr.occ_grid.reshape(-1)
+    assert np.array_equal(np.sort(occ[occ >= 0]), np.arange(fr.K))
+    assert np.array_equal(occ[cells], np.arange(fr.K))
+    dx = np.abs(x[:, None] - x[None, :]); dy = np.abs(y[:, None] - y[None, :])
+    close = (np.maximum(dx, dy) <= 4) & ~np.eye(fr.K, dtype=bool)
+    assert not close.any()                                                   # NMS radius 4
+    assert np.abs(np.linalg.norm(desc, axis=1) - 1).max() < 1e-6             # unit descriptors
+    assert np.all(fr.cov2 >= 1.0) and np.allclose(fr.cov2 * fr.cov2_inv, 1, rtol=1e-6)
+    ext.close()
