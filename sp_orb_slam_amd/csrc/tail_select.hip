@@ -170,7 +170,7 @@ enum : uint8_t { ST_NONE = 0, ST_UNDEC = 1, ST_ALIVE = 2, ST_DEAD = 3, ST_KEPT =
 size_t select_lds_bytes(int H, int W) {
   const size_t C = (size_t)(H / 8) * (W / 8);
   const size_t Cp = (C + 15) & ~(size_t)15;
-  return Cp * 4 + Cp * 2 + Cp + Cp + ((size_t)(H / 8) + 16) * 4 * 2 + 64;
+  return Cp * 4 + Cp * 2 + Cp + Cp + ((size_t)(H / 8) + 16) * 4 * 2 + 64 + 256 * 4;
 }
 
 __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout rl, int H, int W,
@@ -247,30 +247,88 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
     __syncthreads();
   }
 
-  // ---- compact survivors, rank them, keep the num_features+1 best (:211-213) ----
-  for (int c = tid; c < C; c += 1024)
-    if (sState[c] == ST_ALIVE) sList[atomicAdd(&sCnt[1], 1)] = (uint16_t)c;
+  // ---- keep the num_features+1 best-ranked survivors (:211-213) ----
+  // Radix select on the score bits (positive floats order like their bit
+  // patterns): 4 passes of 8 bits, 256-bin LDS histograms.  Afterwards `prefix`
+  // is the key of the (num_features+1)-th best survivor, everything above it is
+  // kept, and among equal keys the lowest cell indices win (tie rule).
+  int *sHist = sRowBase + (hc + 16) + 16;  // [256]
+  int ns = 0;
+  for (int c = tid; c < C; c += 1024) ns += sState[c] == ST_ALIVE;
+  if (ns) atomicAdd(&sCnt[1], ns);
   __syncthreads();
   const int S = sCnt[1];
-  for (int i = tid; i < S; i += 1024) {
-    const int c = sList[i];
-    const float sc = sScore[c];
-    int rank = 0;
-    for (int j = 0; j < S; ++j) {
-      const int cj = sList[j];
-      rank += spfe_ranks_before(sScore[cj], cj, sc, c);
+  uint32_t prefix = 0, pmask = 0;
+  int need = num_features + 1;
+  const bool cut = S > need;
+  if (cut) {
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      if (tid < 256) sHist[tid] = 0;
+      __syncthreads();
+      for (int c = tid; c < C; c += 1024) {
+        if (sState[c] != ST_ALIVE) continue;
+        const uint32_t key = __float_as_uint(sScore[c]);
+        if ((key & pmask) == prefix) atomicAdd(&sHist[(key >> shift) & 255], 1);
+      }
+      __syncthreads();
+      if (tid < 256) {
+        int above = 0;
+#pragma unroll 16
+        for (int bnum = 0; bnum < 256; ++bnum) above += bnum > tid ? sHist[bnum] : 0;
+        const int mine = sHist[tid];
+        if (above < need && above + mine >= need) { sCnt[4] = tid; sCnt[5] = need - above; }
+      }
+      __syncthreads();
+      prefix |= (uint32_t)sCnt[4] << shift;
+      pmask |= 255u << shift;
+      need = sCnt[5];
+      __syncthreads();
     }
-    if (rank <= num_features) {
-      const int cy = c / wc, cx = c - cy * wc;
-      const int k = sK[c];
-      const int x = cx * 8 + (k & 7), y = cy * 8 + (k >> 3);
-      // border reject (:222-224)
-      if (!(x < SPFE_NMS_BORDER || x >= W - SPFE_NMS_BORDER || y < SPFE_NMS_BORDER ||
-            y >= H - SPFE_NMS_BORDER)) {
-        sState[c] = ST_KEPT;
-        atomicAdd(&sRow[cy], 1);
+    // ties on the threshold key: count them; if more than `need`, rank by index
+    if (tid == 0) sCnt[6] = 0;
+    __syncthreads();
+    for (int c = tid; c < C; c += 1024)
+      if (sState[c] == ST_ALIVE && __float_as_uint(sScore[c]) == prefix)
+        sList[atomicAdd(&sCnt[6], 1)] = (uint16_t)c;
+    __syncthreads();
+  }
+  const int nties = cut ? sCnt[6] : 0;
+  for (int c = tid; c < C; c += 1024) {
+    if (sState[c] != ST_ALIVE) continue;
+    bool keep = true;
+    if (cut) {
+      const uint32_t key = __float_as_uint(sScore[c]);
+      if (key < prefix) keep = false;
+      else if (key == prefix && nties > need) {
+        int lower = 0;
+        for (int j = 0; j < nties; ++j) lower += sList[j] < c;
+        keep = lower < need;
       }
     }
+    if (!keep) continue;
+    const int cy = c / wc, cx = c - cy * wc;
+    const int k = sK[c];
+    const int x = cx * 8 + (k & 7), y = cy * 8 + (k >> 3);
+    // border reject (:222-224)
+    if (!(x < SPFE_NMS_BORDER || x >= W - SPFE_NMS_BORDER || y < SPFE_NMS_BORDER ||
+          y >= H - SPFE_NMS_BORDER))
+      sState[c] = ST_KEPT;
+  }
+  __syncthreads();
+
+  // ---- raster order (y outer, x inner) (:220-238) and occ_grid (:227-228) ----
+  // one wavefront per cell row: inside a row the order is (dy, cx), so the rank
+  // of a keypoint is popcounts of ballots over the row's KEPT flags per dy.
+  const int lane = tid & 63, wave = tid >> 6;
+  const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (int cy = wave; cy < hc; cy += 16) {
+    int cnt = 0;
+    for (int cx0 = 0; cx0 < wc; cx0 += 64) {
+      const int cx = cx0 + lane;
+      const bool kept = cx < wc && sState[cy * wc + cx] == ST_KEPT;
+      cnt += __popcll(__ballot(kept));
+    }
+    if (lane == 0) sRow[cy] = cnt;
   }
   __syncthreads();
   if (tid == 0) {
@@ -283,26 +341,49 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
     hdr[3] = S;         // NMS survivors before the cut (diagnostic)
   }
   __syncthreads();
-  // ---- raster order (y outer, x inner) (:220-238) and occ_grid (:227-228) ----
-  for (int c = tid; c < C; c += 1024) {
-    int16_t o = -1;
-    if (sState[c] == ST_KEPT) {
-      const int cy = c / wc, cx = c - cy * wc;
-      const int k = sK[c];
-      const int dyc = k >> 3;
-      int idx = sRowBase[cy];
-      for (int nx = 0; nx < wc; ++nx) {
-        const int n = cy * wc + nx;
-        if (sState[n] != ST_KEPT) continue;
-        const int dyn = sK[n] >> 3;
-        idx += (dyn < dyc) || (dyn == dyc && nx < cx);
-      }
-      o = (int16_t)idx;
-      kp_xy[2 * idx] = (float)(cx * 8 + (k & 7));
-      kp_xy[2 * idx + 1] = (float)(cy * 8 + dyc);
-      kp_cell[idx] = c;
+  for (int cy = wave; cy < hc; cy += 16) {
+    // per-dy totals over the whole row
+    int tot[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) tot[d] = 0;
+    for (int cx0 = 0; cx0 < wc; cx0 += 64) {
+      const int cx = cx0 + lane;
+      const bool kept = cx < wc && sState[cy * wc + cx] == ST_KEPT;
+      const int dyc = kept ? (sK[cy * wc + cx] >> 3) : -1;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) tot[d] += __popcll(__ballot(dyc == d));
     }
-    occ[c] = o;
+    int before[8];  // keypoints of this row in pixel rows above dy
+    int run = sRowBase[cy];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { before[d] = run; run += tot[d]; }
+    int seen[8];    // same dy, earlier 64-cell chunks
+#pragma unroll
+    for (int d = 0; d < 8; ++d) seen[d] = 0;
+    for (int cx0 = 0; cx0 < wc; cx0 += 64) {
+      const int cx = cx0 + lane;
+      const int c = cy * wc + cx;
+      const bool kept = cx < wc && sState[c] == ST_KEPT;
+      const int k = kept ? sK[c] : 0;
+      const int dyc = kept ? (k >> 3) : -1;
+      int idx = 0;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        const uint64_t m = __ballot(dyc == d);
+        if (dyc == d) idx = before[d] + seen[d] + __popcll(m & lt_mask);
+        seen[d] += __popcll(m);
+      }
+      if (cx < wc) {
+        int16_t o = -1;
+        if (kept) {
+          o = (int16_t)idx;
+          kp_xy[2 * idx] = (float)(cx * 8 + (k & 7));
+          kp_xy[2 * idx + 1] = (float)(cy * 8 + dyc);
+          kp_cell[idx] = c;
+        }
+        occ[c] = o;
+      }
+    }
   }
 }
 
