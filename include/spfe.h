@@ -42,6 +42,12 @@ extern "C" {
 /* spfe_config.flags */
 #define SPFE_FLAG_HEAT 1u /* also produce heat / heat_inv (H*W floats each), sp_extractor.cpp:461-474 */
 
+/* spfe_result.status / record header word 2 */
+#define SPFE_STATUS_COV_OVERFLOW 1 /* a covariance region outgrew the device FIFO (SPFE_COV_QCAP, default
+                                      4096 pixels per keypoint).  Device records: cov2/cov2_inv of that frame
+                                      are not valid.  Host calls: the frame's covariance was recomputed by
+                                      the host routine, values are valid. */
+
 #define SPFE_DESC_DIM 256
 #define SPFE_NUM_PARAMS 1300865 /* sp_extractor.cpp:16-43; order = register_module order :46-62 */
 
@@ -74,6 +80,8 @@ typedef struct {
 typedef struct {
   int K;                    /* keypoints emitted, raster order (:220-238) */
   int n_candidates;         /* cells with score >= 0.007 (:122) */
+  int status;               /* 0, or SPFE_STATUS_* bits */
+  int reserved;
   const float *kp_xy;       /* [K][2] pt.x, pt.y (integer valued); size=1, octave=0, angle=-1 (:231-232) */
   const float *kp_response; /* [K] heat_inv at the keypoint (:271) */
   const float *desc;        /* [K][256] unit-L2 rows, CV_32FC1 (:512-513) */
@@ -96,6 +104,15 @@ SPFE_API int spfe_extract(spfe_handle h, const uint8_t *image, int stride, spfe_
 /* n independent frames (n <= max_batch); outs[i] valid until the next call. */
 SPFE_API int spfe_extract_batch(spfe_handle h, const uint8_t *const *images, int stride, int n,
                        spfe_result *outs);
+
+/* Everything after the network (sp_extractor.cpp:105-148 detector tail and
+ * descriptor sampling, :461-514 host glue, nms, computeCovariance) for n frames
+ * whose raw head outputs the caller provides as HOST arrays: semi [n][H/8][W/8][65]
+ * (convPb logits, channels last) and coarse [n][H/8][W/8][256] (convDb output,
+ * not normalised).  Used by the tests to drive the selection kernels with
+ * hand-made logits; also the entry for a caller with its own network. */
+SPFE_API int spfe_postprocess(spfe_handle h, const float *semi, const float *coarse, int n,
+                              spfe_result *outs);
 
 /*
  * Device-resident batch path (multi-GPU pipeline): d_images is a DEVICE pointer

@@ -45,10 +45,10 @@ int fail(int code, const char *fmt, ...) {
                   __LINE__);                                                            \
   } while (0)
 
-constexpr int NSTAGE = 16;
+constexpr int NSTAGE = 17;
 const char *kStageNames[NSTAGE] = {"conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b",
                                    "conv4a", "conv4b", "convPaDa", "convPb", "convDb", "tail",
-                                   "heat_norm", "select", "desc", "total"};
+                                   "heat_norm", "select", "desc", "cov", "total"};
 
 struct ConvLayer {
   int cin, cout_real, nblk, ks;
@@ -78,6 +78,7 @@ struct spfe_handle_s {
   uint8_t *d_cell_k = nullptr;
   int *d_kp_cell = nullptr;
   uint8_t *d_records = nullptr;
+  spfe::CovScratch cov{};
   ConvLayer layers[10];
   spfe::RecordLayout rl{};
   // host side
@@ -252,6 +253,16 @@ int build(spfe_handle h, const spfe_config *cfg) {
   if ((rc = dev_alloc(h, &h->d_heat_consts, (size_t)B * 4))) return rc;
   if ((rc = dev_alloc(h, &h->d_cell_k, (size_t)B * C))) return rc;
   if ((rc = dev_alloc(h, &h->d_kp_cell, (size_t)B * h->kmax))) return rc;
+  {
+    const char *qenv = getenv("SPFE_COV_QCAP");
+    h->cov.qcap = qenv ? atoi(qenv) : 4096;
+    if (h->cov.qcap < 16) h->cov.qcap = 16;
+    if ((rc = dev_alloc(h, &h->cov.claim, (size_t)B * H * W))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.done, (size_t)B * H * W))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.queue, (size_t)B * h->kmax * h->cov.qcap))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.npop, (size_t)B * h->kmax))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.final_flag, (size_t)B * h->kmax))) return rc;
+  }
   make_layout(h->kmax, C, &h->rl);
   if ((rc = dev_alloc(h, &h->d_records, (size_t)B * h->rl.bytes))) return rc;
   HIP_TRY(hipMemset(h->d_records, 0, (size_t)B * h->rl.bytes));
@@ -310,6 +321,8 @@ int build(spfe_handle h, const spfe_config *cfg) {
 #define STAGE_MARK(i) \
   do { if (h->timing) HIP_TRY(hipEventRecord(h->ev[i], s)); } while (0)
 
+int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s);
+
 // Enqueue the whole path for n frames already in device memory.
 int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, hipStream_t s) {
   const int H = h->H, W = h->W;
@@ -330,12 +343,20 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     HIP_TRY(spfe::launch_conv_f32(p, L.cin, L.ks, L.pool, L.relu, L.small_tile, s));
     STAGE_MARK(2 + i);
   }
+  return enqueue_post(h, n, d_records, s);
+}
+
+// Detector tail, selection, descriptors, covariance for n frames whose semi /
+// coarse maps are in the handle's buffers.
+int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s) {
+  const int H = h->H, W = h->W;
   spfe::FrameBufs f{};
   f.semi = h->d_semi; f.coarse = h->d_coarse;
   f.heat_log = h->d_heat_log; f.heat = h->d_heat; f.heat_inv = h->d_heat_inv;
   f.minmax = reinterpret_cast<uint32_t *>(h->d_minmax);
   f.cell_score = h->d_cell_score; f.cell_k = h->d_cell_k; f.kp_cell = h->d_kp_cell;
   f.records = d_records; f.heat_consts = h->d_heat_consts;
+  if (h->timing && !h->ev) return fail(SPFE_EINVAL, "internal: no event set");
   HIP_TRY(spfe::launch_tail(f, h->rl, n, H, W, s));
   STAGE_MARK(12);
   HIP_TRY(spfe::launch_heat_norm(f, n, H, W, s));
@@ -344,6 +365,8 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   STAGE_MARK(14);
   HIP_TRY(spfe::launch_desc(f, h->rl, n, H, W, s));
   STAGE_MARK(15);
+  HIP_TRY(spfe::launch_cov(f, h->rl, h->cov, n, H, W, s));
+  STAGE_MARK(16);
   h->last_n = n;
   return SPFE_OK;
 }
@@ -354,6 +377,7 @@ void view_record(const spfe_handle h, const uint8_t *rec, const float *heat, con
   const int *hdr = reinterpret_cast<const int *>(rec + r.off_hdr);
   out->K = hdr[0];
   out->n_candidates = hdr[1];
+  out->status = hdr[2];
   out->kp_xy = reinterpret_cast<const float *>(rec + r.off_xy);
   out->kp_response = reinterpret_cast<const float *>(rec + r.off_resp);
   out->desc = reinterpret_cast<const float *>(rec + r.off_desc);
@@ -440,6 +464,23 @@ int spfe_extract_batch_device(spfe_handle h, const void *d_images, int n, void *
   return enqueue(h, reinterpret_cast<const uint8_t *>(d_images), n, rec, s);
 }
 
+int finish_host(spfe_handle h, int n, spfe_result *outs);
+
+int spfe_postprocess(spfe_handle h, const float *semi, const float *coarse, int n, spfe_result *outs) {
+  if (!h || !outs || !semi || !coarse) return fail(SPFE_EINVAL, "null argument");
+  if (n < 1 || n > h->B) return fail(SPFE_EINVAL, "batch %d not in [1, %d]", n, h->B);
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  hipStream_t s = h->stream;
+  HIP_TRY(hipMemcpyAsync(h->d_semi, semi, (size_t)n * h->C * SPFE_SEMI_CH * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->d_coarse, coarse, (size_t)n * h->C * SPFE_DESC_DIM * 4, hipMemcpyHostToDevice, s));
+  if (h->timing) h->ev = h->evpool.data() + (size_t)(h->calls % spfe_handle_s::EVSETS) * (NSTAGE + 1);
+  if (h->timing) for (int i = 0; i <= 12; ++i) HIP_TRY(hipEventRecord(h->ev[i], s));
+  h->calls++;
+  int rc = enqueue_post(h, n, h->d_records, s);
+  if (rc) return rc;
+  return finish_host(h, n, outs);
+}
+
 int spfe_extract_batch(spfe_handle h, const uint8_t *const *images, int stride, int n, spfe_result *outs) {
   if (!h || !outs) return fail(SPFE_EINVAL, "null argument");
   if (!images) return fail(SPFE_EEMPTY, "input image is empty");
@@ -456,20 +497,34 @@ int spfe_extract_batch(spfe_handle h, const uint8_t *const *images, int stride, 
   HIP_TRY(hipMemcpyAsync(h->d_img, h->h_img, (size_t)n * H * W, hipMemcpyHostToDevice, s));
   int rc = enqueue(h, h->d_img, n, h->d_records, s);
   if (rc) return rc;
+  return finish_host(h, n, outs);
+}
+
+// D2H of the records (+ maps), sync, host views.
+int finish_host(spfe_handle h, int n, spfe_result *outs) {
+  const int H = h->H, W = h->W;
+  hipStream_t s = h->stream;
+  const bool want = (h->cfg.flags & SPFE_FLAG_HEAT) != 0;
   HIP_TRY(hipMemcpyAsync(h->h_records, h->d_records, (size_t)n * h->rl.bytes, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(h->h_heat_inv, h->d_heat_inv, (size_t)n * H * W * 4, hipMemcpyDeviceToHost, s));
-  if (h->d_heat)
+  if (want) {
+    HIP_TRY(hipMemcpyAsync(h->h_heat_inv, h->d_heat_inv, (size_t)n * H * W * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(h->h_heat, h->d_heat, (size_t)n * H * W * 4, hipMemcpyDeviceToHost, s));
+  }
   HIP_TRY(hipStreamSynchronize(s));
   for (int i = 0; i < n; ++i) {
     uint8_t *rec = h->h_records + (size_t)i * h->rl.bytes;
-    const float *hinv = h->h_heat_inv + (size_t)i * H * W;
-    const int K = reinterpret_cast<const int *>(rec + h->rl.off_hdr)[0];
-    // computeCovariance (sp_extractor.cpp:252-340) — host stage, as in the reference
-    spfe::covariance_host(hinv, H, W, reinterpret_cast<const float *>(rec + h->rl.off_xy), K,
-                          reinterpret_cast<float *>(rec + h->rl.off_cov),
-                          reinterpret_cast<float *>(rec + h->rl.off_cinv));
-    const bool want = (h->cfg.flags & SPFE_FLAG_HEAT) != 0;
+    float *hinv = h->h_heat_inv + (size_t)i * H * W;
+    const int *hdr = reinterpret_cast<const int *>(rec + h->rl.off_hdr);
+    if (hdr[2] & 1) {
+      if (!want)
+        HIP_TRY(hipMemcpy(hinv, h->d_heat_inv + (size_t)i * H * W, (size_t)H * W * 4, hipMemcpyDeviceToHost));
+      // A covariance region outgrew the device FIFO (SPFE_COV_QCAP pixels per
+      // keypoint): redo this frame's computeCovariance (sp_extractor.cpp:252-340)
+      // where the reference runs it, on the host.  status bit 0 stays set.
+      spfe::covariance_host(hinv, H, W, reinterpret_cast<const float *>(rec + h->rl.off_xy), hdr[0],
+                            reinterpret_cast<float *>(rec + h->rl.off_cov),
+                            reinterpret_cast<float *>(rec + h->rl.off_cinv));
+    }
     view_record(h, rec, want ? h->h_heat + (size_t)i * H * W : nullptr, want ? hinv : nullptr, &outs[i]);
   }
   return SPFE_OK;
@@ -534,15 +589,15 @@ int spfe_stage_times(spfe_handle h, float *ms, int cap) {
   std::vector<double> acc(NSTAGE, 0.0);
   for (long c = first; c < h->calls; ++c) {
     hipEvent_t *ev = h->evpool.data() + (size_t)(c % spfe_handle_s::EVSETS) * (NSTAGE + 1);
-    if (hipEventSynchronize(ev[15]) != hipSuccess) return fail(SPFE_EHIP, "event sync failed");
-    for (int i = 0; i < 15; ++i) {
+    if (hipEventSynchronize(ev[NSTAGE - 1]) != hipSuccess) return fail(SPFE_EHIP, "event sync failed");
+    for (int i = 0; i < NSTAGE - 1; ++i) {
       float t = 0;
       (void)hipEventElapsedTime(&t, ev[i], ev[i + 1]);
       acc[i] += t;
     }
     float t = 0;
-    (void)hipEventElapsedTime(&t, ev[0], ev[15]);
-    acc[15] += t;
+    (void)hipEventElapsedTime(&t, ev[0], ev[NSTAGE - 1]);
+    acc[NSTAGE - 1] += t;
   }
   for (int i = 0; i < nst; ++i) ms[i] = (float)(acc[i] / (double)(h->calls - first));
   return nst;

@@ -57,6 +57,18 @@ struct RecordLayout {
   size_t off_hdr, off_xy, off_resp, off_cov, off_cinv, off_desc, off_occ, off_dd, off_sd;
 };
 
+// scratch of the covariance kernel (cov.hip)
+struct CovScratch {
+  int *claim;          // [B][H*W] lowest keypoint index whose lone walk popped the pixel
+  int *done;           // [B][H*W] lowest FINAL keypoint index that popped the pixel
+  int *queue;          // [B][kmax][qcap] per-keypoint FIFO == pop list
+  int *npop;           // [B][kmax]
+  uint8_t *final_flag; // [B][kmax]
+  int qcap;
+};
+hipError_t launch_cov(const FrameBufs &f, const RecordLayout &r, const CovScratch &cs, int B, int H, int W,
+                      hipStream_t s);
+
 hipError_t launch_tail(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s);
 hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H, int W,
                          int num_features, hipStream_t s);

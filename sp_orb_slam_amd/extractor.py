@@ -25,7 +25,7 @@ _ERRORS = {-1: "SPFE_EINVAL", -2: "SPFE_EEMPTY", -3: "SPFE_EHIP", -4: "SPFE_EWEI
 
 # every symbol include/spfe.h declares (tests check that the library exports all)
 ABI_SYMBOLS = [
-    "spfe_create", "spfe_destroy", "spfe_extract", "spfe_extract_batch",
+    "spfe_create", "spfe_destroy", "spfe_extract", "spfe_extract_batch", "spfe_postprocess",
     "spfe_get_record_layout", "spfe_record_bytes", "spfe_extract_batch_device",
     "spfe_view_record", "spfe_debug_read", "spfe_stage_times", "spfe_stage_reset",
     "spfe_stage_name",
@@ -44,7 +44,8 @@ class _Config(C.Structure):
 
 
 class _Result(C.Structure):
-    _fields_ = [("K", C.c_int), ("n_candidates", C.c_int), ("kp_xy", C.c_void_p),
+    _fields_ = [("K", C.c_int), ("n_candidates", C.c_int), ("status", C.c_int),
+                ("reserved", C.c_int), ("kp_xy", C.c_void_p),
                 ("kp_response", C.c_void_p), ("desc", C.c_void_p), ("cov2", C.c_void_p),
                 ("cov2_inv", C.c_void_p), ("occ_grid", C.c_void_p), ("dense_dust", C.c_void_p),
                 ("semi_dust", C.c_void_p), ("heat", C.c_void_p), ("heat_inv", C.c_void_p)]
@@ -78,6 +79,8 @@ def load_library():
     L.spfe_extract_batch.restype = C.c_int
     L.spfe_extract_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int,
                                      C.POINTER(_Result)]
+    L.spfe_postprocess.restype = C.c_int
+    L.spfe_postprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(_Result)]
     L.spfe_get_record_layout.restype = C.c_int
     L.spfe_get_record_layout.argtypes = [C.c_void_p, C.POINTER(RecordLayout)]
     L.spfe_record_bytes.restype = C.c_size_t
@@ -133,6 +136,7 @@ class FrameResult:
         K = r.K
         self.K = K
         self.n_candidates = r.n_candidates
+        self.status = r.status
         xy = _as_np(r.kp_xy, (K, 2), np.float32)
         resp = _as_np(r.kp_response, (K,), np.float32)
         kps = np.zeros(K, KEYPOINT_DTYPE)
@@ -259,6 +263,21 @@ class SPExtractor:
         ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
         res = (_Result * n)()
         _check(self._lib.spfe_extract_batch(self._h, ptrs, imgs[0].strides[0], n, res))
+        out = [FrameResult(res[i], self.height, self.width, self.with_heat) for i in range(n)]
+        self._publish(out[-1])
+        return out
+
+    def postprocess(self, semi, coarse):
+        """Tail + selection + descriptors + covariance from host semi/coarse maps
+        ([n,hc,wc,65], [n,hc,wc,256], or a single frame without the n axis)."""
+        semi = np.ascontiguousarray(semi, np.float32)
+        coarse = np.ascontiguousarray(coarse, np.float32)
+        hc, wc = self.height // 8, self.width // 8
+        semi = semi.reshape(-1, hc, wc, 65)
+        coarse = coarse.reshape(-1, hc, wc, 256)
+        n = semi.shape[0]
+        res = (_Result * n)()
+        _check(self._lib.spfe_postprocess(self._h, semi.ctypes.data, coarse.ctypes.data, n, res))
         out = [FrameResult(res[i], self.height, self.width, self.with_heat) for i in range(n)]
         self._publish(out[-1])
         return out

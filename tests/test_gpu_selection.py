@@ -1,0 +1,177 @@
+"""GPU: the tail / selection / descriptor / covariance kernels driven with
+hand-made head outputs through spfe_postprocess, against the oracle's
+postprocess on the SAME semi/coarse arrays.  With identical inputs every output
+must be identical: integers exactly, floats BITWISE (same operation order,
+include/spfe_exact_math.h)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from sp_orb_slam_amd.extractor import SPExtractor
+from sp_orb_slam_amd import weights
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+_BLOB = None
+
+
+def _blob():
+    global _BLOB
+    if _BLOB is None:
+        _BLOB = weights.synthetic(7, "dense")
+    return _BLOB
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, f32).view(np.uint32)
+
+
+def _check_exact(fr, ref, heat=True):
+    assert fr.status == 0
+    assert fr.n_candidates == ref["n_candidates"] and fr.K == ref["K"]
+    assert np.array_equal(fr.kp_xy, ref["kp_xy"])
+    assert np.array_equal(fr.occ_grid, ref["occ_grid"])
+    assert np.array_equal(_bits(fr.descriptors), _bits(ref["desc"]))
+    assert np.array_equal(_bits(fr.response), _bits(ref["response"]))
+    assert np.array_equal(_bits(fr.cov2), _bits(ref["cov2"]))
+    assert np.array_equal(_bits(fr.cov2_inv), _bits(ref["cov2_inv"]))
+    assert np.array_equal(_bits(fr.dense_dust), _bits(ref["dense_dust"]))
+    assert np.array_equal(_bits(fr.semi_dust), _bits(ref["semi_dust"]))
+    if heat:
+        assert np.array_equal(_bits(fr.heat), _bits(ref["heat"]))
+        assert np.array_equal(_bits(fr.heat_inv), _bits(ref["heat_inv"]))
+
+
+def _run(semi, coarse, H, W, nf):
+    ext = SPExtractor(nf, H, W, _blob())
+    fr = ext.postprocess(semi, coarse)[0]
+    ext.close()
+    return fr, oracle.postprocess(semi, coarse, H, W, nf)
+
+
+def _semi_from_candidates(H, W, cands, empty_dust=20.0):
+    """cands: (x, y, logit).  p = e^a / (e^a + 64) for the chosen channel."""
+    hc, wc = H // 8, W // 8
+    semi = np.zeros((hc, wc, 65), f32)
+    semi[:, :, 64] = empty_dust
+    for x, y, a in cands:
+        cy, cx = y // 8, x // 8
+        semi[cy, cx, :] = 0
+        semi[cy, cx, (y % 8) * 8 + x % 8] = a
+    return semi
+
+
+def _coarse(H, W, seed=0):
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal((H // 8, W // 8, 256)).astype(f32)
+
+
+def test_handmade_nms_cases():
+    H, W = 64, 96
+    cases = [
+        ([(7, 20, 5.0), (8, 30, 4.8), (W - 9, 20, 4.6), (W - 8, 30, 4.4), (40, 7, 4.2), (60, 8, 4.0),
+          (50, H - 9, 3.8), (70, H - 8, 3.6)], 100, [(60, 8), (W - 9, 20), (8, 30), (50, H - 9)]),
+        ([(20, 20, 5.0), (24, 20, 4.0)], 100, [(20, 20)]),               # distance 4 suppresses
+        ([(20, 20, 5.0), (25, 20, 4.0)], 100, [(20, 20), (25, 20)]),     # distance 5 does not
+        ([(23, 23, 4.0), (24, 24, 5.0)], 100, [(24, 24)]),               # across a cell corner
+        ([(20, 20, 5.0), (24, 20, 4.5), (28, 20, 4.0)], 100, [(20, 20), (28, 20)]),  # dead suppress nobody
+        ([(30, 20, 4.5), (60, 40, 4.6), (4, 30, 5.0), (70, 50, 4.4)], 2, [(30, 20), (60, 40)]),  # cut before border
+        ([(20, 20, 4.0), (23, 20, 4.0)], 100, [(20, 20)]),               # tie -> lower cell index
+        ([(40, 7, 5.0), (40, 8, 4.0)], 100, []),                         # border candidate still suppresses
+    ]
+    for cands, nf, expect in cases:
+        semi = _semi_from_candidates(H, W, cands)
+        fr, ref = _run(semi, _coarse(H, W), H, W, nf)
+        _check_exact(fr, ref)
+        assert [(int(x), int(y)) for x, y in fr.kp_xy] == expect
+
+
+def test_threshold_boundary_and_argmax_ties():
+    H, W = 64, 96
+    hc, wc = H // 8, W // 8
+    # p = e^a/(e^a+64) around 0.007: a = ln(64*0.007/0.993) = -0.7959...
+    a0 = np.log(64 * 0.007 / 0.993)
+    semi = np.zeros((hc, wc, 65), f32)
+    for i, cx in enumerate(range(1, wc - 1)):
+        semi[3, cx, 20] = f32(a0 + (i - 5) * 2e-4)     # straddles the >= 0.007 compare
+    semi[5, 4, 9] = 1.0
+    semi[5, 4, 33] = 1.0                                # exact tie inside a cell -> lowest channel
+    semi[5, 7, :64] = 0.25                              # all 64 equal -> channel 0
+    fr, ref = _run(semi, _coarse(H, W, 1), H, W, 500)
+    _check_exact(fr, ref)
+    assert 0 < ref["n_candidates"]
+    kp = {(int(x), int(y)) for x, y in fr.kp_xy}
+    assert (4 * 8 + 1, 5 * 8 + 1) in kp and (7 * 8, 5 * 8) in kp
+
+
+@pytest.mark.parametrize("H,W,nf,scale,seed", [(64, 96, 30, 1.0, 0), (120, 160, 1000, 2.0, 1),
+                                               (240, 320, 100, 0.5, 2), (480, 752, 1000, 1.5, 3),
+                                               (480, 752, 200, 3.0, 4)])
+def test_random_logits_exact(H, W, nf, scale, seed):
+    rng = np.random.default_rng(seed)
+    semi = (rng.standard_normal((H // 8, W // 8, 65)) * scale).astype(f32)
+    fr, ref = _run(semi, _coarse(H, W, seed), H, W, nf)
+    _check_exact(fr, ref)
+    assert fr.K > 0
+
+
+def _hills(H, W, seed, sigma, nh):
+    """Smooth per-pixel logit field (sum of Gaussian bumps): broad hills whose BFS regions overlap."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    g = np.zeros((H, W))
+    for _ in range(nh):
+        cx, cy = rng.uniform(0, W), rng.uniform(0, H)
+        g += rng.uniform(1, 4) * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * sigma ** 2))
+    hc, wc = H // 8, W // 8
+    semi = np.zeros((hc, wc, 65), f32)
+    semi[:, :, :64] = g.reshape(hc, 8, wc, 8).transpose(0, 2, 1, 3).reshape(hc, wc, 64).astype(f32)
+    semi[:, :, 64] = f32(g.max() * 0.6)
+    return semi
+
+
+@pytest.mark.parametrize("H,W,sigma,nh,seed", [(64, 96, 6.0, 6, 0), (128, 160, 10.0, 12, 1),
+                                               (240, 320, 14.0, 40, 2), (240, 320, 4.0, 200, 3)])
+def test_overlapping_covariance_regions_exact(H, W, sigma, nh, seed):
+    """Broad hills: many keypoints whose downhill regions collide, exercising the
+    conflict-resolution rounds of the covariance kernel against the sequential loop."""
+    semi = _hills(H, W, seed, sigma, nh)
+    fr, ref = _run(semi, _coarse(H, W, seed), H, W, 1000)
+    _check_exact(fr, ref)
+    # the case is only meaningful if regions really interact: the lone walk of at least one
+    # keypoint differs from the sequential result
+    hinv = ref["heat_inv"]
+    lone = np.array([oracle.covariance(hinv, ref["kp_xy"][i:i + 1, 0].copy(), ref["kp_xy"][i:i + 1, 1].copy())[0][0]
+                     for i in range(ref["K"])])
+    assert (lone != ref["cov2"]).any(), "test input has no interacting regions"
+
+
+def test_covariance_queue_overflow_is_reported_and_repaired():
+    H, W = 128, 160
+    semi = _hills(H, W, 1, 10.0, 12)
+    coarse = _coarse(H, W, 1)
+    os.environ["SPFE_COV_QCAP"] = "16"
+    try:
+        ext = SPExtractor(1000, H, W, _blob())
+    finally:
+        del os.environ["SPFE_COV_QCAP"]
+    fr = ext.postprocess(semi, coarse)[0]
+    ext.close()
+    ref = oracle.postprocess(semi, coarse, H, W, 1000)
+    assert fr.status & 1                                    # SPFE_STATUS_COV_OVERFLOW
+    assert np.array_equal(_bits(fr.cov2), _bits(ref["cov2"]))   # host call repaired the frame
+    assert np.array_equal(fr.kp_xy, ref["kp_xy"])
+
+
+def test_postprocess_batch():
+    H, W, n = 64, 96, 3
+    rng = np.random.default_rng(5)
+    semi = (rng.standard_normal((n, H // 8, W // 8, 65)) * 1.5).astype(f32)
+    coarse = rng.standard_normal((n, H // 8, W // 8, 256)).astype(f32)
+    ext = SPExtractor(40, H, W, _blob(), max_batch=4)
+    frs = ext.postprocess(semi, coarse)
+    ext.close()
+    for i in range(n):
+        _check_exact(frs[i], oracle.postprocess(semi[i], coarse[i], H, W, 40))
