@@ -44,7 +44,7 @@ extern "C" {
 
 /* spfe_result.status / record header word 2 */
 #define SPFE_STATUS_COV_OVERFLOW 1 /* a covariance region outgrew the device FIFO (SPFE_COV_QCAP, default
-                                      4096 pixels per keypoint).  Device records: cov2/cov2_inv of that frame
+                                      1024 pixels per keypoint).  Device records: cov2/cov2_inv of that frame
                                       are not valid.  Host calls: the frame's covariance was recomputed by
                                       the host routine, values are valid. */
 

@@ -61,11 +61,15 @@ struct RecordLayout {
 struct CovScratch {
   int *claim;          // [B][H*W] lowest keypoint index whose lone walk popped the pixel
   int *done;           // [B][H*W] lowest FINAL keypoint index that popped the pixel
-  int *queue;          // [B][kmax][qcap] per-keypoint FIFO == pop list
+  int *queue;          // [B][kmax][qcap] per-keypoint FIFO == pop list (pixel index)
+  float *qval;         // [B][kmax][qcap] heat_inv value of each queued pixel
   int *npop;           // [B][kmax]
-  uint8_t *final_flag; // [B][kmax]
+  int *dirty;          // [B][kmax] keypoints whose lone region meets a lower keypoint's
+  int *ndirty;         // [B]
+  unsigned long long *dbg;  // [B][16] timestamps of the components kernel (SPFE_COV_DEBUG) or null
   int qcap;
 };
+size_t cov_components_lds(int kmax);
 hipError_t launch_cov(const FrameBufs &f, const RecordLayout &r, const CovScratch &cs, int B, int H, int W,
                       hipStream_t s);
 
