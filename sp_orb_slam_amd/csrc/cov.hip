@@ -6,9 +6,8 @@
 // value > 0, value < current), then cov = sum (s_i / sum s) * delta_i^2 clamped to
 // >= 1.  The shared visited mask makes the loop sequential over keypoints.
 //
-// Parallel form used here (every walk itself stays a sequential FIFO run by one
-// thread, so pop order, duplicate pops and float accumulation order are the
-// reference's):
+// Parallel form used here (every walk itself stays a sequential FIFO, so pop
+// order, duplicate pops and float accumulation order are the reference's):
 //   A. cov_walk_kernel: every keypoint j walks ALONE (sees only its own visits)
 //      and claims each popped pixel with atomicMin(claim[p], j).  -> region iso(j)
 //   B. cov_classify_kernel: j is CLEAN when no pixel of iso(j) except its start
@@ -17,137 +16,196 @@
 //      touch iso(j), and the lone walk IS the sequential result.  Clean keypoints
 //      are final and stamp done[p] = min(done[p], j); the others go on the
 //      frame's dirty list.
-//   C. cov_components_kernel: two keypoints interact only if their lone regions
-//      share a pixel, and every pixel links all its claimants to its lowest
-//      claimant, so the connected components of {(claim[p], j) : p in iso(j)} are
-//      closed under interaction and own disjoint pixel sets.  Each component is
-//      replayed by ONE thread in ascending keypoint order against `done` (blocked
-//      iff a lower FINAL keypoint or an earlier member of the component popped the
-//      pixel) — exactly the sequential loop restricted to that component.  No
-//      rounds, no barriers; the components of a frame run side by side.  For a
-//      trained detector (regions of a few pixels) there are no dirty keypoints.
+//   C. cov_link_kernel + cov_replay_kernel: two keypoints interact only if their
+//      lone regions share a pixel, and every pixel links all its claimants to its
+//      lowest claimant, so the connected components of {(claim[p], j) : p in
+//      iso(j)} are closed under interaction and own disjoint pixel sets.  Each
+//      component is replayed by ONE wavefront in ascending keypoint order against
+//      `done` (blocked iff a lower FINAL keypoint or an earlier member of the
+//      component popped the pixel) — exactly the sequential loop restricted to
+//      that component.  No rounds, no barriers; components run side by side.  For
+//      a trained detector (regions of a few pixels) there are no dirty keypoints.
 // The result equals the sequential algorithm exactly (same pixels, same
 // multiplicities, same order), not approximately.
 //
-// Latency notes (the walks are dependent-load chains, one thread each): the FIFO
-// and the keypoint's own visited set live in LDS (a 32x32-pixel bitmap window
-// around the start; pixels outside it are looked up in the pop list), so a pop
-// costs ONE round of independent global loads and no store or atomic sits in the
-// loop (on CDNA4 stores share vmcnt with loads: a store per pop would put a full
-// write round trip on the critical path).  Claims and stamps are issued in bulk
-// after the walk.
+// Latency design: a walk is a chain of dependent lookups, and every global round
+// trip in it costs ~1-2 us (the maps were last written by other XCDs, so they
+// miss this XCD's L2).  So ONE WAVEFRONT serves one walk: its 64 lanes stage the
+// 32x32-pixel window around the keypoint (heat_inv, and `done` for replays) into
+// LDS with coalesced loads — one round trip — and the FIFO then runs entirely out
+// of LDS (values, own-visited bitmap, FIFO), four lanes checking the four
+// neighbours of each pop side by side.  Pixels outside the window fall back to
+// global loads.  Claims, stamps, the list flush and the products of the moment
+// sums are done by all lanes in parallel after the walk.
 #include "spfe_kernels.h"
 
 namespace spfe {
 
 #define COV_INF 0x7f7f7f7f
-#define COV_LCAP 96      // FIFO entries kept in LDS per thread
-#define COV_WIN 16       // own-visited bitmap covers dx,dy in [-16, 15]
+#define COV_LCAP 128     // FIFO entries kept in LDS per wavefront
+#define COV_WIN 16       // the window covers dx,dy in [-16, 15] around the keypoint
+#define COV_WAVES 4      // wavefronts (= walks) per workgroup
 
-__device__ __forceinline__ int ld_agent(const int *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-struct WalkMem {
-  int *lq;        // LDS [COV_LCAP] pixel ids
-  float *lqv;     // LDS [COV_LCAP] values
-  uint32_t *bm;   // LDS [32] own-visited bitmap rows
-  int *gq;        // global spill / final list [qcap]
-  float *gqv;
-  int qcap;
+struct WaveMem {         // LDS of one wavefront
+  float hv[32 * 32];     // heat_inv window
+  int dn[32 * 32];       // done window (replay only)
+  int lq[COV_LCAP];
+  float lqv[COV_LCAP];
+  uint32_t bm[32];       // own-visited bitmap
 };
 
-__device__ __forceinline__ int fifo_id(const WalkMem &m, int i) { return i < COV_LCAP ? m.lq[i] : m.gq[i]; }
-__device__ __forceinline__ float fifo_val(const WalkMem &m, int i) { return i < COV_LCAP ? m.lqv[i] : m.gqv[i]; }
+struct Walk {
+  WaveMem *m;
+  const float *hinv;     // frame's heat_inv
+  const int *done;       // frame's done map (replay) or null
+  int *gq;               // global pop list of this keypoint [qcap]
+  float *gqv;
+  int qcap, W, H, x0, y0, j;
+};
 
-// One FIFO walk from (x0, y0) for keypoint j.
-// LONE: only the keypoint's own pops block.  !LONE (replay): additionally every
-// pixel with done[p] < j (final lower keypoints, earlier members of the component).
-// Returns the number of pops (entries of the FIFO), or -1 when it outgrew qcap.
-template <bool LONE>
-__device__ int walk(const float *__restrict__ hinv, int W, int H, int x0, int y0, int j, const WalkMem &m,
-                    const int *done) {
+// The slow paths (FIFO entries beyond the LDS part, pixels outside the window) are
+// real calls: written as `cond ? lds[i] : global[i]` the compiler speculates the
+// global load on every iteration and the walk pays a memory round trip per lookup.
+__device__ __attribute__((noinline)) int slow_ld_i(const int *p, int i) { return p[i]; }
+__device__ __attribute__((noinline)) float slow_ld_f(const float *p, int i) { return p[i]; }
+__device__ __forceinline__ int fifo_id(const Walk &w, int i) {
+  if (__builtin_expect(i < COV_LCAP, 1)) return w.m->lq[i];
+  return slow_ld_i(w.gq, i);
+}
+__device__ __forceinline__ float fifo_val(const Walk &w, int i) {
+  if (__builtin_expect(i < COV_LCAP, 1)) return w.m->lqv[i];
+  return slow_ld_f(w.gqv, i);
+}
+
+// all 64 lanes: stage the window (zero outside the image: never read there)
+template <bool REPLAY>
+__device__ __forceinline__ void stage_window(const Walk &w, int lane) {
+  const int wx0 = w.x0 - COV_WIN, wy0 = w.y0 - COV_WIN;
+  float hv[16];
+  int dn[16];
 #pragma unroll
-  for (int i = 0; i < 32; ++i) m.bm[i] = 0;
+  for (int k = 0; k < 16; ++k) {  // all 16 (32) loads in flight together: one round trip
+    const int i = lane + 64 * k;
+    const int dy = i >> 5, dx = i & 31;
+    const int x = wx0 + dx, y = wy0 + dy;
+    const bool in = (unsigned)x < (unsigned)w.W && (unsigned)y < (unsigned)w.H;
+    const size_t g = in ? (size_t)y * w.W + x : 0;
+    hv[k] = w.hinv[g];
+    if (REPLAY) dn[k] = w.done[g];
+    if (!in) { hv[k] = 0.0f; dn[k] = COV_INF; }
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    w.m->hv[lane + 64 * k] = hv[k];
+    if (REPLAY) w.m->dn[lane + 64 * k] = dn[k];
+  }
+  if (lane < 32) w.m->bm[lane] = 0;
+}
+
+// The FIFO walk, run by the whole wavefront in lock step.  All lanes read the
+// popped entry (an LDS broadcast); lanes 0..3 each examine one neighbour (left,
+// up, right, down — :302-313) and the survivors are appended in lane order with a
+// ballot + prefix count, i.e. in the reference's push order.  A pop costs one
+// chain of ~3 dependent LDS reads instead of four.  REPLAY additionally blocks
+// pixels with done[p] < j.  Returns the number of pops, or -1 when the FIFO
+// outgrew qcap.  (head, tail and the result are wave-uniform.)
+template <bool REPLAY>
+__device__ int walk(const Walk &w, int lane) {
+  WaveMem *m = w.m;
+  const int W = w.W, H = w.H, x0 = w.x0, y0 = w.y0;
+  if (lane == 0) {
+    m->lq[0] = y0 * W + x0;
+    m->lqv[0] = m->hv[COV_WIN * 32 + COV_WIN];
+  }
   int head = 0, tail = 1;
+  const int t = lane & 3;
+  const int ox = t == 0 ? -1 : (t == 2 ? 1 : 0), oy = t == 1 ? -1 : (t == 3 ? 1 : 0);
   int id = y0 * W + x0;
-  float here = hinv[id];
-  m.lq[0] = id;
-  m.lqv[0] = here;
+  float here = m->hv[COV_WIN * 32 + COV_WIN];
   while (true) {
     const int y = id / W, x = id - y * W;
-    {  // visited at POP (:285)
-      const int dx = x - x0 + COV_WIN, dy = y - y0 + COV_WIN;
-      if ((unsigned)dx < 32u && (unsigned)dy < 32u) m.bm[dy] |= 1u << dx;
-    }
+    const int cdx = x - x0 + COV_WIN, cdy = y - y0 + COV_WIN;
+    // visited at POP (:285)
+    if (lane == 0 && (unsigned)cdx < 32u && (unsigned)cdy < 32u) m->bm[cdy] |= 1u << cdx;
     ++head;
-    const bool ok[4] = {x - 1 > 0, y - 1 > 0, x + 1 < W, y + 1 < H};  // :302-313
-    const int nx[4] = {x - 1, x, x + 1, x}, ny[4] = {y, y - 1, y, y + 1};
-    int nid[4];
-    float v[4];
-    int dn[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) nid[t] = ok[t] ? ny[t] * W + nx[t] : id;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) v[t] = hinv[nid[t]];
-    if (!LONE) {
-      // plain (cached) loads: during the replay a component's pixels are touched by
-      // its one worker thread only; stamps of finished keypoints came from the
-      // previous kernel.  Agent-scope (sc1) loads would bypass the XCD's L2 and
-      // cost a fabric round trip per pop.
-#pragma unroll
-      for (int t = 0; t < 4; ++t) dn[t] = done[nid[t]];
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {  // left, up, right, down
-      if (!ok[t] || !(v[t] > 0.0f && v[t] < here)) continue;
-      bool blocked = !LONE && dn[t] < j;
-      if (!blocked) {
-        const int dx = nx[t] - x0 + COV_WIN, dy = ny[t] - y0 + COV_WIN;
-        if ((unsigned)dx < 32u && (unsigned)dy < 32u) {
-          blocked = (m.bm[dy] >> dx) & 1u;
-        } else {  // outside the bitmap window: search the pops so far
-          for (int u = 0; u < head && !blocked; ++u) blocked = fifo_id(m, u) == nid[t];
-        }
+    const int nx = x + ox, ny = y + oy;
+    // bounds as in the reference: xx > 0, yy > 0, xx < w, yy < h
+    bool take = lane < 4 && (t == 0 ? nx > 0 : t == 1 ? ny > 0 : t == 2 ? nx < W : ny < H);
+    const int nid = id + oy * W + ox;
+    const int dx = cdx + ox, dy = cdy + oy;
+    const bool inwin = (unsigned)dx < 32u && (unsigned)dy < 32u;
+    float v = 0.0f;
+    if (__builtin_expect(!take || inwin, 1)) {
+      // common case: the three lookups are independent LDS reads issued together
+      const int wi = inwin ? dy * 32 + dx : 0;
+      const float hv = m->hv[wi];
+      const int dstamp = REPLAY ? m->dn[wi] : COV_INF;
+      const uint32_t row = m->bm[inwin ? dy : 0];
+      v = hv;
+      take = take && hv > 0.0f && hv < here && !(REPLAY && dstamp < w.j) && !((row >> dx) & 1u);
+    } else {  // a neighbour outside the staged window (rare): global lookups, pop-list search
+      v = slow_ld_f(w.hinv, nid);
+      take = v > 0.0f && v < here;
+      if (take && REPLAY) take = !(slow_ld_i(w.done, nid) < w.j);
+      if (take) {
+        bool seen = false;
+        for (int u = 0; u < head && !seen; ++u) seen = fifo_id(w, u) == nid;
+        take = !seen;
       }
-      if (blocked) continue;
-      if (tail >= m.qcap) return -1;
-      if (tail < COV_LCAP) { m.lq[tail] = nid[t]; m.lqv[tail] = v[t]; }
-      else { m.gq[tail] = nid[t]; m.gqv[tail] = v[t]; }
-      ++tail;
     }
+    const unsigned mask = (unsigned)(__ballot(take) & 0xFull);
+    const int pos = tail + __popc(mask & ((1u << t) - 1u));
+    const int ntail = tail + __popc(mask);
+    if (ntail > w.qcap) return -1;
+    if (take) {
+      if (pos < COV_LCAP) { m->lq[pos] = nid; m->lqv[pos] = v; }
+      else { w.gq[pos] = nid; w.gqv[pos] = v; }
+    }
+    tail = ntail;
     if (head >= tail) break;
-    id = fifo_id(m, head);
-    here = fifo_val(m, head);
+    id = fifo_id(w, head);
+    here = fifo_val(w, head);
   }
   return tail;
 }
 
-// publish the LDS part of the pop list to global memory (later phases read it)
-__device__ __forceinline__ void flush_list(const WalkMem &m, int n) {
-  const int k = n < COV_LCAP ? n : COV_LCAP;
-  for (int i = 0; i < k; ++i) { m.gq[i] = m.lq[i]; m.gqv[i] = m.lqv[i]; }
-}
-
-// second moments over the popped sequence, in pop order (:316-333)
-__device__ void moments(int W, const WalkMem &m, int n, int x0, int y0, float *cov2, float *cov2_inv) {
+// second moments over the popped sequence, in pop order (:316-333).  Lanes hold
+// one entry each; lane order is pop order, and the running sums are accumulated
+// one entry at a time exactly like the reference's loops.
+__device__ void moments(const Walk &w, int n, int lane, float *cov2, float *cov2_inv) {
   float sum = 0.0f;
-  for (int i = 0; i < n; ++i) sum += fifo_val(m, i);
-  float cx = 0.0f, cy = 0.0f;
-  for (int i = 0; i < n; ++i) {
-    const int id = fifo_id(m, i);
-    const int y = id / W, x = id - y * W;
-    const float wgt = fifo_val(m, i) / sum;
-    const float dx = (float)x - (float)x0, dy = (float)y - (float)y0;
-    cx += wgt * (dx * dx);
-    cy += wgt * (dy * dy);
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    const float v = i < n ? fifo_val(w, i) : 0.0f;
+    const int cnt = n - base < 64 ? n - base : 64;
+    for (int u = 0; u < cnt; ++u) sum += __shfl(v, u, 64);
   }
-  cx = cx < 1.0f ? 1.0f : cx;
-  cy = cy < 1.0f ? 1.0f : cy;
-  cov2[0] = cx;
-  cov2[1] = cy;
-  cov2_inv[0] = 1.0f / cx;
-  cov2_inv[1] = 1.0f / cy;
+  float cx = 0.0f, cy = 0.0f;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    float tx = 0.0f, ty = 0.0f;
+    if (i < n) {
+      const int id = fifo_id(w, i);
+      const int y = id / w.W, x = id - y * w.W;
+      const float wgt = fifo_val(w, i) / sum;
+      const float dx = (float)x - (float)w.x0, dy = (float)y - (float)w.y0;
+      tx = wgt * (dx * dx);
+      ty = wgt * (dy * dy);
+    }
+    const int cnt = n - base < 64 ? n - base : 64;
+    for (int u = 0; u < cnt; ++u) {
+      cx += __shfl(tx, u, 64);
+      cy += __shfl(ty, u, 64);
+    }
+  }
+  if (lane == 0) {
+    cx = cx < 1.0f ? 1.0f : cx;
+    cy = cy < 1.0f ? 1.0f : cy;
+    cov2[0] = cx;
+    cov2[1] = cy;
+    cov2_inv[0] = 1.0f / cx;
+    cov2_inv[1] = 1.0f / cy;
+  }
 }
 
 struct CovFrame {
@@ -155,7 +213,7 @@ struct CovFrame {
   float *cov2, *cinv;
   int *hdr;
   const float *hinv;
-  int *claim, *done, *queues, *npop, *dirty, *ndirty;
+  int *claim, *done, *queues, *npop, *dirty, *ndirty, *nxt, *workers, *nworkers;
   float *qvals;
   int K;
 };
@@ -176,53 +234,59 @@ __device__ __forceinline__ CovFrame cov_frame(const FrameBufs &f, const RecordLa
   c.qvals = cs.qval + (size_t)b * rl.kmax * cs.qcap;
   c.npop = cs.npop + (size_t)b * rl.kmax;
   c.dirty = cs.dirty + (size_t)b * rl.kmax;
-  c.ndirty = cs.ndirty + b;
+  c.nxt = cs.nxt + (size_t)b * rl.kmax;
+  c.workers = cs.workers + (size_t)b * rl.kmax;
+  c.ndirty = cs.counters + 2 * b;
+  c.nworkers = cs.counters + 2 * b + 1;
   return c;
 }
 
-// ---- A: lone walks.  64-thread workgroups spread over the CUs: a wave's accesses
-// are fully divergent, so one CU's memory pipeline cannot feed many walks. ----
-#define WALK_THREADS 64
-__global__ __launch_bounds__(WALK_THREADS) void cov_walk_kernel(FrameBufs f, RecordLayout rl, CovScratch cs,
-                                                                int H, int W) {
-  __shared__ int s_q[WALK_THREADS * COV_LCAP];
-  __shared__ float s_qv[WALK_THREADS * COV_LCAP];
-  __shared__ uint32_t s_bm[WALK_THREADS * 32];
-  const int b = blockIdx.y, tid = threadIdx.x, j = blockIdx.x * WALK_THREADS + tid;
+// ---- A: lone walks, one wavefront per keypoint ----
+__global__ __launch_bounds__(64 * COV_WAVES) void cov_walk_kernel(FrameBufs f, RecordLayout rl, CovScratch cs,
+                                                                  int H, int W) {
+  __shared__ WaveMem s_mem[COV_WAVES];
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = blockIdx.x * COV_WAVES + wv;
   const CovFrame c = cov_frame(f, rl, cs, b, H, W);
   if (j >= c.K) return;
-  WalkMem m{s_q + tid * COV_LCAP, s_qv + tid * COV_LCAP, s_bm + tid * 32, c.queues + (size_t)j * cs.qcap,
-            c.qvals + (size_t)j * cs.qcap, cs.qcap};
-  const int x0 = (int)c.kp_xy[2 * j], y0 = (int)c.kp_xy[2 * j + 1];
-  const int n = walk<true>(c.hinv, W, H, x0, y0, j, m, nullptr);
-  c.npop[j] = n;
-  if (n < 0) { atomicOr(&c.hdr[2], 1); return; }  // region outgrew the queue: report, do not guess
-  flush_list(m, n);
-  // tentative moments: final if the keypoint turns out clean (classify decides)
-  moments(W, m, n, x0, y0, c.cov2 + 2 * j, c.cinv + 2 * j);
-  for (int i = 0; i < n; ++i) atomicMin(&c.claim[fifo_id(m, i)], j);
+  Walk w{&s_mem[wv], c.hinv, nullptr, c.queues + (size_t)j * cs.qcap, c.qvals + (size_t)j * cs.qcap, cs.qcap, W, H,
+         (int)c.kp_xy[2 * j], (int)c.kp_xy[2 * j + 1], j};
+  stage_window<false>(w, lane);
+  const int n = walk<false>(w, lane);
+  if (lane == 0) {
+    c.npop[j] = n;
+    if (n < 0) atomicOr(&c.hdr[2], 1);  // region outgrew the FIFO: report, do not guess
+  }
+  if (n < 0) return;
+  moments(w, n, lane, c.cov2 + 2 * j, c.cinv + 2 * j);  // final if the keypoint turns out clean
+  const int k = n < COV_LCAP ? n : COV_LCAP;
+  for (int i = lane; i < k; i += 64) { w.gq[i] = w.m->lq[i]; w.gqv[i] = w.m->lqv[i]; }  // publish the pop list
+  for (int i = lane; i < n; i += 64) atomicMin(&c.claim[fifo_id(w, i)], j);
 }
 
 // ---- B: clean keypoints are final (their moments are already in the record);
 // the rest go on the frame's dirty list ----
-__global__ __launch_bounds__(64) void cov_classify_kernel(FrameBufs f, RecordLayout rl, CovScratch cs,
-                                                          int H, int W) {
-  const int b = blockIdx.y, j = blockIdx.x * 64 + threadIdx.x;
+__global__ __launch_bounds__(64 * COV_WAVES) void cov_classify_kernel(FrameBufs f, RecordLayout rl,
+                                                                      CovScratch cs, int H, int W) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int j = blockIdx.x * COV_WAVES + (threadIdx.x >> 6);
   const CovFrame c = cov_frame(f, rl, cs, b, H, W);
   if (j >= c.K || (c.hdr[2] & 1)) return;
   const int *q = c.queues + (size_t)j * cs.qcap;
   const int n = c.npop[j];
   int bad = 0;
-  for (int i = 1; i < n; ++i) bad |= ld_agent(&c.claim[q[i]]) < j;  // independent loads, no early exit
-  if (!bad) {
-    for (int i = 0; i < n; ++i) atomicMin(&c.done[q[i]], j);
-  } else {
+  for (int i = 1 + lane; i < n; i += 64) bad |= c.claim[q[i]] < j;  // claims were made by the previous kernel
+  if (__ballot(bad) == 0) {
+    for (int i = lane; i < n; i += 64) atomicMin(&c.done[q[i]], j);
+  } else if (lane == 0) {
     c.dirty[atomicAdd(c.ndirty, 1)] = j;
   }
 }
 
-// ---- C: components (see the header comment) ----
-#define COMP_THREADS 128
+// ---- C1: link.  One workgroup per frame: union-find over the dirty keypoints'
+// claim edges, then per component the ascending chain of its dirty members. ----
+#define LINK_THREADS 256
 
 __device__ __forceinline__ int uf_find(volatile int *parent, int x) {
   while (true) {
@@ -232,32 +296,27 @@ __device__ __forceinline__ int uf_find(volatile int *parent, int x) {
   }
 }
 
-__global__ __launch_bounds__(COMP_THREADS) void cov_components_kernel(FrameBufs f, RecordLayout rl,
-                                                                      CovScratch cs, int H, int W) {
+__global__ __launch_bounds__(LINK_THREADS) void cov_link_kernel(FrameBufs f, RecordLayout rl, CovScratch cs,
+                                                                int H, int W) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const CovFrame c = cov_frame(f, rl, cs, b, H, W);
   const int nd = *c.ndirty;
   const int K = c.K;
   if (nd == 0 || (c.hdr[2] & 1)) return;
   extern __shared__ __attribute__((aligned(16))) int smem_i[];
-  int *parent = smem_i;          // [K] union-find forest over keypoint indices
-  int *leader = smem_i + K;      // [K] lowest DIRTY member of the component rooted here
-  int *nxt = smem_i + 2 * K;     // [K] next dirty member (ascending) of the same component
-  const int kpad = (3 * K + 3) & ~3;
-  int *s_q = smem_i + kpad;
-  float *s_qv = reinterpret_cast<float *>(s_q + COMP_THREADS * COV_LCAP);
-  uint32_t *s_bm = reinterpret_cast<uint32_t *>(s_qv + COMP_THREADS * COV_LCAP);
-  unsigned long long *dbg = cs.dbg ? cs.dbg + (size_t)b * 16 : nullptr;
-  if (dbg && tid == 0) { dbg[0] = wall_clock64(); dbg[8] = nd; }
-  for (int j = tid; j < K; j += COMP_THREADS) { parent[j] = j; leader[j] = COV_INF; nxt[j] = -1; }
+  int *parent = smem_i;      // [K] union-find forest over keypoint indices
+  int *leader = smem_i + K;  // [K] lowest DIRTY member of the component rooted here
+  for (int j = tid; j < K; j += LINK_THREADS) { parent[j] = j; leader[j] = COV_INF; }
   __syncthreads();
-  // union every dirty keypoint with the lowest claimant of each of its pixels
-  for (int d = tid; d < nd; d += COMP_THREADS) {
+  // every pixel links its claimants to its lowest claimant: union(claim[p], j).
+  // (one wavefront per dirty keypoint, lanes over its pixels)
+  const int lane = tid & 63, wv = tid >> 6;
+  for (int d = wv; d < nd; d += LINK_THREADS / 64) {
     const int j = c.dirty[d];
     const int *q = c.queues + (size_t)j * cs.qcap;
     const int n = c.npop[j];
-    for (int i = 1; i < n; ++i) {
-      int a = c.claim[q[i]];  // written by the previous kernels: plain load
+    for (int i = 1 + lane; i < n; i += 64) {
+      int a = c.claim[q[i]];
       int bb = j;
       if (a >= j) continue;
       while (true) {  // hook the larger root under the smaller one
@@ -273,17 +332,16 @@ __global__ __launch_bounds__(COMP_THREADS) void cov_components_kernel(FrameBufs 
     }
   }
   __syncthreads();
-  if (dbg && tid == 0) dbg[1] = wall_clock64();
-  for (int j = tid; j < K; j += COMP_THREADS) parent[j] = uf_find(parent, j);  // flatten (roots are fixed now)
+  for (int j = tid; j < K; j += LINK_THREADS) parent[j] = uf_find(parent, j);  // flatten (roots are fixed now)
   __syncthreads();
-  for (int d = tid; d < nd; d += COMP_THREADS) {
+  for (int d = tid; d < nd; d += LINK_THREADS) {
     const int j = c.dirty[d];
     atomicMin(&leader[parent[j]], j);
   }
   __syncthreads();
-  if (dbg && tid == 0) dbg[2] = wall_clock64();
-  // next dirty member of the same component, ascending index
-  for (int d = tid; d < nd; d += COMP_THREADS) {
+  // chain: next dirty member of the same component in ascending index; leaders
+  // become the workers of the replay kernel
+  for (int d = tid; d < nd; d += LINK_THREADS) {
     const int j = c.dirty[d];
     const int root = parent[j];
     int best = COV_INF;
@@ -291,45 +349,40 @@ __global__ __launch_bounds__(COMP_THREADS) void cov_components_kernel(FrameBufs 
       const int i = c.dirty[e];
       if (i > j && i < best && parent[i] == root) best = i;
     }
-    nxt[j] = best == COV_INF ? -1 : best;
+    c.nxt[j] = best == COV_INF ? -1 : best;
+    if (leader[root] == j) c.workers[atomicAdd(c.nworkers, 1)] = j;
   }
-  __syncthreads();
-  if (dbg && tid == 0) dbg[3] = wall_clock64();
-  // one thread per component replays its dirty members in order
-  for (int d = tid; d < nd; d += COMP_THREADS) {
-    int j = c.dirty[d];
-    if (leader[parent[j]] != j) continue;
-    unsigned long long tw = 0, tm = 0, ts = 0, pops = 0, chain = 0;
-    while (j >= 0) {
-      const unsigned long long t0 = dbg ? wall_clock64() : 0;
-      WalkMem m{s_q + tid * COV_LCAP, s_qv + tid * COV_LCAP, s_bm + tid * 32, c.queues + (size_t)j * cs.qcap,
-                c.qvals + (size_t)j * cs.qcap, cs.qcap};
-      const int x0 = (int)c.kp_xy[2 * j], y0 = (int)c.kp_xy[2 * j + 1];
-      // a replay's pop list is a subsequence of the lone walk's: it cannot overflow
-      const int n = walk<false>(c.hinv, W, H, x0, y0, j, m, c.done);
-      if (n < 0) { atomicOr(&c.hdr[2], 1); break; }
-      const unsigned long long t1 = dbg ? wall_clock64() : 0;
-      moments(W, m, n, x0, y0, c.cov2 + 2 * j, c.cinv + 2 * j);
-      const unsigned long long t2 = dbg ? wall_clock64() : 0;
-      // stamp before the next member starts (same thread, plain stores then plain
-      // loads of the same addresses: coherent within the CU)
-      for (int i = 0; i < n; ++i) {
-        const int p = fifo_id(m, i);
-        if (c.done[p] > j) c.done[p] = j;
-      }
-      if (dbg) { const unsigned long long t3 = wall_clock64(); tw += t1 - t0; tm += t2 - t1; ts += t3 - t2; pops += n; ++chain; }
-      j = nxt[j];
-    }
-    if (dbg) { atomicMax(&dbg[9], tw); atomicMax(&dbg[10], tm); atomicMax(&dbg[11], ts); atomicMax(&dbg[5], chain);
-               atomicMax(&dbg[6], pops); atomicAdd(&dbg[7], 1ull); }
-  }
-  __syncthreads();
-  if (dbg && tid == 0) dbg[4] = wall_clock64();
 }
 
-size_t cov_components_lds(int kmax) {
-  return (((size_t)kmax * 3 + 3) & ~(size_t)3) * sizeof(int) + (size_t)COMP_THREADS * (COV_LCAP * 8 + 32 * 4);
+// ---- C2: replay.  One wavefront per component, members in ascending order. ----
+__global__ __launch_bounds__(64 * COV_WAVES) void cov_replay_kernel(FrameBufs f, RecordLayout rl, CovScratch cs,
+                                                                    int H, int W) {
+  __shared__ WaveMem s_mem[COV_WAVES];
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int widx = blockIdx.x * COV_WAVES + wv;
+  const CovFrame c = cov_frame(f, rl, cs, b, H, W);
+  if ((c.hdr[2] & 1) || widx >= *c.nworkers) return;
+  int j = c.workers[widx];
+  while (j >= 0) {
+    const int jn = c.nxt[j];  // issued together with the coordinates: one round trip per member
+    const float fx = c.kp_xy[2 * j], fy = c.kp_xy[2 * j + 1];
+    Walk w{&s_mem[wv], c.hinv, c.done, c.queues + (size_t)j * cs.qcap, c.qvals + (size_t)j * cs.qcap, cs.qcap, W,
+           H, (int)fx, (int)fy, j};
+    stage_window<true>(w, lane);
+    // a replay's pop list is a subsequence of the lone walk's: it cannot overflow
+    const int n = walk<true>(w, lane);
+    if (n < 0) { if (lane == 0) atomicOr(&c.hdr[2], 1); return; }
+    moments(w, n, lane, c.cov2 + 2 * j, c.cinv + 2 * j);
+    // stamp before the next member starts: this wavefront is the only writer and
+    // the only reader of these pixels during the kernel
+    for (int i = lane; i < n; i += 64) c.done[fifo_id(w, i)] = j;  // popped => its stamp was >= j
+    __threadfence_block();  // same wavefront, same CU: L1 is coherent for it
+    j = jn;
+  }
 }
+
+size_t cov_link_lds(int kmax) { return (size_t)kmax * 2 * sizeof(int); }
 
 hipError_t launch_cov(const FrameBufs &f, const RecordLayout &r, const CovScratch &cs, int B, int H, int W,
                       hipStream_t s) {
@@ -337,17 +390,20 @@ hipError_t launch_cov(const FrameBufs &f, const RecordLayout &r, const CovScratc
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(cs.done, 0x7f, (size_t)B * H * W * 4, s);
   if (e != hipSuccess) return e;
-  e = hipMemsetAsync(cs.ndirty, 0, (size_t)B * 4, s);
+  e = hipMemsetAsync(cs.counters, 0, (size_t)B * 2 * 4, s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(cov_walk_kernel, dim3((r.kmax + WALK_THREADS - 1) / WALK_THREADS, B), dim3(WALK_THREADS), 0,
-                     s, f, r, cs, H, W);
-  hipLaunchKernelGGL(cov_classify_kernel, dim3((r.kmax + 63) / 64, B), dim3(64), 0, s, f, r, cs, H, W);
-  const size_t lds = cov_components_lds(r.kmax);
+  const dim3 grid((r.kmax + COV_WAVES - 1) / COV_WAVES, B), block(64 * COV_WAVES);
+  hipLaunchKernelGGL(cov_walk_kernel, grid, block, 0, s, f, r, cs, H, W);
+  hipLaunchKernelGGL(cov_classify_kernel, grid, block, 0, s, f, r, cs, H, W);
+  const size_t lds = cov_link_lds(r.kmax);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  e = hipFuncSetAttribute(reinterpret_cast<const void *>(cov_components_kernel),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(cov_components_kernel, dim3(B), dim3(COMP_THREADS), lds, s, f, r, cs, H, W);
+  if (lds > 64 * 1024) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(cov_link_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(cov_link_kernel, dim3(B), dim3(LINK_THREADS), lds, s, f, r, cs, H, W);
+  hipLaunchKernelGGL(cov_replay_kernel, grid, block, 0, s, f, r, cs, H, W);
   return hipGetLastError();
 }
 

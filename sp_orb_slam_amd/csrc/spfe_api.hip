@@ -263,12 +263,9 @@ int build(spfe_handle h, const spfe_config *cfg) {
     if ((rc = dev_alloc(h, &h->cov.qval, (size_t)B * h->kmax * h->cov.qcap))) return rc;
     if ((rc = dev_alloc(h, &h->cov.npop, (size_t)B * h->kmax))) return rc;
     if ((rc = dev_alloc(h, &h->cov.dirty, (size_t)B * h->kmax))) return rc;
-    if ((rc = dev_alloc(h, &h->cov.ndirty, (size_t)B))) return rc;
-    if (getenv("SPFE_COV_DEBUG")) {
-      if ((rc = dev_alloc(h, &h->cov.dbg, (size_t)B * 16))) return rc;
-      HIP_TRY(hipMemset(h->cov.dbg, 0, (size_t)B * 16 * 8));
-    }
-
+    if ((rc = dev_alloc(h, &h->cov.nxt, (size_t)B * h->kmax))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.workers, (size_t)B * h->kmax))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.counters, (size_t)B * 2))) return rc;
   }
   make_layout(h->kmax, C, &h->rl);
   if ((rc = dev_alloc(h, &h->d_records, (size_t)B * h->rl.bytes))) return rc;
@@ -413,9 +410,8 @@ int spfe_create(const spfe_config *cfg, spfe_handle *out) {
                 cfg->width, cfg->height);
   if (cfg->height < 16 || cfg->width < 16)
     return fail(SPFE_EINVAL, "image size %dx%d too small", cfg->width, cfg->height);
-  if (cfg->num_features < 1 || spfe::cov_components_lds(cfg->num_features + 1) > 160 * 1024)
-    return fail(SPFE_EINVAL, "num_features %d out of range (1..3800: the covariance stage keeps a "
-                "per-keypoint table in LDS)", cfg->num_features);
+  if (cfg->num_features < 1 || cfg->num_features > 16384)
+    return fail(SPFE_EINVAL, "num_features %d out of range (1..16384)", cfg->num_features);
   if (cfg->max_batch < 1) return fail(SPFE_EINVAL, "max_batch must be >= 1");
   if (cfg->precision != SPFE_PRECISION_F32) return fail(SPFE_EINVAL, "unsupported precision %d", cfg->precision);
   if ((size_t)(cfg->height / 8) * (cfg->width / 8) > 65535 ||
@@ -564,7 +560,6 @@ long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size
   else if (nm == "heat_inv") { src = h->d_heat_inv + frame * HW; bytes = HW * 4; }
   else if (nm == "heat" && h->d_heat) { src = h->d_heat + frame * HW; bytes = HW * 4; }
   else if (nm == "cell_score") { src = h->d_cell_score + frame * C; bytes = C * 4; }
-  else if (nm == "cov_dbg" && h->cov.dbg) { src = h->cov.dbg + frame * 16; bytes = 16 * 8; }
   else if (nm == "feat") { src = h->act[7] + frame * C * 128; bytes = C * 128 * 4; }
   else if (nm.size() == 4 && nm.compare(0, 3, "act") == 0 && nm[3] >= '0' && nm[3] <= '7') {
     const int i = nm[3] - '0';

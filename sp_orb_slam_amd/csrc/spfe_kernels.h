@@ -57,19 +57,20 @@ struct RecordLayout {
   size_t off_hdr, off_xy, off_resp, off_cov, off_cinv, off_desc, off_occ, off_dd, off_sd;
 };
 
-// scratch of the covariance kernel (cov.hip)
+// scratch of the covariance kernels (cov.hip)
 struct CovScratch {
-  int *claim;          // [B][H*W] lowest keypoint index whose lone walk popped the pixel
-  int *done;           // [B][H*W] lowest FINAL keypoint index that popped the pixel
-  int *queue;          // [B][kmax][qcap] per-keypoint FIFO == pop list (pixel index)
-  float *qval;         // [B][kmax][qcap] heat_inv value of each queued pixel
-  int *npop;           // [B][kmax]
-  int *dirty;          // [B][kmax] keypoints whose lone region meets a lower keypoint's
-  int *ndirty;         // [B]
-  unsigned long long *dbg;  // [B][16] timestamps of the components kernel (SPFE_COV_DEBUG) or null
+  int *claim;     // [B][H*W] lowest keypoint index whose lone walk popped the pixel
+  int *done;      // [B][H*W] lowest FINAL keypoint index that popped the pixel
+  int *queue;     // [B][kmax][qcap] per-keypoint pop list (pixel index)
+  float *qval;    // [B][kmax][qcap] heat_inv value of each popped pixel
+  int *npop;      // [B][kmax]
+  int *dirty;     // [B][kmax] keypoints whose lone region meets a lower keypoint's
+  int *nxt;       // [B][kmax] next dirty member of the same component (ascending) or -1
+  int *workers;   // [B][kmax] lowest dirty member of each component
+  int *counters;  // [B][2] number of dirty keypoints, number of components
   int qcap;
 };
-size_t cov_components_lds(int kmax);
+size_t cov_link_lds(int kmax);
 hipError_t launch_cov(const FrameBufs &f, const RecordLayout &r, const CovScratch &cs, int B, int H, int W,
                       hipStream_t s);
 
