@@ -61,24 +61,22 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local))
 
-    from sp_orb_slam_amd import synth, weights
+    from sp_orb_slam_amd import parallel, synth, weights
     from sp_orb_slam_amd.extractor import SPExtractor
 
     H, W, nf, B = args.height, args.width, args.num_features, args.frames_per_gpu
     blob = weights.synthetic(7, args.detector)
     ext = SPExtractor(nf, H, W, blob, max_batch=B, device=local, with_heat=False)
     rec_bytes = ext.record_bytes()
-    # synthetic frames: seeds 200.., distinct per rank
-    frames = synth.make_batch(200 + rank * B, B, H, W)
+    # synthetic frames: seeds 200..; rank r owns global frames [r*B, (r+1)*B)
+    lo, hi = parallel.shard_range(world * B, world, rank)
+    frames = synth.make_batch(200 + lo, hi - lo, H, W)
     d_img = torch.from_numpy(frames).cuda()
-    d_rec = torch.zeros(B * rec_bytes, dtype=torch.uint8, device="cuda")
-    d_all = torch.zeros(world * B * rec_bytes, dtype=torch.uint8, device="cuda") if world > 1 else None
+    sharded = parallel.ShardedExtractor(ext, world, rank, B)
     stream = torch.cuda.current_stream()
 
     def step():
-        ext.extract_batch_device(d_img.data_ptr(), B, d_rec.data_ptr(), stream.cuda_stream)
-        if world > 1:
-            dist.all_gather_into_tensor(d_all, d_rec)
+        sharded.step(d_img, stream)   # HIP path on this rank's shard + RCCL all-gather of the records
 
     for _ in range(args.warmup):
         step()
@@ -102,11 +100,9 @@ def main():
     stages = ext.stage_times()
 
     # sanity: the gathered records decode and carry the expected keypoint counts
-    rec0 = ext.view_record(d_rec[:rec_bytes].cpu().numpy())
-    if world > 1:
-        recl = ext.view_record(d_all[(world * B - 1) * rec_bytes:].cpu().numpy())
-        assert 0 < recl.K <= nf + 1
-    assert 0 < rec0.K <= nf + 1
+    rec0 = sharded.decode(0)
+    recl = sharded.decode(world * B - 1)
+    assert 0 < rec0.K <= nf + 1 and 0 < recl.K <= nf + 1 and rec0.status == 0 and recl.status == 0
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3

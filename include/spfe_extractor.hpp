@@ -1,0 +1,111 @@
+// spfe_extractor.hpp — C++ host adaptor over the C ABI (include/spfe.h).
+//
+// Restores the reference's extractor call shape for the ORB-SLAM2 back-end:
+//   virtual void operator()(cv::InputArray image, cv::InputArray mask,
+//                           std::vector<cv::KeyPoint>& keypoints,
+//                           cv::OutputArray descriptors)
+// (/root/reference/orb_slam2/include/orb_slam/cv/base_extractor.h:54-56, overridden
+// at sp_extractor.h:57-59) and the public side outputs Frame::ExtractORB reads
+// right after the call (/root/reference/orb_slam2/src/type/frame.cpp:296-314):
+// getCov2Inv(), dense_dust_, heat_, occ_grid_ (plus semi_dust_, heat_inv_, mask_,
+// getCov(), getHeatMap(), getMask() — sp_extractor.h:61-73).
+//
+// Header-only; needs OpenCV core on the CONSUMER side only (libspfe.so itself has
+// no OpenCV/Eigen/torch dependency).  The covariance getters return
+// std::vector<spfe::Vec2f>; INTEGRATION.md shows the three-line conversion to
+// the reference's std::vector<Eigen::Vector2f> and the drop-in
+// `orbslam::SPExtractor` built on this class.
+#pragma once
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include <opencv2/core.hpp>
+
+#include "spfe.h"
+
+namespace spfe {
+
+struct Vec2f {
+  float x, y;
+};
+
+class ExtractorCV {
+ public:
+  // Reference ctor: SPExtractor(int nfeatures) reading camera::height/width and
+  // common::model_path from globals (sp_extractor.cpp:342-359).
+  ExtractorCV(int nfeatures, int height, int width, const std::string &weights_path, int device = 0,
+              bool with_heat = true)
+      : height_(height), width_(width) {
+    spfe_config cfg{};
+    cfg.height = height;
+    cfg.width = width;
+    cfg.num_features = nfeatures;
+    cfg.max_batch = 1;
+    cfg.device = device;
+    cfg.precision = SPFE_PRECISION_F32;
+    cfg.flags = with_heat ? SPFE_FLAG_HEAT : 0u;
+    cfg.weights = nullptr;
+    cfg.weights_path = weights_path.c_str();
+    if (spfe_create(&cfg, &h_) != SPFE_OK) throw std::runtime_error(std::string("spfe_create: ") + spfe_last_error());
+  }
+  ExtractorCV(const ExtractorCV &) = delete;
+  ExtractorCV &operator=(const ExtractorCV &) = delete;
+  virtual ~ExtractorCV() { spfe_destroy(h_); }
+
+  // Same signature and semantics as SPExtractor::operator() (sp_extractor.cpp:361-514).
+  // `mask` is ignored, as in the reference.
+  void operator()(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint> &_keypoints,
+                  cv::OutputArray _descriptors) {
+    if (_image.empty()) throw std::runtime_error("input image is empty");  // :364-365
+    cv::Mat image = _image.getMat();
+    if (image.type() != CV_8UC1) throw std::runtime_error("input image must be CV_8UC1");  // assert :368
+    if (image.rows != height_ || image.cols != width_)
+      throw std::runtime_error("input image size differs from the configured extractor size");
+    spfe_result r{};
+    const int rc = spfe_extract(h_, image.data, static_cast<int>(image.step), &r);
+    if (rc == SPFE_EEMPTY) throw std::runtime_error("input image is empty");
+    if (rc != SPFE_OK) throw std::runtime_error(std::string("spfe_extract: ") + spfe_last_error());
+
+    const int hc = height_ / 8, wc = width_ / 8;
+    _keypoints.resize(r.K);
+    cov2_.resize(r.K);
+    cov2_inv_.resize(r.K);
+    for (int i = 0; i < r.K; ++i) {
+      cv::KeyPoint kp(r.kp_xy[2 * i], r.kp_xy[2 * i + 1], 1.0f);  // :231-232
+      kp.response = r.kp_response[i];                              // :271
+      _keypoints[i] = kp;
+      cov2_[i] = {r.cov2[2 * i], r.cov2[2 * i + 1]};
+      cov2_inv_[i] = {r.cov2_inv[2 * i], r.cov2_inv[2 * i + 1]};
+    }
+    _descriptors.create(r.K, SPFE_DESC_DIM, CV_32FC1);  // :512
+    if (r.K > 0)
+      cv::Mat(r.K, SPFE_DESC_DIM, CV_32FC1, const_cast<float *>(r.desc)).copyTo(_descriptors.getMat());
+    // side outputs: deep copies (the library buffers live until the next call)
+    cv::Mat(hc, wc, CV_32FC1, const_cast<float *>(r.semi_dust)).copyTo(semi_dust_);
+    cv::Mat(hc, wc, CV_32FC1, const_cast<float *>(r.dense_dust)).copyTo(dense_dust_);
+    cv::Mat(hc, wc, CV_16SC1, const_cast<int16_t *>(r.occ_grid)).copyTo(occ_grid_);
+    if (r.heat) cv::Mat(height_, width_, CV_32FC1, const_cast<float *>(r.heat)).copyTo(heat_);
+    if (r.heat_inv) cv::Mat(height_, width_, CV_32FC1, const_cast<float *>(r.heat_inv)).copyTo(heat_inv_);
+    status_ = r.status;
+  }
+
+  cv::Mat getMask() { return mask_; }
+  cv::Mat getHeatMap() { return heat_; }
+  const std::vector<Vec2f> &getCov() const { return cov2_; }
+  const std::vector<Vec2f> &getCov2Inv() const { return cov2_inv_; }
+  int status() const { return status_; }
+  spfe_handle handle() const { return h_; }
+
+  cv::Mat semi_dust_, dense_dust_;
+  cv::Mat mask_, heat_, heat_inv_;  // mask_ is never written (nor by the reference)
+  cv::Mat occ_grid_;
+
+ protected:
+  std::vector<Vec2f> cov2_, cov2_inv_;
+  spfe_handle h_ = nullptr;
+  int height_, width_, status_ = 0;
+};
+
+}  // namespace spfe

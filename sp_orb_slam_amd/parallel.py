@@ -1,0 +1,161 @@
+"""Frame-sharded multi-GPU extraction: one process per GPU, RCCL all-gather of
+fixed-stride result records.
+
+The reference is single-GPU, batch 1 (sp_extractor.cpp:70 "TODO: batch-size",
+.squeeze() at :97); frames are independent (operator() reads only the image and
+the weights), so a batch shards contiguously over ranks with NO collective in
+the data path.  The only exchange is the final gather of what every consumer
+needs: keypoints, descriptors, covariances, occ_grid and the dustbin maps, packed
+by the kernels into one record per frame (layout: spfe_record_layout in
+include/spfe.h).  Records have a fixed stride, so one `all_gather_into_tensor`
+moves everything and no count exchange is needed (K lives in the header).
+
+xGMI is point-to-point (7 links per GPU): with 8 frames x ~1.1 MB per rank the
+gather is ~9 MB per rank, far below a millisecond per link — the collective is
+not the bottleneck, so it is issued once per batch, not per frame.
+
+`torch` is used for device buffers, streams and the process group only.  The
+gather and the record codec also run on CPU tensors with the gloo backend,
+which is how tests cover the N > 1 path without GPUs.
+"""
+import numpy as np
+
+DESC_DIM = 256
+
+
+def shard_range(n_frames, world, rank):
+    """Contiguous split of a global batch: frames [lo, hi) belong to `rank`.
+    The first n_frames % world ranks get one extra frame."""
+    if world < 1 or not (0 <= rank < world) or n_frames < 0:
+        raise ValueError("bad shard arguments")
+    base, rem = divmod(n_frames, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _align(v, a):
+    return (v + a - 1) // a * a
+
+
+class RecordLayout:
+    """Python mirror of make_layout() in csrc/spfe_api.hip (checked against the
+    library by tests): byte offsets inside one per-frame record."""
+
+    def __init__(self, height, width, num_features):
+        self.height, self.width = height, width
+        self.kmax = num_features + 1
+        self.cells = (height // 8) * (width // 8)
+        o = 0
+        self.off_hdr = o; o += 16
+        self.off_xy = o; o = _align(o + self.kmax * 2 * 4, 16)
+        self.off_resp = o; o = _align(o + self.kmax * 4, 16)
+        self.off_cov = o; o = _align(o + self.kmax * 2 * 4, 16)
+        self.off_cinv = o; o = _align(o + self.kmax * 2 * 4, 16)
+        self.off_desc = o; o = _align(o + self.kmax * DESC_DIM * 4, 16)
+        self.off_occ = o; o = _align(o + self.cells * 2, 16)
+        self.off_dd = o; o = _align(o + self.cells * 4, 16)
+        self.off_sd = o; o = _align(o + self.cells * 4, 16)
+        self.bytes = _align(o, 256)
+
+    # -- codec (numpy, no GPU, no library) --
+    def pack(self, fr):
+        """Dict/obj with K, n_candidates, kp_xy, response, cov2, cov2_inv, desc,
+        occ_grid, dense_dust, semi_dust -> uint8[bytes]."""
+        g = (lambda k: fr[k]) if isinstance(fr, dict) else (lambda k: getattr(fr, k))
+        K = int(g("K"))
+        if K > self.kmax:
+            raise ValueError("K=%d exceeds kmax=%d" % (K, self.kmax))
+        rec = np.zeros(self.bytes, np.uint8)
+        rec[self.off_hdr:self.off_hdr + 16] = np.array(
+            [K, int(g("n_candidates")), int(g("status")) if self._has(fr, "status") else 0, 0],
+            np.int32).view(np.uint8)
+
+        def put(off, arr, dt):
+            b = np.ascontiguousarray(arr, dt).reshape(-1).view(np.uint8)
+            rec[off:off + b.size] = b
+
+        put(self.off_xy, g("kp_xy"), np.float32)
+        put(self.off_resp, g("response"), np.float32)
+        put(self.off_cov, g("cov2"), np.float32)
+        put(self.off_cinv, g("cov2_inv"), np.float32)
+        put(self.off_desc, g("descriptors") if self._has(fr, "descriptors") else g("desc"), np.float32)
+        put(self.off_occ, g("occ_grid"), np.int16)
+        put(self.off_dd, g("dense_dust"), np.float32)
+        put(self.off_sd, g("semi_dust"), np.float32)
+        return rec
+
+    @staticmethod
+    def _has(fr, k):
+        return (k in fr) if isinstance(fr, dict) else hasattr(fr, k)
+
+    def unpack(self, rec):
+        """uint8[bytes] -> dict (views are copied)."""
+        rec = np.ascontiguousarray(rec, np.uint8)
+        if rec.size != self.bytes:
+            raise ValueError("record has %d bytes, expected %d" % (rec.size, self.bytes))
+        hdr = rec[self.off_hdr:self.off_hdr + 16].view(np.int32)
+        K = int(hdr[0])
+        if not (0 <= K <= self.kmax):
+            raise ValueError("corrupt record: K=%d" % K)
+        hc, wc = self.height // 8, self.width // 8
+
+        def get(off, n, dt):
+            return rec[off:off + n * np.dtype(dt).itemsize].view(dt).copy()
+
+        return dict(K=K, n_candidates=int(hdr[1]), status=int(hdr[2]),
+                    kp_xy=get(self.off_xy, K * 2, np.float32).reshape(K, 2),
+                    response=get(self.off_resp, K, np.float32),
+                    cov2=get(self.off_cov, K * 2, np.float32).reshape(K, 2),
+                    cov2_inv=get(self.off_cinv, K * 2, np.float32).reshape(K, 2),
+                    desc=get(self.off_desc, K * DESC_DIM, np.float32).reshape(K, DESC_DIM),
+                    occ_grid=get(self.off_occ, hc * wc, np.int16).reshape(hc, wc),
+                    dense_dust=get(self.off_dd, hc * wc, np.float32).reshape(hc, wc),
+                    semi_dust=get(self.off_sd, hc * wc, np.float32).reshape(hc, wc))
+
+
+def gather_records(local_records, world, group=None):
+    """all-gather the per-rank record blocks.
+
+    local_records: torch uint8 tensor [frames_per_rank * record_bytes] (every rank
+    the same length: pad the shard if the batch does not divide evenly).
+    Returns [world * frames_per_rank * record_bytes], rank-major = global frame
+    order of shard_range().  On the GPU this is one RCCL all-gather over xGMI
+    (backend "nccl"); on CPU tensors it runs over gloo.
+    """
+    import torch
+    import torch.distributed as dist
+
+    if world == 1:
+        return local_records
+    out = torch.empty(world * local_records.numel(), dtype=torch.uint8, device=local_records.device)
+    dist.all_gather_into_tensor(out, local_records.contiguous(), group=group)
+    return out
+
+
+class ShardedExtractor:
+    """Per-rank driver of the batched path (BASELINE configs[2]): takes this
+    rank's shard of device-resident frames, runs the HIP path, all-gathers the
+    records.  One instance per process / GPU."""
+
+    def __init__(self, extractor, world, rank, frames_per_rank):
+        import torch
+
+        self.ext, self.world, self.rank, self.fpr = extractor, world, rank, frames_per_rank
+        self.rec_bytes = extractor.record_bytes()
+        self.local = torch.zeros(frames_per_rank * self.rec_bytes, dtype=torch.uint8, device="cuda")
+        self.all = (torch.zeros(world * frames_per_rank * self.rec_bytes, dtype=torch.uint8, device="cuda")
+                    if world > 1 else self.local)
+
+    def step(self, d_images, stream):
+        """d_images: torch uint8 [frames_per_rank, H, W] on this rank's GPU."""
+        import torch.distributed as dist
+
+        self.ext.extract_batch_device(d_images.data_ptr(), self.fpr, self.local.data_ptr(), stream.cuda_stream)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.all, self.local)
+        return self.all
+
+    def decode(self, frame):
+        """Host copy + decode of global frame `frame` from the gathered buffer."""
+        rb = self.rec_bytes
+        return self.ext.view_record(self.all[frame * rb:(frame + 1) * rb].cpu().numpy())

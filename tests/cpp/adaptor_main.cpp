@@ -1,0 +1,56 @@
+// Drives include/spfe_extractor.hpp exactly the way Frame::ExtractORB drives the
+// reference extractor (/root/reference/orb_slam2/src/type/frame.cpp:296-314):
+//   (*extractor)(im, cv::Mat(), mvKeys, mDescriptors); then read getCov2Inv(),
+//   dense_dust_, heat_, occ_grid_.
+// usage: adaptor_main <weights.spfw> <image.raw> <H> <W> <nfeatures> <out.bin>
+// out.bin: int32 K, then K x {x, y, response, cov2inv_x, cov2inv_y}, K x 256 desc,
+//          occ_grid int16 [hc*wc], dense_dust f32 [hc*wc], heat f32 [H*W]
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "spfe_extractor.hpp"
+
+int main(int argc, char **argv) {
+  if (argc != 7) return 2;
+  const int H = atoi(argv[3]), W = atoi(argv[4]), nf = atoi(argv[5]);
+  std::vector<unsigned char> pix((size_t)H * W);
+  FILE *f = fopen(argv[2], "rb");
+  if (!f || fread(pix.data(), 1, pix.size(), f) != pix.size()) return 3;
+  fclose(f);
+  try {
+    spfe::ExtractorCV extractor(nf, H, W, argv[1]);
+    cv::Mat im(H, W, CV_8UC1, pix.data());
+    std::vector<cv::KeyPoint> mvKeys;
+    cv::Mat mDescriptors, noMask;
+    extractor(im, noMask, mvKeys, mDescriptors);
+    // empty image must throw like the reference (sp_extractor.cpp:364-365)
+    bool threw = false;
+    try {
+      cv::Mat empty;
+      extractor(empty, noMask, mvKeys, mDescriptors);
+    } catch (const std::runtime_error &e) {
+      threw = std::string(e.what()) == "input image is empty";
+    }
+    if (!threw) return 5;
+    extractor(im, noMask, mvKeys, mDescriptors);
+    const auto &cinv = extractor.getCov2Inv();
+    FILE *o = fopen(argv[6], "wb");
+    const int K = (int)mvKeys.size();
+    fwrite(&K, 4, 1, o);
+    for (int i = 0; i < K; ++i) {
+      const float rec[5] = {mvKeys[i].pt.x, mvKeys[i].pt.y, mvKeys[i].response, cinv[i].x, cinv[i].y};
+      fwrite(rec, 4, 5, o);
+      if (mvKeys[i].size != 1.0f || mvKeys[i].angle != -1.0f || mvKeys[i].octave != 0) return 6;
+    }
+    if (K) fwrite(mDescriptors.data, 4, (size_t)K * 256, o);
+    fwrite(extractor.occ_grid_.data, 2, (size_t)(H / 8) * (W / 8), o);
+    fwrite(extractor.dense_dust_.data, 4, (size_t)(H / 8) * (W / 8), o);
+    fwrite(extractor.heat_.data, 4, (size_t)H * W, o);
+    fclose(o);
+  } catch (const std::exception &e) {
+    fprintf(stderr, "adaptor_main: %s\n", e.what());
+    return 4;
+  }
+  return 0;
+}

@@ -80,3 +80,21 @@ def test_product_does_not_import_oracle():
                     txt = open(os.path.join(dirpath, fn), errors="ignore").read()
                     assert "oracle/" not in txt.replace("oracle/spfe_oracle.c);", "") or fn == "spfe_exact_math.h", fn
                     assert "import oracle" not in txt and "from oracle" not in txt, fn
+
+
+def _build_adaptor(tmpdir):
+    import subprocess
+    exe = os.path.join(str(tmpdir), "adaptor_main")
+    pkg = os.path.join(ROOT, "sp_orb_slam_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "tests", "stubs"),
+                           os.path.join(ROOT, "tests", "cpp", "adaptor_main.cpp"), "-o", exe,
+                           "-L" + pkg, "-lspfe", "-Wl,-rpath," + pkg])
+    return exe
+
+
+def test_cpp_adaptor_compiles_and_links(tmp_path):
+    """include/spfe_extractor.hpp (the BaseExtractor-shaped C++ host class) builds against the
+    C ABI; OpenCV core is stood in for by tests/stubs (the image has no OpenCV)."""
+    exe = _build_adaptor(tmp_path)
+    assert os.path.exists(exe)

@@ -245,3 +245,46 @@ def test_nms_cut_and_border_properties_720p():
     assert np.abs(np.linalg.norm(desc, axis=1) - 1).max() < 1e-6             # unit descriptors
     assert np.all(fr.cov2 >= 1.0) and np.allclose(fr.cov2 * fr.cov2_inv, 1, rtol=1e-6)
     ext.close()
+
+
+def test_cpp_adaptor_matches_python_path(tmp_path):
+    """The C++ adaptor (include/spfe_extractor.hpp), driven like Frame::ExtractORB drives the
+    reference (frame.cpp:296-314), returns the same bits as the ctypes path."""
+    import subprocess
+    from test_abi import _build_adaptor
+    H, W, nf = 120, 160, 200
+    blob = weights.synthetic(7, "dense")
+    img = synth.make_image(12, H, W)
+    wpath, ipath, opath = tmp_path / "w.spfw", tmp_path / "im.raw", tmp_path / "out.bin"
+    weights.save(wpath, blob)
+    img.tofile(ipath)
+    exe = _build_adaptor(tmp_path)
+    subprocess.check_call([exe, str(wpath), str(ipath), str(H), str(W), str(nf), str(opath)])
+    raw = np.fromfile(opath, np.uint8)
+    K = int(raw[:4].view(np.int32)[0])
+    off = 4
+    kp = raw[off:off + K * 20].view(np.float32).reshape(K, 5); off += K * 20
+    desc = raw[off:off + K * 1024].view(np.float32).reshape(K, 256); off += K * 1024
+    C = (H // 8) * (W // 8)
+    occ = raw[off:off + C * 2].view(np.int16).reshape(H // 8, W // 8); off += C * 2
+    dust = raw[off:off + C * 4].view(np.float32).reshape(H // 8, W // 8); off += C * 4
+    heat = raw[off:off + H * W * 4].view(np.float32).reshape(H, W)
+    ext = SPExtractor(nf, H, W, blob)
+    ext(img, None)
+    fr = ext.last
+    assert K == fr.K and np.array_equal(kp[:, :2], fr.kp_xy) and np.array_equal(kp[:, 2], fr.response)
+    assert np.array_equal(kp[:, 3:], fr.cov2_inv) and np.array_equal(desc, fr.descriptors)
+    assert np.array_equal(occ, fr.occ_grid) and np.array_equal(dust, fr.dense_dust)
+    assert np.array_equal(heat, fr.heat)
+    ext.close()
+
+
+def test_python_record_layout_matches_library():
+    from sp_orb_slam_amd import parallel
+    for (H, W, nf) in [(64, 96, 30), (480, 752, 1000), (720, 1280, 800)]:
+        ext = SPExtractor(nf, H, W, weights.synthetic(7, "dense"), with_heat=False)
+        lay = parallel.RecordLayout(H, W, nf)
+        for name in ("bytes", "kmax", "off_hdr", "off_xy", "off_resp", "off_cov", "off_cinv", "off_desc",
+                     "off_occ", "off_dd", "off_sd"):
+            assert getattr(lay, name) == getattr(ext.layout, name), name
+        ext.close()
