@@ -44,15 +44,14 @@ def main():
                    100.0 * a["tot"] / total, "x".join(str(g) for g in a["grid"]), a["wg"], a["lds"],
                    a["vgpr"] + a["agpr"]))
         try:
-            pm = cur.execute("select k.name, p.name, sum(e.value), count(*) from pmc_events e "
-                             "join pmc_info p on p.id = e.pmc_id join kernels k on k.dispatch_id = e.dispatch_id "
-                             "group by k.name, p.name").fetchall()
+            pm = cur.execute("select name, counter_name, sum(counter_value), count(*), min(counter_value), "
+                             "max(counter_value) from pmc_events group by name, counter_name").fetchall()
         except sqlite3.Error:
             pm = []
         if pm:
-            print("\n# PMC counters (sum over dispatches, dispatch count)")
-            for kname, cname, val, cnt in sorted(pm):
-                print("%-74s %-28s %18.0f %6d" % (short(kname)[:74], cname, val, cnt))
+            print("\n# PMC counters per kernel: sum over dispatches, dispatches, min, max per dispatch")
+            for kname, cname, val, cnt, mn, mx in sorted(pm):
+                print("%-74s %-28s %18.1f %5d %16.1f %16.1f" % (short(kname)[:74], cname, val, cnt, mn, mx))
         print()
 
 
