@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--detector", default="dense", choices=["dense", "sparse"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency probe")
+    ap.add_argument("--sync-cov", action="store_true",
+                    help="do not overlap the covariance stage of step i with the convolutions of step i+1")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -66,7 +68,7 @@ def main():
 
     H, W, nf, B = args.height, args.width, args.num_features, args.frames_per_gpu
     blob = weights.synthetic(7, args.detector)
-    ext = SPExtractor(nf, H, W, blob, max_batch=B, device=local, with_heat=False)
+    ext = SPExtractor(nf, H, W, blob, max_batch=B, device=local, with_heat=False, async_cov=not args.sync_cov)
     rec_bytes = ext.record_bytes()
     # synthetic frames: seeds 200..; rank r owns global frames [r*B, (r+1)*B)
     lo, hi = parallel.shard_range(world * B, world, rank)
@@ -80,6 +82,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    sharded.flush(stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -88,6 +91,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    sharded.flush(stream)   # the last batch's covariance + gather are inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -124,8 +128,10 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%dx%d u8 frames, num_features=%d, f32 MFMA, %d frames/GPU/step, "
-                                   "%s synthetic detector weights; records all-gathered over RCCL when n_gpus>1"
-                                   % (W, H, nf, B, args.detector),
+                                   "%s synthetic detector weights; records all-gathered over RCCL when n_gpus>1; %s"
+                                   % (W, H, nf, B, args.detector,
+                                      "covariance stage on the device, synchronous" if args.sync_cov else
+                                      "covariance of step i overlapped with the convolutions of step i+1 (depth-2 pipeline)"),
                        "frames_per_gpu": B, "height": H, "width": W, "num_features": nf,
                        "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": "conv_f32_kernel<64,3,16,...,pool> (conv1b)",

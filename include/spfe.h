@@ -41,6 +41,11 @@ extern "C" {
 
 /* spfe_config.flags */
 #define SPFE_FLAG_HEAT 1u /* also produce heat / heat_inv (H*W floats each), sp_extractor.cpp:461-474 */
+#define SPFE_FLAG_ASYNC_COV 2u /* spfe_extract_batch_device only: the covariance stage (cov2, cov2_inv, status of
+                                  the records) runs on a library-owned side stream and is NOT ordered into the
+                                  caller's stream by the call; order it with spfe_wait_records(ticket) before
+                                  reading the records.  Lets the latency-bound covariance of batch i overlap the
+                                  convolutions of batch i+1.  Pass a different record buffer to consecutive calls. */
 
 /* spfe_result.status / record header word 2 */
 #define SPFE_STATUS_COV_OVERFLOW 1 /* a covariance region outgrew the device FIFO (SPFE_COV_QCAP, default
@@ -140,6 +145,13 @@ SPFE_API int spfe_get_record_layout(spfe_handle h, spfe_record_layout *out);
 SPFE_API size_t spfe_record_bytes(spfe_handle h);
 SPFE_API int spfe_extract_batch_device(spfe_handle h, const void *d_images, int n, void *d_records,
                               void *stream);
+/* Ticket of the most recent spfe_extract_batch_device call on this handle (0, 1, 2, ...), and the
+ * ordering point for SPFE_FLAG_ASYNC_COV: makes `stream` (NULL = the handle's stream) wait until the
+ * records of call `ticket` (one of the last 4 calls) are complete.  Without the flag the call itself
+ * does this and spfe_wait_records is a no-op dependency. */
+SPFE_API long spfe_last_ticket(spfe_handle h);
+SPFE_API int spfe_wait_records(spfe_handle h, long ticket, void *stream);
+
 /* Host view of ONE record that the caller copied to host memory. */
 SPFE_API int spfe_view_record(spfe_handle h, const void *host_record, spfe_result *out);
 

@@ -91,46 +91,65 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(ConvParams p) {
   constexpr int NITER = (NITEM + 255) / 256;
   constexpr int NW4 = TAPS * KC * 16;  // float4 in the weight slab
 
+  // Register-staged software pipeline: the global loads of chunk c+1 are issued
+  // before the MFMA loop of chunk c and only written to LDS after it, so their
+  // latency hides under ~18k cycles of matrix work instead of standing between two
+  // barriers.
+  constexpr int NWITER = (NW4 + 255) / 256;
+  float4 va[NITER], vw[NWITER];
+  int dst[NITER];
+#pragma unroll
+  for (int it = 0; it < NITER; ++it) {  // per-thread staging slots are the same for every chunk
+    const int i = tid + it * 256;
+    const int qq = i % Q, pix = i / Q;
+    const int row = pix / G::COLS, col = pix % G::COLS;
+    dst[it] = (qq * 4) * PLANE + row * ROWP + col;
+  }
+#define SPFE_LOAD_CHUNK(CHUNK_)                                                                       \
+  do {                                                                                                \
+    _Pragma("unroll") for (int it = 0; it < NITER; ++it) {                                            \
+      const int i = tid + it * 256;                                                                   \
+      const int qq = i % Q, pix = i / Q;                                                              \
+      const int row = pix / G::COLS, col = pix % G::COLS;                                             \
+      const int gy = ty0 + row - G::HALO, gx = tx0 + col - G::HALO;                                   \
+      va[it] = make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
+      if (i < NITEM && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)                      \
+        va[it] = *reinterpret_cast<const float4 *>(inb + ((size_t)gy * W + gx) * p.in_stride +       \
+                                                   (CHUNK_) * KC + qq * 4);                           \
+    }                                                                                                 \
+    const float4 *ws_ = reinterpret_cast<const float4 *>(                                             \
+        p.wpack + ((size_t)nb * NCHUNK + (CHUNK_)) * (TAPS * KC * 64));                               \
+    _Pragma("unroll") for (int it = 0; it < NWITER; ++it) {                                           \
+      const int i = tid + it * 256;                                                                   \
+      vw[it] = (i < NW4) ? ws_[i] : make_float4(0.f, 0.f, 0.f, 0.f);                                  \
+    }                                                                                                 \
+  } while (0)
+  SPFE_LOAD_CHUNK(0);
+
 #pragma unroll 1
   for (int chunk = 0; chunk < NCHUNK; ++chunk) {
-    if (chunk) __syncthreads();
-    // ---- stage the input halo tile, channel-major ----
-    {
-      float4 v[NITER];
-      int dst[NITER];
+    if (chunk) __syncthreads();  // every wave is done reading the previous chunk's tiles
 #pragma unroll
-      for (int it = 0; it < NITER; ++it) {
-        const int i = tid + it * 256;
-        const int qq = i % Q, pix = i / Q;
-        const int row = pix / G::COLS, col = pix % G::COLS;
-        const int gy = ty0 + row - G::HALO, gx = tx0 + col - G::HALO;
-        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        dst[it] = (qq * 4) * PLANE + row * ROWP + col;
-        if (i < NITEM && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-          v[it] = *reinterpret_cast<const float4 *>(inb + ((size_t)gy * W + gx) * p.in_stride +
-                                                    chunk * KC + qq * 4);
-      }
-#pragma unroll
-      for (int it = 0; it < NITER; ++it) {
-        const int i = tid + it * 256;
-        if (i < NITEM) {
-          float *d = sA + dst[it];
-          d[0] = v[it].x;
-          d[PLANE] = v[it].y;
-          d[2 * PLANE] = v[it].z;
-          d[3 * PLANE] = v[it].w;
-        }
+    for (int it = 0; it < NITER; ++it) {
+      const int i = tid + it * 256;
+      if (i < NITEM) {
+        float *d = sA + dst[it];
+        d[0] = va[it].x;
+        d[PLANE] = va[it].y;
+        d[2 * PLANE] = va[it].z;
+        d[3 * PLANE] = va[it].w;
       }
     }
-    // ---- stage the weight slab of this chunk (contiguous in global) ----
     {
-      const float4 *ws =
-          reinterpret_cast<const float4 *>(p.wpack + ((size_t)nb * NCHUNK + chunk) * (TAPS * KC * 64));
       float4 *wd = reinterpret_cast<float4 *>(sW);
 #pragma unroll
-      for (int i = tid; i < NW4; i += 256) wd[i] = ws[i];
+      for (int it = 0; it < NWITER; ++it) {
+        const int i = tid + it * 256;
+        if (i < NW4) wd[i] = vw[it];
+      }
     }
     __syncthreads();
+    if (chunk + 1 < NCHUNK) SPFE_LOAD_CHUNK(chunk + 1);  // in flight during the MFMA loop below
 
     // ---- MFMA over (tap, channel pair) in the contract's K order ----
 #pragma unroll

@@ -172,13 +172,16 @@ __device__ int walk(const Walk &w, int lane) {
 // second moments over the popped sequence, in pop order (:316-333).  Lanes hold
 // one entry each; lane order is pop order, and the running sums are accumulated
 // one entry at a time exactly like the reference's loops.
+__device__ __forceinline__ float lane_bcast(float v, int src_lane) {  // src_lane is wave-uniform
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
 __device__ void moments(const Walk &w, int n, int lane, float *cov2, float *cov2_inv) {
   float sum = 0.0f;
   for (int base = 0; base < n; base += 64) {
     const int i = base + lane;
     const float v = i < n ? fifo_val(w, i) : 0.0f;
     const int cnt = n - base < 64 ? n - base : 64;
-    for (int u = 0; u < cnt; ++u) sum += __shfl(v, u, 64);
+    for (int u = 0; u < cnt; ++u) sum += lane_bcast(v, u);
   }
   float cx = 0.0f, cy = 0.0f;
   for (int base = 0; base < n; base += 64) {
@@ -194,8 +197,8 @@ __device__ void moments(const Walk &w, int n, int lane, float *cov2, float *cov2
     }
     const int cnt = n - base < 64 ? n - base : 64;
     for (int u = 0; u < cnt; ++u) {
-      cx += __shfl(tx, u, 64);
-      cy += __shfl(ty, u, 64);
+      cx += lane_bcast(tx, u);
+      cy += lane_bcast(ty, u);
     }
   }
   if (lane == 0) {
@@ -340,14 +343,22 @@ __global__ __launch_bounds__(LINK_THREADS) void cov_link_kernel(FrameBufs f, Rec
   }
   __syncthreads();
   // chain: next dirty member of the same component in ascending index; leaders
-  // become the workers of the replay kernel
+  // become the workers of the replay kernel.  (leader[] doubles as scratch: the
+  // dirty list and each member's root, so the search below stays in LDS.)
+  int *sdirty = smem_i + 2 * K, *sroot = smem_i + 3 * K;
   for (int d = tid; d < nd; d += LINK_THREADS) {
     const int j = c.dirty[d];
-    const int root = parent[j];
+    sdirty[d] = j;
+    sroot[d] = parent[j];
+  }
+  __syncthreads();
+  for (int d = tid; d < nd; d += LINK_THREADS) {
+    const int j = sdirty[d];
+    const int root = sroot[d];
     int best = COV_INF;
     for (int e = 0; e < nd; ++e) {
-      const int i = c.dirty[e];
-      if (i > j && i < best && parent[i] == root) best = i;
+      const int i = sdirty[e];
+      if (i > j && i < best && sroot[e] == root) best = i;
     }
     c.nxt[j] = best == COV_INF ? -1 : best;
     if (leader[root] == j) c.workers[atomicAdd(c.nworkers, 1)] = j;
@@ -382,7 +393,7 @@ __global__ __launch_bounds__(64 * COV_WAVES) void cov_replay_kernel(FrameBufs f,
   }
 }
 
-size_t cov_link_lds(int kmax) { return (size_t)kmax * 2 * sizeof(int); }
+size_t cov_link_lds(int kmax) { return (size_t)kmax * 4 * sizeof(int); }
 
 hipError_t launch_cov(const FrameBufs &f, const RecordLayout &r, const CovScratch &cs, int B, int H, int W,
                       hipStream_t s) {

@@ -67,6 +67,13 @@ struct spfe_handle_s {
   spfe_config cfg{};
   int H = 0, W = 0, hc = 0, wc = 0, C = 0, kmax = 0, B = 0;
   hipStream_t stream = nullptr;
+  // covariance runs on a side stream: with SPFE_FLAG_ASYNC_COV it overlaps the next
+  // call's convolutions (it is latency bound and uses a handful of CUs)
+  hipStream_t side = nullptr;
+  static constexpr int NTICKET = 4;
+  hipEvent_t ev_post[NTICKET] = {}, ev_cov[NTICKET] = {};
+  long ticket = 0;          // calls so far; call t uses slot t % NTICKET
+  bool cov_inflight = false;
   std::vector<void *> dev_allocs;
   std::vector<void *> host_allocs;
   uint8_t *d_img = nullptr;
@@ -209,6 +216,11 @@ int build(spfe_handle h, const spfe_config *cfg) {
   const int H = h->H, W = h->W, B = h->B, C = h->C;
   HIP_TRY(hipSetDevice(cfg->device));
   HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+  for (int i = 0; i < spfe_handle_s::NTICKET; ++i) {
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_post[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_cov[i], hipEventDisableTiming));
+  }
   const char *tenv = getenv("SPFE_STAGE_TIMING");
   h->timing = tenv && atoi(tenv) != 0;
   if (h->timing) {
@@ -361,6 +373,13 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s) {
   f.cell_score = h->d_cell_score; f.cell_k = h->d_cell_k; f.kp_cell = h->d_kp_cell;
   f.records = d_records; f.heat_consts = h->d_heat_consts;
   if (h->timing && !h->ev) return fail(SPFE_EINVAL, "internal: no event set");
+  const int slot = (int)(h->ticket % spfe_handle_s::NTICKET);
+  // the previous call's covariance still reads heat_inv / its record and owns the
+  // covariance scratch: everything from here on must come after it
+  if (h->cov_inflight) {
+    const int prev = (int)((h->ticket + spfe_handle_s::NTICKET - 1) % spfe_handle_s::NTICKET);
+    HIP_TRY(hipStreamWaitEvent(s, h->ev_cov[prev], 0));
+  }
   HIP_TRY(spfe::launch_tail(f, h->rl, n, H, W, s));
   STAGE_MARK(12);
   HIP_TRY(spfe::launch_heat_norm(f, n, H, W, s));
@@ -369,8 +388,19 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s) {
   STAGE_MARK(14);
   HIP_TRY(spfe::launch_desc(f, h->rl, n, H, W, s));
   STAGE_MARK(15);
-  HIP_TRY(spfe::launch_cov(f, h->rl, h->cov, n, H, W, s));
-  STAGE_MARK(16);
+  // covariance on the side stream, ordered after this call's selection / heat maps
+  HIP_TRY(hipEventRecord(h->ev_post[slot], s));
+  HIP_TRY(hipStreamWaitEvent(h->side, h->ev_post[slot], 0));
+  HIP_TRY(spfe::launch_cov(f, h->rl, h->cov, n, H, W, h->side));
+  HIP_TRY(hipEventRecord(h->ev_cov[slot], h->side));
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[16], h->side));
+  h->cov_inflight = true;
+  h->ticket++;
+  if (!(h->cfg.flags & SPFE_FLAG_ASYNC_COV)) {
+    // synchronous contract: the records are complete in `s` order when the call returns
+    HIP_TRY(hipStreamWaitEvent(s, h->ev_cov[slot], 0));
+    h->cov_inflight = false;
+  }
   h->last_n = n;
   return SPFE_OK;
 }
@@ -439,6 +469,12 @@ void spfe_destroy(spfe_handle h) {
   if (!h) return;
   (void)hipSetDevice(h->cfg.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->side) (void)hipStreamSynchronize(h->side);
+  for (int i = 0; i < spfe_handle_s::NTICKET; ++i) {
+    if (h->ev_post[i]) (void)hipEventDestroy(h->ev_post[i]);
+    if (h->ev_cov[i]) (void)hipEventDestroy(h->ev_cov[i]);
+  }
+  if (h->side) (void)hipStreamDestroy(h->side);
   for (void *p : h->dev_allocs) (void)hipFree(p);
   for (void *p : h->host_allocs) (void)hipHostFree(p);
   for (auto &e : h->evpool)
@@ -508,6 +544,11 @@ int spfe_extract_batch(spfe_handle h, const uint8_t *const *images, int stride, 
 int finish_host(spfe_handle h, int n, spfe_result *outs) {
   const int H = h->H, W = h->W;
   hipStream_t s = h->stream;
+  if (h->cov_inflight) {
+    const int prev = (int)((h->ticket + spfe_handle_s::NTICKET - 1) % spfe_handle_s::NTICKET);
+    HIP_TRY(hipStreamWaitEvent(s, h->ev_cov[prev], 0));
+    h->cov_inflight = false;
+  }
   const bool want = (h->cfg.flags & SPFE_FLAG_HEAT) != 0;
   HIP_TRY(hipMemcpyAsync(h->h_records, h->d_records, (size_t)n * h->rl.bytes, hipMemcpyDeviceToHost, s));
   if (want) {
@@ -538,6 +579,18 @@ int spfe_extract(spfe_handle h, const uint8_t *image, int stride, spfe_result *o
   if (!image) return fail(SPFE_EEMPTY, "input image is empty");
   const uint8_t *imgs[1] = {image};
   return spfe_extract_batch(h, imgs, stride, 1, out);
+}
+
+long spfe_last_ticket(spfe_handle h) { return h ? h->ticket - 1 : -1; }
+
+int spfe_wait_records(spfe_handle h, long ticket, void *stream) {
+  if (!h) return fail(SPFE_EINVAL, "null handle");
+  if (ticket < 0 || ticket >= h->ticket || ticket + spfe_handle_s::NTICKET <= h->ticket)
+    return fail(SPFE_EINVAL, "ticket %ld is not one of the last %d calls", ticket, spfe_handle_s::NTICKET);
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
+  HIP_TRY(hipStreamWaitEvent(s, h->ev_cov[ticket % spfe_handle_s::NTICKET], 0));
+  return SPFE_OK;
 }
 
 int spfe_view_record(spfe_handle h, const void *host_record, spfe_result *out) {

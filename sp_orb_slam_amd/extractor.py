@@ -19,6 +19,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libspfe.so")
 
 SPFE_FLAG_HEAT = 1
+SPFE_FLAG_ASYNC_COV = 2
 SPFE_PRECISION_F32 = 0
 NUM_PARAMS = 1300865
 _ERRORS = {-1: "SPFE_EINVAL", -2: "SPFE_EEMPTY", -3: "SPFE_EHIP", -4: "SPFE_EWEIGHTS"}
@@ -26,7 +27,8 @@ _ERRORS = {-1: "SPFE_EINVAL", -2: "SPFE_EEMPTY", -3: "SPFE_EHIP", -4: "SPFE_EWEI
 # every symbol include/spfe.h declares (tests check that the library exports all)
 ABI_SYMBOLS = [
     "spfe_create", "spfe_destroy", "spfe_extract", "spfe_extract_batch", "spfe_postprocess",
-    "spfe_get_record_layout", "spfe_record_bytes", "spfe_extract_batch_device",
+    "spfe_get_record_layout", "spfe_record_bytes", "spfe_extract_batch_device", "spfe_last_ticket",
+    "spfe_wait_records",
     "spfe_view_record", "spfe_debug_read", "spfe_stage_times", "spfe_stage_reset",
     "spfe_stage_name",
     "spfe_math_probe", "spfe_last_error", "spfe_version",
@@ -87,6 +89,10 @@ def load_library():
     L.spfe_record_bytes.argtypes = [C.c_void_p]
     L.spfe_extract_batch_device.restype = C.c_int
     L.spfe_extract_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.spfe_last_ticket.restype = C.c_long
+    L.spfe_last_ticket.argtypes = [C.c_void_p]
+    L.spfe_wait_records.restype = C.c_int
+    L.spfe_wait_records.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
     L.spfe_view_record.restype = C.c_int
     L.spfe_view_record.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Result)]
     L.spfe_debug_read.restype = C.c_long
@@ -165,7 +171,8 @@ class SPExtractor:
     here they are explicit arguments.
     """
 
-    def __init__(self, nfeatures, height, width, weights, max_batch=1, device=0, with_heat=True):
+    def __init__(self, nfeatures, height, width, weights, max_batch=1, device=0, with_heat=True,
+                 async_cov=False):
         self._h = C.c_void_p()
         self._lib = load_library()
         self.nfeatures, self.height, self.width = int(nfeatures), int(height), int(width)
@@ -173,7 +180,8 @@ class SPExtractor:
         cfg = _Config()
         cfg.height, cfg.width, cfg.num_features = self.height, self.width, self.nfeatures
         cfg.max_batch, cfg.device, cfg.precision = self.max_batch, int(device), SPFE_PRECISION_F32
-        cfg.flags = SPFE_FLAG_HEAT if with_heat else 0
+        cfg.flags = (SPFE_FLAG_HEAT if with_heat else 0) | (SPFE_FLAG_ASYNC_COV if async_cov else 0)
+        self.async_cov = bool(async_cov)
         keep = None
         if isinstance(weights, (str, bytes, os.PathLike)):
             cfg.weights, cfg.weights_path = None, os.fsencode(weights)
@@ -306,6 +314,11 @@ class SPExtractor:
         _check(self._lib.spfe_extract_batch_device(self._h, C.c_void_p(d_images), int(n),
                                                    C.c_void_p(d_records or 0),
                                                    C.c_void_p(stream or 0)))
+        return int(self._lib.spfe_last_ticket(self._h))
+
+    def wait_records(self, ticket, stream=None):
+        """Order `stream` after the covariance stage of call `ticket` (async_cov mode)."""
+        _check(self._lib.spfe_wait_records(self._h, int(ticket), C.c_void_p(stream or 0)))
 
     def view_record(self, host_record):
         """Decode ONE record (bytes-like / uint8 array copied from the device)."""

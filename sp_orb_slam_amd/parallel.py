@@ -135,27 +135,59 @@ def gather_records(local_records, world, group=None):
 class ShardedExtractor:
     """Per-rank driver of the batched path (BASELINE configs[2]): takes this
     rank's shard of device-resident frames, runs the HIP path, all-gathers the
-    records.  One instance per process / GPU."""
+    records.  One instance per process / GPU.
+
+    With an extractor built with async_cov=True the driver is software pipelined:
+    step(i) enqueues the compute of batch i and then completes batch i-1 (waits for
+    its covariance, which ran beside batch i's convolutions, and all-gathers its
+    records); flush() completes the last batch.  `gathered` always holds the most
+    recently completed batch."""
 
     def __init__(self, extractor, world, rank, frames_per_rank):
         import torch
 
         self.ext, self.world, self.rank, self.fpr = extractor, world, rank, frames_per_rank
         self.rec_bytes = extractor.record_bytes()
-        self.local = torch.zeros(frames_per_rank * self.rec_bytes, dtype=torch.uint8, device="cuda")
+        nbuf = 2 if extractor.async_cov else 1
+        self.local = [torch.zeros(frames_per_rank * self.rec_bytes, dtype=torch.uint8, device="cuda")
+                      for _ in range(nbuf)]
         self.all = (torch.zeros(world * frames_per_rank * self.rec_bytes, dtype=torch.uint8, device="cuda")
-                    if world > 1 else self.local)
+                    if world > 1 else None)
+        self.gathered = None
+        self._pending = None
+        self._calls = 0
+
+    def _complete(self, ticket, buf, stream):
+        import torch.distributed as dist
+
+        self.ext.wait_records(ticket, stream.cuda_stream)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.all, buf)
+            self.gathered = self.all
+        else:
+            self.gathered = buf
 
     def step(self, d_images, stream):
         """d_images: torch uint8 [frames_per_rank, H, W] on this rank's GPU."""
-        import torch.distributed as dist
+        buf = self.local[self._calls % len(self.local)]
+        self._calls += 1
+        ticket = self.ext.extract_batch_device(d_images.data_ptr(), self.fpr, buf.data_ptr(), stream.cuda_stream)
+        if self.ext.async_cov:
+            if self._pending is not None:
+                self._complete(*self._pending, stream)
+            self._pending = (ticket, buf)
+        else:
+            self._complete(ticket, buf, stream)
+        return self.gathered
 
-        self.ext.extract_batch_device(d_images.data_ptr(), self.fpr, self.local.data_ptr(), stream.cuda_stream)
-        if self.world > 1:
-            dist.all_gather_into_tensor(self.all, self.local)
-        return self.all
+    def flush(self, stream):
+        """Complete the batch still in flight (async mode); returns the gathered records."""
+        if self._pending is not None:
+            self._complete(*self._pending, stream)
+            self._pending = None
+        return self.gathered
 
     def decode(self, frame):
-        """Host copy + decode of global frame `frame` from the gathered buffer."""
+        """Host copy + decode of global frame `frame` of the last completed batch."""
         rb = self.rec_bytes
-        return self.ext.view_record(self.all[frame * rb:(frame + 1) * rb].cpu().numpy())
+        return self.ext.view_record(self.gathered[frame * rb:(frame + 1) * rb].cpu().numpy())

@@ -221,6 +221,17 @@ def test_zero_and_few_candidates():
         ext.close()
 
 
+def test_1280x720_batch_matches_oracle():
+    """BASELINE configs[3] shape (1280x720), f32 path, batch of 2: exact against the oracle."""
+    H, W, nf = 720, 1280, 800
+    blob = weights.synthetic(7, "sparse")
+    imgs = [synth.make_image(300 + i, H, W) for i in range(2)]
+    ext = SPExtractor(nf, H, W, blob, max_batch=2)
+    for fr, im in zip(ext.extract_batch(imgs), imgs):
+        _compare(fr, oracle.extract(blob, im, nf))
+    ext.close()
+
+
 def test_nms_cut_and_border_properties_720p():
     """1280x720 (BASELINE configs[3] shape): size-independent properties of the selection."""
     H, W, nf = 720, 1280, 1000
@@ -287,4 +298,45 @@ def test_python_record_layout_matches_library():
         for name in ("bytes", "kmax", "off_hdr", "off_xy", "off_resp", "off_cov", "off_cinv", "off_desc",
                      "off_occ", "off_dd", "off_sd"):
             assert getattr(lay, name) == getattr(ext.layout, name), name
+        ext.close()
+
+
+def test_device_path_sync_and_async_cov_equal_host_path():
+    """spfe_extract_batch_device (records in device memory), with the covariance stage
+    synchronous and overlapped (SPFE_FLAG_ASYNC_COV + spfe_wait_records): bit-identical
+    to the host-facing call, batch after batch, through the pipelined ShardedExtractor."""
+    import torch
+    from sp_orb_slam_amd import parallel
+    H, W, nf, B = 120, 160, 150, 3
+    blob = weights.synthetic(7, "dense")
+    batches = [np.stack([synth.make_image(60 + 10 * s + i, H, W) for i in range(B)]) for s in range(4)]
+    host = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=False)
+    expect = [host.extract_batch(list(b)) for b in batches]
+    host.close()
+    stream = torch.cuda.current_stream()
+    for async_cov in (False, True):
+        ext = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=False, async_cov=async_cov)
+        sh = parallel.ShardedExtractor(ext, 1, 0, B)
+        d_batches = [torch.from_numpy(b).cuda() for b in batches]
+        done = []
+        for s, d in enumerate(d_batches):
+            sh.step(d, stream)
+            if async_cov:
+                if s > 0:
+                    torch.cuda.synchronize()
+                    done.append([sh.decode(i) for i in range(B)])   # batch s-1 completed by step s
+            else:
+                torch.cuda.synchronize()
+                done.append([sh.decode(i) for i in range(B)])
+        if async_cov:
+            sh.flush(stream)
+            torch.cuda.synchronize()
+            done.append([sh.decode(i) for i in range(B)])
+        assert len(done) == len(batches)
+        for got, exp in zip(done, expect):
+            for g, e in zip(got, exp):
+                assert g.status == 0 and g.K == e.K and np.array_equal(g.kp_xy, e.kp_xy)
+                assert np.array_equal(g.descriptors, e.descriptors) and np.array_equal(g.occ_grid, e.occ_grid)
+                assert np.array_equal(g.cov2, e.cov2) and np.array_equal(g.cov2_inv, e.cov2_inv)
+                assert np.array_equal(g.response, e.response) and np.array_equal(g.dense_dust, e.dense_dust)
         ext.close()
