@@ -38,6 +38,34 @@ struct Geo {
   static constexpr int PLANE = PLANE_RAW + ((2 - PLANE_RAW % 8) + 8) % 8;
 };
 
+// One K step = one (tap, channel pair): MT x NT MFMAs on operand set STEP & 1, while
+// the operands of step STEP + 1 are being read into the other set.  Compile-time
+// recursion keeps every LDS offset an immediate.
+template <int STEP, int NSTEP, int KC, int KS, int MT, int NT, int PLANE, int ROWP>
+__device__ __forceinline__ void mfma_steps(float (&a)[2][MT], float (&bb)[2][NT], f32x16 (&acc)[MT][NT],
+                                           const float *aBase, const float *bBase) {
+  if constexpr (STEP < NSTEP) {
+    constexpr int cur = STEP & 1, nxt = cur ^ 1;
+    if constexpr (STEP + 1 < NSTEP) {
+      constexpr int tap = (STEP + 1) / (KC / 2), t = (STEP + 1) % (KC / 2);
+      constexpr int dy = tap / KS, dx = tap % KS;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[nxt][i] = aBase[(2 * t) * PLANE + (i + dy) * ROWP + dx];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bb[nxt][j] = bBase[(tap * KC + 2 * t) * 64 + j * 32];
+    }
+    // keep the reads of step+1 ABOVE the MFMAs of this step (the machine scheduler
+    // otherwise sinks them to just before their use and exposes the LDS latency)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], bb[cur][j], acc[i][j], 0, 0, 0);
+    mfma_steps<STEP + 1, NSTEP, KC, KS, MT, NT, PLANE, ROWP>(a, bb, acc, aBase, bBase);
+  }
+}
+
 template <int CIN, int KS, int KC, int WM, int WN, int MT, int NT, bool POOL, bool RELU>
 __global__ __launch_bounds__(256, 2) void conv_f32_kernel(ConvParams p) {
   constexpr int TH = WM * MT;
@@ -152,23 +180,23 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(ConvParams p) {
     if (chunk + 1 < NCHUNK) SPFE_LOAD_CHUNK(chunk + 1);  // in flight during the MFMA loop below
 
     // ---- MFMA over (tap, channel pair) in the contract's K order ----
-#pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const int dy = tap / KS, dx = tap % KS;
-#pragma unroll
-      for (int t = 0; t < KC / 2; ++t) {
-        float a[MT], bb[NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) a[i] = aBase[(2 * t) * PLANE + (i + dy) * ROWP + dx];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bb[j] = bBase[(tap * KC + 2 * t) * 64 + j * 32];
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
-      }
-    }
+    // Operand reads are software pipelined one step ahead into a second register
+    // set: issued back to back with the MFMAs that consume the previous set, the
+    // ~100-cycle LDS latency hides under 4 x 64 cycles of matrix work.
+    constexpr int NSTEP = TAPS * (KC / 2);
+    float a[2][MT], bb[2][NT];
+#define SPFE_LOAD_OPS(SET_, STEP_)                                                         \
+  do {                                                                                      \
+    constexpr int tap_ = (STEP_) / (KC / 2), t_ = (STEP_) % (KC / 2);                       \
+    constexpr int dy_ = tap_ / KS, dx_ = tap_ % KS;                                         \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                          \
+        a[SET_][i] = aBase[(2 * t_) * PLANE + (i + dy_) * ROWP + dx_];                      \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j)                                          \
+        bb[SET_][j] = bBase[(tap_ * KC + 2 * t_) * 64 + j * 32];                            \
+  } while (0)
+    SPFE_LOAD_OPS(0, 0);
+    mfma_steps<0, NSTEP, KC, KS, MT, NT, PLANE, ROWP>(a, bb, acc, aBase, bBase);
+#undef SPFE_LOAD_OPS
   }
 
   // ---- epilogue: bias, ReLU, optional 2x2 max-pool, NHWC store ----
