@@ -13,13 +13,15 @@
 //  * LDS holds the input halo tile channel-major ([KC][rows][cols]): the 32
 //    lanes of an MFMA A operand read 32 consecutive floats (conflict free) and a
 //    filter tap is just an address offset; the 9 x KC x 64 weight slab of the
-//    chunk sits next to it.  ~60 KB per workgroup -> 2 workgroups per CU, so one
-//    stages while the other issues MFMAs.
+//    chunk sits next to it (~60 KB), double buffered (120 KB): one persistent
+//    workgroup per CU streams (tile, chunk) stages back to back.
 //  * 64-wide wavefronts: each wave owns MT x NT 32x32 accumulator tiles
 //    (two image rows -> the 2x2 pool is done in registers in the epilogue).
 //  * workgroup -> tile mapping is XCD-aware: the 8 XCDs each get a contiguous
 //    run of tiles so neighbouring tiles (shared halos, shared weight slabs) hit
 //    the same L2.
+#include <utility>
+
 #include "spfe_kernels.h"
 
 namespace spfe {
@@ -38,209 +40,391 @@ struct Geo {
   static constexpr int PLANE = PLANE_RAW + ((2 - PLANE_RAW % 8) + 8) % 8;
 };
 
-// One K step = one (tap, channel pair): MT x NT MFMAs on operand set STEP & 1, while
-// the operands of step STEP + 1 are being read into the other set.  Compile-time
-// recursion keeps every LDS offset an immediate.
-template <int STEP, int NSTEP, int KC, int KS, int MT, int NT, int PLANE, int ROWP>
-__device__ __forceinline__ void mfma_steps(float (&a)[2][MT], float (&bb)[2][NT], f32x16 (&acc)[MT][NT],
-                                           const float *aBase, const float *bBase) {
-  if constexpr (STEP < NSTEP) {
-    constexpr int cur = STEP & 1, nxt = cur ^ 1;
-    if constexpr (STEP + 1 < NSTEP) {
-      constexpr int tap = (STEP + 1) / (KC / 2), t = (STEP + 1) % (KC / 2);
-      constexpr int dy = tap / KS, dx = tap % KS;
-#pragma unroll
-      for (int i = 0; i < MT; ++i) a[nxt][i] = aBase[(2 * t) * PLANE + (i + dy) * ROWP + dx];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) bb[nxt][j] = bBase[(tap * KC + 2 * t) * 64 + j * 32];
+// ---------------------------------------------------------------------------
+// Persistent, double-buffered implicit-GEMM convolution with everything but the
+// MFMAs riding in the MFMA shadow.
+//
+//  * grid = one workgroup per CU (4 waves, one per SIMD, up to 512 registers
+//    each); a workgroup walks an XCD-local run of (frame, tile, 64-channel block)
+//    work items.
+//  * the pipeline stages (tile, K chunk) form one continuous stream.  During the
+//    72 K steps of stage s (4 MFMAs = 256 matrix-pipe cycles each) the same wave
+//    also, a few instructions per step:
+//       - reads the MFMA operands of the next step (LDS, one step ahead),
+//       - issues the global loads of stage s+1           (steps 1 .. NLD),
+//       - stores the PREVIOUS tile's outputs (bias/ReLU/pool epilogue) out of the
+//         other accumulator set                           (steps 1 .. NEG, chunk 0),
+//       - writes the loaded stage s+1 into the other LDS buffer (last NLD steps).
+//    One barrier per stage; the first MFMA of a tile takes C = 0, so nothing is
+//    zeroed or copied between tiles.
+//    A wave issues in order, so work only hides if it is sliced this finely:
+//    a 400-instruction epilogue in one piece idles the matrix pipe for ~3k cycles.
+// ---------------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+#define SPFE_OOB 0x80000000u  // byte offset beyond any buffer: loads return 0, stores are dropped
+
+// Buffer (SRD) addressing: global traffic goes through buffer_load/buffer_store
+// with hardware bounds checking, so zero padding at the image border, ragged
+// tiles and the "no next stage" case cost no compare / exec-mask / select
+// instructions in the MFMA shadow — an out-of-image piece simply carries the
+// offset SPFE_OOB, a missing stage a resource with 0 records.
+template <int NITER, int NWITER>
+struct Pipe {
+  float4 va[NITER];   // staged input pieces of the next stage (4 channels of one pixel each)
+  float4 vw[NWITER];  // staged weight pieces
+  int dst[NITER];     // LDS float offset of each input piece (a dummy slot for unused pieces)
+  unsigned voff[NITER];  // byte offset of the piece inside the frame, or SPFE_OOB
+  unsigned woff[NWITER]; // byte offset inside the weight slab
+  __amdgpu_buffer_rsrc_t rin, rw;  // next stage: input frame (+channel offset), weight slab
+  const float *aBase, *bBase;      // this stage's operands in LDS
+  float *nA, *nW;                  // the other LDS buffer
+};
+
+template <int NT>
+struct EpiCtx {  // the tile whose outputs are being stored
+  __amdgpu_buffer_rsrc_t rout;  // output frame (+channel offset); 0 records = nothing to store
+  unsigned obase[NT];           // per lane: byte offset of (tile origin row of this wave, x = tx0 + 4*hi, channel), or OOB
+  float bias[NT];
+  int xlim;                     // W - tx0 - 4*hi : columns left in the image for this lane
+  int ylim;                     // H - (ty0 + wm*MT) : rows left for this wave
+  unsigned rowstep, pixstep;    // bytes per output row / pixel
+};
+
+template <int MT, int NT, bool POOL, bool RELU, int E>
+__device__ __forceinline__ void epi_store(const EpiCtx<NT> &e, const f32x16 (&acc)[MT][NT]) {
+  // C layout of the 32x32 MFMA: column (N) = lane&31, row (M) = (r&3)+8*(r>>2)+4*(lane>>5)
+  constexpr int NEPI_ = POOL ? NT * 8 : MT * NT * 16;
+  if constexpr (E >= NEPI_) {
+    return;
+  } else if constexpr (!POOL) {
+    constexpr int j = E / (MT * 16), i = (E / 16) % MT, r = E % 16;
+    constexpr int xr = (r & 3) + 8 * (r >> 2);
+    float v = acc[i][j][r] + e.bias[j];
+    if (RELU) v = v > 0.0f ? v : 0.0f;
+    const unsigned off = (xr < e.xlim && i < e.ylim) ? e.obase[j] + i * e.rowstep + xr * e.pixstep : SPFE_OOB;
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), e.rout, off, 0, 0);
+  } else {
+    constexpr int j = E / 8, r = 2 * (E % 8);
+    constexpr int xr = (r & 3) + 8 * (r >> 2);
+    float v00 = acc[0][j][r] + e.bias[j], v01 = acc[0][j][r + 1] + e.bias[j];
+    float v10 = acc[1][j][r] + e.bias[j], v11 = acc[1][j][r + 1] + e.bias[j];
+    if (RELU) {
+      v00 = v00 > 0.0f ? v00 : 0.0f;
+      v01 = v01 > 0.0f ? v01 : 0.0f;
+      v10 = v10 > 0.0f ? v10 : 0.0f;
+      v11 = v11 > 0.0f ? v11 : 0.0f;
     }
-    // keep the reads of step+1 ABOVE the MFMAs of this step (the machine scheduler
-    // otherwise sinks them to just before their use and exposes the LDS latency)
-    __builtin_amdgcn_sched_barrier(0);
+    const float m0 = v00 > v01 ? v00 : v01;
+    const float m1 = v10 > v11 ? v10 : v11;
+    const float v = m0 > m1 ? m0 : m1;
+    const unsigned off = (xr < e.xlim && 0 < e.ylim) ? e.obase[j] + (xr >> 1) * e.pixstep : SPFE_OOB;
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), e.rout, off, 0, 0);
+  }
+}
+
+template <int STEP, int NSTEP, bool FIRST, int KC, int KS, int MT, int NT, int PLANE, int ROWP, int NITER,
+          int NWITER, bool POOL, bool RELU>
+__device__ __forceinline__ void k_steps(float (&a)[2][MT], float (&bb)[2][NT], f32x16 (&acc)[MT][NT],
+                                        const f32x16 (&accPrev)[MT][NT], Pipe<NITER, NWITER> &c,
+                                        const EpiCtx<NT> &e) {
+  if constexpr (STEP < NSTEP) {
+    constexpr int NLD = NITER + NWITER;
+    constexpr int L0 = 1, W0 = NSTEP - NLD - 1;
+    constexpr int NEPI = POOL ? NT * 8 : MT * NT * 16;       // stores per wave per tile
+    constexpr int EPS = (NEPI + (NSTEP - 3)) / (NSTEP - 2);  // stores per step
+    constexpr int cur = STEP & 1, nxt = cur ^ 1;
+    static_assert(L0 + NLD <= W0, "loads and LDS writes of a stage must not overlap");
+    // The four kinds of side work are dealt out over the MT*NT gaps between this
+    // step's MFMAs: a wave issues in order, so only what sits BETWEEN two MFMAs
+    // runs in the 64-cycle shadow of the first.
+    constexpr int M = MT * NT;
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int m = 0; m < M; ++m) {
+      // (1) operands of the next step
+      if (m == 0) {
+        if constexpr (STEP + 1 < NSTEP) {
+          constexpr int tap = (STEP + 1) / (KC / 2), t = (STEP + 1) % (KC / 2);
+          constexpr int dy = tap / KS, dx = tap % KS;
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], bb[cur][j], acc[i][j], 0, 0, 0);
-    mfma_steps<STEP + 1, NSTEP, KC, KS, MT, NT, PLANE, ROWP>(a, bb, acc, aBase, bBase);
+          for (int i = 0; i < MT; ++i) a[nxt][i] = c.aBase[(2 * t) * PLANE + (i + dy) * ROWP + dx];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) bb[nxt][j] = c.bBase[(tap * KC + 2 * t) * 64 + j * 32];
+        }
+      }
+      // (2) one global load of the next stage
+      if (m == 1 % M) {
+        if constexpr (STEP >= L0 && STEP - L0 < NLD) {
+          constexpr int it = STEP - L0;
+          if constexpr (it < NITER) {
+            const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(c.rin, c.voff[it], 0, 0);
+            c.va[it] = make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+          } else {
+            constexpr int wi = it - NITER;
+            const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(c.rw, c.woff[wi], 0, 0);
+            c.vw[wi] = make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+          }
+        }
+      }
+      // (3) a slice of the previous tile's epilogue
+      if (m == 2 % M) {
+        if constexpr (FIRST && STEP >= 1) {
+          constexpr int e0 = (STEP - 1) * EPS;
+          [&]<int... Qs>(std::integer_sequence<int, Qs...>) {
+            (epi_store<MT, NT, POOL, RELU, e0 + Qs>(e, accPrev), ...);
+          }(std::make_integer_sequence<int, EPS>{});
+        }
+      }
+      // (4) one staged piece of the next stage into the other LDS buffer
+      if (m == 3 % M) {
+        if constexpr (STEP >= W0 && STEP - W0 < NLD) {
+          constexpr int it = STEP - W0;
+          if constexpr (it < NITER) {
+            float *d = c.nA + c.dst[it];
+            d[0] = c.va[it].x;
+            d[PLANE] = c.va[it].y;
+            d[2 * PLANE] = c.va[it].z;
+            d[3 * PLANE] = c.va[it].w;
+          } else {
+            constexpr int wi = it - NITER;
+            *reinterpret_cast<float4 *>(reinterpret_cast<char *>(c.nW) + c.woff[wi]) = c.vw[wi];
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const int i = m / NT, j = m % NT;
+        if constexpr (FIRST && STEP == 0) {
+          f32x16 z;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], bb[cur][j], z, 0, 0, 0);
+        } else {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], bb[cur][j], acc[i][j], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    k_steps<STEP + 1, NSTEP, FIRST, KC, KS, MT, NT, PLANE, ROWP, NITER, NWITER, POOL, RELU>(a, bb, acc, accPrev, c, e);
   }
 }
 
 template <int CIN, int KS, int KC, int WM, int WN, int MT, int NT, bool POOL, bool RELU>
-__global__ __launch_bounds__(256, 2) void conv_f32_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, 1) void conv_f32_kernel(ConvParams p) {
   constexpr int TH = WM * MT;
   using G = Geo<KS, TH>;
   constexpr int TAPS = KS * KS;
   constexpr int NCHUNK = CIN / KC;
   constexpr int PLANE = G::PLANE;
   constexpr int ROWP = G::ROWP;
+  constexpr int BUF = KC * PLANE + TAPS * KC * 64;  // floats per LDS buffer
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(WN * NT == 2, "64 output channels per workgroup");
   static_assert(!POOL || MT == 2, "pooling needs two rows per wave");
-  static_assert((KC * PLANE) % 4 == 0, "weight slab must stay 16B aligned");
+  static_assert((KC * PLANE) % 4 == 0 && BUF % 4 == 0, "weight slabs must stay 16B aligned");
+  constexpr int Q = KC / 4;  // float4 per pixel per chunk
+  constexpr int NITEM = G::ROWS * G::COLS * Q;
+  constexpr int NITER = (NITEM + 255) / 256;
+  constexpr int NW4 = TAPS * KC * 16;  // float4 in the weight slab
+  static_assert(NW4 % 256 == 0, "weight slab must be a whole number of 256-thread passes");
+  constexpr int NWITER = NW4 / 256;
+  constexpr int NSTEP = TAPS * (KC / 2);
+  constexpr int SLAB_BYTES = TAPS * KC * 64 * 4;
 
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *sA = smem;               // [KC][PLANE]
-  float *sW = smem + KC * PLANE;  // [TAPS][KC][64]
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 buffers + a dummy slot region
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
   const int wm = wave % WM, wn = wave / WM;
-
-  // XCD-aware bijective remap (blocks are dealt round-robin to the 8 XCDs)
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int nb = wg % p.nblk;
-  wg /= p.nblk;
-  const int tx = wg % p.tiles_x;
-  wg /= p.tiles_x;
-  const int ty = wg % p.tiles_y;
-  const int b = wg / p.tiles_y;
-  const int tx0 = tx * 32, ty0 = ty * TH;
   const int H = p.H, W = p.W;
 
-  f32x16 acc[MT][NT];
+  // XCD-local work range: workgroup g runs on XCD g % 8 (observed placement; only
+  // speed depends on it).  Each XCD owns one contiguous eighth of the work list
+  // (64-channel blocks of a tile adjacent), its workgroups interleave inside it.
+  const int total = p.nblk * p.tiles_x * p.tiles_y * p.B;
+  const int xcd = blockIdx.x & 7, gi = blockIdx.x >> 3, gper = gridDim.x >> 3;
+  const int lo = (int)((long)total * xcd / 8), hi_w = (int)((long)total * (xcd + 1) / 8);
+  int w = lo + gi;
+  if (w >= hi_w) return;
+
+  // work item = (nb, tx, ty, b); advanced incrementally by gper (no divisions in the loop)
+  int i_nb, i_tx, i_ty, i_b;
+  {
+    int t = w;
+    i_nb = t % p.nblk; t /= p.nblk;
+    i_tx = t % p.tiles_x; t /= p.tiles_x;
+    i_ty = t % p.tiles_y; i_b = t / p.tiles_y;
+  }
+  int d_nb, d_tx, d_ty, d_b;
+  {
+    int t = gper;
+    d_nb = t % p.nblk; t /= p.nblk;
+    d_tx = t % p.tiles_x; t /= p.tiles_x;
+    d_ty = t % p.tiles_y; d_b = t / p.tiles_y;
+  }
+
+  const unsigned in_pix_bytes = (unsigned)p.in_stride * 4u;
+  const unsigned frame_in_bytes = (unsigned)H * W * in_pix_bytes;
+  const int Ho = POOL ? H >> 1 : H, Wo = POOL ? W >> 1 : W;
+  const unsigned out_pix_bytes = (unsigned)p.out_stride * 4u;
+  const unsigned frame_out_bytes = (unsigned)Ho * Wo * out_pix_bytes;
+
+  Pipe<NITER, NWITER> c;
+  int prow[NITER], pcol[NITER];
+  unsigned pqb[NITER];
+#pragma unroll
+  for (int it = 0; it < NITER; ++it) {
+    const int i = tid + it * 256;
+    const int qq = i % Q, pix = i / Q;
+    prow[it] = i < NITEM ? pix / G::COLS - G::HALO : (1 << 20);  // unused piece: never inside the image
+    pcol[it] = pix % G::COLS - G::HALO;
+    pqb[it] = qq * 16;
+    c.dst[it] = i < NITEM ? (qq * 4) * PLANE + (pix / G::COLS) * ROWP + pix % G::COLS
+                          : 2 * BUF + tid;  // dummy slots behind the two buffers
+  }
+#pragma unroll
+  for (int it = 0; it < NWITER; ++it) c.woff[it] = (tid + it * 256) * 16;
+
+  // per-thread frame offsets of the input pieces of tile (tx, ty)
+  auto aim_tile = [&](int tx, int ty) {
+#pragma unroll
+    for (int it = 0; it < NITER; ++it) {
+      const int gy = ty * TH + prow[it], gx = tx * 32 + pcol[it];
+      c.voff[it] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                       ? (unsigned)(gy * W + gx) * in_pix_bytes + pqb[it]
+                       : SPFE_OOB;
+    }
+  };
+  // next stage = (frame b, 64-channel block nb, chunk); valid == false: a stage that does not exist
+  auto aim_stage = [&](int nb, int b, int chunk, bool valid) {
+    const float *base = p.in + (size_t)b * H * W * p.in_stride + p.in_choff + chunk * KC;
+    c.rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, valid ? frame_in_bytes : 0u, 0x00020000);
+    const float *wb = p.wpack + ((size_t)nb * NCHUNK + chunk) * (TAPS * KC * 64);
+    c.rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wb), 0, valid ? (unsigned)SLAB_BYTES : 0u, 0x00020000);
+  };
+
+  // prologue: stage (first item, chunk 0) straight into buffer 0
+  aim_tile(i_tx, i_ty);
+  aim_stage(i_nb, i_b, 0, true);
+#pragma unroll
+  for (int it = 0; it < NITER; ++it) {
+    const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(c.rin, c.voff[it], 0, 0);
+    c.va[it] = make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+  }
+#pragma unroll
+  for (int it = 0; it < NWITER; ++it) {
+    const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(c.rw, c.woff[it], 0, 0);
+    c.vw[it] = make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+  }
+#pragma unroll
+  for (int it = 0; it < NITER; ++it) {
+    float *d = smem + c.dst[it];
+    d[0] = c.va[it].x;
+    d[PLANE] = c.va[it].y;
+    d[2 * PLANE] = c.va[it].z;
+    d[3 * PLANE] = c.va[it].w;
+  }
+#pragma unroll
+  for (int it = 0; it < NWITER; ++it)
+    *reinterpret_cast<float4 *>(reinterpret_cast<char *>(smem + KC * PLANE) + c.woff[it]) = c.vw[it];
+  __syncthreads();
+
+  f32x16 accA[MT][NT], accB[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) { accA[i][j][r] = 0.0f; accB[i][j][r] = 0.0f; }
 
-  const float *inb = p.in + (size_t)b * H * W * p.in_stride + p.in_choff;
-  const float *aBase = sA + hi * PLANE + (wm * MT) * ROWP + l31;
-  const float *bBase = sW + hi * 64 + (wn * NT) * 32 + l31;
-
-  constexpr int Q = KC / 4;  // float4 per pixel per chunk
-  constexpr int NITEM = G::ROWS * G::COLS * Q;
-  constexpr int NITER = (NITEM + 255) / 256;
-  constexpr int NW4 = TAPS * KC * 16;  // float4 in the weight slab
-
-  // Register-staged software pipeline: the global loads of chunk c+1 are issued
-  // before the MFMA loop of chunk c and only written to LDS after it, so their
-  // latency hides under ~18k cycles of matrix work instead of standing between two
-  // barriers.
-  constexpr int NWITER = (NW4 + 255) / 256;
-  float4 va[NITER], vw[NWITER];
-  int dst[NITER];
+  int buf = 0;
+  EpiCtx<NT> epi;
+  epi.rout = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0u, 0x00020000);  // nothing to store yet
 #pragma unroll
-  for (int it = 0; it < NITER; ++it) {  // per-thread staging slots are the same for every chunk
-    const int i = tid + it * 256;
-    const int qq = i % Q, pix = i / Q;
-    const int row = pix / G::COLS, col = pix % G::COLS;
-    dst[it] = (qq * 4) * PLANE + row * ROWP + col;
-  }
-#define SPFE_LOAD_CHUNK(CHUNK_)                                                                       \
-  do {                                                                                                \
-    _Pragma("unroll") for (int it = 0; it < NITER; ++it) {                                            \
-      const int i = tid + it * 256;                                                                   \
-      const int qq = i % Q, pix = i / Q;                                                              \
-      const int row = pix / G::COLS, col = pix % G::COLS;                                             \
-      const int gy = ty0 + row - G::HALO, gx = tx0 + col - G::HALO;                                   \
-      va[it] = make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
-      if (i < NITEM && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)                      \
-        va[it] = *reinterpret_cast<const float4 *>(inb + ((size_t)gy * W + gx) * p.in_stride +       \
-                                                   (CHUNK_) * KC + qq * 4);                           \
-    }                                                                                                 \
-    const float4 *ws_ = reinterpret_cast<const float4 *>(                                             \
-        p.wpack + ((size_t)nb * NCHUNK + (CHUNK_)) * (TAPS * KC * 64));                               \
-    _Pragma("unroll") for (int it = 0; it < NWITER; ++it) {                                           \
-      const int i = tid + it * 256;                                                                   \
-      vw[it] = (i < NW4) ? ws_[i] : make_float4(0.f, 0.f, 0.f, 0.f);                                  \
-    }                                                                                                 \
-  } while (0)
-  SPFE_LOAD_CHUNK(0);
+  for (int j = 0; j < NT; ++j) { epi.obase[j] = SPFE_OOB; epi.bias[j] = 0.0f; }
+  epi.xlim = 0; epi.ylim = 0; epi.rowstep = 0; epi.pixstep = out_pix_bytes;
+  bool more = true;
 
+  // describe tile (nb, tx, ty, b) for the epilogue; the bias is loaded one tile ahead
+  auto aim_epi = [&](EpiCtx<NT> &e, int nb, int tx, int ty, int b) {
+    float *obase = p.out + (size_t)b * Ho * Wo * p.out_stride + p.out_choff;
+    e.rout = __builtin_amdgcn_make_buffer_rsrc(obase, 0, frame_out_bytes, 0x00020000);
+    const int y0 = ty * TH + wm * MT, x0 = tx * 32 + 4 * hi;
+    e.xlim = W - x0;
+    e.ylim = H - y0;
+    e.rowstep = (unsigned)Wo * out_pix_bytes;
+    e.pixstep = out_pix_bytes;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int co = nb * 64 + (wn * NT + j) * 32 + l31;
+      const unsigned pix = POOL ? (unsigned)((y0 >> 1) * Wo + (x0 >> 1)) : (unsigned)(y0 * W + x0);
+      e.obase[j] = co < p.cout_real ? pix * out_pix_bytes + (unsigned)co * 4u : SPFE_OOB;
+      e.bias[j] = p.bias[co];
+    }
+  };
+
+  // one tile: NCHUNK stages accumulating into `acc`, while the previous tile's
+  // outputs (in `accPrev`, described by `epi`) are stored during the first stage
+  EpiCtx<NT> epi_next;
+  auto run_tile = [&](f32x16(&acc)[MT][NT], const f32x16(&accPrev)[MT][NT]) {
+    // the item after this one
+    int n_nb = i_nb + d_nb, n_tx = i_tx + d_tx, n_ty = i_ty + d_ty, n_b = i_b + d_b;
+    if (n_nb >= p.nblk) { n_nb -= p.nblk; ++n_tx; }
+    if (n_tx >= p.tiles_x) { n_tx -= p.tiles_x; ++n_ty; }
+    if (n_ty >= p.tiles_y) { n_ty -= p.tiles_y; ++n_b; }
+    const bool have_next_item = w + gper < hi_w;
+    aim_epi(epi_next, i_nb, i_tx, i_ty, i_b);  // this tile's epilogue context (bias in flight for a whole tile)
 #pragma unroll 1
-  for (int chunk = 0; chunk < NCHUNK; ++chunk) {
-    if (chunk) __syncthreads();  // every wave is done reading the previous chunk's tiles
-#pragma unroll
-    for (int it = 0; it < NITER; ++it) {
-      const int i = tid + it * 256;
-      if (i < NITEM) {
-        float *d = sA + dst[it];
-        d[0] = va[it].x;
-        d[PLANE] = va[it].y;
-        d[2 * PLANE] = va[it].z;
-        d[3 * PLANE] = va[it].w;
+    for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+      const bool last = chunk == NCHUNK - 1;
+      if (!last) {
+        aim_stage(i_nb, i_b, chunk + 1, true);
+      } else {
+        aim_tile(n_tx, n_ty);
+        aim_stage(n_nb, n_b, 0, have_next_item);
       }
-    }
-    {
-      float4 *wd = reinterpret_cast<float4 *>(sW);
+      float *cA = smem + buf * BUF;
+      c.nA = smem + (buf ^ 1) * BUF;
+      c.nW = c.nA + KC * PLANE;
+      c.aBase = cA + hi * PLANE + (wm * MT) * ROWP + l31;
+      c.bBase = cA + KC * PLANE + hi * 64 + (wn * NT) * 32 + l31;
+      float a[2][MT], bb[2][NT];
 #pragma unroll
-      for (int it = 0; it < NWITER; ++it) {
-        const int i = tid + it * 256;
-        if (i < NW4) wd[i] = vw[it];
-      }
+      for (int i = 0; i < MT; ++i) a[0][i] = c.aBase[i * ROWP];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bb[0][j] = c.bBase[j * 32];
+      if (chunk == 0)
+        k_steps<0, NSTEP, true, KC, KS, MT, NT, PLANE, ROWP, NITER, NWITER, POOL, RELU>(a, bb, acc, accPrev, c, epi);
+      else
+        k_steps<0, NSTEP, false, KC, KS, MT, NT, PLANE, ROWP, NITER, NWITER, POOL, RELU>(a, bb, acc, accPrev, c, epi);
+      __syncthreads();  // the other buffer is complete, this one is free
+      buf ^= 1;
     }
-    __syncthreads();
-    if (chunk + 1 < NCHUNK) SPFE_LOAD_CHUNK(chunk + 1);  // in flight during the MFMA loop below
+    epi = epi_next;  // this tile's outputs are stored while the next tile starts
+    more = have_next_item;
+    w += gper;
+    i_nb = n_nb; i_tx = n_tx; i_ty = n_ty; i_b = n_b;
+  };
 
-    // ---- MFMA over (tap, channel pair) in the contract's K order ----
-    // Operand reads are software pipelined one step ahead into a second register
-    // set: issued back to back with the MFMAs that consume the previous set, the
-    // ~100-cycle LDS latency hides under 4 x 64 cycles of matrix work.
-    constexpr int NSTEP = TAPS * (KC / 2);
-    float a[2][MT], bb[2][NT];
-#define SPFE_LOAD_OPS(SET_, STEP_)                                                         \
-  do {                                                                                      \
-    constexpr int tap_ = (STEP_) / (KC / 2), t_ = (STEP_) % (KC / 2);                       \
-    constexpr int dy_ = tap_ / KS, dx_ = tap_ % KS;                                         \
-    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                          \
-        a[SET_][i] = aBase[(2 * t_) * PLANE + (i + dy_) * ROWP + dx_];                      \
-    _Pragma("unroll") for (int j = 0; j < NT; ++j)                                          \
-        bb[SET_][j] = bBase[(tap_ * KC + 2 * t_) * 64 + j * 32];                            \
-  } while (0)
-    SPFE_LOAD_OPS(0, 0);
-    mfma_steps<0, NSTEP, KC, KS, MT, NT, PLANE, ROWP>(a, bb, acc, aBase, bBase);
-#undef SPFE_LOAD_OPS
+  bool lastA = true;
+  while (true) {
+    run_tile(accA, accB);
+    lastA = true;
+    if (!more) break;
+    run_tile(accB, accA);
+    lastA = false;
+    if (!more) break;
   }
-
-  // ---- epilogue: bias, ReLU, optional 2x2 max-pool, NHWC store ----
-  // C layout of the 32x32 MFMA: column (N) = lane&31, row (M) = (r&3)+8*(r>>2)+4*(lane>>5)
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int co = nb * 64 + (wn * NT + j) * 32 + l31;
-    const float bias = p.bias[co];
-    const bool cok = co < p.cout_real;
-    if constexpr (!POOL) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int y = ty0 + wm * MT + i;
-        float *orow = p.out + ((size_t)b * H + y) * W * p.out_stride + p.out_choff + co;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int x = tx0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          float v = acc[i][j][r] + bias;
-          if (RELU) v = v > 0.0f ? v : 0.0f;
-          if (cok && y < H && x < W) orow[(size_t)x * p.out_stride] = v;
-        }
-      }
-    } else {
-      const int y = ty0 + wm * MT;
-      const int Ho = H >> 1, Wo = W >> 1;
-      float *orow = p.out + ((size_t)b * Ho + (y >> 1)) * Wo * p.out_stride + p.out_choff + co;
-#pragma unroll
-      for (int rp = 0; rp < 8; ++rp) {
-        const int r = 2 * rp;
-        const int x = tx0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        float v00 = acc[0][j][r] + bias, v01 = acc[0][j][r + 1] + bias;
-        float v10 = acc[1][j][r] + bias, v11 = acc[1][j][r + 1] + bias;
-        if (RELU) {
-          v00 = v00 > 0.0f ? v00 : 0.0f;
-          v01 = v01 > 0.0f ? v01 : 0.0f;
-          v10 = v10 > 0.0f ? v10 : 0.0f;
-          v11 = v11 > 0.0f ? v11 : 0.0f;
-        }
-        const float m0 = v00 > v01 ? v00 : v01;
-        const float m1 = v10 > v11 ? v10 : v11;
-        const float v = m0 > m1 ? m0 : m1;
-        if (cok && y < H && x < W) orow[(size_t)(x >> 1) * p.out_stride] = v;
-      }
-    }
+  // the last tile's outputs: nothing left to hide them under
+  {
+    constexpr int NEPI = POOL ? NT * 8 : MT * NT * 16;
+    auto flush = [&](const f32x16(&acc)[MT][NT]) {
+      [&]<int... E>(std::integer_sequence<int, E...>) {
+        (epi_store<MT, NT, POOL, RELU, E>(epi, acc), ...);
+      }(std::make_integer_sequence<int, NEPI>{});
+    };
+    if (lastA) flush(accA); else flush(accB);
   }
 }
 
@@ -248,14 +432,21 @@ template <int CIN, int KS, int KC, int WM, int WN, int MT, int NT, bool POOL, bo
 static hipError_t launch_one(const ConvParams &p, hipStream_t s) {
   constexpr int TH = WM * MT;
   using G = Geo<KS, TH>;
-  constexpr size_t lds = (size_t)(KC * G::PLANE + KS * KS * KC * 64) * sizeof(float);
-  const int grid = p.nblk * p.tiles_x * p.tiles_y * p.B;
+  constexpr size_t lds = (2 * (size_t)(KC * G::PLANE + KS * KS * KC * 64) + 3 * G::PLANE + 256) * sizeof(float);
+  static_assert(lds <= 160 * 1024, "double buffer must fit the 160 KB LDS");
   auto k = conv_f32_kernel<CIN, KS, KC, WM, WN, MT, NT, POOL, RELU>;
-  if (lds > 64 * 1024) {
+  static bool attr_done = false;  // per instantiation
+  if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    attr_done = true;
   }
+  const int total = p.nblk * p.tiles_x * p.tiles_y * p.B;
+  int grid = p.num_cus > 0 ? p.num_cus : 256;  // one persistent workgroup per CU
+  grid &= ~7;
+  if (grid < 8) grid = 8;
+  (void)total;
   hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p);
   return hipGetLastError();
 }

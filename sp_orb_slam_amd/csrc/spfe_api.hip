@@ -92,6 +92,7 @@ struct spfe_handle_s {
   uint8_t *h_img = nullptr, *h_records = nullptr;
   float *h_heat = nullptr, *h_heat_inv = nullptr;
   int last_n = 0;
+  int num_cus = 256;
   // per-stage timing: a ring of event sets, one set per enqueue() call
   bool timing = false;
   static constexpr int EVSETS = 128;
@@ -215,6 +216,13 @@ int build(spfe_handle h, const spfe_config *cfg) {
   h->B = cfg->max_batch;
   const int H = h->H, W = h->W, B = h->B, C = h->C;
   HIP_TRY(hipSetDevice(cfg->device));
+  {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    h->num_cus = prop.multiProcessorCount;
+    const char *genv = getenv("SPFE_CONV_GRID");
+    if (genv) h->num_cus = atoi(genv);
+  }
   HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
   for (int i = 0; i < spfe_handle_s::NTICKET; ++i) {
@@ -356,6 +364,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     p.B = n; p.H = L.H; p.W = L.W;
     const int th = spfe::conv_tile_rows(L.small_tile);
     p.tiles_x = (L.W + 31) / 32; p.tiles_y = (L.H + th - 1) / th; p.nblk = L.nblk;
+    p.num_cus = h->num_cus;
     HIP_TRY(spfe::launch_conv_f32(p, L.cin, L.ks, L.pool, L.relu, L.small_tile, s));
     STAGE_MARK(2 + i);
   }

@@ -19,6 +19,7 @@ struct ConvParams {
   int out_stride, out_choff, cout_real;
   int B, H, W;  // conv input == conv output size (before the optional 2x2 pool)
   int tiles_x, tiles_y, nblk;
+  int num_cus;  // persistent grid size (multiProcessorCount)
 };
 
 // cin: 64/128/256; ksize: 3 or 1; pool/relu: fused epilogue; small_tile: 4-row
