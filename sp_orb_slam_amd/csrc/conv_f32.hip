@@ -12,7 +12,7 @@
 //    include/spfe_exact_math.h: chunk of KC channels -> tap -> channel.
 //  * LDS holds the input halo tile channel-major ([KC][rows][cols]): the 32
 //    lanes of an MFMA A operand read 32 consecutive floats (conflict free) and a
-//    filter tap is just an address offset; the 9 x KC x 64 weight slab of the
+//    filter tap is just an address offset; the 9 x KC x 64 weight slab ([n-tile][tap][k][32]) of the
 //    chunk sits next to it (~60 KB), double buffered (120 KB): one persistent
 //    workgroup per CU streams (tile, chunk) stages back to back.
 //  * 64-wide wavefronts: each wave owns MT x NT 32x32 accumulator tiles
@@ -76,7 +76,12 @@ struct Pipe {
   unsigned voff[NITER];  // byte offset of the piece inside the frame, or SPFE_OOB
   unsigned woff[NWITER]; // byte offset inside the weight slab
   __amdgpu_buffer_rsrc_t rin, rw;  // next stage: input frame (+channel offset), weight slab
-  const float *aBase, *bBase;      // this stage's operands in LDS
+  // this stage's operands in LDS.  at[t] = channel pair t of the halo tile: every A
+  // read is then base + an 8-bit ds_read2 offset; the weight slab is stored
+  // [n-tile][tap][k][32] so both B values of a step sit a multiple of 256 B apart
+  // (one ds_read2st64_b32, no address arithmetic in the MFMA shadow).
+  const float *at[8];
+  const float *bBase;
   float *nA, *nW;                  // the other LDS buffer
 };
 
@@ -146,9 +151,12 @@ __device__ __forceinline__ void k_steps(float (&a)[2][MT], float (&bb)[2][NT], f
           constexpr int tap = (STEP + 1) / (KC / 2), t = (STEP + 1) % (KC / 2);
           constexpr int dy = tap / KS, dx = tap % KS;
 #pragma unroll
-          for (int i = 0; i < MT; ++i) a[nxt][i] = c.aBase[(2 * t) * PLANE + (i + dy) * ROWP + dx];
+          for (int i = 0; i < MT; ++i) {
+            if constexpr (KC / 2 <= 8) a[nxt][i] = c.at[t][(i + dy) * ROWP + dx];
+            else a[nxt][i] = c.at[0][(2 * t) * PLANE + (i + dy) * ROWP + dx];
+          }
 #pragma unroll
-          for (int j = 0; j < NT; ++j) bb[nxt][j] = c.bBase[(tap * KC + 2 * t) * 64 + j * 32];
+          for (int j = 0; j < NT; ++j) bb[nxt][j] = c.bBase[j * (KS * KS * KC * 32) + (tap * KC + 2 * t) * 32];
         }
       }
       // (2) one global load of the next stage
@@ -387,13 +395,15 @@ __global__ __launch_bounds__(256, 1) void conv_f32_kernel(ConvParams p) {
       float *cA = smem + buf * BUF;
       c.nA = smem + (buf ^ 1) * BUF;
       c.nW = c.nA + KC * PLANE;
-      c.aBase = cA + hi * PLANE + (wm * MT) * ROWP + l31;
-      c.bBase = cA + KC * PLANE + hi * 64 + (wn * NT) * 32 + l31;
+#pragma unroll
+      for (int t = 0; t < (KC / 2 <= 8 ? KC / 2 : 1); ++t)
+        c.at[t] = cA + (2 * t + hi) * PLANE + (wm * MT) * ROWP + l31;
+      c.bBase = cA + KC * PLANE + (wn * NT) * (TAPS * KC * 32) + hi * 32 + l31;
       float a[2][MT], bb[2][NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a[0][i] = c.aBase[i * ROWP];
+      for (int i = 0; i < MT; ++i) a[0][i] = c.at[0][i * ROWP];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bb[0][j] = c.bBase[j * 32];
+      for (int j = 0; j < NT; ++j) bb[0][j] = c.bBase[j * (TAPS * KC * 32)];
       if (chunk == 0)
         k_steps<0, NSTEP, true, KC, KS, MT, NT, PLANE, ROWP, NITER, NWITER, POOL, RELU>(a, bb, acc, accPrev, c, epi);
       else

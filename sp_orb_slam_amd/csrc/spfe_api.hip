@@ -147,8 +147,8 @@ size_t blob_weight_offset(int l) {
   return off;
 }
 
-// pack OIHW weights of one or two layers (concatenated along cout) into
-// [nblk][chunk][tap][KC][64] (K order of spfe_exact_math.h) + padded bias
+// pack OIHW weights of one or two layers (concatenated along cout) into slabs
+// [nblk][chunk][n-tile(2)][tap][KC][32] (K order of spfe_exact_math.h) + padded bias
 int pack_layer(spfe_handle h, const float *blob, const int *lids, int nl, ConvLayer *out) {
   const spfe_layer_t &L0 = SPFE_LAYERS[lids[0]];
   const int cin = L0.cin, ks = L0.ksize, taps = ks * ks;
@@ -167,7 +167,7 @@ int pack_layer(spfe_handle h, const float *blob, const int *lids, int nl, ConvLa
       for (int ci = 0; ci < cin; ++ci) {
         const int ch = ci / kc, c = ci % kc;
         for (int t = 0; t < taps; ++t)
-          w[((((size_t)nb * nchunk + ch) * taps + t) * kc + c) * 64 + j] =
+          w[(((((size_t)nb * nchunk + ch) * 2 + j / 32) * taps + t) * kc + c) * 32 + j % 32] =
               W[((size_t)co * cin + ci) * taps + t];
       }
     }

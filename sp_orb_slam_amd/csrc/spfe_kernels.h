@@ -13,7 +13,7 @@ namespace spfe {
 struct ConvParams {
   const float *in;
   int in_stride, in_choff;
-  const float *wpack;  // [nblk][chunk][tap][KC][64], K order of spfe_exact_math.h
+  const float *wpack;  // [nblk][chunk][n-tile(2)][tap][KC][32], K order of spfe_exact_math.h
   const float *bias;   // [nblk*64]
   float *out;
   int out_stride, out_choff, cout_real;
