@@ -44,7 +44,7 @@ namespace spfe {
 #define COV_INF 0x7f7f7f7f
 #define COV_LCAP 128     // FIFO entries kept in LDS per wavefront
 #define COV_WIN 16       // the window covers dx,dy in [-16, 15] around the keypoint
-#define COV_WAVES 4      // wavefronts (= walks) per workgroup
+#define COV_WAVES 2      // wavefronts (= walks) per workgroup: 19 KB of LDS, fits beside a conv workgroup (127 KB)
 
 struct WaveMem {         // LDS of one wavefront
   float hv[32 * 32];     // heat_inv window

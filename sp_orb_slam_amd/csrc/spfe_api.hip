@@ -93,6 +93,7 @@ struct spfe_handle_s {
   float *h_heat = nullptr, *h_heat_inv = nullptr;
   int last_n = 0;
   int num_cus = 256;
+  int small_maxh = -1;
   // per-stage timing: a ring of event sets, one set per enqueue() call
   bool timing = false;
   static constexpr int EVSETS = 128;
@@ -297,8 +298,9 @@ int build(spfe_handle h, const spfe_config *cfg) {
   const Spec specs[8] = {{1, 1, 0, 0, 1, true},  {1, 2, 0, 1, 2, false}, {1, 3, 0, 2, 3, true},
                          {1, 4, 0, 3, 4, false}, {1, 5, 0, 4, 5, true},  {1, 6, 0, 5, 6, false},
                          {1, 7, 0, 6, 7, false}, {2, 8, 10, 7, -1, false}};
-  const char *senv = getenv("SPFE_SMALL_TILE_MAXH");
-  const int small_maxh = senv ? atoi(senv) : H / 4;  // layers with input height <= this use 4-row tiles
+  const char *senv = getenv("SPFE_SMALL_TILE_MAXH");  // override of the per-call choice in enqueue()
+  const int small_maxh = senv ? atoi(senv) : -1;
+  h->small_maxh = small_maxh;
   for (int i = 0; i < 8; ++i) {
     ConvLayer &L = h->layers[i];
     const int lids[2] = {specs[i].l0, specs[i].l1};
@@ -362,10 +364,22 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     p.wpack = L.d_w; p.bias = L.d_b;
     p.out = L.out; p.out_stride = L.out_stride; p.out_choff = L.out_choff; p.cout_real = L.cout_real;
     p.B = n; p.H = L.H; p.W = L.W;
-    const int th = spfe::conv_tile_rows(L.small_tile);
+    // tile height per layer and batch: 8-row tiles do 4 MFMAs per K step and wave
+    // (better hidden side work), 4-row tiles give twice the work items; pick the
+    // one with the shorter critical path over the persistent grid
+    bool small_tile = L.small_tile;
+    if (L.ks == 3 && h->small_maxh < 0) {
+      const long tx = (L.W + 31) / 32;
+      const long items_big = tx * ((L.H + 7) / 8) * L.nblk * n, items_small = tx * ((L.H + 3) / 4) * L.nblk * n;
+      const long g = h->num_cus > 0 ? h->num_cus : 256;
+      const double cost_big = (double)((items_big + g - 1) / g) * 2.0 * 0.93;
+      const double cost_small = (double)((items_small + g - 1) / g);
+      small_tile = cost_small < cost_big;
+    }
+    const int th = spfe::conv_tile_rows(small_tile);
     p.tiles_x = (L.W + 31) / 32; p.tiles_y = (L.H + th - 1) / th; p.nblk = L.nblk;
     p.num_cus = h->num_cus;
-    HIP_TRY(spfe::launch_conv_f32(p, L.cin, L.ks, L.pool, L.relu, L.small_tile, s));
+    HIP_TRY(spfe::launch_conv_f32(p, L.cin, L.ks, L.pool, L.relu, small_tile, s));
     STAGE_MARK(2 + i);
   }
   return enqueue_post(h, n, d_records, s);
