@@ -134,7 +134,7 @@ def main():
                                       "covariance of step i overlapped with the convolutions of step i+1 (depth-2 pipeline)"),
                        "frames_per_gpu": B, "height": H, "width": W, "num_features": nf,
                        "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "conv_f32_kernel<64,3,16,...,pool> (conv1b)",
+            "roofline": {"bound": "mfma", "kernel": "conv_f32_kernel<1,64,3,16,4,1,2,2,true,true> (conv1b)",
                          "achieved": round(ach, 2) if ach else None, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4) if ach else None,
                          "traffic": traffic},

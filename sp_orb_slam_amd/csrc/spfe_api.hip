@@ -379,7 +379,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     const int th = spfe::conv_tile_rows(small_tile);
     p.tiles_x = (L.W + 31) / 32; p.tiles_y = (L.H + th - 1) / th; p.nblk = L.nblk;
     p.num_cus = h->num_cus;
-    HIP_TRY(spfe::launch_conv_f32(p, L.cin, L.ks, L.pool, L.relu, small_tile, s));
+    HIP_TRY(spfe::launch_conv_f32(p, L.cin, L.ks, L.pool, L.relu, small_tile, i == 0 ? 1 : 0, s));
     STAGE_MARK(2 + i);
   }
   return enqueue_post(h, n, d_records, s);

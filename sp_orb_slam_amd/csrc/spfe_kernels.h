@@ -25,7 +25,7 @@ struct ConvParams {
 // cin: 64/128/256; ksize: 3 or 1; pool/relu: fused epilogue; small_tile: 4-row
 // tiles (more workgroups for the low-resolution layers).
 hipError_t launch_conv_f32(const ConvParams &p, int cin, int ksize, bool pool, bool relu,
-                           bool small_tile, hipStream_t s);
+                           bool small_tile, int layer_tag, hipStream_t s);
 int conv_kc(int ksize);        // K-chunk the kernel stages per barrier (16 for 3x3, 64 for 1x1)
 int conv_tile_rows(bool small_tile);
 

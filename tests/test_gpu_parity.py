@@ -86,6 +86,20 @@ def test_full_path_matches_oracle(H, W, iseed, wseed, det, nf):
     ext.close()
 
 
+@pytest.mark.parametrize("H,W", [(16, 16), (16, 40), (40, 16), (24, 32), (32, 24), (56, 72), (104, 40), (48, 264)])
+def test_odd_sizes_exact(H, W):
+    """Small and lopsided sizes: fewer work items than persistent workgroups, tiles that are
+    mostly outside the image, 2x2-cell grids."""
+    blob = weights.synthetic(7, "dense")
+    img = synth.make_image(H + W, H, W)
+    ext = SPExtractor(64, H, W, blob, max_batch=3)
+    ref = oracle.extract(blob, img, 64)
+    for fr in ext.extract_batch([img, img, img]):
+        _compare(fr, ref)
+    assert np.array_equal(ext.debug_read("coarse", 2).view(np.uint32), ref["coarse"].view(np.uint32))
+    ext.close()
+
+
 def test_layerwise_activations_bitwise():
     """Every conv stage against the oracle's network on a size with ragged tiles."""
     H, W = 88, 120

@@ -14,7 +14,9 @@ def short(name):
     name = re.sub(r"\[clone.*", "", name)
     m = re.match(r"void (spfe::\w+)<(.*)>\(", name)
     if m:
-        return "%s<%s>" % (m.group(1), m.group(2).replace(" ", ""))
+        args = m.group(2).replace(" ", "")
+        tag = " [conv1b]" if m.group(1).endswith("conv_f32_kernel") and args.startswith("1,") else ""
+        return "%s<%s>%s" % (m.group(1), args, tag)
     return name.split("(")[0][:90]
 
 
