@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_FRAME = {(480, 752): 61221703680, (480, 640): 52103577600, (720, 1280): 156310732800}
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 
 
 def conv1b_flop(H, W):
@@ -44,6 +45,9 @@ def main():
     ap.add_argument("--sync-cov", action="store_true",
                     help="do not overlap the covariance stage of step i with the convolutions of step i+1")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
+                    help="f32: BASELINE configs[1]/[2] (bit-exact path, the headline); bf16: configs[3] "
+                         "(bf16 convolutions conv1b..convPa/Da, f32 heads + post-processing)")
     args = ap.parse_args()
 
     os.environ.setdefault("SPFE_STAGE_TIMING", "1")
@@ -68,7 +72,8 @@ def main():
 
     H, W, nf, B = args.height, args.width, args.num_features, args.frames_per_gpu
     blob = weights.synthetic(7, args.detector)
-    ext = SPExtractor(nf, H, W, blob, max_batch=B, device=local, with_heat=False, async_cov=not args.sync_cov)
+    ext = SPExtractor(nf, H, W, blob, max_batch=B, device=local, with_heat=False, async_cov=not args.sync_cov,
+                      precision=args.precision)
     rec_bytes = ext.record_bytes()
     # synthetic frames: seeds 200..; rank r owns global frames [r*B, (r+1)*B)
     lo, hi = parallel.shard_range(world * B, world, rank)
@@ -115,9 +120,11 @@ def main():
         # dominant kernel: conv1b (43.5 % of the FLOPs), one launch covers B frames
         t_conv1b = stages.get("conv1b", 0.0) * 1e-3
         ach = (conv1b_flop(H, W) * B / t_conv1b / 1e12) if t_conv1b > 0 else None
+        bf16 = args.precision == "bf16"
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "conv1b_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not bf16 and (H, W, B) == (480, 752, 8):
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
@@ -126,23 +133,27 @@ def main():
             "metric": "frames/sec SuperPoint extract (752x480, 1k kpts)",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%dx%d u8 frames, num_features=%d, f32 MFMA, %d frames/GPU/step, "
+            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "%dx%d u8 frames, num_features=%d, %s, %d frames/GPU/step, "
                                    "%s synthetic detector weights; records all-gathered over RCCL when n_gpus>1; %s"
-                                   % (W, H, nf, B, args.detector,
+                                   % (W, H, nf,
+                                      "bf16 MFMA convolutions (f32 accumulate), f32 heads and post-processing"
+                                      if bf16 else "f32 MFMA", B, args.detector,
                                       "covariance stage on the device, synchronous" if args.sync_cov else
                                       "covariance of step i overlapped with the convolutions of step i+1 (depth-2 pipeline)"),
                        "frames_per_gpu": B, "height": H, "width": W, "num_features": nf,
                        "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "conv_f32_kernel<1,64,3,16,4,1,2,2,true,true> (conv1b)",
-                         "achieved": round(ach, 2) if ach else None, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4) if ach else None,
+            "roofline": {"bound": "mfma", "kernel": ("conv_bf16_kernel<64,true,false> (conv1b)" if bf16 else
+                                                      "conv_f32_kernel<1,64,3,16,4,1,2,2,true,true> (conv1b)"),
+                         "achieved": round(ach, 2) if ach else None, "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(ach / peak, 4) if ach else None,
                          "traffic": traffic},
             "whole_path_tflops": round(fps * flop_frame / 1e12, 2) if flop_frame else None,
             "stage_ms": {k: round(v, 4) for k, v in stages.items()},
         }
         # batch-1 latency (configs[1] as written: one frame per call)
-        ext1 = None if args.no_latency else SPExtractor(nf, H, W, blob, max_batch=1, device=local, with_heat=False)
+        ext1 = None if args.no_latency else SPExtractor(nf, H, W, blob, max_batch=1, device=local, with_heat=False,
+                                                                precision=args.precision)
         d1 = d_img[:1].contiguous()
         r1 = torch.zeros(rec_bytes, dtype=torch.uint8, device="cuda")
         lat = []

@@ -43,6 +43,8 @@ def lib():
         L.oracle_bias_offset.argtypes = [C.c_int]
         L.oracle_network.restype = C.c_int
         L.oracle_network.argtypes = [f32p, u8p, C.c_int, C.c_int, f32p, f32p, C.c_void_p]
+        L.oracle_network_bf16.restype = C.c_int
+        L.oracle_network_bf16.argtypes = [f32p, u8p, C.c_int, C.c_int, f32p, f32p]
         L.oracle_tail.restype = C.c_int
         L.oracle_tail.argtypes = [f32p, C.c_int, C.c_int, f32p, f32p, f32p, f32p, f32p, f32p, i32p]
         L.oracle_sample_desc.restype = None
@@ -88,6 +90,28 @@ def network(blob, img):
     if rc:
         raise ValueError("oracle_network rc=%d" % rc)
     return semi, coarse, feat
+
+
+def network_bf16(blob, img):
+    """The build's bf16 mode (see oracle_network_bf16): -> (semi, coarse)."""
+    H, W = img.shape
+    hc, wc = H // 8, W // 8
+    semi = np.empty((hc, wc, 65), np.float32)
+    coarse = np.empty((hc, wc, 256), np.float32)
+    rc = lib().oracle_network_bf16(np.ascontiguousarray(blob, np.float32),
+                                   np.ascontiguousarray(img, np.uint8), H, W, semi, coarse)
+    if rc:
+        raise ValueError("oracle_network_bf16 rc=%d" % rc)
+    return semi, coarse
+
+
+def extract_bf16(blob, img, num_features):
+    H, W = img.shape
+    semi, coarse = network_bf16(blob, img)
+    out = postprocess(semi, coarse, H, W, num_features)
+    out["semi"] = semi
+    out["coarse"] = coarse
+    return out
 
 
 def tail(semi, H, W):

@@ -52,7 +52,25 @@ EXPORT size_t oracle_num_params(void) { return oracle_weight_offset(SPFE_NUM_LAY
 /* zero padding ksize/2 (:27-43), relu(:81-99).  in: [H][W][cin], out:          */
 /* [H][W][cout].  Accumulation order = spfe_exact_math.h layer plan.            */
 /* ------------------------------------------------------------------------- */
+/* bf16 mode of the build (SPFE_PRECISION_BF16, BASELINE configs[3]): round-to-nearest-even
+ * to bfloat16, kept in a float. */
+static float bf16_round(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  u &= 0xffff0000u;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+static void conv_layer_ex(int l, const float *blob, const float *in, int H, int W, float *out, int w_bf16,
+                          int out_bf16);
 static void conv_layer(int l, const float *blob, const float *in, int H, int W, float *out) {
+  conv_layer_ex(l, blob, in, H, W, out, 0, 0);
+}
+
+static void conv_layer_ex(int l, const float *blob, const float *in, int H, int W, float *out, int w_bf16,
+                          int out_bf16) {
   const spfe_layer_t *L = &SPFE_LAYERS[l];
   const int cin = L->cin, cout = L->cout, ks = L->ksize, pad = ks / 2, taps = ks * ks;
   const int kc = L->kc < cin ? L->kc : cin;
@@ -74,7 +92,8 @@ static void conv_layer(int l, const float *blob, const float *in, int H, int W, 
       for (int c = 0; c < kc; ++c)
         for (int co = 0; co < cout; ++co)
           wt[(((size_t)ch * taps + t) * kc + c) * coutp + co] =
-              w[((size_t)co * cin + ch * kc + c) * taps + t];
+              w_bf16 ? bf16_round(w[((size_t)co * cin + ch * kc + c) * taps + t])
+                     : w[((size_t)co * cin + ch * kc + c) * taps + t];
 
 #pragma omp parallel for schedule(dynamic, 1)
   for (int y = 0; y < H; ++y) {
@@ -98,7 +117,7 @@ static void conv_layer(int l, const float *blob, const float *in, int H, int W, 
         for (int i = 0; i < nco; ++i) {
           float v = acc[i] + b[cb + i];
           if (L->relu) v = v > 0.0f ? v : 0.0f;
-          o[i] = v;
+          o[i] = out_bf16 ? bf16_round(v) : v;
         }
       }
     }
@@ -157,6 +176,48 @@ EXPORT int oracle_network(const float *blob, const uint8_t *img, int H, int W, f
   conv_layer(9, blob, cPa, h, w, semi);  /* convPb (:97) */
   conv_layer(10, blob, a, h, w, cPa);    /* convDa + relu (:99) */
   conv_layer(11, blob, cPa, h, w, coarse); /* convDb (:100) */
+  free(cPa);
+  free(a);
+  free(b);
+  free(x0);
+  return 0;
+}
+
+/*
+ * The network in the build's bf16 mode: conv1a in f32 with its output rounded to bf16;
+ * conv1b..conv4b with bf16 weights and activations (f32 accumulate, bias, ReLU, pool; outputs
+ * rounded); convPa/convDa with bf16 weights and f32 outputs; convPb/convDb and everything
+ * after them in f32.  (The MFMA's accumulation order differs from this loop's, so the GPU is
+ * compared with a tolerance in this mode, not bitwise.)
+ */
+EXPORT int oracle_network_bf16(const float *blob, const uint8_t *img, int H, int W, float *semi,
+                               float *coarse) {
+  if (H % 8 || W % 8 || H <= 0 || W <= 0) return -1;
+  size_t maxel = (size_t)H * W * 64;
+  float *a = (float *)malloc(maxel * sizeof(float));
+  float *b = (float *)malloc(maxel * sizeof(float));
+  float *x0 = (float *)malloc((size_t)H * W * sizeof(float));
+  for (size_t i = 0; i < (size_t)H * W; ++i) x0[i] = spfe_pixel_to_float(img[i]);
+  int h = H, w = W;
+  conv_layer_ex(0, blob, x0, h, w, a, 0, 1);
+  conv_layer_ex(1, blob, a, h, w, b, 1, 1);
+  maxpool2(b, h, w, 64, a);
+  h /= 2, w /= 2;
+  conv_layer_ex(2, blob, a, h, w, b, 1, 1);
+  conv_layer_ex(3, blob, b, h, w, a, 1, 1);
+  maxpool2(a, h, w, 64, b);
+  h /= 2, w /= 2;
+  conv_layer_ex(4, blob, b, h, w, a, 1, 1);
+  conv_layer_ex(5, blob, a, h, w, b, 1, 1);
+  maxpool2(b, h, w, 128, a);
+  h /= 2, w /= 2;
+  conv_layer_ex(6, blob, a, h, w, b, 1, 1);
+  conv_layer_ex(7, blob, b, h, w, a, 1, 1);
+  float *cPa = (float *)malloc((size_t)h * w * 256 * sizeof(float));
+  conv_layer_ex(8, blob, a, h, w, cPa, 1, 0);
+  conv_layer_ex(9, blob, cPa, h, w, semi, 0, 0);
+  conv_layer_ex(10, blob, a, h, w, cPa, 1, 0);
+  conv_layer_ex(11, blob, cPa, h, w, coarse, 0, 0);
   free(cPa);
   free(a);
   free(b);

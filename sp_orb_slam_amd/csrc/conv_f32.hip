@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256, 1) void conv_f32_kernel(ConvParams p) {
   constexpr int NSTEP = TAPS * (KC / 2);
   constexpr int SLAB_BYTES = TAPS * KC * 64 * 4;
 
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 buffers + a dummy slot region
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 buffers
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -290,8 +290,10 @@ __global__ __launch_bounds__(256, 1) void conv_f32_kernel(ConvParams p) {
     prow[it] = i < NITEM ? pix / G::COLS - G::HALO : (1 << 20);  // unused piece: never inside the image
     pcol[it] = pix % G::COLS - G::HALO;
     pqb[it] = qq * 16;
+    // an unused piece (tid + it*256 >= NITEM) is written where nothing is ever read: a pad
+    // column of the halo rows (planes 0..3), or the pad floats that end each plane
     c.dst[it] = i < NITEM ? (qq * 4) * PLANE + (pix / G::COLS) * ROWP + pix % G::COLS
-                          : 2 * BUF + tid;  // dummy slots behind the two buffers
+                          : (ROWP > G::COLS ? (tid % G::ROWS) * ROWP + G::COLS : G::PLANE_RAW);
   }
 #pragma unroll
   for (int it = 0; it < NWITER; ++it) c.woff[it] = (tid + it * 256) * 16;
@@ -444,7 +446,7 @@ template <int LAYER, int CIN, int KS, int KC, int WM, int WN, int MT, int NT, bo
 static hipError_t launch_one(const ConvParams &p, hipStream_t s) {
   constexpr int TH = WM * MT;
   using G = Geo<KS, TH>;
-  constexpr size_t lds = (2 * (size_t)(KC * G::PLANE + KS * KS * KC * 64) + 3 * G::PLANE + 256) * sizeof(float);
+  constexpr size_t lds = 2 * (size_t)(KC * G::PLANE + KS * KS * KC * 64) * sizeof(float);
   static_assert(lds <= 160 * 1024, "double buffer must fit the 160 KB LDS");
   auto k = conv_f32_kernel<LAYER, CIN, KS, KC, WM, WN, MT, NT, POOL, RELU>;
   static bool attr_done = false;  // per instantiation

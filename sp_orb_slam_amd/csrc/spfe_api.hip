@@ -94,6 +94,7 @@ struct spfe_handle_s {
   int last_n = 0;
   int num_cus = 256;
   int small_maxh = -1;
+  bool bf16 = false;  // SPFE_PRECISION_BF16: bf16 conv stack (conv1a .. convPa/Da), f32 heads and tail
   // per-stage timing: a ring of event sets, one set per enqueue() call
   bool timing = false;
   static constexpr int EVSETS = 128;
@@ -186,6 +187,56 @@ int pack_layer(spfe_handle h, const float *blob, const int *lids, int nl, ConvLa
   return SPFE_OK;
 }
 
+unsigned short host_bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+// bf16 slabs for conv_bf16.hip: [nblk][chunk of 32 channels][tap][n 64][80-byte row: 32 bf16 + pad],
+// each slab padded to conv_bf16_slab_bytes(); bias stays f32
+int pack_layer_bf16(spfe_handle h, const float *blob, const int *lids, int nl, ConvLayer *out) {
+  const spfe_layer_t &L0 = SPFE_LAYERS[lids[0]];
+  const int cin = L0.cin, taps = 9;
+  int cout = 0;
+  for (int i = 0; i < nl; ++i) cout += SPFE_LAYERS[lids[i]].cout;
+  const int nchunk = cin / 32, nblk = (cout + 63) / 64;
+  const size_t slab = spfe::conv_bf16_slab_bytes();
+  std::vector<unsigned char> w((size_t)nblk * nchunk * slab, 0);
+  std::vector<float> bia((size_t)nblk * 64, 0.0f);
+  int co_base = 0;
+  for (int i = 0; i < nl; ++i) {
+    const spfe_layer_t &L = SPFE_LAYERS[lids[i]];
+    const float *W = blob + blob_weight_offset(lids[i]);
+    const float *Bv = W + (size_t)L.cout * L.cin * taps;
+    for (int co = 0; co < L.cout; ++co) {
+      const int g = co_base + co, nb = g / 64, j = g % 64;
+      bia[g] = Bv[co];
+      for (int ci = 0; ci < cin; ++ci) {
+        const int ch = ci / 32, c = ci % 32;
+        for (int t = 0; t < taps; ++t) {
+          const unsigned short v = host_bf16_rne(W[((size_t)co * cin + ci) * taps + t]);
+          memcpy(&w[((size_t)nb * nchunk + ch) * slab + ((size_t)t * 64 + j) * 80 + c * 2], &v, 2);
+        }
+      }
+    }
+    co_base += L.cout;
+  }
+  int rc;
+  unsigned char *dw = nullptr;
+  if ((rc = dev_alloc(h, &dw, w.size()))) return rc;
+  if ((rc = dev_alloc(h, &out->d_b, bia.size()))) return rc;
+  HIP_TRY(hipMemcpy(dw, w.data(), w.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(out->d_b, bia.data(), bia.size() * 4, hipMemcpyHostToDevice));
+  out->d_w = reinterpret_cast<float *>(dw);
+  out->cin = cin;
+  out->cout_real = cout;
+  out->nblk = nblk;
+  out->ks = 3;
+  return SPFE_OK;
+}
+
 int load_blob(const spfe_config *cfg, std::vector<float> *blob) {
   blob->resize(SPFE_NUM_PARAMS);
   if (cfg->weights) {
@@ -215,6 +266,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
   h->hc = h->H / 8; h->wc = h->W / 8; h->C = h->hc * h->wc;
   h->kmax = cfg->num_features + 1;
   h->B = cfg->max_batch;
+  h->bf16 = cfg->precision == SPFE_PRECISION_BF16;
   const int H = h->H, W = h->W, B = h->B, C = h->C;
   HIP_TRY(hipSetDevice(cfg->device));
   {
@@ -304,7 +356,9 @@ int build(spfe_handle h, const spfe_config *cfg) {
   for (int i = 0; i < 8; ++i) {
     ConvLayer &L = h->layers[i];
     const int lids[2] = {specs[i].l0, specs[i].l1};
-    if ((rc = pack_layer(h, blob.data(), lids, specs[i].nl, &L))) return rc;
+    if (h->bf16) rc = pack_layer_bf16(h, blob.data(), lids, specs[i].nl, &L);
+    else rc = pack_layer(h, blob.data(), lids, specs[i].nl, &L);
+    if (rc) return rc;
     L.pool = specs[i].pool;
     L.relu = true;
     L.H = lh[specs[i].src];
@@ -355,7 +409,8 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   if (h->timing) h->ev = h->evpool.data() + (size_t)(h->calls % spfe_handle_s::EVSETS) * (NSTAGE + 1);
   h->calls++;
   STAGE_MARK(0);
-  HIP_TRY(spfe::launch_conv1a(d_images, h->d_w1a, h->d_b1a, h->act[0], n, H, W, s));
+  if (h->bf16) HIP_TRY(spfe::launch_conv1a_bf16(d_images, h->d_w1a, h->d_b1a, h->act[0], n, H, W, s));
+  else HIP_TRY(spfe::launch_conv1a(d_images, h->d_w1a, h->d_b1a, h->act[0], n, H, W, s));
   STAGE_MARK(1);
   for (int i = 0; i < 10; ++i) {
     const ConvLayer &L = h->layers[i];
@@ -367,6 +422,14 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     // tile height per layer and batch: 8-row tiles do 4 MFMAs per K step and wave
     // (better hidden side work), 4-row tiles give twice the work items; pick the
     // one with the shorter critical path over the persistent grid
+    if (h->bf16 && i < 8) {
+      // bf16 stack: 8-row tiles only; convPa/Da (i == 7) write f32 for the f32 heads
+      p.tiles_x = (L.W + 31) / 32; p.tiles_y = (L.H + 7) / 8; p.nblk = L.nblk;
+      p.num_cus = h->num_cus;
+      HIP_TRY(spfe::launch_conv_bf16(p, L.cin, L.pool, i == 7, s));
+      STAGE_MARK(2 + i);
+      continue;
+    }
     bool small_tile = L.small_tile;
     if (L.ks == 3 && h->small_maxh < 0) {
       const long tx = (L.W + 31) / 32;
@@ -452,7 +515,7 @@ void view_record(const spfe_handle h, const uint8_t *rec, const float *heat, con
 extern "C" {
 
 const char *spfe_last_error(void) { return g_err.c_str(); }
-const char *spfe_version(void) { return "spfe 0.1 (gfx950, f32-mfma)"; }
+const char *spfe_version(void) { return "spfe 0.2 (gfx950, f32-mfma + bf16-mfma)"; }
 const char *spfe_stage_name(int i) { return (i >= 0 && i < NSTAGE) ? kStageNames[i] : ""; }
 
 int spfe_create(const spfe_config *cfg, spfe_handle *out) {
@@ -466,7 +529,8 @@ int spfe_create(const spfe_config *cfg, spfe_handle *out) {
   if (cfg->num_features < 1 || cfg->num_features > 16384)
     return fail(SPFE_EINVAL, "num_features %d out of range (1..16384)", cfg->num_features);
   if (cfg->max_batch < 1) return fail(SPFE_EINVAL, "max_batch must be >= 1");
-  if (cfg->precision != SPFE_PRECISION_F32) return fail(SPFE_EINVAL, "unsupported precision %d", cfg->precision);
+  if (cfg->precision != SPFE_PRECISION_F32 && cfg->precision != SPFE_PRECISION_BF16)
+    return fail(SPFE_EINVAL, "unsupported precision %d", cfg->precision);
   if ((size_t)(cfg->height / 8) * (cfg->width / 8) > 65535 ||
       spfe::select_lds_bytes(cfg->height, cfg->width) > 160 * 1024)
     return fail(SPFE_EINVAL, "image %dx%d too large for the single-workgroup selection stage", cfg->width,

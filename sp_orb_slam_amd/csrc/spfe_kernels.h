@@ -29,6 +29,13 @@ hipError_t launch_conv_f32(const ConvParams &p, int cin, int ksize, bool pool, b
 int conv_kc(int ksize);        // K-chunk the kernel stages per barrier (16 for 3x3, 64 for 1x1)
 int conv_tile_rows(bool small_tile);
 
+// bf16 3x3 convolutions (conv_bf16.hip): in/out NHWC bf16 (out f32 when out_f32), strides in
+// elements; wpack = bf16 slabs of conv_bf16_slab_bytes() each, [nblk][chunk of 32 ch][tap][64][80 B]
+hipError_t launch_conv_bf16(const ConvParams &p, int cin, bool pool, bool out_f32, hipStream_t s);
+size_t conv_bf16_slab_bytes();
+hipError_t launch_conv1a_bf16(const uint8_t *img, const float *w9x64, const float *b64, void *out, int B, int H,
+                              int W, hipStream_t s);
+
 // conv1a: u8 image -> (x * 1/255) -> 3x3 conv 1->64 + bias + relu, NHWC out.
 // w: [9][64] (tap-major), b: [64]
 hipError_t launch_conv1a(const uint8_t *img, const float *w9x64, const float *b64, float *out, int B,

@@ -21,6 +21,7 @@ LIB_PATH = os.path.join(_PKG, "libspfe.so")
 SPFE_FLAG_HEAT = 1
 SPFE_FLAG_ASYNC_COV = 2
 SPFE_PRECISION_F32 = 0
+SPFE_PRECISION_BF16 = 1
 NUM_PARAMS = 1300865
 _ERRORS = {-1: "SPFE_EINVAL", -2: "SPFE_EEMPTY", -3: "SPFE_EHIP", -4: "SPFE_EWEIGHTS"}
 
@@ -172,14 +173,18 @@ class SPExtractor:
     """
 
     def __init__(self, nfeatures, height, width, weights, max_batch=1, device=0, with_heat=True,
-                 async_cov=False):
+                 async_cov=False, precision="f32"):
         self._h = C.c_void_p()
         self._lib = load_library()
         self.nfeatures, self.height, self.width = int(nfeatures), int(height), int(width)
         self.max_batch, self.with_heat = int(max_batch), bool(with_heat)
         cfg = _Config()
         cfg.height, cfg.width, cfg.num_features = self.height, self.width, self.nfeatures
-        cfg.max_batch, cfg.device, cfg.precision = self.max_batch, int(device), SPFE_PRECISION_F32
+        if precision not in ("f32", "bf16"):
+            raise SpfeError("precision must be 'f32' or 'bf16'")
+        self.precision = precision
+        cfg.max_batch, cfg.device = self.max_batch, int(device)
+        cfg.precision = SPFE_PRECISION_BF16 if precision == "bf16" else SPFE_PRECISION_F32
         cfg.flags = (SPFE_FLAG_HEAT if with_heat else 0) | (SPFE_FLAG_ASYNC_COV if async_cov else 0)
         self.async_cov = bool(async_cov)
         keep = None
