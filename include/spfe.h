@@ -165,6 +165,30 @@ SPFE_API int spfe_view_record(spfe_handle h, const void *host_record, spfe_resul
  * Returns the number of bytes copied or a negative error. */
 SPFE_API long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size_t cap);
 
+/* ---- descriptor matching ------------------------------------------------
+ * Replaces  cv::BFMatcher::create(cv::NORM_L2, crossCheck)->match(desc_query, matches)  with
+ * desc_train added, as called by SPMatcher::SearchByBruteForce (orb_slam2/src/cv/sp_matcher.cpp:
+ * 1642-1674; the distance is SPMatcher::DescriptorDistance, :1636-1640 = L2 norm of a - b).
+ * Descriptors are rows of 256 floats.  For every query row i: train_idx[i] = matched train row or
+ * -1, distance[i] = its L2 distance (FLT_MAX when unmatched) — i.e. cv::DMatch{queryIdx = i,
+ * trainIdx = train_idx[i], distance}, with the unmatched queries (which OpenCV omits) marked -1.
+ *   cross_check != 0 (the reference's setting): OpenCV's batchDistance rule — every train row votes
+ *     for its nearest query (lowest query index on ties); a query is matched to the closest train
+ *     row that voted for it (lowest train index on ties), queries without votes stay unmatched.
+ *   cross_check == 0: plain nearest train row per query (lowest index on ties).
+ * NaN / infinite distances never match.  n_query or n_train == 0: all -1, SPFE_OK. */
+SPFE_API int spfe_match(spfe_handle h, const float *query, int n_query, const float *train, int n_train,
+                        int cross_check, int32_t *train_idx, float *distance);
+/* Device-resident form: matches the descriptors of n_pairs query records against n_pairs train
+ * records (both arrays of spfe_record_bytes()-strided records in HBM, e.g. the outputs of two
+ * spfe_extract_batch_device calls), reading K from the record headers on the device; no host
+ * synchronisation.  d_out: n_pairs blocks of spfe_match_out_bytes(h) bytes, each
+ * int32 train_idx[kmax] followed by float distance[kmax] (kmax = num_features + 1; entries >= the
+ * query record's K are -1 / FLT_MAX).  stream: hipStream_t (NULL = the handle's stream). */
+SPFE_API int spfe_match_records_device(spfe_handle h, const void *d_query_records, const void *d_train_records,
+                                       int n_pairs, int cross_check, void *d_out, void *stream);
+SPFE_API size_t spfe_match_out_bytes(spfe_handle h);
+
 /* Per-stage GPU time (ms, HIP events recorded on the launch stream around every
  * kernel), averaged over the calls since spfe_stage_reset (the library keeps the
  * last 128 calls).  Enabled by SPFE_STAGE_TIMING=1 in the environment at

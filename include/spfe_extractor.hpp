@@ -91,6 +91,29 @@ class ExtractorCV {
     status_ = r.status;
   }
 
+  // Replaces the body of SPMatcher::SearchByBruteForce's matcher (sp_matcher.cpp:1661-1668):
+  //   auto matcher = cv::BFMatcher::create(cv::NORM_L2, true); matcher->add(desc_train);
+  //   matcher->train(); matcher->match(desc_query, matches);
+  // Both are K x 256 CV_32FC1 with contiguous rows.  Emits one cv::DMatch per matched query, in
+  // query order, like BFMatcher::match.
+  void matchBruteForce(const cv::Mat &desc_query, const cv::Mat &desc_train, std::vector<cv::DMatch> &matches,
+                       bool cross_check = true) {
+    matches.clear();
+    if (desc_query.empty() || desc_train.empty()) return;
+    if (desc_query.cols != 256 || desc_train.cols != 256 || desc_query.type() != CV_32FC1 ||
+        desc_train.type() != CV_32FC1 || desc_query.step != 256 * sizeof(float) ||
+        desc_train.step != 256 * sizeof(float))
+      throw std::runtime_error("matchBruteForce: descriptors must be contiguous K x 256 CV_32FC1");
+    std::vector<int32_t> idx(desc_query.rows);
+    std::vector<float> dist(desc_query.rows);
+    if (spfe_match(h_, reinterpret_cast<const float *>(desc_query.data), desc_query.rows,
+                   reinterpret_cast<const float *>(desc_train.data), desc_train.rows, cross_check ? 1 : 0,
+                   idx.data(), dist.data()) != SPFE_OK)
+      throw std::runtime_error(spfe_last_error());
+    for (int i = 0; i < desc_query.rows; ++i)
+      if (idx[i] >= 0) matches.push_back(cv::DMatch(i, idx[i], 0, dist[i]));
+  }
+
   cv::Mat getMask() { return mask_; }
   cv::Mat getHeatMap() { return heat_; }
   const std::vector<Vec2f> &getCov() const { return cov2_; }

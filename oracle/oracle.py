@@ -63,6 +63,8 @@ def lib():
         L.oracle_postprocess.argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p,
                                          f32p, f32p, f32p, i16p, f32p, f32p, f32p, f32p,
                                          C.POINTER(C.c_int)]
+        L.oracle_match_bruteforce.restype = None
+        L.oracle_match_bruteforce.argtypes = [f32p, C.c_int, f32p, C.c_int, C.c_int, i32p, f32p]
         L.oracle_expf.restype = C.c_float
         L.oracle_expf.argtypes = [C.c_float]
         L.oracle_logf.restype = C.c_float
@@ -214,3 +216,16 @@ def extract(blob, img, num_features):
     out["semi"] = semi
     out["coarse"] = coarse
     return out
+
+
+def match_bruteforce(query, train, cross_check=True):
+    """cv::BFMatcher(NORM_L2, crossCheck).match as SPMatcher::SearchByBruteForce uses it
+    (sp_matcher.cpp:1642-1674): -> (train_idx int32 [nq] with -1 = unmatched, distance f32 [nq])."""
+    q = np.ascontiguousarray(query, np.float32).reshape(-1, 256)
+    t = np.ascontiguousarray(train, np.float32).reshape(-1, 256)
+    idx = np.empty(max(len(q), 1), np.int32)
+    dist = np.empty(max(len(q), 1), np.float32)
+    lib().oracle_match_bruteforce(q if len(q) else np.zeros((1, 256), np.float32), len(q),
+                                  t if len(t) else np.zeros((1, 256), np.float32), len(t),
+                                  1 if cross_check else 0, idx, dist)
+    return idx[:len(q)].copy(), dist[:len(q)].copy()

@@ -25,6 +25,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <float.h>
 #include <math.h>
 
 #include "../include/spfe_exact_math.h"
@@ -552,6 +553,83 @@ EXPORT int oracle_extract(const float *blob, const uint8_t *img, int H, int W, i
   free(semi);
   free(coarse);
   return rc;
+}
+
+/*
+ * SURVEY.md §8(f) rank 1 — descriptor matching.  Restates
+ *   cv::BFMatcher::create(cv::NORM_L2, crossCheck)->add(train); ->match(query, matches)
+ * as called by SPMatcher::SearchByBruteForce (orb_slam2/src/cv/sp_matcher.cpp:1642-1674), with
+ * SPMatcher::DescriptorDistance (:1636-1640) = L2 norm of the difference.
+ *
+ * OpenCV (3.x, `find_package(OpenCV 3.0)` CMakeLists.txt:14; not vendored, not installed here —
+ * PARITY UNPINNED, published algorithm restated): BFMatcher::knnMatchImpl(k = 1) calls
+ * cv::batchDistance(query, train, dist, CV_32F, nidx, NORM_L2, 1, mask, 0, crossCheck), whose L2
+ * distance is sqrt(sum (a-b)^2) in float and whose scans keep the first minimum (strict `<`).
+ * With crossCheck it computes, for every TRAIN row, its nearest QUERY row, and then lets each
+ * query keep the closest train row that chose it (strict `<` over ascending train index);
+ * queries nobody chose get no DMatch.  Without crossCheck: the nearest train row per query.
+ * OpenCV's summation order inside normL2Sqr_ depends on its SIMD build; this restatement fixes
+ * the sequential fused chain of include/spfe.h (spfe_match).
+ * Outputs: train_idx[nq] (-1 = no DMatch for that query), distance[nq] (FLT_MAX when -1).
+ */
+static float match_dist(const float *a, const float *b) {
+  float s = 0.0f;
+  for (int k = 0; k < 256; ++k) {
+    const float d = a[k] - b[k];
+    s = fmaf(d, d, s);
+  }
+  return sqrtf(s);
+}
+
+EXPORT void oracle_match_bruteforce(const float *query, int nq, const float *train, int nt, int cross_check,
+                                    int32_t *train_idx, float *distance) {
+  for (int i = 0; i < nq; ++i) {
+    train_idx[i] = -1;
+    distance[i] = FLT_MAX;
+  }
+  if (nq <= 0 || nt <= 0) return;
+  if (!cross_check) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < nq; ++i) {
+      float best = FLT_MAX;
+      int bi = -1;
+      for (int j = 0; j < nt; ++j) {
+        const float d = match_dist(query + (size_t)i * 256, train + (size_t)j * 256);
+        if (d < best) {
+          best = d;
+          bi = j;
+        }
+      }
+      train_idx[i] = bi;
+      distance[i] = best;
+    }
+    return;
+  }
+  float *tdist = (float *)malloc((size_t)nt * sizeof(float));
+  int *tidx = (int *)malloc((size_t)nt * sizeof(int));
+#pragma omp parallel for schedule(static)
+  for (int j = 0; j < nt; ++j) {  /* nearest query of every train row */
+    float best = FLT_MAX;
+    int bi = -1;
+    for (int i = 0; i < nq; ++i) {
+      const float d = match_dist(train + (size_t)j * 256, query + (size_t)i * 256);
+      if (d < best) {
+        best = d;
+        bi = i;
+      }
+    }
+    tdist[j] = best;
+    tidx[j] = bi;
+  }
+  for (int j = 0; j < nt; ++j) {  /* each query keeps the closest train row that chose it */
+    const int i = tidx[j];
+    if (i >= 0 && tdist[j] < distance[i]) {
+      distance[i] = tdist[j];
+      train_idx[i] = j;
+    }
+  }
+  free(tdist);
+  free(tidx);
 }
 
 /* exact-math probes so GPU tests can compare device bits with host bits */

@@ -1,0 +1,166 @@
+// match.hip — brute-force L2 descriptor matching with OpenCV's cross-check rule, on the GPU.
+//
+// the step right after extraction.  Replaces
+//   cv::BFMatcher::create(cv::NORM_L2, /*crossCheck=*/true)->match(desc_query, matches)
+// as called by SPMatcher::SearchByBruteForce
+// (/root/reference/orb_slam2/src/cv/sp_matcher.cpp:1642-1674; distance =
+// SPMatcher::DescriptorDistance :1636-1640 = L2 norm of the difference), so that two frames'
+// descriptors can be matched while their records are still in HBM.
+//
+// Arithmetic contract (oracle_match_bruteforce restates the same):
+//   dist(a, b) = sqrtf(s_255),  s_k = fmaf(a[k] - b[k], a[k] - b[k], s_{k-1}),  s_{-1} = 0
+// — a sequential chain in k, which is what a thread that owns a (row, column) pair
+// computes anyway; no |a|^2 + |b|^2 - 2ab expansion (that is not the reference's arithmetic
+// and loses the small distances).  "Nearest" = smallest dist, lowest index on ties
+// (OpenCV's strict `<` scans).
+//
+//   match_nn_kernel      rows x cols distance tiles (64 x 64 per workgroup, 4 x 4 per lane,
+//                        operands staged through LDS 64 dimensions at a time); every row's
+//                        nearest column is folded with a 64-bit atomic min of
+//                        (dist bits << 32 | column) — dist >= 0, so the bit pattern orders
+//                        like the value and the low word breaks ties toward the lower index.
+//   match_resolve_kernel cross-check as OpenCV's batchDistance does it: rows = train,
+//                        cols = query; each train row votes for its nearest query, each
+//                        query keeps the closest train that voted for it (lowest train index
+//                        on ties) — again one 64-bit atomic min.
+//   match_emit_kernel    unpack to int32 train index (-1 = no match) + float distance.
+#include <float.h>
+
+#include "spfe_kernels.h"
+
+namespace spfe {
+
+namespace {
+constexpr int M_TILE = 64;        // rows / columns per workgroup
+constexpr int M_KC = 64;          // descriptor dimensions staged per pass
+constexpr int M_PITCH = M_KC + 4; // floats per staged row: 272 B keeps float4 alignment, spreads banks
+constexpr int M_DIM = 256;
+constexpr unsigned long long M_NONE = ~0ull;
+
+__device__ __forceinline__ int side_count(const MatchSide &s, int pair) {
+  const int n = *reinterpret_cast<const int *>(s.base + (size_t)pair * s.stride + s.off_cnt);
+  return n < 0 ? 0 : (n > s.cap ? s.cap : n);
+}
+__device__ __forceinline__ const float *side_desc(const MatchSide &s, int pair) {
+  return reinterpret_cast<const float *>(s.base + (size_t)pair * s.stride + s.off_desc);
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void match_nn_kernel(MatchSide rows, MatchSide cols,
+                                                       unsigned long long *__restrict__ best) {
+  const int pair = blockIdx.z;
+  const int nr = side_count(rows, pair), nc = side_count(cols, pair);
+  const int r0 = blockIdx.y * M_TILE, c0 = blockIdx.x * M_TILE;
+  if (r0 >= nr || c0 >= nc) return;
+  const float *R = side_desc(rows, pair), *Cd = side_desc(cols, pair);
+
+  __shared__ __attribute__((aligned(16))) float sR[M_TILE * M_PITCH];
+  __shared__ __attribute__((aligned(16))) float sC[M_TILE * M_PITCH];
+  const int tid = threadIdx.x;
+  const int ty = tid >> 4, tx = tid & 15;
+
+  float acc[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[r][c] = 0.0f;
+
+  for (int k0 = 0; k0 < M_DIM; k0 += M_KC) {
+    if (k0) __syncthreads();
+#pragma unroll
+    for (int i = tid; i < M_TILE * (M_KC / 4); i += 256) {
+      const int row = i >> 4, k4 = i & 15;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f), u = v;
+      if (r0 + row < nr) v = *reinterpret_cast<const float4 *>(R + (size_t)(r0 + row) * M_DIM + k0 + k4 * 4);
+      if (c0 + row < nc) u = *reinterpret_cast<const float4 *>(Cd + (size_t)(c0 + row) * M_DIM + k0 + k4 * 4);
+      *reinterpret_cast<float4 *>(&sR[row * M_PITCH + k4 * 4]) = v;
+      *reinterpret_cast<float4 *>(&sC[row * M_PITCH + k4 * 4]) = u;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < M_KC; k += 4) {
+      float4 a[4], b[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[r] = *reinterpret_cast<const float4 *>(&sR[(ty * 4 + r) * M_PITCH + k]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) b[c] = *reinterpret_cast<const float4 *>(&sC[(tx + 16 * c) * M_PITCH + k]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float d;
+          d = a[r].x - b[c].x; acc[r][c] = __builtin_fmaf(d, d, acc[r][c]);
+          d = a[r].y - b[c].y; acc[r][c] = __builtin_fmaf(d, d, acc[r][c]);
+          d = a[r].z - b[c].z; acc[r][c] = __builtin_fmaf(d, d, acc[r][c]);
+          d = a[r].w - b[c].w; acc[r][c] = __builtin_fmaf(d, d, acc[r][c]);
+        }
+    }
+  }
+
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    unsigned long long p = M_NONE;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int col = c0 + tx + 16 * c;
+      const float dist = __builtin_sqrtf(acc[r][c]);  // correctly rounded (v_sqrt_f32 + the fma fix-up), unlike __fsqrt_rn
+      if (col < nc && dist < FLT_MAX) {  // NaN / inf distances are never "nearer" (OpenCV: d < FLT_MAX start)
+        const unsigned long long cand = ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned)col;
+        p = cand < p ? cand : p;
+      }
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {  // the 16 lanes sharing this row
+      const unsigned lo = __shfl_xor((unsigned)p, off), hi = __shfl_xor((unsigned)(p >> 32), off);
+      const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+      p = o < p ? o : p;
+    }
+    const int row = r0 + ty * 4 + r;
+    if (tx == 0 && row < nr && p != M_NONE) atomicMin(&best[(size_t)pair * rows.cap + row], p);
+  }
+}
+
+// best_t: [pairs][cap_t] (dist, query) per train row; best_q: [pairs][cap_q] (dist, train) per query
+__global__ __launch_bounds__(256) void match_resolve_kernel(const unsigned long long *__restrict__ best_t,
+                                                            int cap_t, unsigned long long *__restrict__ best_q,
+                                                            int cap_q) {
+  const int t = blockIdx.x * 256 + threadIdx.x, pair = blockIdx.y;
+  if (t >= cap_t) return;
+  const unsigned long long p = best_t[(size_t)pair * cap_t + t];
+  if (p == M_NONE) return;
+  const unsigned q = (unsigned)p;
+  atomicMin(&best_q[(size_t)pair * cap_q + q], (p & 0xffffffff00000000ull) | (unsigned)t);
+}
+
+__global__ __launch_bounds__(256) void match_emit_kernel(const unsigned long long *__restrict__ best, int cap,
+                                                         uint8_t *__restrict__ out, size_t out_stride) {
+  const int q = blockIdx.x * 256 + threadIdx.x, pair = blockIdx.y;
+  if (q >= cap) return;
+  const unsigned long long p = best[(size_t)pair * cap + q];
+  int32_t *idx = reinterpret_cast<int32_t *>(out + (size_t)pair * out_stride);
+  float *dist = reinterpret_cast<float *>(out + (size_t)pair * out_stride + (size_t)cap * 4);
+  idx[q] = p == M_NONE ? -1 : (int32_t)(unsigned)p;
+  dist[q] = p == M_NONE ? FLT_MAX : __uint_as_float((unsigned)(p >> 32));
+}
+
+hipError_t launch_match(const MatchSide &query, const MatchSide &train, int pairs, bool cross_check,
+                        unsigned long long *best_t, unsigned long long *best_q, uint8_t *out, size_t out_stride,
+                        hipStream_t s) {
+  hipError_t e;
+  if ((e = hipMemsetAsync(best_q, 0xff, (size_t)pairs * query.cap * 8, s)) != hipSuccess) return e;
+  if (cross_check) {
+    if ((e = hipMemsetAsync(best_t, 0xff, (size_t)pairs * train.cap * 8, s)) != hipSuccess) return e;
+    dim3 g((query.cap + M_TILE - 1) / M_TILE, (train.cap + M_TILE - 1) / M_TILE, pairs);
+    hipLaunchKernelGGL(match_nn_kernel, g, dim3(256), 0, s, train, query, best_t);
+    hipLaunchKernelGGL(match_resolve_kernel, dim3((train.cap + 255) / 256, pairs), dim3(256), 0, s, best_t,
+                       train.cap, best_q, query.cap);
+  } else {
+    dim3 g((train.cap + M_TILE - 1) / M_TILE, (query.cap + M_TILE - 1) / M_TILE, pairs);
+    hipLaunchKernelGGL(match_nn_kernel, g, dim3(256), 0, s, query, train, best_q);
+  }
+  hipLaunchKernelGGL(match_emit_kernel, dim3((query.cap + 255) / 256, pairs), dim3(256), 0, s, best_q, query.cap,
+                     out, out_stride);
+  return hipGetLastError();
+}
+
+}  // namespace spfe

@@ -7,6 +7,8 @@
 // operator() (:361-514) the extract calls replace.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cfloat>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -94,6 +96,11 @@ struct spfe_handle_s {
   int last_n = 0;
   int num_cus = 256;
   int small_maxh = -1;
+  // descriptor matching (spfe_match*): scratch grown on demand
+  unsigned long long *m_best_t = nullptr, *m_best_q = nullptr;
+  uint8_t *m_stage_q = nullptr, *m_stage_t = nullptr, *m_out = nullptr;
+  int m_pairs = 0, m_cap = 0;      // capacity of m_best_* ([pairs][cap])
+  int m_host_cap = 0;              // rows the host-API staging blocks / m_out hold
   bool bf16 = false;  // SPFE_PRECISION_BF16: bf16 conv stack (conv1a .. convPa/Da), f32 heads and tail
   // per-stage timing: a ring of event sets, one set per enqueue() call
   bool timing = false;
@@ -562,6 +569,9 @@ void spfe_destroy(spfe_handle h) {
     if (h->ev_cov[i]) (void)hipEventDestroy(h->ev_cov[i]);
   }
   if (h->side) (void)hipStreamDestroy(h->side);
+  for (void *p : {(void *)h->m_best_t, (void *)h->m_best_q, (void *)h->m_stage_q, (void *)h->m_stage_t,
+                  (void *)h->m_out})
+    if (p) (void)hipFree(p);
   for (void *p : h->dev_allocs) (void)hipFree(p);
   for (void *p : h->host_allocs) (void)hipHostFree(p);
   for (auto &e : h->evpool)
@@ -745,6 +755,83 @@ int spfe_stage_times(spfe_handle h, float *ms, int cap) {
   }
   for (int i = 0; i < nst; ++i) ms[i] = (float)(acc[i] / (double)(h->calls - first));
   return nst;
+}
+
+// ---- descriptor matching ------------------------------------------------
+namespace {
+int match_scratch(spfe_handle h, int pairs, int cap) {
+  if (pairs <= h->m_pairs && cap <= h->m_cap) return SPFE_OK;
+  pairs = std::max(pairs, h->m_pairs);
+  cap = std::max(cap, h->m_cap);
+  HIP_TRY(hipDeviceSynchronize());
+  if (h->m_best_t) (void)hipFree(h->m_best_t);
+  if (h->m_best_q) (void)hipFree(h->m_best_q);
+  h->m_best_t = h->m_best_q = nullptr;
+  h->m_pairs = h->m_cap = 0;
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->m_best_t), (size_t)pairs * cap * 8));
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->m_best_q), (size_t)pairs * cap * 8));
+  h->m_pairs = pairs;
+  h->m_cap = cap;
+  return SPFE_OK;
+}
+constexpr size_t kMatchHdr = 16;  // staging block of the host API: int32 count, pad, then rows
+}  // namespace
+
+size_t spfe_match_out_bytes(spfe_handle h) { return h ? (size_t)h->kmax * 8 : 0; }
+
+int spfe_match_records_device(spfe_handle h, const void *d_query_records, const void *d_train_records, int n_pairs,
+                              int cross_check, void *d_out, void *stream) {
+  if (!h || !d_query_records || !d_train_records || !d_out) return fail(SPFE_EINVAL, "null argument");
+  if (n_pairs < 1) return fail(SPFE_EINVAL, "n_pairs %d must be >= 1", n_pairs);
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  int rc = match_scratch(h, n_pairs, h->kmax);
+  if (rc) return rc;
+  hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
+  spfe::MatchSide q{reinterpret_cast<const uint8_t *>(d_query_records), h->rl.bytes, h->rl.off_hdr, h->rl.off_desc,
+                    h->kmax};
+  spfe::MatchSide t{reinterpret_cast<const uint8_t *>(d_train_records), h->rl.bytes, h->rl.off_hdr, h->rl.off_desc,
+                    h->kmax};
+  HIP_TRY(spfe::launch_match(q, t, n_pairs, cross_check != 0, h->m_best_t, h->m_best_q,
+                             reinterpret_cast<uint8_t *>(d_out), (size_t)h->kmax * 8, s));
+  return SPFE_OK;
+}
+
+int spfe_match(spfe_handle h, const float *query, int n_query, const float *train, int n_train, int cross_check,
+               int32_t *train_idx, float *distance) {
+  if (!h || !train_idx || !distance) return fail(SPFE_EINVAL, "null argument");
+  if (n_query < 0 || n_train < 0) return fail(SPFE_EINVAL, "negative descriptor count");
+  if ((n_query && !query) || (n_train && !train)) return fail(SPFE_EINVAL, "null descriptor array");
+  for (int i = 0; i < n_query; ++i) { train_idx[i] = -1; distance[i] = FLT_MAX; }
+  if (n_query == 0 || n_train == 0) return SPFE_OK;
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const int cap = std::max(n_query, n_train);
+  if (cap > h->m_host_cap) {
+    HIP_TRY(hipDeviceSynchronize());
+    for (uint8_t **p : {&h->m_stage_q, &h->m_stage_t, &h->m_out})
+      if (*p) { (void)hipFree(*p); *p = nullptr; }
+    h->m_host_cap = 0;
+    const int want = std::max(cap, h->kmax);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->m_stage_q), kMatchHdr + (size_t)want * 1024));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->m_stage_t), kMatchHdr + (size_t)want * 1024));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->m_out), (size_t)want * 8));
+    h->m_host_cap = want;
+  }
+  int rc = match_scratch(h, 1, std::max(cap, h->kmax));
+  if (rc) return rc;
+  hipStream_t s = h->stream;
+  const int32_t hq[4] = {n_query, 0, 0, 0}, ht[4] = {n_train, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(h->m_stage_q, hq, 16, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->m_stage_t, ht, 16, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->m_stage_q + kMatchHdr, query, (size_t)n_query * 1024, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->m_stage_t + kMatchHdr, train, (size_t)n_train * 1024, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));  // hq / ht live on this frame
+  spfe::MatchSide q{h->m_stage_q, 0, 0, kMatchHdr, n_query};
+  spfe::MatchSide t{h->m_stage_t, 0, 0, kMatchHdr, n_train};
+  HIP_TRY(spfe::launch_match(q, t, 1, cross_check != 0, h->m_best_t, h->m_best_q, h->m_out, 0, s));
+  HIP_TRY(hipMemcpyAsync(train_idx, h->m_out, (size_t)n_query * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(distance, h->m_out + (size_t)n_query * 4, (size_t)n_query * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return SPFE_OK;
 }
 
 // test hook: run the exact-math device functions on n floats (host buffers)

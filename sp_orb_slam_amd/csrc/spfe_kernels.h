@@ -89,6 +89,23 @@ hipError_t launch_heat_norm(const FrameBufs &f, int B, int H, int W, hipStream_t
 hipError_t launch_desc(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s);
 size_t select_lds_bytes(int H, int W);
 
+// ---------------------------------------------------------------------------
+// brute-force descriptor matching (match.hip)
+// One "side" = `pairs` blocks `stride` bytes apart, each holding an int32 count at off_cnt
+// and count x 256 f32 descriptors at off_desc (a record of the extraction path has this
+// shape; so has the staging block of the host API).  cap bounds the count.
+// ---------------------------------------------------------------------------
+struct MatchSide {
+  const uint8_t *base;
+  size_t stride, off_cnt, off_desc;
+  int cap;
+};
+// out: per pair `out_stride` bytes: int32 train_idx[query.cap] (-1 = none), float dist[query.cap].
+// best_t: [pairs][train.cap], best_q: [pairs][query.cap] scratch.
+hipError_t launch_match(const MatchSide &query, const MatchSide &train, int pairs, bool cross_check,
+                        unsigned long long *best_t, unsigned long long *best_q, uint8_t *out, size_t out_stride,
+                        hipStream_t s);
+
 // exact-math probe kernels for tests (device bits vs host bits)
 hipError_t launch_math_probe(const float *in, float *out_exp, float *out_log, int n, hipStream_t s);
 

@@ -33,6 +33,7 @@ ABI_SYMBOLS = [
     "spfe_view_record", "spfe_debug_read", "spfe_stage_times", "spfe_stage_reset",
     "spfe_stage_name",
     "spfe_math_probe", "spfe_last_error", "spfe_version",
+    "spfe_match", "spfe_match_records_device", "spfe_match_out_bytes",
 ]
 
 
@@ -106,6 +107,14 @@ def load_library():
     L.spfe_stage_name.argtypes = [C.c_int]
     L.spfe_math_probe.restype = C.c_int
     L.spfe_math_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.spfe_match.restype = C.c_int
+    L.spfe_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                             C.c_void_p]
+    L.spfe_match_records_device.restype = C.c_int
+    L.spfe_match_records_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                            C.c_void_p]
+    L.spfe_match_out_bytes.restype = C.c_size_t
+    L.spfe_match_out_bytes.argtypes = [C.c_void_p]
     L.spfe_last_error.restype = C.c_char_p
     L.spfe_version.restype = C.c_char_p
     _lib = L
@@ -332,6 +341,39 @@ class SPExtractor:
         r = _Result()
         _check(self._lib.spfe_view_record(self._h, rec.ctypes.data, C.byref(r)))
         return FrameResult(r, self.height, self.width, False)
+
+    # -- descriptor matching --
+    def match(self, query, train, cross_check=True):
+        """cv::BFMatcher(NORM_L2, crossCheck).match(query) with `train` added, as
+        SPMatcher::SearchByBruteForce calls it (sp_matcher.cpp:1642-1674).
+        query [nq,256], train [nt,256] f32 -> (train_idx int32 [nq], -1 = no match; distance f32 [nq])."""
+        q = np.ascontiguousarray(query, np.float32).reshape(-1, 256)
+        t = np.ascontiguousarray(train, np.float32).reshape(-1, 256)
+        idx = np.empty(len(q), np.int32)
+        dist = np.empty(len(q), np.float32)
+        _check(self._lib.spfe_match(self._h, q.ctypes.data if len(q) else None, len(q),
+                                    t.ctypes.data if len(t) else None, len(t), 1 if cross_check else 0,
+                                    idx.ctypes.data, dist.ctypes.data))
+        return idx, dist
+
+    def match_out_bytes(self):
+        return int(self._lib.spfe_match_out_bytes(self._h))
+
+    def match_records_device(self, d_query_records, d_train_records, n_pairs, d_out, cross_check=True,
+                             stream=None):
+        """Device pointers (ints) to n_pairs query / train records and to n_pairs * match_out_bytes()
+        bytes of output; enqueues on `stream` (int hipStream_t, None = the handle's stream)."""
+        _check(self._lib.spfe_match_records_device(self._h, d_query_records, d_train_records, n_pairs,
+                                                   1 if cross_check else 0, d_out, stream))
+
+    def decode_match_out(self, host_block, n_query=None):
+        """uint8[match_out_bytes()] copied from the device -> (train_idx, distance)."""
+        b = np.ascontiguousarray(host_block, np.uint8)
+        kmax = self.match_out_bytes() // 8
+        idx = b[:kmax * 4].view(np.int32)
+        dist = b[kmax * 4:kmax * 8].view(np.float32)
+        n = kmax if n_query is None else n_query
+        return idx[:n].copy(), dist[:n].copy()
 
     def debug_read(self, name, frame=0):
         shapes = {"semi": (self.height // 8, self.width // 8, 65),

@@ -48,6 +48,13 @@ int main(int argc, char **argv) {
     fwrite(extractor.dense_dust_.data, 4, (size_t)(H / 8) * (W / 8), o);
     fwrite(extractor.heat_.data, 4, (size_t)H * W, o);
     fclose(o);
+    // SearchByBruteForce's matcher (sp_matcher.cpp:1661-1668) through the adaptor: a frame
+    // matched against itself pairs every keypoint with itself at distance 0
+    std::vector<cv::DMatch> matches;
+    extractor.matchBruteForce(mDescriptors, mDescriptors, matches);
+    if ((int)matches.size() != K) return 7;
+    for (int i = 0; i < K; ++i)
+      if (matches[i].queryIdx != i || matches[i].trainIdx != i || matches[i].distance != 0.0f) return 7;
   } catch (const std::exception &e) {
     fprintf(stderr, "adaptor_main: %s\n", e.what());
     return 4;

@@ -53,6 +53,13 @@ class KeyPoint {
       : size(s), angle(a), response(r), octave(o), class_id(c) { pt.x = x; pt.y = y; }
 };
 
+struct DMatch {
+  int queryIdx = -1, trainIdx = -1, imgIdx = -1;
+  float distance = 0;
+  DMatch() {}
+  DMatch(int q, int t, int i, float d) : queryIdx(q), trainIdx(t), imgIdx(i), distance(d) {}
+};
+
 class _InputArray {
  public:
   _InputArray(const Mat &m) : m_(&m) {}
