@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--sync-cov", action="store_true",
                     help="do not overlap the covariance stage of step i with the convolutions of step i+1")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-match", action="store_true", help="skip the descriptor-matching leg (SURVEY 8f-1)")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
                     help="f32: BASELINE configs[1]/[2] (bit-exact path, the headline); bf16: configs[3] "
                          "(bf16 convolutions conv1b..convPa/Da, f32 heads + post-processing)")
@@ -167,6 +168,48 @@ def main():
             lat = sorted(lat[10:])
             out["latency_batch1_ms"] = {"p50": round(lat[len(lat) // 2], 4), "p99": round(lat[-1], 4)}
             ext1.close()
+
+        if not args.no_match:
+            # SURVEY.md §8(f) rank 1 (outside the timed region): match this step's B frames against
+            # the same frames shifted by one cell, records resident in HBM, cross-check on.
+            extm = SPExtractor(nf, H, W, blob, max_batch=B, device=local, with_heat=False,
+                               precision=args.precision)
+            d_img2 = torch.roll(d_img, (8, 16), (1, 2)).contiguous()
+            ra = torch.zeros(B * rec_bytes, dtype=torch.uint8, device="cuda")
+            rb2 = torch.zeros(B * rec_bytes, dtype=torch.uint8, device="cuda")
+            mo = torch.zeros(B * extm.match_out_bytes(), dtype=torch.uint8, device="cuda")
+            mstream = torch.cuda.Stream()   # an explicit stream: a NULL stream argument means "the handle's own"
+            torch.cuda.synchronize()
+            extm.extract_batch_device(d_img.data_ptr(), B, ra.data_ptr(), mstream.cuda_stream)
+            extm.extract_batch_device(d_img2.data_ptr(), B, rb2.data_ptr(), mstream.cuda_stream)
+            for _ in range(3):
+                extm.match_records_device(rb2.data_ptr(), ra.data_ptr(), B, mo.data_ptr(), True, mstream.cuda_stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            nit = 30
+            e0.record(mstream)
+            for _ in range(nit):
+                extm.match_records_device(rb2.data_ptr(), ra.data_ptr(), B, mo.data_ptr(), True, mstream.cuda_stream)
+            e1.record(mstream)
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / nit
+            ka = [extm.view_record(ra[i * rec_bytes:(i + 1) * rec_bytes].cpu().numpy()) for i in range(B)]
+            kb = [extm.view_record(rb2[i * rec_bytes:(i + 1) * rec_bytes].cpu().numpy()) for i in range(B)]
+            pair_elems = sum(a.K * b.K for a, b in zip(ka, kb)) * 256
+            mb = extm.match_out_bytes()
+            idx0, _ = extm.decode_match_out(mo[:mb].cpu().numpy(), kb[0].K)
+            out["match_bruteforce"] = {
+                "what": "cv::BFMatcher(NORM_L2, crossCheck=true) rule, %d frame pairs per launch, K~%d x %d, "
+                        "records in HBM" % (B, kb[0].K, ka[0].K),
+                "ms_per_batch": round(ms, 4), "pairs_per_s": round(B / ms * 1e3, 1),
+                # 1 subtract + 1 fma per descriptor element pair, on the f32 VALU
+                "valu_tflops": round(pair_elems * 3 / (ms * 1e-3) / 1e12, 2),
+                "matched_frac_pair0": round(float((idx0 >= 0).mean()), 3)}
+            if world == 1 and not args.no_cpu_baseline:
+                from oracle import oracle as _orc
+                t1 = time.perf_counter()
+                _orc.match_bruteforce(kb[0].descriptors, ka[0].descriptors, True)
+                out["match_bruteforce"]["cpu_oracle_ms_per_pair"] = round((time.perf_counter() - t1) * 1e3, 2)
+            extm.close()
 
         if world == 1 and not args.no_cpu_baseline:
             # CPU baseline: the C oracle (a port of the path; the reference has no CPU

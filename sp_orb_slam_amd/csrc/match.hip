@@ -59,11 +59,14 @@ __global__ __launch_bounds__(256) void match_nn_kernel(MatchSide rows, MatchSide
   const int tid = threadIdx.x;
   const int ty = tid >> 4, tx = tid & 15;
 
-  float acc[4][4];
+  // two columns per packed register: v_pk_add_f32 / v_pk_fma_f32 do two IEEE f32 lanes per
+  // issue slot (bitwise the scalar ops), which is what this VALU-bound loop is made of
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 acc2[4][2];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[r][c] = 0.0f;
+    for (int c = 0; c < 2; ++c) acc2[r][c] = (f32x2){0.0f, 0.0f};
 
   for (int k0 = 0; k0 < M_DIM; k0 += M_KC) {
     if (k0) __syncthreads();
@@ -87,15 +90,24 @@ __global__ __launch_bounds__(256) void match_nn_kernel(MatchSide rows, MatchSide
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          float d;
-          d = a[r].x - b[c].x; acc[r][c] = __builtin_fmaf(d, d, acc[r][c]);
-          d = a[r].y - b[c].y; acc[r][c] = __builtin_fmaf(d, d, acc[r][c]);
-          d = a[r].z - b[c].z; acc[r][c] = __builtin_fmaf(d, d, acc[r][c]);
-          d = a[r].w - b[c].w; acc[r][c] = __builtin_fmaf(d, d, acc[r][c]);
+        for (int c = 0; c < 2; ++c) {
+          f32x2 d;
+          d = (f32x2){a[r].x, a[r].x} - (f32x2){b[2 * c].x, b[2 * c + 1].x};
+          acc2[r][c] = __builtin_elementwise_fma(d, d, acc2[r][c]);
+          d = (f32x2){a[r].y, a[r].y} - (f32x2){b[2 * c].y, b[2 * c + 1].y};
+          acc2[r][c] = __builtin_elementwise_fma(d, d, acc2[r][c]);
+          d = (f32x2){a[r].z, a[r].z} - (f32x2){b[2 * c].z, b[2 * c + 1].z};
+          acc2[r][c] = __builtin_elementwise_fma(d, d, acc2[r][c]);
+          d = (f32x2){a[r].w, a[r].w} - (f32x2){b[2 * c].w, b[2 * c + 1].w};
+          acc2[r][c] = __builtin_elementwise_fma(d, d, acc2[r][c]);
         }
     }
   }
+  float acc[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[r][c] = acc2[r][c >> 1][c & 1];
 
 #pragma unroll
   for (int r = 0; r < 4; ++r) {

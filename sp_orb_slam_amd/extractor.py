@@ -65,6 +65,31 @@ class RecordLayout(C.Structure):
 _lib = None
 
 
+def _bind_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels ship their own libamdhip64.so.7 (+ HSA
+    runtime) under torch/lib; libspfe.so needs the same SONAME.  Whichever copy the dynamic loader
+    sees first serves both, and a torch imported AFTER libspfe had pulled in /opt/rocm's copy finds
+    no devices.  So when a torch wheel with a bundled runtime is installed (it is the plumbing the
+    multi-GPU driver uses), load that copy first; torch itself is not imported here."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     """dlopen libspfe.so (built by __graft_entry__.build()).  Raises if missing."""
     global _lib
@@ -73,6 +98,7 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise SpfeError("libspfe.so not built at %s — run `python -c 'import __graft_entry__ as g; "
                         "g.build()'` (there is no CPU fallback)" % LIB_PATH)
+    _bind_hip_runtime()
     L = C.CDLL(LIB_PATH)
     L.spfe_create.restype = C.c_int
     L.spfe_create.argtypes = [C.POINTER(_Config), C.POINTER(C.c_void_p)]
