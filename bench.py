@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--sync-cov", action="store_true",
                     help="do not overlap the covariance stage of step i with the convolutions of step i+1")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--no-match", action="store_true", help="skip the descriptor-matching leg (SURVEY 8f-1)")
+    ap.add_argument("--no-match", action="store_true", help="skip the descriptor-matching and input-staging legs (SURVEY 8f-1, 8f-2)")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
                     help="f32: BASELINE configs[1]/[2] (bit-exact path, the headline); bf16: configs[3] "
                          "(bf16 convolutions conv1b..convPa/Da, f32 heads + post-processing)")
@@ -210,6 +210,34 @@ def main():
                 _orc.match_bruteforce(kb[0].descriptors, ka[0].descriptors, True)
                 out["match_bruteforce"]["cpu_oracle_ms_per_pair"] = round((time.perf_counter() - t1) * 1e3, 2)
             extm.close()
+
+        if not args.no_match:
+            # SURVEY.md §8(f) rank 2 (outside the timed region): staging kernel on B raw BGR frames
+            exts = SPExtractor(nf, H, W, blob, max_batch=B, device=local, with_heat=False)
+            vv, uu = np.mgrid[0:H, 0:W].astype(np.float64)
+            r2 = ((uu - W / 2) / W) ** 2 + ((vv - H / 2) / W) ** 2
+            mx = (uu + (uu - W / 2) * (-0.28 * r2)).astype(np.float32)
+            my = (vv + (vv - H / 2) * (-0.28 * r2)).astype(np.float32)
+            exts.set_staging(H, W, 3, False, mx, my)
+            d_raw = d_img[:, :, :, None].expand(B, H, W, 3).contiguous()
+            d_gray = torch.zeros((B, H, W), dtype=torch.uint8, device="cuda")
+            sstream = torch.cuda.Stream()
+            torch.cuda.synchronize()
+            for _ in range(3):
+                exts.stage_batch_device(d_raw.data_ptr(), B, d_gray.data_ptr(), sstream.cuda_stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(sstream)
+            for _ in range(30):
+                exts.stage_batch_device(d_raw.data_ptr(), B, d_gray.data_ptr(), sstream.cuda_stream)
+            e1.record(sstream)
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 30
+            # algorithmic bytes: 4 taps x 3 ch gathered (hits L2: ~1 raw frame) + 2 maps + 1 gray out
+            alg = B * H * W * (3 + 8 + 1)
+            out["input_staging"] = {"what": "cv::remap(INTER_LINEAR) + crop + BGR2GRAY, %d frames %dx%dx3 per launch"
+                                            % (B, W, H), "ms_per_batch": round(ms, 4),
+                                    "hbm_GBps_algorithmic": round(alg / (ms * 1e-3) / 1e9, 1)}
+            exts.close()
 
         if world == 1 and not args.no_cpu_baseline:
             # CPU baseline: the C oracle (a port of the path; the reference has no CPU

@@ -189,6 +189,33 @@ SPFE_API int spfe_match_records_device(spfe_handle h, const void *d_query_record
                                        int n_pairs, int cross_check, void *d_out, void *stream);
 SPFE_API size_t spfe_match_out_bytes(spfe_handle h);
 
+/* ---- input staging -----------------------------------------------------
+ * Replaces, per frame, the host OpenCV sequence in front of the extractor:
+ *   cv::remap(mono, mono, m1, m2, cv::INTER_LINEAR)       orb_slam2/src/io/data_loader.cc:519-521
+ *   mono(cv::Rect(0, 0, camera::width, camera::height))   orb_slam2/src/system.cpp:160-161
+ *   cvtColor(im, im, CV_BGR2GRAY / CV_RGB2GRAY / CV_BGRA2GRAY / CV_RGBA2GRAY)
+ *                                                         orb_slam2/src/tracking/mono_tracker.cpp:18-28
+ * with one gather kernel that writes the gray H x W frame conv1a reads (OpenCV 3.x integer
+ * arithmetic: 5-bit sub-pixel positions, 15-bit bilinear weights, BORDER_CONSTANT 0; gray =
+ * (1868 B + 9617 G + 4899 R + 8192) >> 14).  The maps are the CV_32FC1 pair of
+ * cv::initUndistortRectifyMap (data_loader.cc:485-486), src_height x src_width, copied to the
+ * device once; map_x == map_y == NULL means "no remap" (crop + gray only).  src_height >= height
+ * and src_width >= width of the handle (the crop keeps the top-left corner). */
+typedef struct spfe_staging {
+  int src_height, src_width; /* camera image == map size */
+  int channels;              /* 1, 3 or 4 interleaved 8-bit channels (cv::imread gives 3: BGR) */
+  int rgb;                   /* 0: blue first (mbRGB == false), 1: red first */
+  const float *map_x, *map_y;
+} spfe_staging;
+SPFE_API int spfe_set_staging(spfe_handle h, const spfe_staging *st);
+/* spfe_extract / spfe_extract_batch on raw camera frames (stride in bytes >= src_width * channels) */
+SPFE_API int spfe_extract_staged(spfe_handle h, const uint8_t *src, int stride, spfe_result *out);
+SPFE_API int spfe_extract_batch_staged(spfe_handle h, const uint8_t *const *srcs, int stride, int n,
+                                       spfe_result *outs);
+/* Device form: n packed raw frames [n][src_height][src_width][channels] in HBM -> gray frames
+ * [n][height][width] (d_gray, ready for spfe_extract_batch_device), enqueued on `stream`. */
+SPFE_API int spfe_stage_batch_device(spfe_handle h, const void *d_src, int n, void *d_gray, void *stream);
+
 /* Per-stage GPU time (ms, HIP events recorded on the launch stream around every
  * kernel), averaged over the calls since spfe_stage_reset (the library keeps the
  * last 128 calls).  Enabled by SPFE_STAGE_TIMING=1 in the environment at

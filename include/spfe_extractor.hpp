@@ -67,7 +67,46 @@ class ExtractorCV {
     const int rc = spfe_extract(h_, image.data, static_cast<int>(image.step), &r);
     if (rc == SPFE_EEMPTY) throw std::runtime_error("input image is empty");
     if (rc != SPFE_OK) throw std::runtime_error(std::string("spfe_extract: ") + spfe_last_error());
+    publish(r, _keypoints, _descriptors);
+  }
 
+  // Input staging on the GPU.  setStaging() once, with the CV_32FC1 maps of
+  // cv::initUndistortRectifyMap (data_loader.cc:485-486; empty Mats = no remap); then extractRaw()
+  // takes the frame as cv::imread returned it and does what data_loader.cc:519-521 (cv::remap,
+  // INTER_LINEAR), system.cpp:160-161 (crop to camera::width x height) and mono_tracker.cpp:18-28
+  // (cvtColor to gray; rgb = mbRGB) did on the host, followed by operator()'s work.
+  void setStaging(int src_height, int src_width, int channels, bool rgb, const cv::Mat &map_x,
+                  const cv::Mat &map_y) {
+    spfe_staging st{};
+    st.src_height = src_height;
+    st.src_width = src_width;
+    st.channels = channels;
+    st.rgb = rgb ? 1 : 0;
+    if (!map_x.empty() || !map_y.empty()) {
+      if (map_x.type() != CV_32FC1 || map_y.type() != CV_32FC1 || map_x.rows != src_height ||
+          map_y.rows != src_height || map_x.cols != src_width || map_y.cols != src_width ||
+          map_x.step != src_width * sizeof(float) || map_y.step != src_width * sizeof(float))
+        throw std::runtime_error("setStaging: maps must be contiguous CV_32FC1 of the source size");
+      st.map_x = reinterpret_cast<const float *>(map_x.data);
+      st.map_y = reinterpret_cast<const float *>(map_y.data);
+    }
+    if (spfe_set_staging(h_, &st) != SPFE_OK) throw std::runtime_error(std::string("spfe_set_staging: ") + spfe_last_error());
+    raw_row_bytes_ = static_cast<size_t>(src_width) * channels;
+    raw_rows_ = src_height;
+  }
+  void extractRaw(const cv::Mat &raw, std::vector<cv::KeyPoint> &_keypoints, cv::OutputArray _descriptors) {
+    if (raw.empty()) throw std::runtime_error("input image is empty");  // :364-365
+    if (raw.rows != raw_rows_ || raw.step < raw_row_bytes_)
+      throw std::runtime_error("extractRaw: frame does not match setStaging()");
+    spfe_result r{};
+    const int rc = spfe_extract_staged(h_, raw.data, static_cast<int>(raw.step), &r);
+    if (rc == SPFE_EEMPTY) throw std::runtime_error("input image is empty");
+    if (rc != SPFE_OK) throw std::runtime_error(std::string("spfe_extract_staged: ") + spfe_last_error());
+    publish(r, _keypoints, _descriptors);
+  }
+
+ protected:
+  void publish(const spfe_result &r, std::vector<cv::KeyPoint> &_keypoints, cv::OutputArray _descriptors) {
     const int hc = height_ / 8, wc = width_ / 8;
     _keypoints.resize(r.K);
     cov2_.resize(r.K);
@@ -91,6 +130,7 @@ class ExtractorCV {
     status_ = r.status;
   }
 
+ public:
   // Replaces the body of SPMatcher::SearchByBruteForce's matcher (sp_matcher.cpp:1661-1668):
   //   auto matcher = cv::BFMatcher::create(cv::NORM_L2, true); matcher->add(desc_train);
   //   matcher->train(); matcher->match(desc_query, matches);
@@ -129,6 +169,8 @@ class ExtractorCV {
   std::vector<Vec2f> cov2_, cov2_inv_;
   spfe_handle h_ = nullptr;
   int height_, width_, status_ = 0;
+  size_t raw_row_bytes_ = 0;
+  int raw_rows_ = -1;
 };
 
 }  // namespace spfe

@@ -65,6 +65,9 @@ def lib():
                                          C.POINTER(C.c_int)]
         L.oracle_match_bruteforce.restype = None
         L.oracle_match_bruteforce.argtypes = [f32p, C.c_int, f32p, C.c_int, C.c_int, i32p, f32p]
+        L.oracle_stage_input.restype = C.c_int
+        L.oracle_stage_input.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_int, C.c_int, u8p]
         L.oracle_expf.restype = C.c_float
         L.oracle_expf.argtypes = [C.c_float]
         L.oracle_logf.restype = C.c_float
@@ -229,3 +232,23 @@ def match_bruteforce(query, train, cross_check=True):
                                   t if len(t) else np.zeros((1, 256), np.float32), len(t),
                                   1 if cross_check else 0, idx, dist)
     return idx[:len(q)].copy(), dist[:len(q)].copy()
+
+
+def stage_input(src, H, W, map_x=None, map_y=None, rgb=False):
+    """cv::remap(INTER_LINEAR) -> crop to H x W -> cvtColor(*2GRAY) on one raw frame
+    (data_loader.cc:519-521, system.cpp:160-161, mono_tracker.cpp:18-28).  src: u8 [Hs,Ws] or [Hs,Ws,C]."""
+    src = np.ascontiguousarray(src, np.uint8)
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    hs, ws = src.shape[:2]
+    gray = np.empty((H, W), np.uint8)
+    mx = my = None
+    if map_x is not None:
+        mx = np.ascontiguousarray(map_x, np.float32)
+        my = np.ascontiguousarray(map_y, np.float32)
+        assert mx.shape == (hs, ws) and my.shape == (hs, ws)
+    rc = lib().oracle_stage_input(src.reshape(-1), hs, ws, ws * cn, cn, 1 if rgb else 0,
+                                  mx.ctypes.data if mx is not None else None,
+                                  my.ctypes.data if my is not None else None, H, W, gray)
+    if rc:
+        raise ValueError("oracle_stage_input rc=%d" % rc)
+    return gray

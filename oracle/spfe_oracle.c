@@ -632,6 +632,72 @@ EXPORT void oracle_match_bruteforce(const float *query, int nq, const float *tra
   free(tidx);
 }
 
+/*
+ * SURVEY.md §8(f) rank 2 — input staging.  Restates, for ONE frame, the host OpenCV sequence the
+ * reference runs in front of the extractor:
+ *   cv::remap(mono, mono, m1, m2, cv::INTER_LINEAR)      orb_slam2/src/io/data_loader.cc:519-521
+ *   mono(cv::Rect(0, 0, camera::width, camera::height))  orb_slam2/src/system.cpp:160-161
+ *   cvtColor(.., CV_BGR2GRAY | CV_RGB2GRAY | ..A2GRAY)    orb_slam2/src/tracking/mono_tracker.cpp:18-28
+ * OpenCV 3.x (not vendored, not installed — PARITY UNPINNED; published algorithm restated):
+ *  - cv::remap with CV_32FC1 maps, INTER_LINEAR, 8-bit source: the maps are converted to fixed
+ *    point with INTER_BITS = 5: sx = cvRound(mx * 32), sy = cvRound(my * 32) (round half to even),
+ *    integer part saturate_cast<short>(s >> 5), fraction s & 31; remapBilinear with the 15-bit
+ *    weight table BilinearTab_i (initInterTab2D: w = saturate_cast<short>(wy * wx * 32768), and
+ *    when the four do not sum to 32768 — only the (0,0) entry, whose 32768 saturates to 32767 —
+ *    the difference is added at table index [ksize/2][ksize/2] = the LAST tap, giving
+ *    {32767, 0, 0, 1}); D = saturate_cast<uchar>((sum + (1 << 14)) >> 15); BORDER_CONSTANT with
+ *    value 0: taps outside the source contribute 0.
+ *  - cvtColor 8-bit to gray (3.0 - 3.4.1, yuv_shift = 14): (B*1868 + G*9617 + R*4899 + 8192) >> 14;
+ *    alpha ignored.  (Later OpenCV uses 15-bit coefficients; identical for gray-valued BGR input
+ *    such as EuRoC's, since both sets sum to one.)
+ * src: [src_h] rows of src_stride bytes, `channels` interleaved u8; map_x/map_y: [src_h][src_w]
+ * or NULL; gray: [H][W].  Returns 0, or -1 on bad geometry.
+ */
+EXPORT int oracle_stage_input(const uint8_t *src, int src_h, int src_w, int src_stride, int channels, int rgb,
+                              const float *map_x, const float *map_y, int H, int W, uint8_t *gray) {
+  if (H > src_h || W > src_w || (channels != 1 && channels != 3 && channels != 4)) return -1;
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      int ch[4] = {0, 0, 0, 0};
+      if (map_x) {
+        const int sx = (int)lrintf(map_x[(size_t)y * src_w + x] * 32.0f);
+        const int sy = (int)lrintf(map_y[(size_t)y * src_w + x] * 32.0f);
+        int ix = sx >> 5, iy = sy >> 5;
+        ix = ix < -32768 ? -32768 : (ix > 32767 ? 32767 : ix);
+        iy = iy < -32768 ? -32768 : (iy > 32767 ? 32767 : iy);
+        const int fx = sx & 31, fy = sy & 31;
+        int w[4] = {(32 - fy) * (32 - fx) * 32, (32 - fy) * fx * 32, fy * (32 - fx) * 32, fy * fx * 32};
+        if (fx == 0 && fy == 0) {
+          w[0] = 32767;
+          w[3] = 1;
+        }
+        for (int k = 0; k < channels; ++k) {
+          int sum = 0;
+          for (int t = 0; t < 4; ++t) {
+            const int px = ix + (t & 1), py = iy + (t >> 1);
+            const int v = (px >= 0 && px < src_w && py >= 0 && py < src_h)
+                              ? src[(size_t)py * src_stride + (size_t)px * channels + k]
+                              : 0;
+            sum += v * w[t];
+          }
+          int v = (sum + (1 << 14)) >> 15;
+          ch[k] = v < 0 ? 0 : (v > 255 ? 255 : v);
+        }
+      } else {
+        for (int k = 0; k < channels; ++k) ch[k] = src[(size_t)y * src_stride + (size_t)x * channels + k];
+      }
+      int g;
+      if (channels == 1) {
+        g = ch[0];
+      } else {
+        const int bl = rgb ? ch[2] : ch[0], rd = rgb ? ch[0] : ch[2];
+        g = (bl * 1868 + ch[1] * 9617 + rd * 4899 + (1 << 13)) >> 14;
+      }
+      gray[(size_t)y * W + x] = (uint8_t)g;
+    }
+  return 0;
+}
+
 /* exact-math probes so GPU tests can compare device bits with host bits */
 EXPORT float oracle_expf(float x) { return spfe_expf(x); }
 EXPORT float oracle_logf(float x) { return spfe_logf(x); }

@@ -96,6 +96,11 @@ struct spfe_handle_s {
   int last_n = 0;
   int num_cus = 256;
   int small_maxh = -1;
+  // input staging (spfe_set_staging)
+  spfe_staging st{};
+  bool st_set = false;
+  float *d_map_x = nullptr, *d_map_y = nullptr;
+  uint8_t *d_raw = nullptr, *h_raw = nullptr;
   // descriptor matching (spfe_match*): scratch grown on demand
   unsigned long long *m_best_t = nullptr, *m_best_q = nullptr;
   uint8_t *m_stage_q = nullptr, *m_stage_t = nullptr, *m_out = nullptr;
@@ -569,6 +574,9 @@ void spfe_destroy(spfe_handle h) {
     if (h->ev_cov[i]) (void)hipEventDestroy(h->ev_cov[i]);
   }
   if (h->side) (void)hipStreamDestroy(h->side);
+  for (void *p : {(void *)h->d_map_x, (void *)h->d_map_y, (void *)h->d_raw})
+    if (p) (void)hipFree(p);
+  if (h->h_raw) (void)hipHostFree(h->h_raw);
   for (void *p : {(void *)h->m_best_t, (void *)h->m_best_q, (void *)h->m_stage_q, (void *)h->m_stage_t,
                   (void *)h->m_out})
     if (p) (void)hipFree(p);
@@ -709,6 +717,7 @@ long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size
   else if (nm == "heat_log") { src = h->d_heat_log + frame * HW; bytes = HW * 4; }
   else if (nm == "heat_inv") { src = h->d_heat_inv + frame * HW; bytes = HW * 4; }
   else if (nm == "heat" && h->d_heat) { src = h->d_heat + frame * HW; bytes = HW * 4; }
+  else if (nm == "image") { src = h->d_img + frame * HW; bytes = HW; }
   else if (nm == "cell_score") { src = h->d_cell_score + frame * C; bytes = C * 4; }
   else if (nm == "feat") { src = h->act[7] + frame * C * 128; bytes = C * 128 * 4; }
   else if (nm.size() == 4 && nm.compare(0, 3, "act") == 0 && nm[3] >= '0' && nm[3] <= '7') {
@@ -755,6 +764,96 @@ int spfe_stage_times(spfe_handle h, float *ms, int cap) {
   }
   for (int i = 0; i < nst; ++i) ms[i] = (float)(acc[i] / (double)(h->calls - first));
   return nst;
+}
+
+// ---- input staging ------------------------------------------------------
+int spfe_set_staging(spfe_handle h, const spfe_staging *st) {
+  if (!h || !st) return fail(SPFE_EINVAL, "null argument");
+  if (st->channels != 1 && st->channels != 3 && st->channels != 4)
+    return fail(SPFE_EINVAL, "staging: %d channels unsupported (1, 3, 4)", st->channels);
+  if (st->src_height < h->H || st->src_width < h->W)
+    return fail(SPFE_EINVAL, "staging: source %dx%d smaller than the extractor's %dx%d (system.cpp:160 crop)",
+                st->src_width, st->src_height, h->W, h->H);
+  if (st->src_height > 32767 || st->src_width > 32767) return fail(SPFE_EINVAL, "staging: source too large");
+  if ((st->map_x == nullptr) != (st->map_y == nullptr)) return fail(SPFE_EINVAL, "staging: one map is null");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  HIP_TRY(hipDeviceSynchronize());
+  for (void **p : {(void **)&h->d_map_x, (void **)&h->d_map_y, (void **)&h->d_raw})
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (h->h_raw) { (void)hipHostFree(h->h_raw); h->h_raw = nullptr; }
+  h->st_set = false;
+  const size_t npx = (size_t)st->src_height * st->src_width;
+  if (st->map_x) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->d_map_x), npx * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->d_map_y), npx * 4));
+    HIP_TRY(hipMemcpy(h->d_map_x, st->map_x, npx * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_map_y, st->map_y, npx * 4, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->d_raw), (size_t)h->B * npx * st->channels));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->h_raw), (size_t)h->B * npx * st->channels,
+                        hipHostMallocDefault));
+  h->st = *st;
+  h->st.map_x = h->st.map_y = nullptr;  // the caller's arrays are not kept
+  h->st_set = true;
+  return SPFE_OK;
+}
+
+namespace {
+int enqueue_stage(spfe_handle h, const uint8_t *d_src, int n, uint8_t *d_gray, hipStream_t s) {
+  spfe::StageParams p{};
+  p.src = d_src;
+  p.src_stride = h->st.src_width * h->st.channels;
+  p.src_frame_bytes = (size_t)h->st.src_height * p.src_stride;
+  p.src_h = h->st.src_height;
+  p.src_w = h->st.src_width;
+  p.map_x = h->d_map_x;
+  p.map_y = h->d_map_y;
+  p.rgb = h->st.rgb;
+  p.gray = d_gray;
+  p.H = h->H;
+  p.W = h->W;
+  HIP_TRY(spfe::launch_stage_input(p, h->st.channels, n, s));
+  return SPFE_OK;
+}
+}  // namespace
+
+int spfe_stage_batch_device(spfe_handle h, const void *d_src, int n, void *d_gray, void *stream) {
+  if (!h || !d_gray) return fail(SPFE_EINVAL, "null argument");
+  if (!h->st_set) return fail(SPFE_EINVAL, "spfe_set_staging has not been called");
+  if (!d_src) return fail(SPFE_EEMPTY, "input image is empty");
+  if (n < 1 || n > h->B) return fail(SPFE_EINVAL, "batch %d not in [1, %d]", n, h->B);
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
+  return enqueue_stage(h, reinterpret_cast<const uint8_t *>(d_src), n, reinterpret_cast<uint8_t *>(d_gray), s);
+}
+
+int spfe_extract_batch_staged(spfe_handle h, const uint8_t *const *srcs, int stride, int n, spfe_result *outs) {
+  if (!h || !outs) return fail(SPFE_EINVAL, "null argument");
+  if (!h->st_set) return fail(SPFE_EINVAL, "spfe_set_staging has not been called");
+  if (!srcs) return fail(SPFE_EEMPTY, "input image is empty");
+  if (n < 1 || n > h->B) return fail(SPFE_EINVAL, "batch %d not in [1, %d]", n, h->B);
+  const int row = h->st.src_width * h->st.channels;
+  if (stride < row) return fail(SPFE_EINVAL, "stride %d smaller than a source row (%d bytes)", stride, row);
+  const size_t frame = (size_t)h->st.src_height * row;
+  for (int i = 0; i < n; ++i) {
+    if (!srcs[i]) return fail(SPFE_EEMPTY, "input image is empty");  // sp_extractor.cpp:364-365
+    for (int y = 0; y < h->st.src_height; ++y)
+      memcpy(h->h_raw + i * frame + (size_t)y * row, srcs[i] + (size_t)y * stride, row);
+  }
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  hipStream_t s = h->stream;
+  HIP_TRY(hipMemcpyAsync(h->d_raw, h->h_raw, n * frame, hipMemcpyHostToDevice, s));
+  int rc = enqueue_stage(h, h->d_raw, n, h->d_img, s);
+  if (rc) return rc;
+  rc = enqueue(h, h->d_img, n, h->d_records, s);
+  if (rc) return rc;
+  return finish_host(h, n, outs);
+}
+
+int spfe_extract_staged(spfe_handle h, const uint8_t *src, int stride, spfe_result *out) {
+  if (!src) return fail(SPFE_EEMPTY, "input image is empty");
+  const uint8_t *one[1] = {src};
+  return spfe_extract_batch_staged(h, one, stride, 1, out);
 }
 
 // ---- descriptor matching ------------------------------------------------

@@ -106,6 +106,20 @@ hipError_t launch_match(const MatchSide &query, const MatchSide &train, int pair
                         unsigned long long *best_t, unsigned long long *best_q, uint8_t *out, size_t out_stride,
                         hipStream_t s);
 
+// ---------------------------------------------------------------------------
+// input staging (stage_input.hip): raw camera frames -> cropped gray u8 frames
+// ---------------------------------------------------------------------------
+struct StageParams {
+  const uint8_t *src;        // [n] frames, src_frame_bytes apart, rows src_stride bytes apart
+  size_t src_frame_bytes;
+  int src_stride, src_h, src_w;
+  const float *map_x, *map_y;  // [src_h][src_w] or null (no remap)
+  int rgb;                     // 1: R first
+  uint8_t *gray;               // [n][H][W]
+  int H, W;
+};
+hipError_t launch_stage_input(const StageParams &p, int channels, int n, hipStream_t s);
+
 // exact-math probe kernels for tests (device bits vs host bits)
 hipError_t launch_math_probe(const float *in, float *out_exp, float *out_log, int n, hipStream_t s);
 

@@ -34,6 +34,7 @@ ABI_SYMBOLS = [
     "spfe_stage_name",
     "spfe_math_probe", "spfe_last_error", "spfe_version",
     "spfe_match", "spfe_match_records_device", "spfe_match_out_bytes",
+    "spfe_set_staging", "spfe_extract_staged", "spfe_extract_batch_staged", "spfe_stage_batch_device",
 ]
 
 
@@ -60,6 +61,11 @@ class RecordLayout(C.Structure):
                 ("off_xy", C.c_size_t), ("off_resp", C.c_size_t), ("off_cov", C.c_size_t),
                 ("off_cinv", C.c_size_t), ("off_desc", C.c_size_t), ("off_occ", C.c_size_t),
                 ("off_dd", C.c_size_t), ("off_sd", C.c_size_t)]
+
+
+class _Staging(C.Structure):
+    _fields_ = [("src_height", C.c_int), ("src_width", C.c_int), ("channels", C.c_int), ("rgb", C.c_int),
+                ("map_x", C.c_void_p), ("map_y", C.c_void_p)]
 
 
 _lib = None
@@ -133,6 +139,15 @@ def load_library():
     L.spfe_stage_name.argtypes = [C.c_int]
     L.spfe_math_probe.restype = C.c_int
     L.spfe_math_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.spfe_set_staging.restype = C.c_int
+    L.spfe_set_staging.argtypes = [C.c_void_p, C.POINTER(_Staging)]
+    L.spfe_extract_staged.restype = C.c_int
+    L.spfe_extract_staged.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(_Result)]
+    L.spfe_extract_batch_staged.restype = C.c_int
+    L.spfe_extract_batch_staged.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int,
+                                            C.POINTER(_Result)]
+    L.spfe_stage_batch_device.restype = C.c_int
+    L.spfe_stage_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.spfe_match.restype = C.c_int
     L.spfe_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                              C.c_void_p]
@@ -368,6 +383,52 @@ class SPExtractor:
         _check(self._lib.spfe_view_record(self._h, rec.ctypes.data, C.byref(r)))
         return FrameResult(r, self.height, self.width, False)
 
+    # -- input staging --
+    def set_staging(self, src_height, src_width, channels=3, rgb=False, map_x=None, map_y=None):
+        """Configure the raw-frame front end: cv::remap(m1, m2, INTER_LINEAR) (data_loader.cc:519-521),
+        crop (system.cpp:160-161), cvtColor to gray (mono_tracker.cpp:18-28).  Maps: f32
+        [src_height, src_width] (cv::initUndistortRectifyMap, CV_32FC1) or None."""
+        st = _Staging(src_height, src_width, channels, 1 if rgb else 0, None, None)
+        keep = []
+        if map_x is not None or map_y is not None:
+            mx = np.ascontiguousarray(map_x, np.float32)
+            my = np.ascontiguousarray(map_y, np.float32)
+            if mx.shape != (src_height, src_width) or my.shape != (src_height, src_width):
+                raise SpfeError("maps must be [src_height, src_width]")
+            keep = [mx, my]
+            st.map_x, st.map_y = mx.ctypes.data, my.ctypes.data
+        _check(self._lib.spfe_set_staging(self._h, C.byref(st)))
+        self._staging = (src_height, src_width, channels)
+        del keep
+
+    def _check_raw(self, src):
+        if src is None or getattr(src, "size", 0) == 0:
+            raise RuntimeError("input image is empty")  # sp_extractor.cpp:364-365
+        hs, ws, cn = self._staging
+        src = np.asarray(src)
+        want = (hs, ws) if cn == 1 else (hs, ws, cn)
+        if src.dtype != np.uint8 or src.shape != want:
+            raise SpfeError("raw frame must be uint8 %s, got %s %s" % (want, src.dtype, src.shape))
+        return np.ascontiguousarray(src)
+
+    def extract_staged(self, src):
+        """Raw camera frame -> Frame (remap + crop + gray on the GPU, then the extraction path)."""
+        return self.extract_batch_staged([src])[0]
+
+    def extract_batch_staged(self, srcs):
+        srcs = [self._check_raw(s) for s in srcs]
+        n = len(srcs)
+        hs, ws, cn = self._staging
+        ptrs = (C.c_void_p * n)(*[s.ctypes.data for s in srcs])
+        res = (_Result * n)()
+        _check(self._lib.spfe_extract_batch_staged(self._h, ptrs, ws * cn, n, res))
+        frames = [FrameResult(res[i], self.height, self.width, self.with_heat) for i in range(n)]
+        self._publish(frames[-1])
+        return frames
+
+    def stage_batch_device(self, d_src, n, d_gray, stream=None):
+        _check(self._lib.spfe_stage_batch_device(self._h, d_src, n, d_gray, stream))
+
     # -- descriptor matching (SURVEY.md §8(f) rank 1) --
     def match(self, query, train, cross_check=True):
         """cv::BFMatcher(NORM_L2, crossCheck).match(query) with `train` added, as
@@ -413,7 +474,8 @@ class SPExtractor:
         ch = [64, 64, 64, 64, 128, 128, 128, 128]
         for i in range(8):
             shapes["act%d" % i] = (self.height // div[i], self.width // div[i], ch[i])
-        out = np.empty(shapes[name], np.float32)
+        out = (np.empty((self.height, self.width), np.uint8) if name == "image"   # the staged gray frame
+               else np.empty(shapes[name], np.float32))
         n = self._lib.spfe_debug_read(self._h, name.encode(), frame, out.ctypes.data, out.nbytes)
         if n < 0:
             _check(int(n))

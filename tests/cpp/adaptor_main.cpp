@@ -6,6 +6,7 @@
 // out.bin: int32 K, then K x {x, y, response, cov2inv_x, cov2inv_y}, K x 256 desc,
 //          occ_grid int16 [hc*wc], dense_dust f32 [hc*wc], heat f32 [H*W]
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 
@@ -55,6 +56,16 @@ int main(int argc, char **argv) {
     if ((int)matches.size() != K) return 7;
     for (int i = 0; i < K; ++i)
       if (matches[i].queryIdx != i || matches[i].trainIdx != i || matches[i].distance != 0.0f) return 7;
+    // input staging through the adaptor: a 1-channel source without maps is the identity, so
+    // extractRaw() must reproduce operator()'s result
+    std::vector<cv::KeyPoint> k2;
+    cv::Mat d2, noMap;
+    extractor.setStaging(H, W, 1, false, noMap, noMap);
+    extractor.extractRaw(im, k2, d2);
+    if ((int)k2.size() != K) return 8;
+    for (int i = 0; i < K; ++i)
+      if (k2[i].pt.x != mvKeys[i].pt.x || k2[i].pt.y != mvKeys[i].pt.y) return 8;
+    if (K && memcmp(d2.data, mDescriptors.data, (size_t)K * 256 * 4)) return 8;
   } catch (const std::exception &e) {
     fprintf(stderr, "adaptor_main: %s\n", e.what());
     return 4;
