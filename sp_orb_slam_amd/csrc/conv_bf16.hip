@@ -15,6 +15,17 @@
 //  * the MFMA fragments want 8 consecutive channels per lane, which IS the NHWC
 //    order: the halo tile sits in LDS pixel-major ([row][col][32 ch]) and staging is
 //    one ds_write_b128 per 16-byte global piece — no transposition;
+//  * the MFMA is issued as (weights, pixels): D[cout][pixel], so a lane owns ONE pixel and its 16
+//    accumulator registers are output channels 4 at a time — the epilogue is packed f32 ops
+//    (v_pk_add_f32 bias, v_pk_max_f32 / v_max3_f32 ReLU + pool, the pool's horizontal neighbour one
+//    DPP lane away), v_cvt_pk_bf16_f32, and 8-byte (bf16) / 16-byte (f32) stores of 4 channels:
+//    ~100 instructions per tile instead of ~700 scalar ones, cut into sub-items of 3-8
+//    instructions that fit the 32-cycle MFMA shadows;
+//  * staging is `buffer_load_dwordx4 ... lds` (gfx950): the next stage goes from HBM/L2 straight
+//    into the other LDS buffer, lane l of a wave writing LDS[M0 + 16 l] — no staging registers,
+//    no ds_write, and the loads have a whole stage (72 MFMAs x 32 cycles) to land instead of the
+//    half stage a register round trip leaves at this MFMA rate.  Out-of-range buffer offsets
+//    write zeros (tools/microbench/lds_direct_probe.hip), which is the conv's zero padding;
 //  * pixel / weight rows are padded from 64 to 80 bytes: 16 lanes reading
 //    consecutive pixels at the same channel offset then hit 16 different 16-byte
 //    bank slots (5 is coprime to 16) — conflict-free ds_read_b128 without an XOR
@@ -42,81 +53,199 @@ constexpr int BPITCH = 80;    // bytes per pixel / weight row in LDS and in the 
 template <int TH>
 struct GeoB {
   static constexpr int ROWS = TH + 2, COLS = 34;
-  static constexpr int A_BYTES = ROWS * COLS * BPITCH;
+  static constexpr int A_PIECES = ROWS * COLS * (BPITCH / 16);  // 16-byte pieces, the pad piece included
+  static constexpr int A_BYTES = (A_PIECES + 255) / 256 * 256 * 16;  // whole 256-lane passes
   static constexpr int W_BYTES = 12 * 256 * 16;  // 9 * 64 * BPITCH = 46080, padded to whole 256-thread passes
   static constexpr int BUF_BYTES = A_BYTES + W_BYTES;
 };
 
+typedef __attribute__((address_space(3))) void lds_void;
+
 template <int NITER, int NWITER>
 struct PipeB {
-  i32x4 va[NITER], vw[NWITER];
-  unsigned dst[NITER];     // LDS byte offset of each input piece (dummy slot for unused pieces)
-  unsigned voff[NITER];    // byte offset inside the input frame, or SPFE_OOB
-  unsigned woff[NWITER];   // byte offset inside the weight slab (== LDS offset)
+  unsigned voff[NITER];    // byte offset of each input piece inside the input frame, or SPFE_OOB
+  unsigned woff;           // tid * 16: byte offset inside the weight slab (== LDS offset) of pass 0
   __amdgpu_buffer_rsrc_t rin, rw;
   const char *aBase, *bBase;  // this stage's operands (LDS)
-  char *nA, *nW;              // the other LDS buffer
+  char *nA, *nW;              // the other LDS buffer, at this wave's 1 KiB slot of pass 0
+
+  // one direct-to-LDS pass: 256 lanes x 16 bytes; pass IT lands at +4096 * IT
+  template <int IT>
+  __device__ __forceinline__ void dma() const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (IT < NITER) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void *)(nA + IT * 4096), 16, voff[IT], 0, 0, 0);
+    } else if constexpr (IT < NITER + NWITER) {
+      constexpr int W = IT - NITER;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(nW + W * 4096), 16, woff, W * 4096, 0, 0);
+    }
+#endif
+  }
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Accumulator layout after mfma(weights, pixels): lane = (pixel column p = lane & 31, hi = lane >> 5),
+// register r <-> output channel j*32 + 8*(r>>2) + 4*hi + (r&3).  Register PAIR q (r = 2q, 2q+1) <->
+// channels j*32 + 8*(q>>1) + 4*hi + 2*(q&1) + {0,1}; pairs 2g, 2g+1 make the 4-channel group g.
 template <int NT>
 struct EpiB {
   __amdgpu_buffer_rsrc_t rout;
-  unsigned obase[NT];
-  float bias[NT];
-  int xlim, ylim;
-  unsigned rowstep, pixstep;
+  unsigned rowoff[2];  // byte offset of this lane's pixel (+ its 4*hi channels) in output row i (pool: [0]), or OOB
+  f32x2 bias[NT][8];   // bias of pair q
+};
+struct EpiHold {       // first pair of a 4-channel group, waiting for the second
+  unsigned h16;
+  f32x2 h32;
 };
 
+__device__ __forceinline__ float dpp_xor1(float v) {  // the value of lane ^ 1
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+}
+
+// Sub-item E of the epilogue: one register pair of one accumulator tile (no pool: MT*NT*8 of them;
+// pool: NT*8, each folding the wave's two rows and the neighbouring pixel column).
 template <int MT, int NT, bool POOL, bool OUT_F32, int E>
-__device__ __forceinline__ void epi_store_b(const EpiB<NT> &e, const f32x16 (&acc)[MT][NT]) {
-  constexpr int NEPI_ = POOL ? NT * 8 : MT * NT * 16;
-  if constexpr (E >= NEPI_) {
-    return;
-  } else {
-    float v;
-    unsigned off;
-    if constexpr (!POOL) {
-      constexpr int j = E / (MT * 16), i = (E / 16) % MT, r = E % 16;
-      constexpr int xr = (r & 3) + 8 * (r >> 2);
-      v = acc[i][j][r] + e.bias[j];
-      v = v > 0.0f ? v : 0.0f;
-      off = (xr < e.xlim && i < e.ylim) ? e.obase[j] + i * e.rowstep + xr * e.pixstep : SPFE_OOB;
+__device__ __forceinline__ void epi_item(const EpiB<NT> &e, EpiHold &hold, const f32x16 (&acc)[MT][NT]) {
+  constexpr int NEPI_ = (POOL ? 1 : MT) * NT * 8;
+  if constexpr (E < NEPI_) {
+    constexpr int q = E % 8, j = (E / 8) % NT, i = POOL ? 0 : E / (8 * NT);
+    constexpr unsigned OEL = OUT_F32 ? 4u : 2u;
+    f32x2 v = (f32x2){acc[i][j][2 * q], acc[i][j][2 * q + 1]} + e.bias[j][q];
+    if constexpr (POOL) {
+      static_assert(MT == 2, "pool folds the wave's two rows");
+      const f32x2 w = (f32x2){acc[1][j][2 * q], acc[1][j][2 * q + 1]} + e.bias[j][q];
+      v = __builtin_elementwise_max(v, w);
+      v.x = __builtin_fmaxf(__builtin_fmaxf(v.x, dpp_xor1(v.x)), 0.0f);
+      v.y = __builtin_fmaxf(__builtin_fmaxf(v.y, dpp_xor1(v.y)), 0.0f);
     } else {
-      constexpr int j = E / 8, r = 2 * (E % 8);
-      constexpr int xr = (r & 3) + 8 * (r >> 2);
-      float v00 = acc[0][j][r] + e.bias[j], v01 = acc[0][j][r + 1] + e.bias[j];
-      float v10 = acc[1][j][r] + e.bias[j], v11 = acc[1][j][r + 1] + e.bias[j];
-      v00 = v00 > 0.0f ? v00 : 0.0f;
-      v01 = v01 > 0.0f ? v01 : 0.0f;
-      v10 = v10 > 0.0f ? v10 : 0.0f;
-      v11 = v11 > 0.0f ? v11 : 0.0f;
-      const float m0 = v00 > v01 ? v00 : v01;
-      const float m1 = v10 > v11 ? v10 : v11;
-      v = m0 > m1 ? m0 : m1;
-      off = (xr < e.xlim && 0 < e.ylim) ? e.obase[j] + (xr >> 1) * e.pixstep : SPFE_OOB;
+      v = __builtin_elementwise_max(v, (f32x2){0.0f, 0.0f});
     }
-    if constexpr (OUT_F32) __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), e.rout, off, 0, 0);
-    else __builtin_amdgcn_raw_buffer_store_b16((short)f32_to_bf16_rne(v), e.rout, off, 0, 0);
+    if constexpr ((q & 1) == 0) {
+      if constexpr (OUT_F32) hold.h32 = v;
+      else hold.h16 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    } else {
+      constexpr unsigned cb = (unsigned)(j * 32 + 8 * (q >> 1)) * OEL;
+      if constexpr (OUT_F32) {
+        const u32x4 d = {__float_as_uint(hold.h32.x), __float_as_uint(hold.h32.y), __float_as_uint(v.x),
+                         __float_as_uint(v.y)};
+        __builtin_amdgcn_raw_buffer_store_b128(d, e.rout, e.rowoff[i] + cb, 0, 0);
+      } else {
+        const u32x2 d = {hold.h16, __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2))};
+        __builtin_amdgcn_raw_buffer_store_b64(d, e.rout, e.rowoff[i] + cb, 0, 0);
+      }
+    }
   }
 }
 
-template <int STEP, int NSTEP, bool FIRST, int MT, int NT, int NITER, int NWITER, bool POOL, bool OUT_F32>
-__device__ __forceinline__ void k_steps_b(bf16x8 (&a)[2][MT], bf16x8 (&bb)[2][NT], f32x16 (&acc)[MT][NT],
-                                          const f32x16 (&accPrev)[MT][NT], PipeB<NITER, NWITER> &c,
-                                          const EpiB<NT> &e) {
+// Everything the side work in the MFMA shadows needs to prepare the next stage / tile / epilogue.
+template <int NITER, int NT>
+struct CtlB {
+  // per-lane geometry of the staging pieces (fixed for the kernel)
+  int prow[NITER], pcol[NITER];
+  unsigned pqb[NITER];
+  // work items: current, next, and the per-step increment (workgroups stride through an XCD-local range)
+  int i_nb, i_tx, i_ty, i_b, n_nb, n_tx, n_ty, n_b, d_nb, d_tx, d_ty, d_b;
+  int w, gper, hi_w;
+  bool have_next;
+  int chunk;  // K chunk the current stage computes
+  // constants
+  int H, W, Ho, Wo, wm, l31, hi;
+  unsigned in_pix_bytes, frame_in_bytes, out_pix_bytes, frame_out_bytes;
+};
+
+template <int CIN, int TH, int NITER, int NWITER>
+__device__ __forceinline__ void aim_stage_b(const ConvParams &p, PipeB<NITER, NWITER> &c, unsigned frame_in_bytes,
+                                            int nb, int b, int chunk, bool valid) {
+  using G = GeoB<TH>;
+  const char *base = reinterpret_cast<const char *>(p.in) +
+                     ((size_t)b * p.H * p.W * p.in_stride + p.in_choff + chunk * BKC) * 2;
+  c.rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, valid ? frame_in_bytes : 0u, 0x00020000);
+  const char *wb = reinterpret_cast<const char *>(p.wpack) + ((size_t)nb * (CIN / BKC) + chunk) * G::W_BYTES;
+  c.rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wb), 0, valid ? (unsigned)G::W_BYTES : 0u, 0x00020000);
+}
+
+template <int TH, int NITER, int NWITER, int NT, int IT>
+__device__ __forceinline__ void aim_piece_b(PipeB<NITER, NWITER> &c, const CtlB<NITER, NT> &t, int tx, int ty) {
+  if constexpr (IT < NITER) {
+    const int gy = ty * TH + t.prow[IT], gx = tx * 32 + t.pcol[IT];
+    c.voff[IT] = ((unsigned)gy < (unsigned)t.H && (unsigned)gx < (unsigned)t.W)
+                     ? (unsigned)(gy * t.W + gx) * t.in_pix_bytes + t.pqb[IT]
+                     : SPFE_OOB;
+  }
+}
+
+template <int NITER, int NT>
+__device__ __forceinline__ void next_item_b(const ConvParams &p, CtlB<NITER, NT> &t) {
+  int n_nb = t.i_nb + t.d_nb, n_tx = t.i_tx + t.d_tx, n_ty = t.i_ty + t.d_ty, n_b = t.i_b + t.d_b;
+  if (n_nb >= p.nblk) { n_nb -= p.nblk; ++n_tx; }
+  if (n_tx >= p.tiles_x) { n_tx -= p.tiles_x; ++n_ty; }
+  if (n_ty >= p.tiles_y) { n_ty -= p.tiles_y; ++n_b; }
+  t.n_nb = n_nb; t.n_tx = n_tx; t.n_ty = n_ty; t.n_b = n_b;
+  t.have_next = t.w + t.gper < t.hi_w;
+}
+
+// epilogue context of the CURRENT tile (used one tile later), in two pieces
+template <int TH, int MT, int NT, bool POOL, bool OUT_F32, int NITER>
+__device__ __forceinline__ void aim_epi_geom_b(const ConvParams &p, const CtlB<NITER, NT> &t, EpiB<NT> &e) {
+  constexpr unsigned OEL = OUT_F32 ? 4u : 2u;
+  char *obase = reinterpret_cast<char *>(p.out) + ((size_t)t.i_b * t.Ho * t.Wo * p.out_stride + p.out_choff) * OEL;
+  e.rout = __builtin_amdgcn_make_buffer_rsrc(obase, 0, t.frame_out_bytes, 0x00020000);
+  const int y0 = t.i_ty * TH + t.wm * MT, x = t.i_tx * 32 + t.l31;
+  const unsigned chan = (unsigned)(t.i_nb * 64 + 4 * t.hi) * OEL;
+  if constexpr (POOL) {
+    const bool ok = x < t.W && y0 < t.H && (t.l31 & 1) == 0;
+    e.rowoff[0] = ok ? (unsigned)((y0 >> 1) * t.Wo + (x >> 1)) * t.out_pix_bytes + chan : SPFE_OOB;
+    e.rowoff[1] = SPFE_OOB;
+  } else {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+      e.rowoff[i] = (x < t.W && y0 + i < t.H) ? (unsigned)((y0 + i) * t.W + x) * t.out_pix_bytes + chan : SPFE_OOB;
+  }
+}
+template <int NT, int NITER, int G4>
+__device__ __forceinline__ void aim_epi_bias_b(const ConvParams &p, const CtlB<NITER, NT> &t, EpiB<NT> &e) {
+  if constexpr (G4 < NT * 4) {
+    constexpr int j = G4 / 4, g = G4 % 4;
+    const float4 b4 = *reinterpret_cast<const float4 *>(p.bias + t.i_nb * 64 + 4 * t.hi + j * 32 + 8 * g);
+    e.bias[j][2 * g] = (f32x2){b4.x, b4.y};
+    e.bias[j][2 * g + 1] = (f32x2){b4.z, b4.w};
+  }
+}
+
+// One stage = NSTEP K steps of MT x NT MFMAs; all side work sits in the MFMA shadows:
+//   m0: operand fragments of the next K step (LDS -> registers)
+//   m1: steps 0..: the next stage, HBM/L2 -> the other LDS buffer (two passes per step); later steps:
+//       what the FOLLOWING stage's passes will need, i.e. the stage two ahead (PREP 0: this tile's
+//       chunk + 2; PREP 1, second-last stage: the next work item, its first descriptors and piece
+//       offsets; PREP 2, last stage: the next item's chunk 1, and this tile's epilogue context)
+//   m2, m3: sub-items of the PREVIOUS tile's epilogue (first stage of a tile only)
+template <int STEP, int NSTEP, bool FIRST, int PREP, int CIN, int TH, int MT, int NT, int NITER, int NWITER,
+          bool POOL, bool OUT_F32>
+__device__ __forceinline__ void k_steps_b(const ConvParams &p, bf16x8 (&a)[3][MT], bf16x8 (&bb)[3][NT],
+                                          f32x16 (&acc)[MT][NT], const f32x16 (&accPrev)[MT][NT],
+                                          PipeB<NITER, NWITER> &c, CtlB<NITER, NT> &t, EpiB<NT> &eMine,
+                                          const EpiB<NT> &ePrev, EpiHold &hold) {
   if constexpr (STEP < NSTEP) {
+    constexpr int NEPI = (POOL ? 1 : MT) * NT * 8;             // epilogue sub-items of the previous tile
+    constexpr int ES = 8;                                      // ... spread over steps 1..ES,
+    constexpr int HALF = (NEPI + 2 * ES - 1) / (2 * ES);       // HALF of them in each of the m2 / m3 shadows
     constexpr int NLD = NITER + NWITER;
-    constexpr int NEPI = POOL ? NT * 8 : MT * NT * 16;
-    constexpr int EPS = (NEPI + (NSTEP - 2)) / (NSTEP - 1);
-    constexpr int cur = STEP & 1, nxt = cur ^ 1;
-    // loads of the next stage: one per step from step 0; LDS writes: one per step, NLD steps
-    // later (the stage has NSTEP >= NLD steps; a write for load k sits at step k + NSTEP - NLD ... )
+    constexpr int DPS = NLD > 10 ? 2 : 1;        // LDS-direct passes per step
+    constexpr int S0 = (NLD + DPS - 1) / DPS;    // first step without passes
+    static_assert(S0 + 1 + NITER <= NSTEP, "side work does not fit the stage");
+    // operand fragments live in a ring of three K steps: a step's MFMAs take 4 x 32 cycles, less than
+    // an LDS round trip under load, so the fragments of step s + 2 are requested during step s
+    constexpr int cur = STEP % 3, nxt = (STEP + 2) % 3;
     constexpr int M = MT * NT;
 #pragma unroll
     for (int m = 0; m < M; ++m) {
-      if (m == 0) {  // (1) fragments of the next step
-        if constexpr (STEP + 1 < NSTEP) {
-          constexpr int tap = (STEP + 1) / 2, kk = (STEP + 1) % 2;
+      if (m == 0) {
+        if constexpr (STEP + 2 < NSTEP) {
+          constexpr int tap = (STEP + 2) / 2, kk = (STEP + 2) % 2;
           constexpr int dy = tap / 3, dx = tap % 3;
 #pragma unroll
           for (int i = 0; i < MT; ++i)
@@ -125,40 +254,42 @@ __device__ __forceinline__ void k_steps_b(bf16x8 (&a)[2][MT], bf16x8 (&bb)[2][NT
           for (int j = 0; j < NT; ++j)
             bb[nxt][j] = *reinterpret_cast<const bf16x8 *>(c.bBase + (tap * 64 + j * 32) * BPITCH + kk * 32);
         }
-      }
-      if (m == 1 % M) {  // (2) global loads of the next stage: two per step in the first steps
-        if constexpr (STEP * 2 < NLD) {
-          constexpr int it = STEP * 2;
-          if constexpr (it < NITER) c.va[it] = __builtin_amdgcn_raw_buffer_load_b128(c.rin, c.voff[it], 0, 0);
-          else c.vw[it - NITER] = __builtin_amdgcn_raw_buffer_load_b128(c.rw, c.woff[it - NITER], 0, 0);
-        }
-        if constexpr (STEP * 2 + 1 < NLD) {
-          constexpr int it = STEP * 2 + 1;
-          if constexpr (it < NITER) c.va[it] = __builtin_amdgcn_raw_buffer_load_b128(c.rin, c.voff[it], 0, 0);
-          else c.vw[it - NITER] = __builtin_amdgcn_raw_buffer_load_b128(c.rw, c.woff[it - NITER], 0, 0);
+        if constexpr (PREP == 2 && STEP < NT * 2) {  // this tile's bias (early: they are vmcnt loads too)
+          aim_epi_bias_b<NT, NITER, STEP * 2>(p, t, eMine);
+          aim_epi_bias_b<NT, NITER, STEP * 2 + 1>(p, t, eMine);
         }
       }
-      if (m == 2 % M) {  // (3) a slice of the previous tile's epilogue
-        if constexpr (FIRST && STEP >= 1) {
-          constexpr int e0 = (STEP - 1) * EPS;
-          [&]<int... Qs>(std::integer_sequence<int, Qs...>) {
-            (epi_store_b<MT, NT, POOL, OUT_F32, e0 + Qs>(e, accPrev), ...);
-          }(std::make_integer_sequence<int, EPS>{});
-        }
-      }
-      if (m == 3 % M) {  // (4) staged pieces into the other LDS buffer: two per step in the last steps
-        constexpr int W0 = NSTEP - (NLD + 1) / 2;
-        if constexpr (STEP >= W0) {
-          constexpr int it0 = (STEP - W0) * 2;
-          if constexpr (it0 < NLD) {
-            if constexpr (it0 < NITER) *reinterpret_cast<i32x4 *>(c.nA + c.dst[it0]) = c.va[it0];
-            else *reinterpret_cast<i32x4 *>(c.nW + c.woff[it0 - NITER]) = c.vw[it0 - NITER];
+      if (m == 1 % M) {
+        if constexpr (STEP < S0) {
+          c.template dma<STEP * DPS>();
+          if constexpr (DPS == 2) c.template dma<STEP * DPS + 1>();
+        } else if constexpr (PREP == 0) {
+          if constexpr (STEP == S0) aim_stage_b<CIN, TH>(p, c, t.frame_in_bytes, t.i_nb, t.i_b, t.chunk + 2, true);
+        } else if constexpr (PREP == 1) {
+          if constexpr (STEP == S0) {
+            next_item_b(p, t);
+            aim_stage_b<CIN, TH>(p, c, t.frame_in_bytes, t.n_nb, t.n_b, 0, t.have_next);
           }
-          if constexpr (it0 + 1 < NLD) {
-            constexpr int it1 = it0 + 1;
-            if constexpr (it1 < NITER) *reinterpret_cast<i32x4 *>(c.nA + c.dst[it1]) = c.va[it1];
-            else *reinterpret_cast<i32x4 *>(c.nW + c.woff[it1 - NITER]) = c.vw[it1 - NITER];
-          }
+          if constexpr (STEP > S0) aim_piece_b<TH, NITER, NWITER, NT, STEP - S0 - 1>(c, t, t.n_tx, t.n_ty);
+        } else {
+          if constexpr (STEP == S0) aim_stage_b<CIN, TH>(p, c, t.frame_in_bytes, t.n_nb, t.n_b, 1, t.have_next);
+          if constexpr (STEP == S0 + 1) aim_epi_geom_b<TH, MT, NT, POOL, OUT_F32>(p, t, eMine);
+        }
+      }
+      // The previous tile's epilogue goes EARLY in the stage (steps 1..ES): the stage ends with
+      // vmcnt(0) for the LDS-direct loads, and stores issued late would be waited for as well.
+      if (m == 2 % M) {
+        if constexpr (FIRST && STEP >= 1 && STEP <= ES) {
+          [&]<int... Q>(std::integer_sequence<int, Q...>) {
+            (epi_item<MT, NT, POOL, OUT_F32, (STEP - 1) * 2 * HALF + Q>(ePrev, hold, accPrev), ...);
+          }(std::make_integer_sequence<int, HALF>{});
+        }
+      }
+      if (m == 3 % M) {
+        if constexpr (FIRST && STEP >= 1 && STEP <= ES) {
+          [&]<int... Q>(std::integer_sequence<int, Q...>) {
+            (epi_item<MT, NT, POOL, OUT_F32, (STEP - 1) * 2 * HALF + HALF + Q>(ePrev, hold, accPrev), ...);
+          }(std::make_integer_sequence<int, HALF>{});
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -168,14 +299,15 @@ __device__ __forceinline__ void k_steps_b(bf16x8 (&a)[2][MT], bf16x8 (&bb)[2][NT
           f32x16 z;
 #pragma unroll
           for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][i], bb[cur][j], z, 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb[cur][j], a[cur][i], z, 0, 0, 0);
         } else {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][i], bb[cur][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb[cur][j], a[cur][i], acc[i][j], 0, 0, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    k_steps_b<STEP + 1, NSTEP, FIRST, MT, NT, NITER, NWITER, POOL, OUT_F32>(a, bb, acc, accPrev, c, e);
+    k_steps_b<STEP + 1, NSTEP, FIRST, PREP, CIN, TH, MT, NT, NITER, NWITER, POOL, OUT_F32>(p, a, bb, acc, accPrev, c, t,
+                                                                                         eMine, ePrev, hold);
   }
 }
 
@@ -186,96 +318,106 @@ __global__ __launch_bounds__(256, 1) void conv_bf16_kernel(ConvParams p) {
   constexpr int WM = 4, MT = 2, NT = 2, TH = WM * MT;
   using G = GeoB<TH>;
   constexpr int NCHUNK = CIN / BKC;
-  constexpr int NITEM = G::ROWS * G::COLS * 4;  // 16-byte pieces of the halo tile (4 per pixel)
+  static_assert(NCHUNK >= 2, "first and last stage of a tile are different stages");
+  constexpr int NITEM = G::A_PIECES;  // 16-byte pieces of the halo tile (5 per pixel: 4 data + the pad)
   constexpr int NITER = (NITEM + 255) / 256;
   constexpr int NW16 = G::W_BYTES / 16;
-  constexpr int NWITER = (NW16 + 255) / 256;
+  constexpr int NWPASS = NW16 / 256;
+  // Cin = 64: both K chunks of the 64-channel weight block (2 x 48 KB) stay in LDS for the whole
+  // kernel and only the halo tiles stream (7 passes per stage instead of 19): at this MFMA rate
+  // re-fetching the weights for every tile is what the L2 cannot feed.  Cin = 128 (4 chunks =
+  // 192 KB) streams weights with the tile, double buffered.
+  constexpr bool RESW = NCHUNK == 2;
+  constexpr int NWITER = RESW ? 0 : NWPASS;
   constexpr int NSTEP = 9 * (BKC / 16);
-  static_assert((NITER + NWITER + 1) / 2 <= NSTEP / 2, "staging does not fit the K steps");
+  static_assert(NW16 % 256 == 0, "padded weight slab is a whole number of passes");
 
   extern __shared__ __attribute__((aligned(16))) char smem_b[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5, l31 = lane & 31;
-  const int wm = wave;
-  const int H = p.H, W = p.W;
 
   const int total = p.nblk * p.tiles_x * p.tiles_y * p.B;
-  const int xcd = blockIdx.x & 7, gi = blockIdx.x >> 3, gper = gridDim.x >> 3;
-  const int lo = (int)((long)total * xcd / 8), hi_w = (int)((long)total * (xcd + 1) / 8);
-  int w = lo + gi;
-  if (w >= hi_w) return;
+  const int xcd = blockIdx.x & 7, gi = blockIdx.x >> 3;
+  const int lo = (int)((long)total * xcd / 8);
 
-  int i_nb, i_tx, i_ty, i_b;
-  {
-    int t = w;
-    i_nb = t % p.nblk; t /= p.nblk;
-    i_tx = t % p.tiles_x; t /= p.tiles_x;
-    i_ty = t % p.tiles_y; i_b = t / p.tiles_y;
-  }
-  int d_nb, d_tx, d_ty, d_b;
-  {
-    int t = gper;
-    d_nb = t % p.nblk; t /= p.nblk;
-    d_tx = t % p.tiles_x; t /= p.tiles_x;
-    d_ty = t % p.tiles_y; d_b = t / p.tiles_y;
-  }
-
-  const unsigned in_pix_bytes = (unsigned)p.in_stride * 2u;
-  const unsigned frame_in_bytes = (unsigned)H * W * in_pix_bytes;
-  const int Ho = POOL ? H >> 1 : H, Wo = POOL ? W >> 1 : W;
+  CtlB<NITER, NT> t;
+  t.gper = gridDim.x >> 3;
+  t.hi_w = (int)((long)total * (xcd + 1) / 8);
+  t.w = lo + gi;
+  if (t.w >= t.hi_w) return;
+  t.H = p.H; t.W = p.W;
+  t.Ho = POOL ? p.H >> 1 : p.H;
+  t.Wo = POOL ? p.W >> 1 : p.W;
+  t.wm = wave; t.l31 = lane & 31; t.hi = lane >> 5;
   constexpr unsigned OEL = OUT_F32 ? 4u : 2u;
-  const unsigned out_pix_bytes = (unsigned)p.out_stride * OEL;
-  const unsigned frame_out_bytes = (unsigned)Ho * Wo * out_pix_bytes;
-
-  PipeB<NITER, NWITER> c;
-  int prow[NITER], pcol[NITER];
-  unsigned pqb[NITER];
+  t.in_pix_bytes = (unsigned)p.in_stride * 2u;
+  t.frame_in_bytes = (unsigned)p.H * p.W * t.in_pix_bytes;
+  t.out_pix_bytes = (unsigned)p.out_stride * OEL;
+  t.frame_out_bytes = (unsigned)t.Ho * t.Wo * t.out_pix_bytes;
+  {
+    int q = t.w;
+    t.i_nb = q % p.nblk; q /= p.nblk;
+    t.i_tx = q % p.tiles_x; q /= p.tiles_x;
+    t.i_ty = q % p.tiles_y; t.i_b = q / p.tiles_y;
+    q = t.gper;
+    t.d_nb = q % p.nblk; q /= p.nblk;
+    t.d_tx = q % p.tiles_x; q /= p.tiles_x;
+    t.d_ty = q % p.tiles_y; t.d_b = q / p.tiles_y;
+  }
+  t.n_nb = t.n_tx = t.n_ty = t.n_b = 0;
+  t.have_next = false;
+  t.chunk = 0;
 #pragma unroll
   for (int it = 0; it < NITER; ++it) {
     const int i = tid + it * 256;
-    const int qq = i & 3, pix = i >> 2;
-    prow[it] = i < NITEM ? pix / G::COLS - 1 : (1 << 20);
-    pcol[it] = pix % G::COLS - 1;
-    pqb[it] = qq * 16;
-    // unused piece: the 16 pad bytes of some pixel (never read)
-    c.dst[it] = i < NITEM ? (unsigned)(pix * BPITCH + qq * 16) : (unsigned)((tid % (G::ROWS * G::COLS)) * BPITCH + 64);
+    const int qq = i % 5, pix = i / 5;
+    // the pad piece of a pixel and the pieces past the tile read out of range (-> zeros)
+    t.prow[it] = (i < NITEM && qq < 4) ? pix / G::COLS - 1 : (1 << 20);
+    t.pcol[it] = pix % G::COLS - 1;
+    t.pqb[it] = qq * 16;
   }
-  static_assert(NW16 % 256 == 0, "padded weight slab is a whole number of passes");
-#pragma unroll
-  for (int it = 0; it < NWITER; ++it) c.woff[it] = (unsigned)(tid + it * 256) * 16u;
 
-  auto aim_tile = [&](int tx, int ty) {
+  PipeB<NITER, NWITER> c;
+  c.woff = (unsigned)tid * 16u;
+  const unsigned wave_slot = (unsigned)wave * 1024u;
+
+  // LDS map.  streaming weights: [A0 | W0 | A1 | W1]; resident weights: [W chunk 0 | W chunk 1 | A0 | A1]
+  auto lds_a = [&](int b) -> char * { return smem_b + (RESW ? 2 * G::W_BYTES + b * G::A_BYTES : b * G::BUF_BYTES); };
+  auto lds_w = [&](int b_or_chunk) -> char * {
+    return smem_b + (RESW ? b_or_chunk * G::W_BYTES : b_or_chunk * G::BUF_BYTES + G::A_BYTES);
+  };
+  auto load_resident_weights = [&](int nb) {  // both chunks of block nb, all passes, this wave's slots
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-    for (int it = 0; it < NITER; ++it) {
-      const int gy = ty * TH + prow[it], gx = tx * 32 + pcol[it];
-      c.voff[it] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-                       ? (unsigned)(gy * W + gx) * in_pix_bytes + pqb[it]
-                       : SPFE_OOB;
+    for (int ch = 0; ch < NCHUNK; ++ch) {
+      const char *wb = reinterpret_cast<const char *>(p.wpack) + ((size_t)nb * NCHUNK + ch) * G::W_BYTES;
+      const __amdgpu_buffer_rsrc_t rw =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wb), 0, (unsigned)G::W_BYTES, 0x00020000);
+      [&]<int... PS>(std::integer_sequence<int, PS...>) {
+        (__builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(lds_w(ch) + wave_slot + PS * 4096), 16, c.woff,
+                                                  PS * 4096, 0, 0),
+         ...);
+      }(std::make_integer_sequence<int, NWPASS>{});
     }
-  };
-  auto aim_stage = [&](int nb, int b, int chunk, bool valid) {
-    const char *base = reinterpret_cast<const char *>(p.in) +
-                       ((size_t)b * H * W * p.in_stride + p.in_choff + chunk * BKC) * 2;
-    c.rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, valid ? frame_in_bytes : 0u, 0x00020000);
-    const char *wb = reinterpret_cast<const char *>(p.wpack) + ((size_t)nb * NCHUNK + chunk) * G::W_BYTES;
-    c.rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wb), 0, valid ? (unsigned)G::W_BYTES : 0u, 0x00020000);
+#endif
   };
 
-  // prologue: first stage straight into buffer 0
-  aim_tile(i_tx, i_ty);
-  aim_stage(i_nb, i_b, 0, true);
-#pragma unroll
-  for (int it = 0; it < NITER; ++it) c.va[it] = __builtin_amdgcn_raw_buffer_load_b128(c.rin, c.voff[it], 0, 0);
-#pragma unroll
-  for (int it = 0; it < NWITER; ++it) c.vw[it] = __builtin_amdgcn_raw_buffer_load_b128(c.rw, c.woff[it], 0, 0);
-#pragma unroll
-  for (int it = 0; it < NITER; ++it) *reinterpret_cast<i32x4 *>(smem_b + c.dst[it]) = c.va[it];
-#pragma unroll
-  for (int it = 0; it < NWITER; ++it) *reinterpret_cast<i32x4 *>(smem_b + G::A_BYTES + c.woff[it]) = c.vw[it];
+  // prologue: first stage straight into buffer 0 (and the resident weights)
+  [&]<int... IT>(std::integer_sequence<int, IT...>) {
+    (aim_piece_b<TH, NITER, NWITER, NT, IT>(c, t, t.i_tx, t.i_ty), ...);
+  }(std::make_integer_sequence<int, NITER>{});
+  aim_stage_b<CIN, TH>(p, c, t.frame_in_bytes, t.i_nb, t.i_b, 0, true);
+  c.nA = lds_a(0) + wave_slot;
+  c.nW = lds_w(0) + wave_slot;
+  if constexpr (RESW) load_resident_weights(t.i_nb);
+  [&]<int... IT>(std::integer_sequence<int, IT...>) {
+    (c.template dma<IT>(), ...);
+  }(std::make_integer_sequence<int, NITER + NWITER>{});
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the direct-to-LDS loads have landed
   __syncthreads();
+  aim_stage_b<CIN, TH>(p, c, t.frame_in_bytes, t.i_nb, t.i_b, 1, true);  // what the first stage's passes load
 
   f32x16 accA[MT][NT], accB[MT][NT];
 #pragma unroll
@@ -285,85 +427,94 @@ __global__ __launch_bounds__(256, 1) void conv_bf16_kernel(ConvParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { accA[i][j][r] = 0.0f; accB[i][j][r] = 0.0f; }
 
-  int buf = 0;
-  EpiB<NT> epi, epi_next;
-  epi.rout = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0u, 0x00020000);
+  EpiB<NT> epiA, epiB;
+  EpiHold hold;
+  hold.h16 = 0u;
+  hold.h32 = (f32x2){0.0f, 0.0f};
+  epiA.rout = epiB.rout = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0u, 0x00020000);  // nothing to store yet
+  epiA.rowoff[0] = epiA.rowoff[1] = epiB.rowoff[0] = epiB.rowoff[1] = SPFE_OOB;
 #pragma unroll
-  for (int j = 0; j < NT; ++j) { epi.obase[j] = SPFE_OOB; epi.bias[j] = 0.0f; }
-  epi.xlim = 0; epi.ylim = 0; epi.rowstep = 0; epi.pixstep = out_pix_bytes;
-  bool more = true;
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) epiA.bias[j][q] = epiB.bias[j][q] = (f32x2){0.0f, 0.0f};
 
-  auto aim_epi = [&](EpiB<NT> &e, int nb, int tx, int ty, int b) {
-    char *obase = reinterpret_cast<char *>(p.out) + ((size_t)b * Ho * Wo * p.out_stride + p.out_choff) * OEL;
-    e.rout = __builtin_amdgcn_make_buffer_rsrc(obase, 0, frame_out_bytes, 0x00020000);
-    const int y0 = ty * TH + wm * MT, x0 = tx * 32 + 4 * hi;
-    e.xlim = W - x0;
-    e.ylim = H - y0;
-    e.rowstep = (unsigned)Wo * out_pix_bytes;
-    e.pixstep = out_pix_bytes;
+  int buf = 0;
+  bf16x8 a[3][MT], bb[3][NT];
+  auto begin_stage = [&]() {  // operand bases of the stage in `buf`, DMA targets in the other buffer, first fragments
+    c.nA = lds_a(buf ^ 1) + wave_slot;
+    c.nW = lds_w(buf ^ 1) + wave_slot;  // (unused with resident weights)
+    c.aBase = lds_a(buf) + ((t.wm * MT) * 34 + t.l31) * BPITCH + t.hi * 16;
+    c.bBase = lds_w(RESW ? t.chunk : buf) + t.l31 * BPITCH + t.hi * 16;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int co = nb * 64 + j * 32 + l31;
-      const unsigned pix = POOL ? (unsigned)((y0 >> 1) * Wo + (x0 >> 1)) : (unsigned)(y0 * W + x0);
-      e.obase[j] = co < p.cout_real ? pix * out_pix_bytes + (unsigned)co * OEL : SPFE_OOB;
-      e.bias[j] = p.bias[co];
+    for (int st = 0; st < 2; ++st) {  // K steps 0 and 1: tap 0, channels 0-15 and 16-31
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[st][i] = *reinterpret_cast<const bf16x8 *>(c.aBase + (i * 34) * BPITCH + st * 32);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bb[st][j] = *reinterpret_cast<const bf16x8 *>(c.bBase + (j * 32) * BPITCH + st * 32);
     }
   };
+  auto end_stage = [&]() {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the next stage is in LDS (and this tile's stores are out)
+    __syncthreads();
+    buf ^= 1;
+  };
 
-  auto run_tile = [&](f32x16(&acc)[MT][NT], const f32x16(&accPrev)[MT][NT]) {
-    int n_nb = i_nb + d_nb, n_tx = i_tx + d_tx, n_ty = i_ty + d_ty, n_b = i_b + d_b;
-    if (n_nb >= p.nblk) { n_nb -= p.nblk; ++n_tx; }
-    if (n_tx >= p.tiles_x) { n_tx -= p.tiles_x; ++n_ty; }
-    if (n_ty >= p.tiles_y) { n_ty -= p.tiles_y; ++n_b; }
-    const bool have_next_item = w + gper < hi_w;
-    aim_epi(epi_next, i_nb, i_tx, i_ty, i_b);
+  auto run_tile = [&](f32x16(&acc)[MT][NT], const f32x16(&accPrev)[MT][NT], EpiB<NT> &eMine, const EpiB<NT> &ePrev) {
+    t.chunk = 0;
+    begin_stage();
+    k_steps_b<0, NSTEP, true, NCHUNK == 2 ? 1 : 0, CIN, TH, MT, NT, NITER, NWITER, POOL, OUT_F32>(
+        p, a, bb, acc, accPrev, c, t, eMine, ePrev, hold);
+    end_stage();
+    if constexpr (NCHUNK > 2) {
 #pragma unroll 1
-    for (int chunk = 0; chunk < NCHUNK; ++chunk) {
-      const bool last = chunk == NCHUNK - 1;
-      if (!last) {
-        aim_stage(i_nb, i_b, chunk + 1, true);
-      } else {
-        aim_tile(n_tx, n_ty);
-        aim_stage(n_nb, n_b, 0, have_next_item);
+      for (int ch = 1; ch < NCHUNK - 2; ++ch) {
+        t.chunk = ch;
+        begin_stage();
+        k_steps_b<0, NSTEP, false, 0, CIN, TH, MT, NT, NITER, NWITER, POOL, OUT_F32>(p, a, bb, acc, accPrev, c, t,
+                                                                                    eMine, ePrev, hold);
+        end_stage();
       }
-      const char *cA = smem_b + buf * G::BUF_BYTES;
-      c.nA = smem_b + (buf ^ 1) * G::BUF_BYTES;
-      c.nW = c.nA + G::A_BYTES;
-      c.aBase = cA + ((wm * MT) * 34 + l31) * BPITCH + hi * 16;
-      c.bBase = cA + G::A_BYTES + l31 * BPITCH + hi * 16;
-      bf16x8 a[2][MT], bb[2][NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) a[0][i] = *reinterpret_cast<const bf16x8 *>(c.aBase + (i * 34) * BPITCH);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) bb[0][j] = *reinterpret_cast<const bf16x8 *>(c.bBase + (j * 32) * BPITCH);
-      if (chunk == 0) k_steps_b<0, NSTEP, true, MT, NT, NITER, NWITER, POOL, OUT_F32>(a, bb, acc, accPrev, c, epi);
-      else k_steps_b<0, NSTEP, false, MT, NT, NITER, NWITER, POOL, OUT_F32>(a, bb, acc, accPrev, c, epi);
-      __syncthreads();
-      buf ^= 1;
+      t.chunk = NCHUNK - 2;
+      begin_stage();
+      k_steps_b<0, NSTEP, false, 1, CIN, TH, MT, NT, NITER, NWITER, POOL, OUT_F32>(p, a, bb, acc, accPrev, c, t, eMine,
+                                                                                  ePrev, hold);
+      end_stage();
     }
-    epi = epi_next;
-    more = have_next_item;
-    w += gper;
-    i_nb = n_nb; i_tx = n_tx; i_ty = n_ty; i_b = n_b;
+    t.chunk = NCHUNK - 1;
+    begin_stage();
+    k_steps_b<0, NSTEP, false, 2, CIN, TH, MT, NT, NITER, NWITER, POOL, OUT_F32>(p, a, bb, acc, accPrev, c, t, eMine,
+                                                                                ePrev, hold);
+    end_stage();
+    if constexpr (RESW) {
+      // another 64-channel block next (only when the workgroup stride is not a multiple of nblk): every
+      // wave is past its last read of the resident weights (end_stage barrier), so replace them now
+      if (t.have_next && t.n_nb != t.i_nb) {
+        load_resident_weights(t.n_nb);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+      }
+    }
+    t.w += t.gper;
+    t.i_nb = t.n_nb; t.i_tx = t.n_tx; t.i_ty = t.n_ty; t.i_b = t.n_b;
   };
 
   bool lastA = true;
   while (true) {
-    run_tile(accA, accB);
+    run_tile(accA, accB, epiA, epiB);
     lastA = true;
-    if (!more) break;
-    run_tile(accB, accA);
+    if (!t.have_next) break;
+    run_tile(accB, accA, epiB, epiA);
     lastA = false;
-    if (!more) break;
+    if (!t.have_next) break;
   }
   {
-    constexpr int NEPI = POOL ? NT * 8 : MT * NT * 16;
-    auto flush = [&](const f32x16(&acc)[MT][NT]) {
+    constexpr int NEPI = (POOL ? 1 : MT) * NT * 8;
+    auto flush = [&](const f32x16(&acc)[MT][NT], const EpiB<NT> &e) {
       [&]<int... E>(std::integer_sequence<int, E...>) {
-        (epi_store_b<MT, NT, POOL, OUT_F32, E>(epi, acc), ...);
+        (epi_item<MT, NT, POOL, OUT_F32, E>(e, hold, acc), ...);
       }(std::make_integer_sequence<int, NEPI>{});
     };
-    if (lastA) flush(accA); else flush(accB);
+    if (lastA) flush(accA, epiA); else flush(accB, epiB);
   }
 }
 
