@@ -81,7 +81,8 @@ def main():
     frames = synth.make_batch(200 + lo, hi - lo, H, W)
     d_img = torch.from_numpy(frames).cuda()
     sharded = parallel.ShardedExtractor(ext, world, rank, B)
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.Stream()   # compute stream (not the legacy default stream: no implicit barriers)
+    torch.cuda.synchronize()
 
     def step():
         sharded.step(d_img, stream)   # HIP path on this rank's shard + RCCL all-gather of the records

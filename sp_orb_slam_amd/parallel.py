@@ -133,61 +133,104 @@ def gather_records(local_records, world, group=None):
 
 
 class ShardedExtractor:
-    """Per-rank driver of the batched path (BASELINE configs[2]): takes this
-    rank's shard of device-resident frames, runs the HIP path, all-gathers the
-    records.  One instance per process / GPU.
+    """Per-rank driver of the batched path (BASELINE configs[2]): takes this rank's shard of
+    device-resident frames, runs the HIP path, all-gathers the records.  One instance per
+    process / GPU.
 
-    With an extractor built with async_cov=True the driver is software pipelined:
-    step(i) enqueues the compute of batch i and then completes batch i-1 (waits for
-    its covariance, which ran beside batch i's convolutions, and all-gathers its
-    records); flush() completes the last batch.  `gathered` always holds the most
-    recently completed batch."""
+    Streams.  Compute runs on the caller's `stream`; with world > 1 the collective runs on a
+    dedicated communication stream that waits only for the records of the batch it gathers
+    (spfe_wait_records), never for younger compute — so the all-gather of batch i-1 overlaps the
+    convolutions of batch i instead of queueing behind them, and nothing goes through the
+    legacy default stream (whose implicit barriers would serialise compute and collective).
+    Record buffers rotate (3 deep when pipelined) so a batch being gathered is never the one
+    being written; gather outputs alternate between two buffers.
 
-    def __init__(self, extractor, world, rank, frames_per_rank):
+    With an extractor built with async_cov=True the driver is software pipelined: step(i)
+    enqueues the compute of batch i and then completes batch i-1 (its covariance ran beside
+    batch i's convolutions); flush() completes the last batch.  `gathered` is the most recently
+    completed batch; call sync(stream) (or decode()) before consuming it.
+
+    gather_fn(out, local) defaults to torch.distributed.all_gather_into_tensor; tests inject a
+    single-process stand-in to exercise the stream / buffer logic on one GPU."""
+
+    def __init__(self, extractor, world, rank, frames_per_rank, gather_fn=None):
         import torch
 
         self.ext, self.world, self.rank, self.fpr = extractor, world, rank, frames_per_rank
         self.rec_bytes = extractor.record_bytes()
-        nbuf = 2 if extractor.async_cov else 1
-        self.local = [torch.zeros(frames_per_rank * self.rec_bytes, dtype=torch.uint8, device="cuda")
-                      for _ in range(nbuf)]
-        self.all = (torch.zeros(world * frames_per_rank * self.rec_bytes, dtype=torch.uint8, device="cuda")
-                    if world > 1 else None)
+        self._gather_fn = gather_fn
+        self._collective = world > 1 or gather_fn is not None
+        nbuf = 3 if extractor.async_cov else (2 if self._collective else 1)
+        nbytes = frames_per_rank * self.rec_bytes
+        self.local = [torch.zeros(nbytes, dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
+        self._local_free = [None] * nbuf          # event: the gather that last read local[k] is done
+        self.all = ([torch.zeros(world * nbytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
+                    if self._collective else None)
+        self.comm = torch.cuda.Stream() if self._collective else None
         self.gathered = None
+        self._gathered_event = None
         self._pending = None
         self._calls = 0
+        self._gathers = 0
 
-    def _complete(self, ticket, buf, stream):
-        import torch.distributed as dist
+    def _complete(self, ticket, k, stream):
+        import torch
 
-        self.ext.wait_records(ticket, stream.cuda_stream)
-        if self.world > 1:
-            dist.all_gather_into_tensor(self.all, buf)
-            self.gathered = self.all
-        else:
-            self.gathered = buf
+        if not self._collective:
+            self.ext.wait_records(ticket, stream.cuda_stream)
+            self.gathered = self.local[k]
+            self._gathered_event = None
+            return
+        out = self.all[self._gathers % 2]
+        self._gathers += 1
+        # the communication stream waits for exactly this batch's records (covariance included)
+        self.ext.wait_records(ticket, self.comm.cuda_stream)
+        with torch.cuda.stream(self.comm):
+            if self._gather_fn is not None:
+                self._gather_fn(out, self.local[k])
+            else:
+                import torch.distributed as dist
+
+                dist.all_gather_into_tensor(out, self.local[k])
+            ev = torch.cuda.Event()
+            ev.record(self.comm)
+        self._local_free[k] = ev
+        self.gathered, self._gathered_event = out, ev
 
     def step(self, d_images, stream):
-        """d_images: torch uint8 [frames_per_rank, H, W] on this rank's GPU."""
-        buf = self.local[self._calls % len(self.local)]
+        """d_images: torch uint8 [frames_per_rank, H, W] on this rank's GPU; `stream`: torch.cuda.Stream
+        the compute is enqueued on (a non-default stream when world > 1)."""
+        k = self._calls % len(self.local)
         self._calls += 1
+        if self._local_free[k] is not None:      # (long done: it was issued len(local) steps ago)
+            stream.wait_event(self._local_free[k])
+            self._local_free[k] = None
+        buf = self.local[k]
         ticket = self.ext.extract_batch_device(d_images.data_ptr(), self.fpr, buf.data_ptr(), stream.cuda_stream)
         if self.ext.async_cov:
             if self._pending is not None:
                 self._complete(*self._pending, stream)
-            self._pending = (ticket, buf)
+            self._pending = (ticket, k)
         else:
-            self._complete(ticket, buf, stream)
+            self._complete(ticket, k, stream)
         return self.gathered
 
     def flush(self, stream):
-        """Complete the batch still in flight (async mode); returns the gathered records."""
+        """Complete the batch still in flight (async mode) and order `stream` after the last gather."""
         if self._pending is not None:
             self._complete(*self._pending, stream)
             self._pending = None
+        self.sync(stream)
         return self.gathered
+
+    def sync(self, stream):
+        """Make `stream` wait until `gathered` is complete."""
+        if self._gathered_event is not None:
+            stream.wait_event(self._gathered_event)
 
     def decode(self, frame):
         """Host copy + decode of global frame `frame` of the last completed batch."""
+        if self._gathered_event is not None:
+            self._gathered_event.synchronize()
         rb = self.rec_bytes
         return self.ext.view_record(self.gathered[frame * rb:(frame + 1) * rb].cpu().numpy())

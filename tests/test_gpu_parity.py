@@ -354,3 +354,59 @@ def test_device_path_sync_and_async_cov_equal_host_path():
                 assert np.array_equal(g.cov2, e.cov2) and np.array_equal(g.cov2_inv, e.cov2_inv)
                 assert np.array_equal(g.response, e.response) and np.array_equal(g.dense_dust, e.dense_dust)
         ext.close()
+
+
+def test_sharded_driver_comm_stream_and_buffer_rotation():
+    """The N > 1 code path of ShardedExtractor (communication stream, rotating record buffers, two
+    gather outputs) on one GPU: the collective is replaced by a device copy, everything else — the
+    stream waits, spfe_wait_records on the communication stream, buffer reuse — is the real thing.
+    Many steps back to back without host synchronisation, alternating inputs."""
+    import torch
+    from sp_orb_slam_amd import parallel
+    H, W, nf, B = 120, 160, 150, 2
+    blob = weights.synthetic(7, "dense")
+    batches = [np.stack([synth.make_image(900 + 10 * s + i, H, W) for i in range(B)]) for s in range(3)]
+    host = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=False)
+    expect = [host.extract_batch(list(b)) for b in batches]
+    host.close()
+    d_batches = [torch.from_numpy(b).cuda() for b in batches]
+    torch.cuda.synchronize()
+    calls = []
+
+    def fake_gather(out, local):
+        calls.append(torch.cuda.current_stream().cuda_stream)
+        out.copy_(local)
+
+    for async_cov in (False, True):
+        ext = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=False, async_cov=async_cov)
+        sh = parallel.ShardedExtractor(ext, 1, 0, B, gather_fn=fake_gather)
+        calls.clear()
+        comp, cons = torch.cuda.Stream(), torch.cuda.Stream()
+        snaps, order = [], []
+        nsteps = 11
+        for k in range(nsteps):
+            out = sh.step(d_batches[k % 3], comp)
+            done = k - 1 if async_cov else k
+            if done >= 0:
+                sh.sync(cons)
+                with torch.cuda.stream(cons):
+                    snaps.append(out.clone())
+                order.append(done)
+        if async_cov:
+            out = sh.flush(comp)
+            sh.sync(cons)
+            with torch.cuda.stream(cons):
+                snaps.append(out.clone())
+            order.append(nsteps - 1)
+        torch.cuda.synchronize()
+        assert order == list(range(nsteps))
+        assert all(c == sh.comm.cuda_stream for c in calls) and sh.comm.cuda_stream != comp.cuda_stream
+        rb = ext.record_bytes()
+        for k, snap in zip(order, snaps):
+            hrec = snap.cpu().numpy()
+            for i, e in enumerate(expect[k % 3]):
+                g = ext.view_record(hrec[i * rb:(i + 1) * rb])
+                assert g.status == 0 and g.K == e.K and np.array_equal(g.kp_xy, e.kp_xy)
+                assert np.array_equal(g.descriptors, e.descriptors) and np.array_equal(g.cov2_inv, e.cov2_inv)
+        assert sh.decode(0).K == expect[(nsteps - 1) % 3][0].K
+        ext.close()
