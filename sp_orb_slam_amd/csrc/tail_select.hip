@@ -170,7 +170,7 @@ enum : uint8_t { ST_NONE = 0, ST_UNDEC = 1, ST_ALIVE = 2, ST_DEAD = 3, ST_KEPT =
 size_t select_lds_bytes(int H, int W) {
   const size_t C = (size_t)(H / 8) * (W / 8);
   const size_t Cp = (C + 15) & ~(size_t)15;
-  return Cp * 4 + Cp * 2 + Cp + Cp + ((size_t)(H / 8) + 16) * 4 * 2 + 64 + 256 * 4;
+  return Cp * 4 + Cp * 2 + Cp + Cp + Cp + ((size_t)(H / 8) + 16) * 4 * 2 + 64 + 256 * 4 + 64;
 }
 
 __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout rl, int H, int W,
@@ -183,7 +183,8 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
   uint16_t *sList = reinterpret_cast<uint16_t *>(sScore + Cp);
   uint8_t *sK = reinterpret_cast<uint8_t *>(sList + Cp);
   uint8_t *sState = sK + Cp;
-  int *sRow = reinterpret_cast<int *>(sState + Cp);  // [hc+1] counts, then [hc+1] bases
+  uint8_t *sMask = sState + Cp;                      // per candidate: which of its 8 neighbours can suppress it
+  int *sRow = reinterpret_cast<int *>(sMask + Cp);   // [hc+1] counts, then [hc+1] bases
   int *sRowBase = sRow + (hc + 16);
   int *sCnt = sRowBase + (hc + 16);  // [0] undecided flag, [1] survivors, [2] candidates, [3] K
 
@@ -210,32 +211,50 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
   __syncthreads();
 
   // ---- NMS fixed point ----
+  // Which neighbours CAN suppress a candidate (inside the window and ranked before it) never
+  // changes, only their states do: one pass builds that 8-bit mask per candidate from 24
+  // independent LDS reads (the serial version paid an LDS round trip per branch), the rounds
+  // then read 8 neighbour states each.  Neighbour q: 0..2 row above (dx -1, 0, +1), 3 / 4 left /
+  // right, 5..7 row below.
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < C; c += 1024) {
+    if (sState[c] == ST_NONE) continue;
+    const int cy = c / wc, cx = c - cy * wc;
+    const int k = sK[c];
+    const int x = cx * 8 + (k & 7), y = cy * 8 + (k >> 3);
+    const float sc = sScore[c];
+    unsigned m = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int dy = q < 3 ? -1 : (q < 5 ? 0 : 1);
+      const int dx = q < 3 ? q - 1 : (q == 3 ? -1 : (q == 4 ? 1 : q - 6));
+      const int ny = cy + dy, nx = cx + dx;
+      const bool valid = (unsigned)ny < (unsigned)hc && (unsigned)nx < (unsigned)wc;
+      const int n = valid ? ny * wc + nx : c;
+      const float sn = sScore[n];   // 0 where there is no candidate
+      const int kn = sK[n];
+      const int ddx = nx * 8 + (kn & 7) - x, ddy = ny * 8 + (kn >> 3) - y;
+      const bool close = ddx <= SPFE_NMS_DIST && ddx >= -SPFE_NMS_DIST && ddy <= SPFE_NMS_DIST && ddy >= -SPFE_NMS_DIST;
+      if (valid && sn > 0.0f && close && spfe_ranks_before(sn, n, sc, c)) m |= 1u << q;
+    }
+    sMask[c] = (uint8_t)m;
+  }
+  __syncthreads();
   for (int round = 0; round < 4096; ++round) {
     if (tid == 0) sCnt[0] = 0;
     __syncthreads();
     int pending = 0;
     for (int c = tid; c < C; c += 1024) {
       if (sState[c] != ST_UNDEC) continue;
-      const int cy = c / wc, cx = c - cy * wc;
-      const int k = sK[c];
-      const int x = cx * 8 + (k & 7), y = cy * 8 + (k >> 3);
-      const float sc = sScore[c];
+      const unsigned m = sMask[c];
       bool dead = false, blocked = false;
-      for (int ny = cy - 1; ny <= cy + 1; ++ny) {
-        if (ny < 0 || ny >= hc) continue;
-        for (int nx = cx - 1; nx <= cx + 1; ++nx) {
-          if (nx < 0 || nx >= wc) continue;
-          const int n = ny * wc + nx;
-          if (n == c) continue;
-          const uint8_t st = sState[n];
-          if (st == ST_NONE || st == ST_DEAD) continue;
-          const int kn = sK[n];
-          const int ddx = nx * 8 + (kn & 7) - x, ddy = ny * 8 + (kn >> 3) - y;
-          if (ddx > SPFE_NMS_DIST || ddx < -SPFE_NMS_DIST || ddy > SPFE_NMS_DIST || ddy < -SPFE_NMS_DIST)
-            continue;
-          if (!spfe_ranks_before(sScore[n], n, sc, c)) continue;
-          if (st == ST_ALIVE) dead = true; else blocked = true;
-        }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int off = (q < 3 ? -wc : (q < 5 ? 0 : wc)) + (q < 3 ? q - 1 : (q == 3 ? -1 : (q == 4 ? 1 : q - 6)));
+        const bool on = (m >> q) & 1u;
+        const uint8_t st = sState[on ? c + off : c];  // own state (UNDEC) when the neighbour does not matter
+        dead |= on && st == ST_ALIVE;
+        blocked |= on && st == ST_UNDEC;
       }
       if (dead) sState[c] = ST_DEAD;
       else if (!blocked) sState[c] = ST_ALIVE;
@@ -262,20 +281,45 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
   int need = num_features + 1;
   const bool cut = S > need;
   if (cut) {
+    int *sWaveTot = sHist + 256;  // [4] histogram totals of the four 64-bin groups
     for (int shift = 24; shift >= 0; shift -= 8) {
       if (tid < 256) sHist[tid] = 0;
       __syncthreads();
-      for (int c = tid; c < C; c += 1024) {
-        if (sState[c] != ST_ALIVE) continue;
-        const uint32_t key = __float_as_uint(sScore[c]);
-        if ((key & pmask) == prefix) atomicAdd(&sHist[(key >> shift) & 255], 1);
+      for (int c0 = 0; c0 < C; c0 += 1024) {  // uniform trip count: ballots below need whole waves
+        const int c = c0 + tid;
+        bool has = false;
+        uint32_t bin = 0;
+        if (c < C && sState[c] == ST_ALIVE) {
+          const uint32_t key = __float_as_uint(sScore[c]);
+          has = (key & pmask) == prefix;
+          bin = (key >> shift) & 255u;
+        }
+        // lanes of this wave with the same bin: one atomic per distinct bin per wave (scores cluster,
+        // the top-byte pass has a handful of bins)
+        uint64_t same = __ballot(has);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+          const uint64_t bal = __ballot(has && ((bin >> bit) & 1u));
+          same &= ((bin >> bit) & 1u) ? bal : ~bal;
+        }
+        if (has && lane == (int)__ffsll((long long)same) - 1) atomicAdd(&sHist[bin], __popcll(same));
+      }
+      __syncthreads();
+      int mine = 0, suffix = 0;
+      if (tid < 256) {  // suffix sums: `above` = survivors in higher bins
+        mine = sHist[tid];
+        suffix = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const int o = __shfl_down(suffix, off, 64);
+          if (lane + off < 64) suffix += o;
+        }
+        if (lane == 0) sWaveTot[wave] = suffix;
       }
       __syncthreads();
       if (tid < 256) {
-        int above = 0;
-#pragma unroll 16
-        for (int bnum = 0; bnum < 256; ++bnum) above += bnum > tid ? sHist[bnum] : 0;
-        const int mine = sHist[tid];
+        int above = suffix - mine;
+        for (int w2 = wave + 1; w2 < 4; ++w2) above += sWaveTot[w2];
         if (above < need && above + mine >= need) { sCnt[4] = tid; sCnt[5] = need - above; }
       }
       __syncthreads();
@@ -319,7 +363,6 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
   // ---- raster order (y outer, x inner) (:220-238) and occ_grid (:227-228) ----
   // one wavefront per cell row: inside a row the order is (dy, cx), so the rank
   // of a keypoint is popcounts of ballots over the row's KEPT flags per dy.
-  const int lane = tid & 63, wave = tid >> 6;
   const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   for (int cy = wave; cy < hc; cy += 16) {
     int cnt = 0;
@@ -331,14 +374,27 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
     if (lane == 0) sRow[cy] = cnt;
   }
   __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int r = 0; r < hc; ++r) { sRowBase[r] = acc; acc += sRow[r]; }
-    sCnt[3] = acc;
-    hdr[0] = acc;       // K
-    hdr[1] = sCnt[2];   // n_candidates
-    hdr[2] = 0;         // status
-    hdr[3] = S;         // NMS survivors before the cut (diagnostic)
+  if (wave == 0) {  // exclusive prefix over the cell rows: a wave scan per 64 rows
+    int carry = 0;
+    for (int r0 = 0; r0 < hc; r0 += 64) {
+      const int r = r0 + lane;
+      const int v = r < hc ? sRow[r] : 0;
+      int incl = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+      }
+      if (r < hc) sRowBase[r] = carry + incl - v;
+      carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) {
+      sCnt[3] = carry;
+      hdr[0] = carry;     // K
+      hdr[1] = sCnt[2];   // n_candidates
+      hdr[2] = 0;         // status
+      hdr[3] = S;         // NMS survivors before the cut (diagnostic)
+    }
   }
   __syncthreads();
   for (int cy = wave; cy < hc; cy += 16) {
