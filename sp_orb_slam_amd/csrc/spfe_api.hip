@@ -47,10 +47,10 @@ int fail(int code, const char *fmt, ...) {
                   __LINE__);                                                            \
   } while (0)
 
-constexpr int NSTAGE = 17;
+constexpr int NSTAGE = 15;
 const char *kStageNames[NSTAGE] = {"conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b",
                                    "conv4a", "conv4b", "convPaDa", "convPb", "convDb", "tail",
-                                   "heat_norm", "select", "desc", "cov", "total"};
+                                   "select", "post_side", "total"};  // post_side = heat_norm + desc + cov
 
 struct ConvLayer {
   int cin, cout_real, nblk, ks;
@@ -480,18 +480,18 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s) {
   }
   HIP_TRY(spfe::launch_tail(f, h->rl, n, H, W, s));
   STAGE_MARK(12);
-  HIP_TRY(spfe::launch_heat_norm(f, n, H, W, s));
-  STAGE_MARK(13);
   HIP_TRY(spfe::launch_select(f, h->rl, n, H, W, h->cfg.num_features, s));
-  STAGE_MARK(14);
-  HIP_TRY(spfe::launch_desc(f, h->rl, n, H, W, s));
-  STAGE_MARK(15);
-  // covariance on the side stream, ordered after this call's selection / heat maps
+  STAGE_MARK(13);
+  // Everything that only the finished record needs — heat normalisation (input of the covariance),
+  // descriptor sampling, covariance — goes to the side stream, ordered after this call's
+  // selection: small latency-bound kernels that run beside the next call's convolutions.
   HIP_TRY(hipEventRecord(h->ev_post[slot], s));
   HIP_TRY(hipStreamWaitEvent(h->side, h->ev_post[slot], 0));
+  HIP_TRY(spfe::launch_heat_norm(f, n, H, W, h->side));
+  HIP_TRY(spfe::launch_desc(f, h->rl, n, H, W, h->side));
   HIP_TRY(spfe::launch_cov(f, h->rl, h->cov, n, H, W, h->side));
   HIP_TRY(hipEventRecord(h->ev_cov[slot], h->side));
-  if (h->timing) HIP_TRY(hipEventRecord(h->ev[16], h->side));
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[14], h->side));
   h->cov_inflight = true;
   h->ticket++;
   if (!(h->cfg.flags & SPFE_FLAG_ASYNC_COV)) {
@@ -619,7 +619,7 @@ int spfe_postprocess(spfe_handle h, const float *semi, const float *coarse, int 
   HIP_TRY(hipMemcpyAsync(h->d_semi, semi, (size_t)n * h->C * SPFE_SEMI_CH * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(h->d_coarse, coarse, (size_t)n * h->C * SPFE_DESC_DIM * 4, hipMemcpyHostToDevice, s));
   if (h->timing) h->ev = h->evpool.data() + (size_t)(h->calls % spfe_handle_s::EVSETS) * (NSTAGE + 1);
-  if (h->timing) for (int i = 0; i <= 12; ++i) HIP_TRY(hipEventRecord(h->ev[i], s));
+  if (h->timing) for (int i = 0; i <= 11; ++i) HIP_TRY(hipEventRecord(h->ev[i], s));
   h->calls++;
   int rc = enqueue_post(h, n, h->d_records, s);
   if (rc) return rc;

@@ -27,7 +27,7 @@ def test_library_reports_version_and_stage_names():
     names = []
     while L.spfe_stage_name(len(names)):
         names.append(L.spfe_stage_name(len(names)).decode())
-    assert names[0] == "conv1a" and names[-1] == "total" and "select" in names and "cov" in names
+    assert names[0] == "conv1a" and names[-1] == "total" and "select" in names and "post_side" in names
 
 
 def test_create_rejects_bad_config_without_gpu():
