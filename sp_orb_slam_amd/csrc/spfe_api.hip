@@ -74,6 +74,8 @@ struct spfe_handle_s {
   hipStream_t side = nullptr;
   static constexpr int NTICKET = 4;
   hipEvent_t ev_post[NTICKET] = {}, ev_cov[NTICKET] = {};
+  hipEvent_t ev_desc = nullptr;  // side stream: the last call's descriptor sampling (reader of d_coarse) is done
+  bool desc_recorded = false;
   long ticket = 0;          // calls so far; call t uses slot t % NTICKET
   bool cov_inflight = false;
   std::vector<void *> dev_allocs;
@@ -294,6 +296,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
     HIP_TRY(hipEventCreateWithFlags(&h->ev_post[i], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_cov[i], hipEventDisableTiming));
   }
+  HIP_TRY(hipEventCreateWithFlags(&h->ev_desc, hipEventDisableTiming));
   const char *tenv = getenv("SPFE_STAGE_TIMING");
   h->timing = tenv && atoi(tenv) != 0;
   if (h->timing) {
@@ -426,6 +429,9 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   STAGE_MARK(1);
   for (int i = 0; i < 10; ++i) {
     const ConvLayer &L = h->layers[i];
+    // convDb overwrites the coarse descriptor map the PREVIOUS call's descriptor sampling reads on
+    // the side stream (pipelined callers): order it after that, by event, not by timing
+    if (i == 9 && h->desc_recorded) HIP_TRY(hipStreamWaitEvent(s, h->ev_desc, 0));
     spfe::ConvParams p;
     p.in = L.in; p.in_stride = L.in_stride; p.in_choff = L.in_choff;
     p.wpack = L.d_w; p.bias = L.d_b;
@@ -489,6 +495,8 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s) {
   HIP_TRY(hipStreamWaitEvent(h->side, h->ev_post[slot], 0));
   HIP_TRY(spfe::launch_heat_norm(f, n, H, W, h->side));
   HIP_TRY(spfe::launch_desc(f, h->rl, n, H, W, h->side));
+  HIP_TRY(hipEventRecord(h->ev_desc, h->side));  // d_coarse may be overwritten after this (next call's convDb)
+  h->desc_recorded = true;
   HIP_TRY(spfe::launch_cov(f, h->rl, h->cov, n, H, W, h->side));
   HIP_TRY(hipEventRecord(h->ev_cov[slot], h->side));
   if (h->timing) HIP_TRY(hipEventRecord(h->ev[14], h->side));
@@ -573,6 +581,7 @@ void spfe_destroy(spfe_handle h) {
     if (h->ev_post[i]) (void)hipEventDestroy(h->ev_post[i]);
     if (h->ev_cov[i]) (void)hipEventDestroy(h->ev_cov[i]);
   }
+  if (h->ev_desc) (void)hipEventDestroy(h->ev_desc);
   if (h->side) (void)hipStreamDestroy(h->side);
   for (void *p : {(void *)h->d_map_x, (void *)h->d_map_y, (void *)h->d_raw})
     if (p) (void)hipFree(p);
@@ -616,6 +625,7 @@ int spfe_postprocess(spfe_handle h, const float *semi, const float *coarse, int 
   if (n < 1 || n > h->B) return fail(SPFE_EINVAL, "batch %d not in [1, %d]", n, h->B);
   HIP_TRY(hipSetDevice(h->cfg.device));
   hipStream_t s = h->stream;
+  if (h->desc_recorded) HIP_TRY(hipStreamWaitEvent(s, h->ev_desc, 0));  // previous call's reader of d_coarse
   HIP_TRY(hipMemcpyAsync(h->d_semi, semi, (size_t)n * h->C * SPFE_SEMI_CH * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(h->d_coarse, coarse, (size_t)n * h->C * SPFE_DESC_DIM * 4, hipMemcpyHostToDevice, s));
   if (h->timing) h->ev = h->evpool.data() + (size_t)(h->calls % spfe_handle_s::EVSETS) * (NSTAGE + 1);
