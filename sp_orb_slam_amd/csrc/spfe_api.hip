@@ -336,7 +336,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
   if ((rc = dev_alloc(h, &h->d_heat_inv, (size_t)B * H * W))) return rc;
   if (cfg->flags & SPFE_FLAG_HEAT)
     if ((rc = dev_alloc(h, &h->d_heat, (size_t)B * H * W))) return rc;
-  if ((rc = dev_alloc(h, &h->d_minmax, (size_t)B * 64 * 2))) return rc;
+  if ((rc = dev_alloc(h, &h->d_minmax, (size_t)B * spfe::tail_parts(h->H, h->W) * 2))) return rc;
   if ((rc = dev_alloc(h, &h->d_cell_score, (size_t)B * C))) return rc;
   if ((rc = dev_alloc(h, &h->d_heat_consts, (size_t)B * 4))) return rc;
   if ((rc = dev_alloc(h, &h->d_cell_k, (size_t)B * C))) return rc;

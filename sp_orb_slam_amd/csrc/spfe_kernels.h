@@ -51,7 +51,7 @@ struct FrameBufs {
   float *heat_log;      // [B][H][W]
   float *heat;          // [B][H][W] or null
   float *heat_inv;      // [B][H][W]
-  uint32_t *minmax;     // [B][2] ordered-uint keys of min/max of heat_log
+  uint32_t *minmax;     // [B][tail_parts][2] float partials of min/max of heat_log
   float *cell_score;    // [B][C]  0 = no candidate
   uint8_t *cell_k;      // [B][C]  arg-max channel
   int *kp_cell;         // [B][kmax] cell index of emitted keypoint
@@ -82,6 +82,7 @@ size_t cov_link_lds(int kmax);
 hipError_t launch_cov(const FrameBufs &f, const RecordLayout &r, const CovScratch &cs, int B, int H, int W,
                       hipStream_t s);
 
+int tail_parts(int H, int W);  // min/max partials per frame written by the tail kernel
 hipError_t launch_tail(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s);
 hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H, int W,
                          int num_features, hipStream_t s);

@@ -16,7 +16,7 @@
 
 namespace spfe {
 
-#define TAIL_BLOCKS_PER_FRAME 64
+#define TAIL_THREADS 256  // tail_kernel: 4 waves x 16 cells per workgroup (a DPP quad per cell)
 
 __device__ __forceinline__ float wave_sum64(float v) {
 #pragma unroll
@@ -40,80 +40,150 @@ __device__ __forceinline__ float wave_min64(float v) {
   return v;
 }
 
-// One wavefront per 8x8 cell: lane k owns position channel k, the dustbin logit
-// is a wave-uniform load.  grid = (TAIL_BLOCKS_PER_FRAME, B), 4 waves per block,
-// each wave strides over the frame's cells.  min/max of the log-heat are reduced
-// per block and written as partials (no atomics, no init).
-__global__ __launch_bounds__(256) void tail_kernel(FrameBufs f, RecordLayout rl, int H, int W) {
+// Four lanes (a DPP quad) per 8x8 cell, 16 cells per wave: lane q of the quad owns position
+// channels 16q .. 16q+15 (= pixel rows 2q, 2q+1 of the cell) in registers, so the soft-max, the
+// arg-max and the log-heat need two quad exchanges per reduction instead of the six dependent
+// ds_bpermute round trips per reduction of a wave-per-cell form.  The wave first copies its 16 x 65
+// contiguous logits into LDS with coalesced loads, each lane then reads its 16 (+ the dustbin).
+// The sum of the 64 exponentials follows the butterfly of spfe_sum64_host level by level — pairs
+// 32 apart (quad lane ^ 2), 16 apart (quad lane ^ 1), then 8, 4, 2, 1 inside the lane — so it is
+// bit-identical.  min/max of the log-heat: one partial per workgroup (no atomics, no init).
+__device__ __forceinline__ float quad_xor1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float quad_xor2(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+}
+__device__ __forceinline__ int quad_xor1i(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true); }
+__device__ __forceinline__ int quad_xor2i(int v) { return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true); }
+
+__global__ __launch_bounds__(TAIL_THREADS) void tail_kernel(FrameBufs f, RecordLayout rl, int H, int W, int nparts) {
+  constexpr int CPW = 16, NW = TAIL_THREADS / 64;  // cells per wave, waves per workgroup
   const int wc = W >> 3, hc = H >> 3, C = hc * wc;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane & 3, lc = lane >> 2;
   const int b = blockIdx.y;
   const float *semi = f.semi + (size_t)b * C * SPFE_SEMI_CH;
   float *heat_log = f.heat_log + (size_t)b * H * W;
   uint8_t *rec = f.records + (size_t)b * rl.bytes;
   float *dense_dust = reinterpret_cast<float *>(rec + rl.off_dd);
   float *semi_dust = reinterpret_cast<float *>(rec + rl.off_sd);
-  float lmin = 0.0f, lmax = -1e30f;  // log-heat is <= 0
-  const int dy = lane >> 3, dx = lane & 7;
-  for (int cell = blockIdx.x * 4 + wave; cell < C; cell += gridDim.x * 4) {
+  __shared__ float sm[NW][CPW * SPFE_SEMI_CH];
+  __shared__ float smin[NW], smax[NW];
+
+  const int cell0 = (blockIdx.x * NW + wave) * CPW;            // first cell of this wave
+  const int ncell = C - cell0 < CPW ? C - cell0 : CPW;         // (<= 0: nothing to do)
+  float lmin = 0.0f, lmax = -1e30f;                            // log-heat is <= 0
+  if (ncell > 0) {
+    const float *g = semi + (size_t)cell0 * SPFE_SEMI_CH;
+    const int nfl = ncell * SPFE_SEMI_CH;
+    for (int i = lane; i < nfl; i += 64) sm[wave][i] = g[i];
+  }
+  __builtin_amdgcn_wave_barrier();
+  // whole quads are active or idle together (DPP reads inactive lanes as 0 with bound_ctrl)
+  if (lc < ncell) {
+    const int cell = cell0 + lc;
     const int cy = cell / wc, cx = cell - cy * wc;
-    const float *s = semi + (size_t)cell * SPFE_SEMI_CH;
-    const float v = s[lane];
-    const float vd = s[64];
-    float m = wave_max64(v);
-    m = vd > m ? vd : m;
-    const float e = spfe_expf(v - m);
-    const float ed = spfe_expf(vd - m);
-    const float total = wave_sum64(e) + ed;
-    const float p = e / total;
-    // arg-max over the 64 position channels, lowest index on ties (:112)
-    float bv = p;
-    int bi = lane;
+    const float *row = &sm[wave][lc * SPFE_SEMI_CH];
+    float v[16];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const float ov = __shfl_xor(bv, off, 64);
-      const int oi = __shfl_xor(bi, off, 64);
+    for (int k = 0; k < 16; ++k) v[k] = row[q * 16 + k];
+    const float vd = row[64];
+    float m = vd;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m = v[k] > m ? v[k] : m;
+    { const float o = quad_xor2(m); m = o > m ? o : m; }
+    { const float o = quad_xor1(m); m = o > m ? o : m; }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = spfe_expf(v[k] - m);
+    const float ed = spfe_expf(vd - m);
+    float t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = v[k] + quad_xor2(v[k]);   // channels 32 apart
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = t[k] + quad_xor1(t[k]);   // 16 apart
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = t[j] + t[j + 8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] = t[j] + t[j + 4];
+    t[0] = t[0] + t[2];
+    t[1] = t[1] + t[3];
+    const float total = (t[0] + t[1]) + ed;
+    // arg-max over the 64 position channels, lowest index on ties (:112)
+    float bv = -1.0f;
+    int bi = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      v[k] = v[k] / total;
+      if (v[k] > bv) { bv = v[k]; bi = q * 16 + k; }
+    }
+    {
+      const float ov = quad_xor2(bv);
+      const int oi = quad_xor2i(bi);
       if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
     }
-    const float pc = p < SPFE_HEAT_FLOOR ? SPFE_HEAT_FLOOR : p;
-    const float L = spfe_logf(pc);
-    heat_log[(size_t)(cy * 8 + dy) * W + cx * 8 + dx] = L;
-    lmin = L < lmin ? L : lmin;
-    lmax = L > lmax ? L : lmax;
-    if (lane == 0) {
+    {
+      const float ov = quad_xor1(bv);
+      const int oi = quad_xor1i(bi);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    float *hl = heat_log + (size_t)(cy * 8 + 2 * q) * W + cx * 8;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      float L[8];
+#pragma unroll
+      for (int dx = 0; dx < 8; ++dx) {
+        const float p = v[r * 8 + dx];
+        L[dx] = spfe_logf(p < SPFE_HEAT_FLOOR ? SPFE_HEAT_FLOOR : p);
+        lmin = L[dx] < lmin ? L[dx] : lmin;
+        lmax = L[dx] > lmax ? L[dx] : lmax;
+      }
+      *reinterpret_cast<float4 *>(hl + (size_t)r * W) = make_float4(L[0], L[1], L[2], L[3]);
+      *reinterpret_cast<float4 *>(hl + (size_t)r * W + 4) = make_float4(L[4], L[5], L[6], L[7]);
+    }
+    if (q == 0) {
       semi_dust[cell] = vd;
       dense_dust[cell] = ed / total;
       f.cell_score[(size_t)b * C + cell] = bv >= SPFE_SCORE_THRESH ? bv : 0.0f;
       f.cell_k[(size_t)b * C + cell] = (uint8_t)bi;
     }
   }
-  __shared__ float smin[4], smax[4];
   lmin = wave_min64(lmin);
   lmax = wave_max64(lmax);
   if (lane == 0) { smin[wave] = lmin; smax[wave] = lmax; }
   __syncthreads();
   if (threadIdx.x == 0) {
     float a = smin[0], c = smax[0];
-    for (int i = 1; i < 4; ++i) { a = smin[i] < a ? smin[i] : a; c = smax[i] > c ? smax[i] : c; }
-    float *part = reinterpret_cast<float *>(f.minmax) + ((size_t)b * TAIL_BLOCKS_PER_FRAME + blockIdx.x) * 2;
+    for (int i = 1; i < NW; ++i) { a = smin[i] < a ? smin[i] : a; c = smax[i] > c ? smax[i] : c; }
+    float *part = reinterpret_cast<float *>(f.minmax) + ((size_t)b * nparts + blockIdx.x) * 2;
     part[0] = a;
     part[1] = c;
   }
 }
 
+int tail_parts(int H, int W) {  // workgroups (= min/max partials) per frame
+  const int C = (H / 8) * (W / 8);
+  return (C + TAIL_THREADS / 4 - 1) / (TAIL_THREADS / 4);
+}
+
 hipError_t launch_tail(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s) {
-  hipLaunchKernelGGL(tail_kernel, dim3(TAIL_BLOCKS_PER_FRAME, B), dim3(256), 0, s, f, r, H, W);
+  const int nparts = tail_parts(H, W);
+  hipLaunchKernelGGL(tail_kernel, dim3(nparts, B), dim3(TAIL_THREADS), 0, s, f, r, H, W, nparts);
   return hipGetLastError();
 }
 
 // to_heat (:461-474): img = -L, min/max as doubles, one affine map per pixel with
 // float scale/shift, float multiply then float add (oracle_heat has the rule).
-__global__ __launch_bounds__(256) void heat_norm_kernel(FrameBufs f, int H, int W) {
+__global__ __launch_bounds__(256) void heat_norm_kernel(FrameBufs f, int H, int W, int nparts) {
   const int b = blockIdx.y;
   __shared__ float sc[4];
   if (threadIdx.x < 64) {
-    const float *part = reinterpret_cast<const float *>(f.minmax) + (size_t)b * TAIL_BLOCKS_PER_FRAME * 2;
-    float lo = part[threadIdx.x * 2], hi = part[threadIdx.x * 2 + 1];
+    const float *part = reinterpret_cast<const float *>(f.minmax) + (size_t)b * nparts * 2;
+    float lo = 0.0f, hi = -1e30f;
+    for (int i = threadIdx.x; i < nparts; i += 64) {
+      lo = part[i * 2] < lo ? part[i * 2] : lo;
+      hi = part[i * 2 + 1] > hi ? part[i * 2 + 1] : hi;
+    }
     lo = wave_min64(lo);
     hi = wave_max64(hi);
     if (threadIdx.x == 0) {
@@ -150,7 +220,7 @@ __global__ __launch_bounds__(256) void heat_norm_kernel(FrameBufs f, int H, int 
 
 hipError_t launch_heat_norm(const FrameBufs &f, int B, int H, int W, hipStream_t s) {
   const int blocks = (int)(((size_t)H * W / 4 + 255) / 256);
-  hipLaunchKernelGGL(heat_norm_kernel, dim3(blocks < 128 ? blocks : 128, B), dim3(256), 0, s, f, H, W);
+  hipLaunchKernelGGL(heat_norm_kernel, dim3(blocks < 128 ? blocks : 128, B), dim3(256), 0, s, f, H, W, tail_parts(H, W));
   return hipGetLastError();
 }
 
