@@ -20,9 +20,11 @@
 //  * workgroup -> tile mapping is XCD-aware: the 8 XCDs each get a contiguous
 //    run of tiles so neighbouring tiles (shared halos, shared weight slabs) hit
 //    the same L2.
+#include <type_traits>
 #include <utility>
 
 #include "spfe_kernels.h"
+#include "../../include/spfe_exact_math.h"
 
 namespace spfe {
 
@@ -127,13 +129,78 @@ __device__ __forceinline__ void epi_store(const EpiCtx<NT> &e, const f32x16 (&ac
   }
 }
 
+// ---------------------------------------------------------------------------
+// conv1a fused into conv1b (LAYER tag 2).  conv1a (u8 -> x 1/255 -> 3x3 conv 1->64, bias, ReLU,
+// sp_extractor.cpp:81,388) is K = 9 VALU work whose only real cost as its own kernel is writing —
+// and conv1b then re-reading — 92 MB of f32 activations per frame.  Fused, the workgroup keeps the
+// 12 x 36 patch of the image under its halo tile in LDS and each lane COMPUTES the pieces of the
+// next stage it used to load: 4 channels of one halo pixel = 4 chains of 9 fmaf in tap order,
+// + bias, ReLU — the arithmetic of conv1a_kernel, so the result is bit-identical — sliced into the
+// MFMA shadows (6 pieces x 6 sub-steps per stage).  Halo pixels outside the image are conv1b's
+// zero padding, not conv1a evaluated there.
+// ---------------------------------------------------------------------------
+constexpr int F1_PROWS = 12, F1_PCOLS = 36, F1_PATCH = F1_PROWS * F1_PCOLS;  // floats per patch buffer
+
+template <int NITER>
+struct Fuse1a {
+  float4 w[9], bias;        // taps / bias of this lane's 4 channels in the chunk being produced
+  float px[9];              // 3x3 patch of the piece in flight
+  float4 o;                 // its 4 outputs
+  unsigned pb[NITER];       // patch float index (top-left of the 3x3) of each piece; ~0u: unused piece
+  const float *patch;       // LDS patch of the tile whose stage is being produced
+  float *patch_next;        // LDS patch buffer being filled for the tile after this one
+  const float *wsrc;        // conv1a taps of the chunk being produced: w1a + chunk*16 + qq*4
+  const float *bsrc;
+  __amdgpu_buffer_rsrc_t rimg;  // frame of the tile after this one (0 records: none)
+  unsigned poff[2];         // byte offset of this lane's two patch pixels in that frame, or OOB
+  unsigned pidx[2];         // their float index in the patch buffer (>= F1_PATCH: none)
+  unsigned pval[2];         // loaded bytes
+  bool fill;                // this stage fills patch_next
+};
+struct NoFuse {};
+
+constexpr int F1_SUBS = 10;  // sub-steps per piece: patch reads, 4 channels x 2 halves, LDS writes
+template <int NITER, int IT, int SUB, int PLANE, int NWITER>
+__device__ __forceinline__ void fuse_piece(Fuse1a<NITER> &z, Pipe<NITER, NWITER> &c) {
+  if constexpr (SUB == 0) {
+    const unsigned b = z.pb[IT] == ~0u ? 0u : z.pb[IT];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) z.px[t] = z.patch[b + (t / 3) * F1_PCOLS + t % 3];
+  } else if constexpr (SUB <= 8) {
+    constexpr int j = (SUB - 1) / 2, half = (SUB - 1) % 2;
+    float acc = half == 0 ? 0.0f : (j == 0 ? z.o.x : (j == 1 ? z.o.y : (j == 2 ? z.o.z : z.o.w)));
+#pragma unroll
+    for (int t = half * 5; t < (half == 0 ? 5 : 9); ++t) {
+      const float wt = j == 0 ? z.w[t].x : (j == 1 ? z.w[t].y : (j == 2 ? z.w[t].z : z.w[t].w));
+      acc = __builtin_fmaf(z.px[t], wt, acc);
+    }
+    if constexpr (half == 1) {
+      const float bj = j == 0 ? z.bias.x : (j == 1 ? z.bias.y : (j == 2 ? z.bias.z : z.bias.w));
+      acc = acc + bj;
+      acc = acc > 0.0f ? acc : 0.0f;
+      if (c.voff[IT] == SPFE_OOB) acc = 0.0f;  // outside the image: conv1b's zero padding
+    }
+    if constexpr (j == 0) z.o.x = acc;
+    else if constexpr (j == 1) z.o.y = acc;
+    else if constexpr (j == 2) z.o.z = acc;
+    else z.o.w = acc;
+  } else {
+    float *d = c.nA + c.dst[IT];
+    d[0] = z.o.x;
+    d[PLANE] = z.o.y;
+    d[2 * PLANE] = z.o.z;
+    d[3 * PLANE] = z.o.w;
+  }
+}
+
 template <int STEP, int NSTEP, bool FIRST, int KC, int KS, int MT, int NT, int PLANE, int ROWP, int NITER,
-          int NWITER, bool POOL, bool RELU>
+          int NWITER, bool POOL, bool RELU, bool FUSE, class FZ>
 __device__ __forceinline__ void k_steps(float (&a)[2][MT], float (&bb)[2][NT], f32x16 (&acc)[MT][NT],
                                         const f32x16 (&accPrev)[MT][NT], Pipe<NITER, NWITER> &c,
-                                        const EpiCtx<NT> &e) {
+                                        const EpiCtx<NT> &e, FZ &fz) {
   if constexpr (STEP < NSTEP) {
-    constexpr int NLD = NITER + NWITER;
+    constexpr int NLDA = FUSE ? 0 : NITER;  // fused: the input pieces are computed, not loaded
+    constexpr int NLD = NLDA + NWITER;
     constexpr int L0 = 1, W0 = NSTEP - NLD - 1;
     constexpr int NEPI = POOL ? NT * 8 : MT * NT * 16;       // stores per wave per tile
     constexpr int EPS = (NEPI + (NSTEP - 3)) / (NSTEP - 2);  // stores per step
@@ -163,11 +230,11 @@ __device__ __forceinline__ void k_steps(float (&a)[2][MT], float (&bb)[2][NT], f
       if (m == 1 % M) {
         if constexpr (STEP >= L0 && STEP - L0 < NLD) {
           constexpr int it = STEP - L0;
-          if constexpr (it < NITER) {
+          if constexpr (it < NLDA) {
             const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(c.rin, c.voff[it], 0, 0);
             c.va[it] = make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
           } else {
-            constexpr int wi = it - NITER;
+            constexpr int wi = it - NLDA;
             const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(c.rw, c.woff[wi], 0, 0);
             c.vw[wi] = make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
           }
@@ -186,15 +253,45 @@ __device__ __forceinline__ void k_steps(float (&a)[2][MT], float (&bb)[2][NT], f
       if (m == 3 % M) {
         if constexpr (STEP >= W0 && STEP - W0 < NLD) {
           constexpr int it = STEP - W0;
-          if constexpr (it < NITER) {
+          if constexpr (it < NLDA) {
             float *d = c.nA + c.dst[it];
             d[0] = c.va[it].x;
             d[PLANE] = c.va[it].y;
             d[2 * PLANE] = c.va[it].z;
             d[3 * PLANE] = c.va[it].w;
           } else {
-            constexpr int wi = it - NITER;
+            constexpr int wi = it - NLDA;
             *reinterpret_cast<float4 *>(reinterpret_cast<char *>(c.nW) + c.woff[wi]) = c.vw[wi];
+          }
+        }
+      }
+      // (5) fused conv1a: taps of the chunk being produced (steps 2..11, gap 3), its NITER pieces
+      //     (10 sub-steps of <= 6 instructions each from step 12, gap 1 — free once the slab loads are
+      //     out), the next tile's image patch (load at 50, LDS at 58, gap 3)
+      if (m == 1 % M) {
+        if constexpr (FUSE) {
+          constexpr int F0 = 12;
+          static_assert(L0 + NLD <= F0 && F0 + F1_SUBS * NITER <= NSTEP, "fused conv1a schedule does not fit the stage");
+          if constexpr (STEP >= F0 && STEP < F0 + F1_SUBS * NITER)
+            fuse_piece<NITER, (STEP - F0) / F1_SUBS, (STEP - F0) % F1_SUBS, PLANE, NWITER>(fz, c);
+        }
+      }
+      if (m == 3 % M) {
+        if constexpr (FUSE) {
+          static_assert(58 < W0, "fused conv1a schedule does not fit the stage");
+          if constexpr (STEP >= 2 && STEP < 11) fz.w[STEP - 2] = *reinterpret_cast<const float4 *>(fz.wsrc + (STEP - 2) * 64);
+          if constexpr (STEP == 11) fz.bias = *reinterpret_cast<const float4 *>(fz.bsrc);
+          if constexpr (STEP == 50) {
+            if (fz.fill) {
+              fz.pval[0] = __builtin_amdgcn_raw_buffer_load_b8(fz.rimg, fz.poff[0], 0, 0);
+              fz.pval[1] = __builtin_amdgcn_raw_buffer_load_b8(fz.rimg, fz.poff[1], 0, 0);
+            }
+          }
+          if constexpr (STEP == 58) {
+            if (fz.fill) {
+              if (fz.pidx[0] < F1_PATCH) fz.patch_next[fz.pidx[0]] = spfe_pixel_to_float((uint8_t)fz.pval[0]);
+              if (fz.pidx[1] < F1_PATCH) fz.patch_next[fz.pidx[1]] = spfe_pixel_to_float((uint8_t)fz.pval[1]);
+            }
           }
         }
       }
@@ -212,7 +309,7 @@ __device__ __forceinline__ void k_steps(float (&a)[2][MT], float (&bb)[2][NT], f
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    k_steps<STEP + 1, NSTEP, FIRST, KC, KS, MT, NT, PLANE, ROWP, NITER, NWITER, POOL, RELU>(a, bb, acc, accPrev, c, e);
+    k_steps<STEP + 1, NSTEP, FIRST, KC, KS, MT, NT, PLANE, ROWP, NITER, NWITER, POOL, RELU, FUSE, FZ>(a, bb, acc, accPrev, c, e, fz);
   }
 }
 
@@ -240,7 +337,11 @@ __global__ __launch_bounds__(256, 1) void conv_f32_kernel(ConvParams p) {
   constexpr int NSTEP = TAPS * (KC / 2);
   constexpr int SLAB_BYTES = TAPS * KC * 64 * 4;
 
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 buffers
+  constexpr bool FUSE = LAYER == 2;  // conv1a computed in place of the input loads (conv1b only)
+  static_assert(!FUSE || (CIN == 64 && KS == 3 && KC == 16 && TH == 8), "fused conv1a is conv1b's first operand");
+  using FZ = typename std::conditional<FUSE, Fuse1a<NITER>, NoFuse>::type;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 buffers (+ 2 image patches when fused)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -319,23 +420,71 @@ __global__ __launch_bounds__(256, 1) void conv_f32_kernel(ConvParams p) {
   // prologue: stage (first item, chunk 0) straight into buffer 0
   aim_tile(i_tx, i_ty);
   aim_stage(i_nb, i_b, 0, true);
+  FZ fz;
+  [[maybe_unused]] float *sP = smem + 2 * BUF;  // fused: two 12 x 36 image patches
+  [[maybe_unused]] int pcur = 0;
+  [[maybe_unused]] int php[2] = {0, 0}, pwp[2] = {0, 0};
+  if constexpr (FUSE) {
+    const int qq = tid % Q;
 #pragma unroll
-  for (int it = 0; it < NITER; ++it) {
-    const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(c.rin, c.voff[it], 0, 0);
-    c.va[it] = make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+    for (int it = 0; it < NITER; ++it) {
+      const int i = tid + it * 256, pix = i / Q;
+      fz.pb[it] = i < NITEM ? (unsigned)((pix / G::COLS) * F1_PCOLS + pix % G::COLS) : ~0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + k * 256;
+      fz.pidx[k] = i < F1_PATCH ? (unsigned)i : 0xffffu;
+      php[k] = i / F1_PCOLS;
+      pwp[k] = i % F1_PCOLS;
+      fz.poff[k] = SPFE_OOB;
+      fz.pval[k] = 0u;
+    }
+    fz.fill = false;
+    fz.patch = sP;
+    fz.patch_next = sP + F1_PATCH;
+    fz.rimg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.img), 0, 0u, 0x00020000);
+    fz.wsrc = p.w1a + qq * 4;
+    fz.bsrc = p.b1a + qq * 4;
+    // the first tile's patch, then its chunk-0 pieces, computed in the open
+    {
+      const uint8_t *ib = p.img + (size_t)i_b * H * W;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int gy = i_ty * TH - 2 + php[k], gx = i_tx * 32 - 2 + pwp[k];
+        const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        if (fz.pidx[k] < F1_PATCH) sP[fz.pidx[k]] = in ? spfe_pixel_to_float(ib[(size_t)gy * W + gx]) : 0.0f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; ++t) fz.w[t] = *reinterpret_cast<const float4 *>(fz.wsrc + t * 64);
+    fz.bias = *reinterpret_cast<const float4 *>(fz.bsrc);
+    c.nA = smem;
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+      (fuse_piece<NITER, I / F1_SUBS, I % F1_SUBS, PLANE, NWITER>(fz, c), ...);
+    }(std::make_integer_sequence<int, F1_SUBS * NITER>{});
+  } else {
+#pragma unroll
+    for (int it = 0; it < NITER; ++it) {
+      const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(c.rin, c.voff[it], 0, 0);
+      c.va[it] = make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+    }
   }
 #pragma unroll
   for (int it = 0; it < NWITER; ++it) {
     const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(c.rw, c.woff[it], 0, 0);
     c.vw[it] = make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
   }
+  if constexpr (!FUSE) {
 #pragma unroll
-  for (int it = 0; it < NITER; ++it) {
-    float *d = smem + c.dst[it];
-    d[0] = c.va[it].x;
-    d[PLANE] = c.va[it].y;
-    d[2 * PLANE] = c.va[it].z;
-    d[3 * PLANE] = c.va[it].w;
+    for (int it = 0; it < NITER; ++it) {
+      float *d = smem + c.dst[it];
+      d[0] = c.va[it].x;
+      d[PLANE] = c.va[it].y;
+      d[2 * PLANE] = c.va[it].z;
+      d[3 * PLANE] = c.va[it].w;
+    }
   }
 #pragma unroll
   for (int it = 0; it < NWITER; ++it)
@@ -396,6 +545,24 @@ __global__ __launch_bounds__(256, 1) void conv_f32_kernel(ConvParams p) {
         aim_tile(n_tx, n_ty);
         aim_stage(n_nb, n_b, 0, have_next_item);
       }
+      if constexpr (FUSE) {
+        const int produced = last ? 0 : chunk + 1;   // chunk of the stage being produced
+        const int qq = tid % Q;
+        fz.wsrc = p.w1a + produced * KC + qq * 4;
+        fz.bsrc = p.b1a + produced * KC + qq * 4;
+        fz.patch = sP + (last ? pcur ^ 1 : pcur) * F1_PATCH;  // the last stage produces the NEXT tile's first
+        fz.patch_next = sP + (pcur ^ 1) * F1_PATCH;
+        fz.fill = chunk == NCHUNK - 2 && have_next_item;      // one stage earlier its patch is fetched
+        if (fz.fill) {
+          fz.rimg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.img) + (size_t)n_b * H * W, 0,
+                                                      (unsigned)(H * W), 0x00020000);
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int gy = n_ty * TH - 2 + php[k], gx = n_tx * 32 - 2 + pwp[k];
+            fz.poff[k] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? (unsigned)(gy * W + gx) : SPFE_OOB;
+          }
+        }
+      }
       float *cA = smem + buf * BUF;
       c.nA = smem + (buf ^ 1) * BUF;
       c.nW = c.nA + KC * PLANE;
@@ -409,13 +576,14 @@ __global__ __launch_bounds__(256, 1) void conv_f32_kernel(ConvParams p) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) bb[0][j] = c.bBase[j * (TAPS * KC * 32)];
       if (chunk == 0)
-        k_steps<0, NSTEP, true, KC, KS, MT, NT, PLANE, ROWP, NITER, NWITER, POOL, RELU>(a, bb, acc, accPrev, c, epi);
+        k_steps<0, NSTEP, true, KC, KS, MT, NT, PLANE, ROWP, NITER, NWITER, POOL, RELU, FUSE, FZ>(a, bb, acc, accPrev, c, epi, fz);
       else
-        k_steps<0, NSTEP, false, KC, KS, MT, NT, PLANE, ROWP, NITER, NWITER, POOL, RELU>(a, bb, acc, accPrev, c, epi);
+        k_steps<0, NSTEP, false, KC, KS, MT, NT, PLANE, ROWP, NITER, NWITER, POOL, RELU, FUSE, FZ>(a, bb, acc, accPrev, c, epi, fz);
       __syncthreads();  // the other buffer is complete, this one is free
       buf ^= 1;
     }
     epi = epi_next;  // this tile's outputs are stored while the next tile starts
+    if constexpr (FUSE) pcur ^= 1;
     more = have_next_item;
     w += gper;
     i_nb = n_nb; i_tx = n_tx; i_ty = n_ty; i_b = n_b;
@@ -446,7 +614,7 @@ template <int LAYER, int CIN, int KS, int KC, int WM, int WN, int MT, int NT, bo
 static hipError_t launch_one(const ConvParams &p, hipStream_t s) {
   constexpr int TH = WM * MT;
   using G = Geo<KS, TH>;
-  constexpr size_t lds = 2 * (size_t)(KC * G::PLANE + KS * KS * KC * 64) * sizeof(float);
+  constexpr size_t lds = (2 * (size_t)(KC * G::PLANE + KS * KS * KC * 64) + (LAYER == 2 ? 2 * F1_PATCH : 0)) * sizeof(float);
   static_assert(lds <= 160 * 1024, "double buffer must fit the 160 KB LDS");
   auto k = conv_f32_kernel<LAYER, CIN, KS, KC, WM, WN, MT, NT, POOL, RELU>;
   static bool attr_done = false;  // per instantiation
@@ -472,6 +640,8 @@ hipError_t launch_conv_f32(const ConvParams &p, int cin, int ksize, bool pool, b
                            bool small_tile, int layer_tag, hipStream_t s) {
   if (layer_tag == 1 && cin == 64 && ksize == 3 && pool && relu && !small_tile)
     return launch_one<1, 64, 3, 16, 4, 1, 2, 2, true, true>(p, s);  // conv1b
+  if (layer_tag == 2 && cin == 64 && ksize == 3 && pool && relu && !small_tile && p.img && p.w1a && p.b1a)
+    return launch_one<2, 64, 3, 16, 4, 1, 2, 2, true, true>(p, s);  // conv1a + conv1b fused
 #define SPFE_CONV(CIN_, KS_, KC_, WM_, WN_, MT_, NT_, POOL_, RELU_)                       \
   if (cin == CIN_ && ksize == KS_ && pool == POOL_ && relu == RELU_ &&                    \
       small_tile == (WM_ * MT_ == 4))                                                     \

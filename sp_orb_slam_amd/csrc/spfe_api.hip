@@ -108,6 +108,7 @@ struct spfe_handle_s {
   uint8_t *m_stage_q = nullptr, *m_stage_t = nullptr, *m_out = nullptr;
   int m_pairs = 0, m_cap = 0;      // capacity of m_best_* ([pairs][cap])
   int m_host_cap = 0;              // rows the host-API staging blocks / m_out hold
+  bool fuse1a = false;  // f32: conv1a computed inside conv1b (opt-in: SPFE_FUSE_CONV1A=1; measured perf-neutral)
   bool bf16 = false;  // SPFE_PRECISION_BF16: bf16 conv stack (conv1a .. convPa/Da), f32 heads and tail
   // per-stage timing: a ring of event sets, one set per enqueue() call
   bool timing = false;
@@ -297,6 +298,10 @@ int build(spfe_handle h, const spfe_config *cfg) {
     HIP_TRY(hipEventCreateWithFlags(&h->ev_cov[i], hipEventDisableTiming));
   }
   HIP_TRY(hipEventCreateWithFlags(&h->ev_desc, hipEventDisableTiming));
+  {
+    const char *fenv = getenv("SPFE_FUSE_CONV1A");
+    h->fuse1a = fenv && atoi(fenv) != 0;
+  }
   const char *tenv = getenv("SPFE_STAGE_TIMING");
   h->timing = tenv && atoi(tenv) != 0;
   if (h->timing) {
@@ -424,8 +429,9 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   if (h->timing) h->ev = h->evpool.data() + (size_t)(h->calls % spfe_handle_s::EVSETS) * (NSTAGE + 1);
   h->calls++;
   STAGE_MARK(0);
+  const bool fused = !h->bf16 && h->fuse1a;  // f32: conv1b computes conv1a's outputs itself
   if (h->bf16) HIP_TRY(spfe::launch_conv1a_bf16(d_images, h->d_w1a, h->d_b1a, h->act[0], n, H, W, s));
-  else HIP_TRY(spfe::launch_conv1a(d_images, h->d_w1a, h->d_b1a, h->act[0], n, H, W, s));
+  else if (!fused) HIP_TRY(spfe::launch_conv1a(d_images, h->d_w1a, h->d_b1a, h->act[0], n, H, W, s));
   STAGE_MARK(1);
   for (int i = 0; i < 10; ++i) {
     const ConvLayer &L = h->layers[i];
@@ -437,6 +443,8 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     p.wpack = L.d_w; p.bias = L.d_b;
     p.out = L.out; p.out_stride = L.out_stride; p.out_choff = L.out_choff; p.cout_real = L.cout_real;
     p.B = n; p.H = L.H; p.W = L.W;
+    p.img = nullptr; p.w1a = nullptr; p.b1a = nullptr;
+    if (i == 0 && fused) { p.img = d_images; p.w1a = h->d_w1a; p.b1a = h->d_b1a; }
     // tile height per layer and batch: 8-row tiles do 4 MFMAs per K step and wave
     // (better hidden side work), 4-row tiles give twice the work items; pick the
     // one with the shorter critical path over the persistent grid
@@ -457,10 +465,11 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
       const double cost_small = (double)((items_small + g - 1) / g);
       small_tile = cost_small < cost_big;
     }
+    if (i == 0 && fused) small_tile = false;  // the fused first layer exists for 8-row tiles only
     const int th = spfe::conv_tile_rows(small_tile);
     p.tiles_x = (L.W + 31) / 32; p.tiles_y = (L.H + th - 1) / th; p.nblk = L.nblk;
     p.num_cus = h->num_cus;
-    HIP_TRY(spfe::launch_conv_f32(p, L.cin, L.ks, L.pool, L.relu, small_tile, i == 0 ? 1 : 0, s));
+    HIP_TRY(spfe::launch_conv_f32(p, L.cin, L.ks, L.pool, L.relu, small_tile, i == 0 ? (fused ? 2 : 1) : 0, s));
     STAGE_MARK(2 + i);
   }
   return enqueue_post(h, n, d_records, s);
@@ -732,6 +741,8 @@ long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size
   else if (nm == "feat") { src = h->act[7] + frame * C * 128; bytes = C * 128 * 4; }
   else if (nm.size() == 4 && nm.compare(0, 3, "act") == 0 && nm[3] >= '0' && nm[3] <= '7') {
     const int i = nm[3] - '0';
+    if (i == 0 && !h->bf16 && h->fuse1a)
+      return fail(SPFE_EINVAL, "act0 is not materialised: conv1a is fused into conv1b (SPFE_FUSE_CONV1A=1)");
     const int lh[8] = {1, 2, 2, 4, 4, 8, 8, 8};
     const int lc[8] = {64, 64, 64, 64, 128, 128, 128, 128};
     const size_t per = (size_t)(h->H / lh[i]) * (h->W / lh[i]) * lc[i];

@@ -20,6 +20,10 @@ struct ConvParams {
   int B, H, W;  // conv input == conv output size (before the optional 2x2 pool)
   int tiles_x, tiles_y, nblk;
   int num_cus;  // persistent grid size (multiProcessorCount)
+  // layer_tag 2 (conv1a fused into conv1b): the u8 frames [B][H][W] and conv1a's taps [9][64] / bias [64];
+  // `in` is then unused
+  const uint8_t *img;
+  const float *w1a, *b1a;
 };
 
 // cin: 64/128/256; ksize: 3 or 1; pool/relu: fused epilogue; small_tile: 4-row

@@ -113,6 +113,33 @@ def test_layerwise_activations_bitwise():
     ext.close()
 
 
+@pytest.mark.parametrize("H,W,B", [(88, 120, 1), (480, 752, 2), (120, 160, 8), (64, 96, 3)])
+def test_fused_first_layer_equals_separate_conv1a(H, W, B, monkeypatch):
+    """conv1a computed inside conv1b (SPFE_FUSE_CONV1A=1) vs the separate conv1a kernel (default):
+    conv1b's output and everything after it bit-identical, over sizes with ragged tiles, several
+    tiles per workgroup (the image patch double buffer) and batches."""
+    blob = weights.synthetic(7, "dense")
+    imgs = [synth.make_image(40 + i, H, W) for i in range(B)]
+    outs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("SPFE_FUSE_CONV1A", fuse)
+        ext = SPExtractor(100, H, W, blob, max_batch=B, with_heat=False)
+        frs = ext.extract_batch(imgs)
+        act1 = [ext.debug_read("act1", i) for i in range(B)]
+        if fuse == "1":
+            with pytest.raises(Exception, match="not materialised"):
+                ext.debug_read("act0")
+        outs.append((frs, act1))
+        ext.close()
+    for i in range(B):
+        assert np.array_equal(outs[0][1][i].view(np.uint32), outs[1][1][i].view(np.uint32))
+        a, b = outs[0][0][i], outs[1][0][i]
+        assert a.K == b.K and np.array_equal(a.kp_xy, b.kp_xy)
+        assert np.array_equal(a.descriptors.view(np.uint32), b.descriptors.view(np.uint32))
+    ref = oracle.extract(blob, imgs[-1], 100)
+    assert outs[0][0][-1].K == ref["K"] and np.array_equal(outs[0][0][-1].kp_xy, ref["kp_xy"])
+
+
 def test_bench_config_752x480_1000_keypoints():
     """BASELINE configs[1]: 752x480, 1000 keypoints, f32."""
     H, W, nf = 480, 752, 1000
