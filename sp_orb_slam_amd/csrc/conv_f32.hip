@@ -316,7 +316,7 @@ __device__ __forceinline__ void k_steps(float (&a)[2][MT], float (&bb)[2][NT], f
 // LAYER only names the instantiation (conv1b gets its own symbol so profiles can
 // tell the dominant launch from the other layers that share its shape).
 template <int LAYER, int CIN, int KS, int KC, int WM, int WN, int MT, int NT, bool POOL, bool RELU>
-__global__ __launch_bounds__(256, 1) void conv_f32_kernel(ConvParams p) {
+__global__ __launch_bounds__(64 * WM * WN, 1) void conv_f32_kernel(ConvParams p) {
   constexpr int TH = WM * MT;
   using G = Geo<KS, TH>;
   constexpr int TAPS = KS * KS;
@@ -324,16 +324,19 @@ __global__ __launch_bounds__(256, 1) void conv_f32_kernel(ConvParams p) {
   constexpr int PLANE = G::PLANE;
   constexpr int ROWP = G::ROWP;
   constexpr int BUF = KC * PLANE + TAPS * KC * 64;  // floats per LDS buffer
-  static_assert(WM * WN == 4, "4 waves per workgroup");
+  // 4 waves = one per SIMD; 8 waves = two per SIMD on a 16-row tile: while one wave of a SIMD does
+  // its side work (operand reads, staging, epilogue — it issues in order, so that work costs matrix
+  // time when the wave is alone) the other one's MFMAs keep the matrix pipe busy.
+  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
+  constexpr int NTHR = 64 * WM * WN;
   static_assert(WN * NT == 2, "64 output channels per workgroup");
   static_assert(!POOL || MT == 2, "pooling needs two rows per wave");
   static_assert((KC * PLANE) % 4 == 0 && BUF % 4 == 0, "weight slabs must stay 16B aligned");
   constexpr int Q = KC / 4;  // float4 per pixel per chunk
   constexpr int NITEM = G::ROWS * G::COLS * Q;
-  constexpr int NITER = (NITEM + 255) / 256;
+  constexpr int NITER = (NITEM + NTHR - 1) / NTHR;
   constexpr int NW4 = TAPS * KC * 16;  // float4 in the weight slab
-  static_assert(NW4 % 256 == 0, "weight slab must be a whole number of 256-thread passes");
-  constexpr int NWITER = NW4 / 256;
+  constexpr int NWITER = (NW4 + NTHR - 1) / NTHR;  // a ragged last pass re-stages pieces of the first (same data, same place)
   constexpr int NSTEP = TAPS * (KC / 2);
   constexpr int SLAB_BYTES = TAPS * KC * 64 * 4;
 
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(256, 1) void conv_f32_kernel(ConvParams p) {
   unsigned pqb[NITER];
 #pragma unroll
   for (int it = 0; it < NITER; ++it) {
-    const int i = tid + it * 256;
+    const int i = tid + it * NTHR;
     const int qq = i % Q, pix = i / Q;
     prow[it] = i < NITEM ? pix / G::COLS - G::HALO : (1 << 20);  // unused piece: never inside the image
     pcol[it] = pix % G::COLS - G::HALO;
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(256, 1) void conv_f32_kernel(ConvParams p) {
                           : (ROWP > G::COLS ? (tid % G::ROWS) * ROWP + G::COLS : G::PLANE_RAW);
   }
 #pragma unroll
-  for (int it = 0; it < NWITER; ++it) c.woff[it] = (tid + it * 256) * 16;
+  for (int it = 0; it < NWITER; ++it) c.woff[it] = ((tid + it * NTHR) % NW4) * 16;
 
   // per-thread frame offsets of the input pieces of tile (tx, ty)
   auto aim_tile = [&](int tx, int ty) {
@@ -629,15 +632,24 @@ static hipError_t launch_one(const ConvParams &p, hipStream_t s) {
   grid &= ~7;
   if (grid < 8) grid = 8;
   (void)total;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WM * WN), lds, s, p);
   return hipGetLastError();
 }
 
 int conv_kc(int ksize) { return ksize == 3 ? 16 : 64; }
-int conv_tile_rows(bool small_tile) { return small_tile ? 4 : 8; }
+int conv_tile_rows(int tile_mode) { return tile_mode == 1 ? 4 : (tile_mode == 2 ? 16 : 8); }
 
 hipError_t launch_conv_f32(const ConvParams &p, int cin, int ksize, bool pool, bool relu,
-                           bool small_tile, int layer_tag, hipStream_t s) {
+                           int tile_mode, int layer_tag, hipStream_t s) {
+  const bool small_tile = tile_mode == 1;
+  if (tile_mode == 2 && ksize == 3 && relu) {  // 16-row tiles, 8 waves (two per SIMD)
+    if (layer_tag == 1 && cin == 64 && pool) return launch_one<1, 64, 3, 16, 8, 1, 2, 2, true, true>(p, s);  // conv1b
+    if (cin == 64 && pool) return launch_one<0, 64, 3, 16, 8, 1, 2, 2, true, true>(p, s);
+    if (cin == 64 && !pool) return launch_one<0, 64, 3, 16, 8, 1, 2, 2, false, true>(p, s);
+    if (cin == 128 && pool) return launch_one<0, 128, 3, 16, 8, 1, 2, 2, true, true>(p, s);
+    if (cin == 128 && !pool) return launch_one<0, 128, 3, 16, 8, 1, 2, 2, false, true>(p, s);
+    return hipErrorInvalidValue;
+  }
   if (layer_tag == 1 && cin == 64 && ksize == 3 && pool && relu && !small_tile)
     return launch_one<1, 64, 3, 16, 4, 1, 2, 2, true, true>(p, s);  // conv1b
   if (layer_tag == 2 && cin == 64 && ksize == 3 && pool && relu && !small_tile && p.img && p.w1a && p.b1a)

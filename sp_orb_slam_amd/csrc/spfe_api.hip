@@ -108,6 +108,7 @@ struct spfe_handle_s {
   uint8_t *m_stage_q = nullptr, *m_stage_t = nullptr, *m_out = nullptr;
   int m_pairs = 0, m_cap = 0;      // capacity of m_best_* ([pairs][cap])
   int m_host_cap = 0;              // rows the host-API staging blocks / m_out hold
+  unsigned tile16_mask = 0;  // f32 layers (bit i = conv layer i of enqueue()) on 16-row / 8-wave tiles
   bool fuse1a = false;  // f32: conv1a computed inside conv1b (opt-in: SPFE_FUSE_CONV1A=1; measured perf-neutral)
   bool bf16 = false;  // SPFE_PRECISION_BF16: bf16 conv stack (conv1a .. convPa/Da), f32 heads and tail
   // per-stage timing: a ring of event sets, one set per enqueue() call
@@ -301,6 +302,8 @@ int build(spfe_handle h, const spfe_config *cfg) {
   {
     const char *fenv = getenv("SPFE_FUSE_CONV1A");
     h->fuse1a = fenv && atoi(fenv) != 0;
+    const char *menv = getenv("SPFE_TILE16_MASK");
+    if (menv) h->tile16_mask = (unsigned)strtoul(menv, nullptr, 0);
   }
   const char *tenv = getenv("SPFE_STAGE_TIMING");
   h->timing = tenv && atoi(tenv) != 0;
@@ -466,10 +469,12 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
       small_tile = cost_small < cost_big;
     }
     if (i == 0 && fused) small_tile = false;  // the fused first layer exists for 8-row tiles only
-    const int th = spfe::conv_tile_rows(small_tile);
+    int tile_mode = small_tile ? 1 : 0;
+    if (L.ks == 3 && !(i == 0 && fused) && ((h->tile16_mask >> i) & 1)) tile_mode = 2;
+    const int th = spfe::conv_tile_rows(tile_mode);
     p.tiles_x = (L.W + 31) / 32; p.tiles_y = (L.H + th - 1) / th; p.nblk = L.nblk;
     p.num_cus = h->num_cus;
-    HIP_TRY(spfe::launch_conv_f32(p, L.cin, L.ks, L.pool, L.relu, small_tile, i == 0 ? (fused ? 2 : 1) : 0, s));
+    HIP_TRY(spfe::launch_conv_f32(p, L.cin, L.ks, L.pool, L.relu, tile_mode, i == 0 ? (fused ? 2 : 1) : 0, s));
     STAGE_MARK(2 + i);
   }
   return enqueue_post(h, n, d_records, s);

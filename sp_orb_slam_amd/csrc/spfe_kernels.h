@@ -28,10 +28,11 @@ struct ConvParams {
 
 // cin: 64/128/256; ksize: 3 or 1; pool/relu: fused epilogue; small_tile: 4-row
 // tiles (more workgroups for the low-resolution layers).
+// tile_mode: 0 = 8-row tiles (4 waves), 1 = 4-row tiles, 2 = 16-row tiles (8 waves, two per SIMD)
 hipError_t launch_conv_f32(const ConvParams &p, int cin, int ksize, bool pool, bool relu,
-                           bool small_tile, int layer_tag, hipStream_t s);
+                           int tile_mode, int layer_tag, hipStream_t s);
 int conv_kc(int ksize);        // K-chunk the kernel stages per barrier (16 for 3x3, 64 for 1x1)
-int conv_tile_rows(bool small_tile);
+int conv_tile_rows(int tile_mode);
 
 // bf16 3x3 convolutions (conv_bf16.hip): in/out NHWC bf16 (out f32 when out_f32), strides in
 // elements; wpack = bf16 slabs of conv_bf16_slab_bytes() each, [nblk][chunk of 32 ch][tap][64][80 B]
