@@ -68,6 +68,9 @@ def lib():
         L.oracle_stage_input.restype = C.c_int
         L.oracle_stage_input.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_int, C.c_int, u8p]
+        L.oracle_set_num_threads.restype = None
+        L.oracle_set_num_threads.argtypes = [C.c_int]
+        L.oracle_get_max_threads.restype = C.c_int
         L.oracle_expf.restype = C.c_float
         L.oracle_expf.argtypes = [C.c_float]
         L.oracle_logf.restype = C.c_float
@@ -252,3 +255,9 @@ def stage_input(src, H, W, map_x=None, map_y=None, rgb=False):
     if rc:
         raise ValueError("oracle_stage_input rc=%d" % rc)
     return gray
+
+
+def set_num_threads(n):
+    """OpenMP team size of the oracle's loops (timing legs only; results do not depend on it)."""
+    lib().oracle_set_num_threads(int(n))
+    return int(lib().oracle_get_max_threads())

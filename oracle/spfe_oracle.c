@@ -698,6 +698,17 @@ EXPORT int oracle_stage_input(const uint8_t *src, int src_h, int src_w, int src_
   return 0;
 }
 
+/* OpenMP team size for the timing legs (bench.py cpu_baseline, tools/cpu_baseline.py): the loops
+ * scale to a few dozen threads, far fewer than a 256-thread host offers. */
+#ifdef _OPENMP
+#include <omp.h>
+EXPORT void oracle_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+EXPORT int oracle_get_max_threads(void) { return omp_get_max_threads(); }
+#else
+EXPORT void oracle_set_num_threads(int n) { (void)n; }
+EXPORT int oracle_get_max_threads(void) { return 1; }
+#endif
+
 /* exact-math probes so GPU tests can compare device bits with host bits */
 EXPORT float oracle_expf(float x) { return spfe_expf(x); }
 EXPORT float oracle_logf(float x) { return spfe_logf(x); }
