@@ -140,6 +140,16 @@ def test_fused_first_layer_equals_separate_conv1a(H, W, B, monkeypatch):
     assert outs[0][0][-1].K == ref["K"] and np.array_equal(outs[0][0][-1].kp_xy, ref["kp_xy"])
 
 
+def test_base_extractor_getters():
+    """BaseExtractor with ctor args (n, 1.0, 1, 1, 1) (sp_extractor.cpp:343): one level, unit scales —
+    what Frame reads at frame.cpp:211-217."""
+    ext = SPExtractor(10, 64, 96, weights.synthetic(7, "dense"))
+    assert ext.GetLevels() == 1 and ext.GetScaleFactor() == 1.0
+    assert ext.GetScaleFactors() == [1.0] and ext.GetInverseScaleFactors() == [1.0]
+    assert ext.GetScaleSigmaSquares() == [1.0] and ext.GetInverseScaleSigmaSquares() == [1.0]
+    ext.close()
+
+
 def test_bench_config_752x480_1000_keypoints():
     """BASELINE configs[1]: 752x480, 1000 keypoints, f32."""
     H, W, nf = 480, 752, 1000
