@@ -40,6 +40,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define SPFE_OOB 0x80000000u
+#ifndef SPFE_A_AUX
+#define SPFE_A_AUX 0  // cache policy of the halo-tile passes (2 = nt)
+#endif
 
 __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
   unsigned u = __float_as_uint(f);
@@ -74,7 +77,7 @@ struct PipeB {
   __device__ __forceinline__ void dma() const {
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (IT < NITER) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void *)(nA + IT * 4096), 16, voff[IT], 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void *)(nA + IT * 4096), 16, voff[IT], 0, 0, SPFE_A_AUX);
     } else if constexpr (IT < NITER + NWITER) {
       constexpr int W = IT - NITER;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(nW + W * 4096), 16, woff, W * 4096, 0, 0);
