@@ -206,6 +206,28 @@ def main():
                 # 1 subtract + 1 fma per descriptor element pair, on the f32 VALU
                 "valu_tflops": round(pair_elems * 3 / (ms * 1e-3) / 1e12, 2),
                 "matched_frac_pair0": round(float((idx0 >= 0).mean()), 3)}
+            # patch-wise association of 200 projected map points against frame 0's resident record
+            # (tracker_dust.cpp:113-172; mps_for_track holds 150-200 points)
+            f0 = ka[0]
+            rngp = np.random.default_rng(3)
+            kk = rngp.integers(0, f0.K, 200)
+            mpd = f0.descriptors[kk] + np.float32(0.3) * (rngp.standard_normal((200, 256)).astype(np.float32) / 16)
+            mpuv = np.stack([f0.kp_xy[kk, 0] // 8 + 0.5 - rngp.integers(0, 2, 200), f0.kp_xy[kk, 1] // 8 + 0.5 - rngp.integers(0, 2, 200)], 1)
+            d_mpd, d_mpuv = torch.from_numpy(mpd.astype(np.float32)).cuda(), torch.from_numpy(mpuv.astype(np.float32)).cuda()
+            d_pidx = torch.zeros(200, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            for _ in range(3):
+                extm.match_patches_record_device(d_mpd.data_ptr(), d_mpuv.data_ptr(), 200, ra.data_ptr(), d_pidx.data_ptr(),
+                                                 0.75, mstream.cuda_stream)
+            e0.record(mstream)
+            for _ in range(nit):
+                extm.match_patches_record_device(d_mpd.data_ptr(), d_mpuv.data_ptr(), 200, ra.data_ptr(), d_pidx.data_ptr(),
+                                                 0.75, mstream.cuda_stream)
+            e1.record(mstream)
+            torch.cuda.synchronize()
+            out["match_patches"] = {"what": "tracker_dust.cpp:113-172 association, 200 map points vs one resident record",
+                                    "us_per_call": round(e0.elapsed_time(e1) / nit * 1e3, 2),
+                                    "matched": int((d_pidx.cpu().numpy() >= 0).sum())}
             if world == 1 and not args.no_cpu_baseline:
                 from oracle import oracle as _orc
                 t1 = time.perf_counter()

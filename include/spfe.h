@@ -189,6 +189,25 @@ SPFE_API int spfe_match_records_device(spfe_handle h, const void *d_query_record
                                        int n_pairs, int cross_check, void *d_out, void *stream);
 SPFE_API size_t spfe_match_out_bytes(spfe_handle h);
 
+/* Patch-wise association of projected map points — the loop of Tracker::trackFrameDustKFLocal,
+ * orb_slam2/src/tracking/tracker_dust.cpp:113-172 (the caller filters `!in_view || isBad()` points out).
+ * Map point i sits at dust-map position (mp_uv[2i], mp_uv[2i+1]) in CELL units (dust_proj_u / _v) and
+ * carries descriptor mp_desc[i]; it examines the keypoints of cells (floor(u)+du, floor(v)+dv),
+ * du, dv in {0,1}, du outer, and takes the one with the smallest L2 distance below max_dist (0.75 in
+ * the reference; first one on ties); a taken keypoint is gone for the map points after it (the
+ * reference clears its occ_grid cell).  kp_idx[i] = keypoint index or -1.  Distances are
+ * (float) cv::norm(a, b, NORM_L2): squared differences accumulated in double.  Cells outside the grid
+ * hold no keypoint (the reference does not check).  n_points <= 4096.
+ * occ_grid: int16 [height/8][width/8] and kp_desc: [n_keypoints][256] of the frame (spfe_result). */
+SPFE_API int spfe_match_patches(spfe_handle h, const float *mp_desc, const float *mp_uv, int n_points,
+                                const int16_t *occ_grid, const float *kp_desc, int n_keypoints, float max_dist,
+                                int32_t *kp_idx);
+/* The same against ONE record resident in HBM (occ_grid, descriptors and K read on the device);
+ * d_mp_desc / d_mp_uv / d_kp_idx are device arrays; enqueued on `stream`, no host synchronisation. */
+SPFE_API int spfe_match_patches_record_device(spfe_handle h, const void *d_mp_desc, const void *d_mp_uv,
+                                              int n_points, const void *d_record, float max_dist, void *d_kp_idx,
+                                              void *stream);
+
 /* ---- input staging -----------------------------------------------------
  * Replaces, per frame, the host OpenCV sequence in front of the extractor:
  *   cv::remap(mono, mono, m1, m2, cv::INTER_LINEAR)       orb_slam2/src/io/data_loader.cc:519-521

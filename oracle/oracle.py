@@ -65,6 +65,8 @@ def lib():
                                          C.POINTER(C.c_int)]
         L.oracle_match_bruteforce.restype = None
         L.oracle_match_bruteforce.argtypes = [f32p, C.c_int, f32p, C.c_int, C.c_int, i32p, f32p]
+        L.oracle_match_patches.restype = None
+        L.oracle_match_patches.argtypes = [f32p, f32p, C.c_int, i16p, C.c_int, C.c_int, f32p, C.c_int, C.c_float, i32p]
         L.oracle_stage_input.restype = C.c_int
         L.oracle_stage_input.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_int, C.c_int, u8p]
@@ -261,3 +263,16 @@ def set_num_threads(n):
     """OpenMP team size of the oracle's loops (timing legs only; results do not depend on it)."""
     lib().oracle_set_num_threads(int(n))
     return int(lib().oracle_get_max_threads())
+
+
+def match_patches(mp_desc, mp_uv, occ_grid, kp_desc, max_dist=0.75):
+    """Patch-wise association of projected map points (tracker_dust.cpp:113-172)."""
+    m = np.ascontiguousarray(mp_desc, np.float32).reshape(-1, 256)
+    uv = np.ascontiguousarray(mp_uv, np.float32).reshape(-1, 2)
+    occ = np.ascontiguousarray(occ_grid, np.int16)
+    kd = np.ascontiguousarray(kp_desc, np.float32).reshape(-1, 256)
+    out = np.full(max(len(m), 1), -1, np.int32)
+    if len(m):
+        lib().oracle_match_patches(m, uv, len(m), occ, occ.shape[0], occ.shape[1],
+                                   kd if len(kd) else np.zeros((1, 256), np.float32), len(kd), max_dist, out)
+    return out[:len(m)].copy()

@@ -633,6 +633,72 @@ EXPORT void oracle_match_bruteforce(const float *query, int nq, const float *tra
 }
 
 /*
+ * Patch-wise association of projected map points: the loop of Tracker::trackFrameDustKFLocal,
+ * orb_slam2/src/tracking/tracker_dust.cpp:113-172, literally: occ_grid is cloned (:104); for every map
+ * point in order (the caller has dropped `!in_view || isBad()` ones, :115-116) u = floor(dust_proj_u),
+ * v = floor(dust_proj_v) (:118-119); best_dist starts at 0.75f (:122, here max_dist); du outer, dv inner
+ * (:126-127); idx = occ_grid(v+dv, u+du) (:130), -1 = empty; dist = SPMatcher::DescriptorDistance =
+ * (float)cv::norm(a, b, NORM_L2) (sp_matcher.cpp:1636-1640); strict `<` keeps the first minimum
+ * (:134); a match clears its cell (:167).  The reference reads the grid without a bounds check;
+ * here cells outside it are empty.
+ * cv::norm accumulates the squared float differences in double; its order inside a row is an
+ * OpenCV build detail — fixed here as: lane l of 64 adds dims 4l..4l+3 in order, then the butterfly
+ * of spfe_sum64_host (what one wavefront computes).  kp_idx[i] = matched keypoint or -1.
+ */
+static float patch_dist(const float *a, const float *b) {
+  double v[64];
+  for (int l = 0; l < 64; ++l) {
+    double s = 0.0;
+    for (int q = 0; q < 4; ++q) {
+      const float d = a[4 * l + q] - b[4 * l + q];
+      if (q == 0) s = (double)d * (double)d;
+      else s = s + (double)d * (double)d;
+    }
+    v[l] = s;
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    double nv[64];
+    for (int i = 0; i < 64; ++i) nv[i] = v[i] + v[i ^ off];
+    memcpy(v, nv, sizeof(v));
+  }
+  return (float)sqrt(v[0]);
+}
+
+EXPORT void oracle_match_patches(const float *mp_desc, const float *mp_uv, int n_points, const int16_t *occ_grid,
+                                 int hc, int wc, const float *kp_desc, int n_keypoints, float max_dist,
+                                 int32_t *kp_idx) {
+  int16_t *occ = (int16_t *)malloc((size_t)hc * wc * sizeof(int16_t));
+  memcpy(occ, occ_grid, (size_t)hc * wc * sizeof(int16_t));
+  for (int i = 0; i < n_points; ++i) {
+    kp_idx[i] = -1;
+    const float fu = floorf(mp_uv[2 * i]), fv = floorf(mp_uv[2 * i + 1]);
+    if (!(fu >= 0.0f && fv >= 0.0f && fu < (float)wc && fv < (float)hc)) continue;
+    const int u = (int)fu, v = (int)fv;
+    int best = -1, bu = 0, bv = 0;
+    float bd = max_dist;
+    for (int du = 0; du < 2; ++du)
+      for (int dv = 0; dv < 2; ++dv) {
+        const int uu = u + du, vv = v + dv;
+        if (uu >= wc || vv >= hc) continue;
+        const int idx = occ[vv * wc + uu];
+        if (idx < 0 || idx >= n_keypoints) continue;
+        const float d = patch_dist(mp_desc + (size_t)i * 256, kp_desc + (size_t)idx * 256);
+        if (d < bd) {
+          bd = d;
+          best = idx;
+          bu = uu;
+          bv = vv;
+        }
+      }
+    if (best != -1) {
+      kp_idx[i] = best;
+      occ[bv * wc + bu] = -1;
+    }
+  }
+  free(occ);
+}
+
+/*
  * SURVEY.md §8(f) rank 2 — input staging.  Restates, for ONE frame, the host OpenCV sequence the
  * reference runs in front of the extractor:
  *   cv::remap(mono, mono, m1, m2, cv::INTER_LINEAR)      orb_slam2/src/io/data_loader.cc:519-521

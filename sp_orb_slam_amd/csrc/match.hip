@@ -176,3 +176,148 @@ hipError_t launch_match(const MatchSide &query, const MatchSide &train, int pair
 }
 
 }  // namespace spfe
+
+// ---------------------------------------------------------------------------
+// Patch-wise association of projected map points (tracker_dust.cpp:113-172): every map point looks at
+// the 2 x 2 cells at its projected dust-map position, takes the keypoint (one per cell, occ_grid) whose
+// descriptor is nearest and nearer than max_dist (0.75), and REMOVES it from the grid — the map points
+// are served in order, so an earlier one can take a later one's best candidate.
+//
+//   patch_dist_kernel     one wave per map point: the (up to) four candidate keypoints and their
+//                         distances.  dist = (float)sqrt(S), S = sum of (double)(a_k - b_k)^2 (cv::norm
+//                         accumulates in double) — lane l adds its dims 4l..4l+3 in order, then the
+//                         64-lane butterfly, the order oracle_match_patches restates.
+//   patch_resolve_kernel  the greedy order as a fixed point, one workgroup: a map point is final as
+//                         soon as it is the earliest unresolved claimant of every candidate it could
+//                         still take; it then takes its nearest free candidate (first one on ties,
+//                         cells in the reference's (du, dv) loop order).
+// ---------------------------------------------------------------------------
+namespace spfe {
+
+__global__ __launch_bounds__(256) void patch_dist_kernel(PatchArgs a, int *__restrict__ cand_idx,
+                                                         float *__restrict__ cand_dist) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= a.n_points) return;
+  const float uf = a.mp_uv[2 * i], vf = a.mp_uv[2 * i + 1];
+  const float fu = __builtin_floorf(uf), fv = __builtin_floorf(vf);
+  // positions that do not floor into the grid have no candidates (the reference does not check)
+  const bool ok = fu >= 0.0f && fv >= 0.0f && fu < (float)a.wc && fv < (float)a.hc;
+  const int u = ok ? (int)fu : 0, v = ok ? (int)fv : 0;
+  const int K = a.k_ptr ? *a.k_ptr : a.k_imm;
+  const float4 m4 = *reinterpret_cast<const float4 *>(a.mp_desc + (size_t)i * 256 + lane * 4);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int uu = u + (c >> 1), vv = v + (c & 1);  // du outer, dv inner (tracker_dust.cpp:126-127)
+    int idx = -1;
+    if (ok && uu < a.wc && vv < a.hc) idx = a.occ[vv * a.wc + uu];
+    if (idx >= K) idx = -1;
+    float dist = 3.0e38f;
+    if (idx >= 0) {  // wave-uniform
+      const float4 k4 = *reinterpret_cast<const float4 *>(a.kp_desc + (size_t)idx * 256 + lane * 4);
+      const float d0 = m4.x - k4.x, d1 = m4.y - k4.y, d2 = m4.z - k4.z, d3 = m4.w - k4.w;
+      double s = (double)d0 * (double)d0;
+      s = s + (double)d1 * (double)d1;
+      s = s + (double)d2 * (double)d2;
+      s = s + (double)d3 * (double)d3;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, 64);
+      dist = (float)__builtin_sqrt(s);
+    }
+    if (lane == 0) {
+      cand_idx[i * 4 + c] = idx;
+      cand_dist[i * 4 + c] = dist;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void patch_resolve_kernel(const int *__restrict__ cand_idx,
+                                                             const float *__restrict__ cand_dist, int n_points,
+                                                             int kcap, float max_dist, int32_t *__restrict__ out) {
+  extern __shared__ int sm_p[];
+  int *claim = sm_p;                                             // [kcap] earliest unresolved claimant
+  uint8_t *taken = reinterpret_cast<uint8_t *>(claim + kcap);    // [kcap]
+  __shared__ int pending;
+  const int tid = threadIdx.x;
+  for (int k = tid; k < kcap; k += 1024) taken[k] = 0;
+  constexpr int PER = 4;  // map points per thread (n_points <= 4096)
+  int ci[PER][4];
+  float cd[PER][4];
+  bool done[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int i = tid + q * 1024;
+    done[q] = i >= n_points;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      ci[q][c] = -1;
+      cd[q][c] = 3.0e38f;
+      if (i < n_points) {
+        const int idx = cand_idx[i * 4 + c];
+        const float d = cand_dist[i * 4 + c];
+        if (idx >= 0 && idx < kcap && d < max_dist) { ci[q][c] = idx; cd[q][c] = d; }  // others can never match
+      }
+    }
+  }
+  for (int round = 0; round < 8192; ++round) {
+    for (int k = tid; k < kcap; k += 1024) claim[k] = 0x7fffffff;
+    if (tid == 0) pending = 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+      if (!done[q])
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (ci[q][c] >= 0 && !taken[ci[q][c]]) atomicMin(&claim[ci[q][c]], tid + q * 1024);
+    __syncthreads();
+    bool fin[PER];
+    int pick[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      fin[q] = false;
+      pick[q] = -1;
+      if (done[q]) continue;
+      const int i = tid + q * 1024;
+      bool first = true;
+      float bd = max_dist;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = ci[q][c];
+        if (k < 0 || taken[k]) continue;
+        first &= claim[k] == i;
+        if (cd[q][c] < bd) { bd = cd[q][c]; pick[q] = k; }
+      }
+      fin[q] = first;
+    }
+    __syncthreads();  // every decision read `taken` before anybody writes it
+    bool mine = false;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      if (done[q]) continue;
+      if (fin[q]) {
+        out[tid + q * 1024] = pick[q];
+        if (pick[q] >= 0) taken[pick[q]] = 1;
+        done[q] = true;
+      } else {
+        mine = true;
+      }
+    }
+    if (mine) pending = 1;
+    __syncthreads();
+    if (!pending) break;
+    __syncthreads();
+  }
+}
+
+hipError_t launch_match_patches(const PatchArgs &a, int kcap, float max_dist, int *cand_idx, float *cand_dist,
+                                int32_t *out, hipStream_t s) {
+  if (a.n_points <= 0) return hipSuccess;
+  if (a.n_points > 4096) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(patch_dist_kernel, dim3((a.n_points + 3) / 4), dim3(256), 0, s, a, cand_idx, cand_dist);
+  const size_t lds = (size_t)kcap * 5 + 16;
+  hipLaunchKernelGGL(patch_resolve_kernel, dim3(1), dim3(1024), lds, s, cand_idx, cand_dist, a.n_points, kcap,
+                     max_dist, out);
+  return hipGetLastError();
+}
+
+}  // namespace spfe

@@ -106,6 +106,10 @@ struct spfe_handle_s {
   // descriptor matching (spfe_match*): scratch grown on demand
   unsigned long long *m_best_t = nullptr, *m_best_q = nullptr;
   uint8_t *m_stage_q = nullptr, *m_stage_t = nullptr, *m_out = nullptr;
+  int *p_cidx = nullptr;           // patch association scratch: [4096][4] candidates, distances, host staging
+  float *p_cdist = nullptr;
+  uint8_t *p_stage = nullptr;
+  size_t p_stage_bytes = 0;
   int m_pairs = 0, m_cap = 0;      // capacity of m_best_* ([pairs][cap])
   int m_host_cap = 0;              // rows the host-API staging blocks / m_out hold
   unsigned tile16_mask = 0;  // f32 layers (bit i = conv layer i of enqueue()) on 16-row / 8-wave tiles
@@ -600,6 +604,8 @@ void spfe_destroy(spfe_handle h) {
   for (void *p : {(void *)h->d_map_x, (void *)h->d_map_y, (void *)h->d_raw})
     if (p) (void)hipFree(p);
   if (h->h_raw) (void)hipHostFree(h->h_raw);
+  for (void *p : {(void *)h->p_cidx, (void *)h->p_cdist, (void *)h->p_stage})
+    if (p) (void)hipFree(p);
   for (void *p : {(void *)h->m_best_t, (void *)h->m_best_q, (void *)h->m_stage_q, (void *)h->m_stage_t,
                   (void *)h->m_out})
     if (p) (void)hipFree(p);
@@ -880,6 +886,88 @@ int spfe_extract_staged(spfe_handle h, const uint8_t *src, int stride, spfe_resu
   if (!src) return fail(SPFE_EEMPTY, "input image is empty");
   const uint8_t *one[1] = {src};
   return spfe_extract_batch_staged(h, one, stride, 1, out);
+}
+
+// ---- patch-wise association (tracker_dust.cpp:113-172) -------------------------------------------
+namespace {
+constexpr int kPatchMax = 4096;
+int patch_scratch(spfe_handle h) {
+  if (h->p_cidx) return SPFE_OK;
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->p_cidx), (size_t)kPatchMax * 4 * sizeof(int)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->p_cdist), (size_t)kPatchMax * 4 * sizeof(float)));
+  return SPFE_OK;
+}
+}  // namespace
+
+int spfe_match_patches_record_device(spfe_handle h, const void *d_mp_desc, const void *d_mp_uv, int n_points,
+                                     const void *d_record, float max_dist, void *d_kp_idx, void *stream) {
+  if (!h || !d_record || !d_kp_idx) return fail(SPFE_EINVAL, "null argument");
+  if (n_points < 0 || n_points > kPatchMax) return fail(SPFE_EINVAL, "n_points %d not in [0, %d]", n_points, kPatchMax);
+  if (n_points == 0) return SPFE_OK;
+  if (!d_mp_desc || !d_mp_uv) return fail(SPFE_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  int rc = patch_scratch(h);
+  if (rc) return rc;
+  hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
+  const uint8_t *rec = reinterpret_cast<const uint8_t *>(d_record);
+  spfe::PatchArgs a{};
+  a.mp_desc = reinterpret_cast<const float *>(d_mp_desc);
+  a.mp_uv = reinterpret_cast<const float *>(d_mp_uv);
+  a.n_points = n_points;
+  a.occ = reinterpret_cast<const int16_t *>(rec + h->rl.off_occ);
+  a.hc = h->hc; a.wc = h->wc;
+  a.kp_desc = reinterpret_cast<const float *>(rec + h->rl.off_desc);
+  a.k_ptr = reinterpret_cast<const int *>(rec + h->rl.off_hdr);
+  a.k_imm = 0;
+  HIP_TRY(spfe::launch_match_patches(a, h->kmax, max_dist, h->p_cidx, h->p_cdist,
+                                     reinterpret_cast<int32_t *>(d_kp_idx), s));
+  return SPFE_OK;
+}
+
+int spfe_match_patches(spfe_handle h, const float *mp_desc, const float *mp_uv, int n_points,
+                       const int16_t *occ_grid, const float *kp_desc, int n_keypoints, float max_dist,
+                       int32_t *kp_idx) {
+  if (!h || !kp_idx) return fail(SPFE_EINVAL, "null argument");
+  if (n_points < 0 || n_points > kPatchMax) return fail(SPFE_EINVAL, "n_points %d not in [0, %d]", n_points, kPatchMax);
+  if (n_keypoints < 0 || n_keypoints > 32767) return fail(SPFE_EINVAL, "n_keypoints %d out of range", n_keypoints);
+  for (int i = 0; i < n_points; ++i) kp_idx[i] = -1;
+  if (n_points == 0 || n_keypoints == 0) return SPFE_OK;
+  if (!mp_desc || !mp_uv || !occ_grid || !kp_desc) return fail(SPFE_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  int rc = patch_scratch(h);
+  if (rc) return rc;
+  const size_t cells = (size_t)h->hc * h->wc;
+  const size_t o_mp = 0, o_uv = o_mp + (size_t)n_points * 1024, o_occ = align_up(o_uv + (size_t)n_points * 8, 16),
+               o_kp = align_up(o_occ + cells * 2, 16), o_out = o_kp + (size_t)n_keypoints * 1024,
+               total = o_out + (size_t)n_points * 4;
+  if (total > h->p_stage_bytes) {
+    HIP_TRY(hipDeviceSynchronize());
+    if (h->p_stage) (void)hipFree(h->p_stage);
+    h->p_stage = nullptr;
+    h->p_stage_bytes = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->p_stage), total));
+    h->p_stage_bytes = total;
+  }
+  hipStream_t s = h->stream;
+  uint8_t *d = h->p_stage;
+  HIP_TRY(hipMemcpyAsync(d + o_mp, mp_desc, (size_t)n_points * 1024, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d + o_uv, mp_uv, (size_t)n_points * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d + o_occ, occ_grid, cells * 2, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d + o_kp, kp_desc, (size_t)n_keypoints * 1024, hipMemcpyHostToDevice, s));
+  spfe::PatchArgs a{};
+  a.mp_desc = reinterpret_cast<const float *>(d + o_mp);
+  a.mp_uv = reinterpret_cast<const float *>(d + o_uv);
+  a.n_points = n_points;
+  a.occ = reinterpret_cast<const int16_t *>(d + o_occ);
+  a.hc = h->hc; a.wc = h->wc;
+  a.kp_desc = reinterpret_cast<const float *>(d + o_kp);
+  a.k_ptr = nullptr;
+  a.k_imm = n_keypoints;
+  HIP_TRY(spfe::launch_match_patches(a, n_keypoints, max_dist, h->p_cidx, h->p_cdist,
+                                     reinterpret_cast<int32_t *>(d + o_out), s));
+  HIP_TRY(hipMemcpyAsync(kp_idx, d + o_out, (size_t)n_points * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return SPFE_OK;
 }
 
 // ---- descriptor matching ------------------------------------------------

@@ -126,6 +126,21 @@ struct StageParams {
 };
 hipError_t launch_stage_input(const StageParams &p, int channels, int n, hipStream_t s);
 
+// patch-wise association of projected map points (match.hip; tracker_dust.cpp:113-172)
+struct PatchArgs {
+  const float *mp_desc;  // [n_points][256]
+  const float *mp_uv;    // [n_points][2] projected dust-map position (cells)
+  int n_points;
+  const int16_t *occ;    // [hc][wc] keypoint index per cell, -1 = empty
+  int hc, wc;
+  const float *kp_desc;  // [K][256]
+  const int *k_ptr;      // K on the device (a record header), or null -> k_imm
+  int k_imm;
+};
+// cand_idx / cand_dist: [n_points][4] scratch; out: [n_points] keypoint index or -1; kcap >= K
+hipError_t launch_match_patches(const PatchArgs &a, int kcap, float max_dist, int *cand_idx, float *cand_dist,
+                                int32_t *out, hipStream_t s);
+
 // exact-math probe kernels for tests (device bits vs host bits)
 hipError_t launch_math_probe(const float *in, float *out_exp, float *out_log, int n, hipStream_t s);
 

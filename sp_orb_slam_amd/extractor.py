@@ -34,6 +34,7 @@ ABI_SYMBOLS = [
     "spfe_stage_name",
     "spfe_math_probe", "spfe_last_error", "spfe_version",
     "spfe_match", "spfe_match_records_device", "spfe_match_out_bytes",
+    "spfe_match_patches", "spfe_match_patches_record_device",
     "spfe_set_staging", "spfe_extract_staged", "spfe_extract_batch_staged", "spfe_stage_batch_device",
 ]
 
@@ -148,6 +149,12 @@ def load_library():
                                             C.POINTER(_Result)]
     L.spfe_stage_batch_device.restype = C.c_int
     L.spfe_stage_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.spfe_match_patches.restype = C.c_int
+    L.spfe_match_patches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_float, C.c_void_p]
+    L.spfe_match_patches_record_device.restype = C.c_int
+    L.spfe_match_patches_record_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                   C.c_float, C.c_void_p, C.c_void_p]
     L.spfe_match.restype = C.c_int
     L.spfe_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                              C.c_void_p]
@@ -442,6 +449,27 @@ class SPExtractor:
                                     t.ctypes.data if len(t) else None, len(t), 1 if cross_check else 0,
                                     idx.ctypes.data, dist.ctypes.data))
         return idx, dist
+
+    def match_patches(self, mp_desc, mp_uv, occ_grid, kp_desc, max_dist=0.75):
+        """Patch-wise association of projected map points (tracker_dust.cpp:113-172): map point i at
+        dust-map position mp_uv[i] (cells) takes the nearest keypoint of its 2 x 2 cells below max_dist,
+        earlier map points first.  -> int32 [n_points] keypoint index or -1."""
+        m = np.ascontiguousarray(mp_desc, np.float32).reshape(-1, 256)
+        uv = np.ascontiguousarray(mp_uv, np.float32).reshape(-1, 2)
+        occ = np.ascontiguousarray(occ_grid, np.int16)
+        kd = np.ascontiguousarray(kp_desc, np.float32).reshape(-1, 256)
+        if occ.shape != (self.height // 8, self.width // 8):
+            raise SpfeError("occ_grid must be [height/8, width/8]")
+        out = np.empty(len(m), np.int32)
+        _check(self._lib.spfe_match_patches(self._h, m.ctypes.data if len(m) else None, uv.ctypes.data if len(m) else None,
+                                            len(m), occ.ctypes.data, kd.ctypes.data if len(kd) else None, len(kd),
+                                            max_dist, out.ctypes.data if len(m) else np.empty(1, np.int32).ctypes.data))
+        return out
+
+    def match_patches_record_device(self, d_mp_desc, d_mp_uv, n_points, d_record, d_kp_idx, max_dist=0.75,
+                                    stream=None):
+        _check(self._lib.spfe_match_patches_record_device(self._h, d_mp_desc, d_mp_uv, n_points, d_record, max_dist,
+                                                          d_kp_idx, stream))
 
     def match_out_bytes(self):
         return int(self._lib.spfe_match_out_bytes(self._h))
