@@ -154,6 +154,29 @@ class ExtractorCV {
       if (idx[i] >= 0) matches.push_back(cv::DMatch(i, idx[i], 0, dist[i]));
   }
 
+  // The association loop of Tracker::trackFrameDustKFLocal (tracker_dust.cpp:113-172) against the frame
+  // extracted last: map point i (descriptor row i, projected dust-map position uv[i] in cells —
+  // dust_proj_u / dust_proj_v) takes the nearest keypoint of its 2 x 2 cells below max_dist, earlier map
+  // points first; kp_idx[i] = index into the keypoints / descriptors of that frame, or -1.
+  void matchPatches(const cv::Mat &mp_desc, const std::vector<cv::Point2f> &uv, const cv::Mat &frame_desc,
+                    std::vector<int> &kp_idx, float max_dist = 0.75f) {
+    const int m = static_cast<int>(uv.size());
+    kp_idx.assign(m, -1);
+    if (m == 0 || frame_desc.empty()) return;
+    if (mp_desc.rows != m || mp_desc.cols != 256 || mp_desc.type() != CV_32FC1 || mp_desc.step != 256 * sizeof(float) ||
+        frame_desc.cols != 256 || frame_desc.type() != CV_32FC1 || frame_desc.step != 256 * sizeof(float))
+      throw std::runtime_error("matchPatches: descriptors must be contiguous rows of 256 CV_32F");
+    std::vector<float> puv(2 * static_cast<size_t>(m));
+    for (int i = 0; i < m; ++i) { puv[2 * i] = uv[i].x; puv[2 * i + 1] = uv[i].y; }
+    std::vector<int32_t> out(m);
+    if (spfe_match_patches(h_, reinterpret_cast<const float *>(mp_desc.data), puv.data(), m,
+                           reinterpret_cast<const int16_t *>(occ_grid_.data),
+                           reinterpret_cast<const float *>(frame_desc.data), frame_desc.rows, max_dist,
+                           out.data()) != SPFE_OK)
+      throw std::runtime_error(spfe_last_error());
+    for (int i = 0; i < m; ++i) kp_idx[i] = out[i];
+  }
+
   cv::Mat getMask() { return mask_; }
   cv::Mat getHeatMap() { return heat_; }
   const std::vector<Vec2f> &getCov() const { return cov2_; }

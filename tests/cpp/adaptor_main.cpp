@@ -56,6 +56,17 @@ int main(int argc, char **argv) {
     if ((int)matches.size() != K) return 7;
     for (int i = 0; i < K; ++i)
       if (matches[i].queryIdx != i || matches[i].trainIdx != i || matches[i].distance != 0.0f) return 7;
+    // trackFrameDustKFLocal's association (tracker_dust.cpp:113-172) through the adaptor: map points that
+    // ARE the frame's keypoints, projected to their own cells, each get their own keypoint back
+    {
+      std::vector<cv::Point2f> uv(K);
+      for (int i = 0; i < K; ++i) { uv[i].x = (float)((int)mvKeys[i].pt.x / 8) + 0.5f; uv[i].y = (float)((int)mvKeys[i].pt.y / 8) + 0.5f; }
+      std::vector<int> kp_idx;
+      extractor.matchPatches(mDescriptors, uv, mDescriptors, kp_idx);
+      if ((int)kp_idx.size() != K) return 9;
+      for (int i = 0; i < K; ++i)
+        if (kp_idx[i] != i) return 9;
+    }
     // input staging through the adaptor: a 1-channel source without maps is the identity, so
     // extractRaw() must reproduce operator()'s result
     std::vector<cv::KeyPoint> k2;
