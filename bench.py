@@ -125,8 +125,8 @@ def main():
         bf16 = args.precision == "bf16"
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "conv1b_traffic.json")
-        if os.path.exists(tpath) and not bf16 and (H, W, B) == (480, 752, 8):
+        tpath = os.path.join(ROOT, "profiles", "conv1b_bf16_traffic.json" if bf16 else "conv1b_traffic.json")
+        if os.path.exists(tpath) and (H, W, B) == (480, 752, 8):
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
