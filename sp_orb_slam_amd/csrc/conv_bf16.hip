@@ -577,36 +577,41 @@ __global__ __launch_bounds__(256) void conv1a_bf16_kernel(const uint8_t *__restr
       v = (float)ib[(size_t)gy * W + gx] * (1.0f / 255.0f);
     sI[i] = v;
   }
+  // this kernel is VALU bound (9 fma + bias + ReLU + rounding per output, 185 M outputs per batch),
+  // so the channels go two to a register pair: v_pk_fma_f32 / v_pk_add_f32 and v_cvt_pk_bf16_f32
   const int c4 = tid & 15;
-  float4 w[9];
+  f32x2 w01[9], w23[9];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const float4 *>(w9x64 + t * 64 + c4 * 4);
+  for (int t = 0; t < 9; ++t) {
+    const float4 wv = *reinterpret_cast<const float4 *>(w9x64 + t * 64 + c4 * 4);
+    w01[t] = (f32x2){wv.x, wv.y};
+    w23[t] = (f32x2){wv.z, wv.w};
+  }
   const float4 bias = *reinterpret_cast<const float4 *>(b64 + c4 * 4);
+  const f32x2 b01 = {bias.x, bias.y}, b23 = {bias.z, bias.w};
   __syncthreads();
   const int psub = tid >> 4;
 #pragma unroll 4
   for (int it = 0; it < 16; ++it) {
     const int pix = it * 16 + psub;
     const int row = pix >> 5, col = pix & 31;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const float x = sI[(row + t / 3) * (TW + 2) + col + t % 3];
-      a.x = fmaf(x, w[t].x, a.x);
-      a.y = fmaf(x, w[t].y, a.y);
-      a.z = fmaf(x, w[t].z, a.z);
-      a.w = fmaf(x, w[t].w, a.w);
+      const f32x2 xx = {x, x};
+      a01 = __builtin_elementwise_fma(xx, w01[t], a01);
+      a23 = __builtin_elementwise_fma(xx, w23[t], a23);
     }
-    a.x += bias.x; a.y += bias.y; a.z += bias.z; a.w += bias.w;
-    a.x = a.x > 0.f ? a.x : 0.f;
-    a.y = a.y > 0.f ? a.y : 0.f;
-    a.z = a.z > 0.f ? a.z : 0.f;
-    a.w = a.w > 0.f ? a.w : 0.f;
+    a01 = a01 + b01;
+    a23 = a23 + b23;
+    a01 = __builtin_elementwise_max(a01, (f32x2){0.f, 0.f});
+    a23 = __builtin_elementwise_max(a23, (f32x2){0.f, 0.f});
     const int gy = ty0 + row, gx = tx0 + col;
     if (gy < H && gx < W) {
       uint2 o;
-      o.x = (unsigned)f32_to_bf16_rne(a.x) | ((unsigned)f32_to_bf16_rne(a.y) << 16);
-      o.y = (unsigned)f32_to_bf16_rne(a.z) | ((unsigned)f32_to_bf16_rne(a.w) << 16);
+      o.x = __builtin_bit_cast(unsigned, __builtin_convertvector(a01, bf16x2));
+      o.y = __builtin_bit_cast(unsigned, __builtin_convertvector(a23, bf16x2));
       *reinterpret_cast<uint2 *>(out + (((size_t)b * H + gy) * W + gx) * 64 + c4 * 4) = o;
     }
   }
