@@ -38,10 +38,11 @@ extern "C" {
 
 /* spfe_config.precision */
 #define SPFE_PRECISION_F32 0  /* exact f32 on v_mfma_f32_32x32x2_f32; bit-identical to the CPU oracle */
-#define SPFE_PRECISION_BF16 1 /* conv1b..convPa/Da on v_mfma_f32_32x32x16_bf16: bf16 activations and weights,
-                                 f32 accumulate / bias / ReLU / pool; convPb, convDb, softmax, NMS, descriptors
-                                 and covariance stay f32 (BASELINE configs[3]: "bf16 conv path with fp32 NMS").
-                                 Keypoints / descriptors match the f32 path within tolerance, not bitwise. */
+#define SPFE_PRECISION_BF16 1 /* conv1b..convPa/Da and the descriptor head convDb on v_mfma_f32_32x32x16_bf16:
+                                 bf16 activations and weights, f32 accumulate / bias / ReLU / pool; the detector
+                                 head convPb, softmax, NMS, descriptor sampling and covariance stay f32
+                                 (BASELINE configs[3]: "bf16 conv path with fp32 NMS").  Keypoints /
+                                 descriptors match the f32 path within tolerance, not bitwise. */
 
 /* spfe_config.flags */
 #define SPFE_FLAG_HEAT 1u /* also produce heat / heat_inv (H*W floats each), sp_extractor.cpp:461-474 */

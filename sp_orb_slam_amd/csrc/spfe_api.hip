@@ -84,6 +84,8 @@ struct spfe_handle_s {
   float *d_w1a = nullptr, *d_b1a = nullptr;
   float *act[8] = {};
   float *d_head = nullptr, *d_semi = nullptr, *d_coarse = nullptr;
+  unsigned short *d_da = nullptr;    // bf16 mode: convDa's output [B][C][256] bf16 (input of the bf16 descriptor head)
+  unsigned char *d_wdb = nullptr;    // bf16 mode: convDb weights, head_bf16.hip layout
   float *d_heat_log = nullptr, *d_heat = nullptr, *d_heat_inv = nullptr;
   float *d_minmax = nullptr, *d_cell_score = nullptr, *d_heat_consts = nullptr;
   uint8_t *d_cell_k = nullptr;
@@ -414,6 +416,19 @@ int build(spfe_handle h, const spfe_config *cfg) {
     L.in = h->d_head; L.in_stride = 512; L.in_choff = 256;
     L.out = h->d_coarse; L.out_stride = SPFE_DESC_DIM; L.out_choff = 0;
   }
+  if (h->bf16) {  // descriptor head in bf16: convDa writes bf16, convDb is head_bf16.hip's GEMM
+    if ((rc = dev_alloc(h, &h->d_da, (size_t)B * C * 256))) return rc;
+    const spfe_layer_t &Ld = SPFE_LAYERS[11];
+    const float *Wd = blob.data() + blob_weight_offset(11);
+    std::vector<unsigned char> w(spfe::head_bf16_weight_bytes(), 0);
+    for (int co = 0; co < Ld.cout; ++co)
+      for (int ci = 0; ci < Ld.cin; ++ci) {
+        const unsigned short v = host_bf16_rne(Wd[(size_t)co * Ld.cin + ci]);
+        memcpy(&w[(size_t)(co / 64) * 40960 + ((size_t)(ci / 32) * 64 + co % 64) * 80 + (ci % 32) * 2], &v, 2);
+      }
+    if ((rc = dev_alloc(h, &h->d_wdb, w.size()))) return rc;
+    HIP_TRY(hipMemcpy(h->d_wdb, w.data(), w.size(), hipMemcpyHostToDevice));
+  }
 
   // pinned host mirrors for the host-facing calls
   if ((rc = host_alloc(h, &h->h_img, (size_t)B * H * W))) return rc;
@@ -459,7 +474,23 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
       // bf16 stack: 8-row tiles only; convPa/Da (i == 7) write f32 for the f32 heads
       p.tiles_x = (L.W + 31) / 32; p.tiles_y = (L.H + 7) / 8; p.nblk = L.nblk;
       p.num_cus = h->num_cus;
-      HIP_TRY(spfe::launch_conv_bf16(p, L.cin, L.pool, i == 7, s));
+      if (i == 7) {
+        // convPa -> f32 (the detector head stays f32), convDa -> bf16 (the descriptor head is bf16 too)
+        const size_t half_w = (size_t)4 * (L.cin / 32) * spfe::conv_bf16_slab_bytes();
+        p.nblk = 4; p.cout_real = 256;
+        HIP_TRY(spfe::launch_conv_bf16(p, L.cin, L.pool, true, s));
+        p.wpack = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(L.d_w) + half_w);
+        p.bias = L.d_b + 256;
+        p.out = reinterpret_cast<float *>(h->d_da); p.out_stride = 256; p.out_choff = 0;
+        HIP_TRY(spfe::launch_conv_bf16(p, L.cin, L.pool, false, s));
+      } else {
+        HIP_TRY(spfe::launch_conv_bf16(p, L.cin, L.pool, false, s));
+      }
+      STAGE_MARK(2 + i);
+      continue;
+    }
+    if (h->bf16 && i == 9) {  // convDb: bf16 GEMM over all cells of the batch
+      HIP_TRY(spfe::launch_head1x1_bf16(h->d_da, h->d_wdb, L.d_b, h->d_coarse, n * h->C, s));
       STAGE_MARK(2 + i);
       continue;
     }
