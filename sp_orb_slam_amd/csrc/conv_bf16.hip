@@ -527,12 +527,14 @@ static hipError_t launch_b(const ConvParams &p, hipStream_t s) {
   constexpr size_t lds = 2 * (size_t)G::BUF_BYTES;
   static_assert(lds <= 160 * 1024, "double buffer must fit the 160 KB LDS");
   auto k = conv_bf16_kernel<CIN, POOL, OUT_F32>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[64] = {};  // per instantiation and device: one process may hold handles on several GPUs
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_done[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    if (dev >= 0 && dev < 64) attr_done[dev] = true;
   }
   int grid = p.num_cus > 0 ? p.num_cus : 256;
   grid &= ~7;

@@ -620,12 +620,14 @@ static hipError_t launch_one(const ConvParams &p, hipStream_t s) {
   constexpr size_t lds = (2 * (size_t)(KC * G::PLANE + KS * KS * KC * 64) + (LAYER == 2 ? 2 * F1_PATCH : 0)) * sizeof(float);
   static_assert(lds <= 160 * 1024, "double buffer must fit the 160 KB LDS");
   auto k = conv_f32_kernel<LAYER, CIN, KS, KC, WM, WN, MT, NT, POOL, RELU>;
-  static bool attr_done = false;  // per instantiation
-  if (!attr_done) {
+  static bool attr_done[64] = {};  // per instantiation and device: one process may hold handles on several GPUs
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_done[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    if (dev >= 0 && dev < 64) attr_done[dev] = true;
   }
   const int total = p.nblk * p.tiles_x * p.tiles_y * p.B;
   int grid = p.num_cus > 0 ? p.num_cus : 256;  // one persistent workgroup per CU

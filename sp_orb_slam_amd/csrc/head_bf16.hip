@@ -102,12 +102,14 @@ size_t head_bf16_weight_bytes() { return (size_t)4 * H_BLOCK; }
 hipError_t launch_head1x1_bf16(const void *in_bf16, const void *wpack, const float *bias, float *out, int npix,
                                hipStream_t s) {
   constexpr size_t lds = 3 * (size_t)H_BLOCK;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[64] = {};  // per device: one process may hold handles on several GPUs
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_done[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(head1x1_bf16_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    if (dev >= 0 && dev < 64) attr_done[dev] = true;
   }
   if (npix <= 0) return hipSuccess;
   hipLaunchKernelGGL(head1x1_bf16_kernel, dim3((npix + H_TILE - 1) / H_TILE), dim3(256), lds, s,
