@@ -239,7 +239,8 @@ SPFE_API int spfe_stage_batch_device(spfe_handle h, const void *d_src, int n, vo
 /* Per-stage GPU time (ms, HIP events recorded on the launch stream around every
  * kernel), averaged over the calls since spfe_stage_reset (the library keeps the
  * last 128 calls).  Enabled by SPFE_STAGE_TIMING=1 in the environment at
- * spfe_create; returns the number of stages written (names: spfe_stage_name). */
+ * spfe_create (SPFE_STAGE_TIMING=2: only the dominant kernel, conv1b, is bracketed — two events
+ * per call instead of sixteen; the other stages then read 0); returns the number of stages written (names: spfe_stage_name). */
 SPFE_API int spfe_stage_times(spfe_handle h, float *ms, int cap);
 SPFE_API int spfe_stage_reset(spfe_handle h);
 SPFE_API const char *spfe_stage_name(int i);

@@ -119,6 +119,7 @@ struct spfe_handle_s {
   bool bf16 = false;  // SPFE_PRECISION_BF16: bf16 conv stack (conv1a .. convPa/Da), f32 heads and tail
   // per-stage timing: a ring of event sets, one set per enqueue() call
   bool timing = false;
+  bool timing_all = true;  // false (SPFE_STAGE_TIMING=2): events around the dominant kernel (conv1b) only
   static constexpr int EVSETS = 128;
   std::vector<hipEvent_t> evpool;  // [EVSETS][NSTAGE + 1]
   long calls = 0, calls_at_reset = 0;
@@ -313,6 +314,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
   }
   const char *tenv = getenv("SPFE_STAGE_TIMING");
   h->timing = tenv && atoi(tenv) != 0;
+  h->timing_all = !(tenv && atoi(tenv) == 2);
   if (h->timing) {
     h->evpool.resize((size_t)spfe_handle_s::EVSETS * (NSTAGE + 1), nullptr);
     for (auto &e : h->evpool) HIP_TRY(hipEventCreate(&e));
@@ -441,7 +443,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
 }
 
 #define STAGE_MARK(i) \
-  do { if (h->timing) HIP_TRY(hipEventRecord(h->ev[i], s)); } while (0)
+  do { if (h->timing && (h->timing_all || (i) == 1 || (i) == 2)) HIP_TRY(hipEventRecord(h->ev[i], s)); } while (0)
 
 int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s);
 
@@ -548,7 +550,7 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s) {
   h->desc_recorded = true;
   HIP_TRY(spfe::launch_cov(f, h->rl, h->cov, n, H, W, h->side));
   HIP_TRY(hipEventRecord(h->ev_cov[slot], h->side));
-  if (h->timing) HIP_TRY(hipEventRecord(h->ev[14], h->side));
+  if (h->timing && h->timing_all) HIP_TRY(hipEventRecord(h->ev[14], h->side));
   h->cov_inflight = true;
   h->ticket++;
   if (!(h->cfg.flags & SPFE_FLAG_ASYNC_COV)) {
@@ -815,6 +817,13 @@ int spfe_stage_times(spfe_handle h, float *ms, int cap) {
   std::vector<double> acc(NSTAGE, 0.0);
   for (long c = first; c < h->calls; ++c) {
     hipEvent_t *ev = h->evpool.data() + (size_t)(c % spfe_handle_s::EVSETS) * (NSTAGE + 1);
+    if (!h->timing_all) {  // only the bracket of the dominant kernel was recorded
+      float t = 0;
+      if (hipEventSynchronize(ev[2]) != hipSuccess) return fail(SPFE_EHIP, "event sync failed");
+      (void)hipEventElapsedTime(&t, ev[1], ev[2]);
+      acc[1] += t;
+      continue;
+    }
     if (hipEventSynchronize(ev[NSTAGE - 1]) != hipSuccess) return fail(SPFE_EHIP, "event sync failed");
     for (int i = 0; i < NSTAGE - 1; ++i) {
       float t = 0;
