@@ -30,6 +30,69 @@ def conv1b_flop(H, W):
     return 2 * H * W * 64 * 64 * 9
 
 
+def file_sha16(path):
+    import hashlib
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def stamped_traffic(profile_json, kernel_sources, H, W, B):
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile, or None when the
+    profile was taken on other kernel sources than the ones built now (stale) or another workload."""
+    path = os.path.join(ROOT, "profiles", profile_json)
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None
+    if tuple(d.get("workload_hwb", (480, 752, 8))) != (H, W, B):
+        return None
+    want = d.get("kernel_source_sha16") or {}
+    for src in kernel_sources:
+        if want.get(src) != file_sha16(os.path.join(ROOT, "sp_orb_slam_amd", "csrc", src)):
+            return None
+    return d.get("hbm_bytes_per_launch")
+
+
+def run_timed(ext, sharded, d_img, stream, steps, warmup, world, dist, torch):
+    """W untimed + K timed steps bracketed by barrier + synchronize; returns seconds (max over ranks)."""
+    for _ in range(warmup):
+        sharded.step(d_img, stream)
+    sharded.flush(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ext.stage_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sharded.step(d_img, stream)
+    sharded.flush(stream)   # the last batch's covariance + gather are inside the timed region
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def roofline_of(precision, stages, H, W, B, traffic):
+    t_conv1b = stages.get("conv1b", 0.0) * 1e-3
+    ach = (conv1b_flop(H, W) * B / t_conv1b / 1e12) if t_conv1b > 0 else None
+    bf16 = precision == "bf16"
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    return {"bound": "mfma", "kernel": ("conv_bf16_ws_kernel<true> (conv1b)" if bf16 else
+                                        "conv_f32_kernel<1,64,3,16,4,1,2,2,true,true> (conv1b)"),
+            "achieved": round(ach, 2) if ach else None, "peak": peak, "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4) if ach else None, "traffic": traffic,
+            "kernel_ms": round(t_conv1b * 1e3, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -47,6 +110,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-stage-table", action="store_true", help="skip the separate per-stage timing pass")
     ap.add_argument("--no-match", action="store_true", help="skip the descriptor-matching and input-staging legs (SURVEY 8f-1, 8f-2)")
+    ap.add_argument("--no-bf16-leg", action="store_true", help="skip the configs[3] leg (bf16, 1280x720, batch 8)")
+    ap.add_argument("--no-aten", action="store_true", help="skip the ATen-CPU baseline")
+    ap.add_argument("--latency-calls", type=int, default=1000)
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
                     help="f32: BASELINE configs[1]/[2] (bit-exact path, the headline); bf16: configs[3] "
                          "(bf16 convolutions conv1b..convPa/Da, f32 heads + post-processing)")
@@ -94,30 +160,7 @@ def main():
     stream = torch.cuda.Stream()   # compute stream (not the legacy default stream: no implicit barriers)
     torch.cuda.synchronize()
 
-    def step():
-        sharded.step(d_img, stream)   # HIP path on this rank's shard + RCCL all-gather of the records
-
-    for _ in range(args.warmup):
-        step()
-    sharded.flush(stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ext.stage_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sharded.flush(stream)   # the last batch's covariance + gather are inside the timed region
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = run_timed(ext, sharded, d_img, stream, args.steps, args.warmup, world, dist, torch)
     stages = ext.stage_times()
 
     # sanity: the gathered records decode and carry the expected keypoint counts
@@ -130,19 +173,11 @@ def main():
         fps = world * B * args.steps / dt
         flop_frame = FLOP_PER_FRAME.get((H, W))
         # dominant kernel: conv1b (43.5 % of the FLOPs), one launch covers B frames
-        t_conv1b = stages.get("conv1b", 0.0) * 1e-3
-        ach = (conv1b_flop(H, W) * B / t_conv1b / 1e12) if t_conv1b > 0 else None
         bf16 = args.precision == "bf16"
-        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "conv1b_bf16_traffic.json" if bf16 else "conv1b_traffic.json")
-        if os.path.exists(tpath) and (H, W, B) == (480, 752, 8):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic = (stamped_traffic("conv1b_bf16_traffic.json", ["conv_bf16_ws.hip"], H, W, B) if bf16 else
+                   stamped_traffic("conv1b_traffic.json", ["conv_f32.hip"], H, W, B))
         out = {
-            "metric": "frames/sec SuperPoint extract (752x480, 1k kpts)",
+            "metric": "frames/sec SuperPoint extract (%dx%d, %s kpts)" % (W, H, "1k" if nf == 1000 else str(nf)),
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
@@ -155,11 +190,7 @@ def main():
                                       "covariance of step i overlapped with the convolutions of step i+1 (depth-2 pipeline)"),
                        "frames_per_gpu": B, "height": H, "width": W, "num_features": nf,
                        "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": ("conv_bf16_kernel<64,true,false> (conv1b)" if bf16 else
-                                                      "conv_f32_kernel<1,64,3,16,4,1,2,2,true,true> (conv1b)"),
-                         "achieved": round(ach, 2) if ach else None, "peak": peak,
-                         "unit": "TFLOP/s", "frac": round(ach / peak, 4) if ach else None,
-                         "traffic": traffic},
+            "roofline": roofline_of(args.precision, stages, H, W, B, traffic),
             "whole_path_tflops": round(fps * flop_frame / 1e12, 2) if flop_frame else None,
         }
         if not args.no_stage_table:
@@ -180,20 +211,46 @@ def main():
             out["stage_ms"] = {k: round(v, 4) for k, v in ext_t.stage_times().items()}
             out["stage_ms_note"] = "separate 8-step pass with events around every stage (this rank only)"
             ext_t.close()
+        os.environ["SPFE_STAGE_TIMING"] = "0"   # no events in the latency / matching / host-path legs
+        if world == 1 and not args.no_bf16_leg and not (bf16 and (H, W, B) == (720, 1280, 8)):
+            # BASELINE configs[3]: 1280x720, batch 8, bf16 convolutions + f32 NMS, 1 GPU — the same
+            # pipelined schedule and the same in-region event bracket around conv1b as the headline
+            os.environ["SPFE_STAGE_TIMING"] = "2"
+            H3, W3, B3 = 720, 1280, 8
+            ext3 = SPExtractor(nf, H3, W3, blob, max_batch=B3, device=local, with_heat=False,
+                               async_cov=not args.sync_cov, precision="bf16")
+            d3 = torch.from_numpy(synth.make_batch(300, B3, H3, W3)).cuda()
+            sh3 = parallel.ShardedExtractor(ext3, 1, 0, B3)
+            k3 = max(10, args.steps)
+            dt3 = run_timed(ext3, sh3, d3, stream, k3, args.warmup, 1, dist, torch)
+            st3 = ext3.stage_times()
+            r3 = sh3.decode(0)
+            assert 0 < r3.K <= nf + 1 and r3.status == 0
+            fps3 = B3 * k3 / dt3
+            out["bf16_1280x720_b8"] = {
+                "what": "BASELINE configs[3]: 1280x720 frames, batch 8, bf16 MFMA convolutions (f32 accumulate), "
+                        "f32 detector head / NMS / descriptors / covariance, 1 GPU, %d timed steps" % k3,
+                "value": round(fps3, 2), "unit": "frames/s", "ms_per_step": round(dt3 / k3 * 1e3, 4), "dtype": "bf16",
+                "roofline": roofline_of("bf16", st3, H3, W3, B3,
+                                        stamped_traffic("conv1b_bf16_720p_traffic.json", ["conv_bf16_ws.hip"], H3, W3, B3)),
+                "whole_path_tflops": round(fps3 * FLOP_PER_FRAME[(H3, W3)] / 1e12, 2)}
+            ext3.close()
+            del d3
+            os.environ["SPFE_STAGE_TIMING"] = "0"
         # batch-1 latency (configs[1] as written: one frame per call)
         ext1 = None if args.no_latency else SPExtractor(nf, H, W, blob, max_batch=1, device=local, with_heat=False,
                                                                 precision=args.precision)
         d1 = d_img[:1].contiguous()
         r1 = torch.zeros(rec_bytes, dtype=torch.uint8, device="cuda")
         lat = []
-        for i in range(0 if ext1 is None else 250):
+        for i in range(0 if ext1 is None else args.latency_calls + 50):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             ext1.extract_batch_device(d1.data_ptr(), 1, r1.data_ptr(), stream.cuda_stream)
             torch.cuda.synchronize()
             lat.append((time.perf_counter() - t1) * 1e3)
         if ext1 is not None:
-            lat = sorted(lat[50:])   # 200 timed calls after 50 warm-up calls
+            lat = sorted(lat[50:])   # 1000 timed calls after 50 warm-up calls
             out["latency_batch1_ms"] = {"p50": round(lat[len(lat) // 2], 4), "p99": round(lat[int(len(lat) * 0.99) - 1], 4),
                                         "calls": len(lat)}
             ext1.close()
@@ -297,7 +354,7 @@ def main():
             # the port's loops scale to a few dozen threads (tools/cpu_baseline.py sweeps 1..all: the
             # best team on the 256-thread GPU-box host is 32), so that is the team it gets
             nthr = oracle.set_num_threads(min(32, os.cpu_count() or 1))
-            oracle.extract(blob, frames[0], nf)   # warm-up (thread team, caches)
+            ref0 = oracle.extract(blob, frames[0], nf)   # warm-up (thread team, caches) + the parity check below
             done, t1 = 0, time.perf_counter()
             while True:
                 oracle.extract(blob, frames[done % B], nf)
@@ -309,6 +366,50 @@ def main():
                                    "kind": "port",
                                    "sample": "%d frames of the same %dx%d workload through oracle/spfe_oracle.c "
                                              "(OpenMP, %d threads), %.1f s" % (done, W, H, nthr, el)}
+            # self-check of the timed workload: frame 0 of the LAST timed batch (pipelined, device
+            # resident) against the oracle's extraction of the same frame
+            kp_ok = rec0.K == ref0["K"] and np.array_equal(rec0.kp_xy, ref0["kp_xy"]) and \
+                np.array_equal(rec0.occ_grid, ref0["occ_grid"])
+            if bf16:
+                a = {(int(x), int(y)) for x, y in rec0.kp_xy}
+                b = {(int(x), int(y)) for x, y in ref0["kp_xy"]}
+                idx = {(int(x), int(y)): i for i, (x, y) in enumerate(ref0["kp_xy"])}
+                cos = [float(np.dot(rec0.descriptors[i], ref0["desc"][idx[k]]))
+                       for i, k in enumerate((int(x), int(y)) for x, y in rec0.kp_xy) if k in idx]
+                jac = len(a & b) / max(1, len(a | b))
+                out["parity_frame0"] = bool(jac >= 0.8 and (not cos or min(cos) >= 0.999))
+                out["parity_frame0_detail"] = {"rule": "bf16 mode vs the f32 oracle: keypoint-set Jaccard >= 0.8, "
+                                                       "descriptor cosine of common keypoints >= 0.999",
+                                               "jaccard": round(jac, 4), "desc_cos_min": round(min(cos), 6) if cos else None}
+            else:
+                desc_bits = kp_ok and np.array_equal(rec0.descriptors.view(np.uint32), ref0["desc"].view(np.uint32))
+                cov_bits = kp_ok and np.array_equal(rec0.cov2.view(np.uint32), ref0["cov2"].view(np.uint32)) and \
+                    np.array_equal(rec0.cov2_inv.view(np.uint32), ref0["cov2_inv"].view(np.uint32))
+                out["parity_frame0"] = bool(kp_ok and desc_bits and cov_bits)
+                out["parity_frame0_detail"] = {"rule": "f32 mode vs the oracle: keypoints / occ_grid exact, descriptors "
+                                                       "and cov2 / cov2_inv bitwise",
+                                               "keypoints_exact": bool(kp_ok), "desc_bitwise": bool(desc_bits),
+                                               "cov2_bitwise": bool(cov_bits), "K": int(rec0.K)}
+            if not args.no_aten:
+                # north_star: "the reference's CPU libtorch path timed on the same box's host cores".  The
+                # reference has no CPU path (CUDA hard-wired); libtorch-CPU == ATen-CPU, and torch is here
+                # for device plumbing, so the builder's statement of SPFrontend::forward's op sequence
+                # (tools/aten_path.py) is timed on the best of a thread sweep.  Network + detector tail +
+                # descriptor sampling only (the host glue nms / computeCovariance is not ATen code).
+                from tools import aten_path
+                named = weights.to_named_tensors(blob)
+                ncpu = os.cpu_count() or 1
+                sweep, best = {}, None
+                for thr in [t for t in (8, 16, 32, 64, 128) if t <= ncpu] or [ncpu]:
+                    fps_a, n_a, el_a = aten_path.time_forward(named, list(frames), thr, seconds=2.5, max_frames=48)
+                    sweep[str(thr)] = round(fps_a, 2)
+                    if best is None or fps_a > best[0]:
+                        best = (fps_a, thr, n_a, el_a)
+                out["cpu_baseline_aten"] = {
+                    "value": round(best[0], 3), "unit": "frames/s", "cores": best[1],
+                    "kind": "aten-cpu op sequence (torch %s, MKL-DNN), network + tail + descriptor sampling" % torch.__version__,
+                    "sample": "%d frames of the same %dx%d workload, %.1f s, best of the thread sweep" % (best[2], W, H, best[3]),
+                    "thread_sweep_fps": sweep, "host_cpus": ncpu}
         print(json.dumps(out), flush=True)
     ext.close()
     if world > 1:

@@ -1,0 +1,464 @@
+// conv_bf16_ws.hip — wave-specialised bf16 3x3 convolution for the Cin = 64 layers of the bf16 mode
+// (conv1b, conv2a, conv2b, conv3a of SPFrontend::forward, /root/reference/orb_slam2/src/cv/
+// sp_extractor.cpp:82-88; BASELINE.json configs[3] "bf16 conv path").  Same arithmetic as
+// conv_bf16.hip's kernel (v_mfma_f32_32x32x16_bf16, K order chunk(32 ch) -> tap -> 16 channels, f32
+// accumulate / bias / ReLU / 2x2 max-pool, RNE to bf16), so the two are bit-identical; what changes is
+// who does what:
+//
+//   * 512-thread workgroups, one per CU: waves 0-3 are CONSUMERS (one per SIMD: MFMAs, operand
+//     fragment reads, the previous tile's epilogue in the MFMA shadows — nothing else), waves 4-7 are
+//     PRODUCERS (one per SIMD: tile scheduling, address generation and the `buffer_load ... lds`
+//     passes that bring the next halo tile HBM/L2 -> LDS).  An LDS-direct pass costs 60-180 issue
+//     cycles in the stream that carries it (MI355X_MICROARCH.md, per-instruction constants) — two to
+//     five MFMA slots — and its vmcnt(0) + barrier parked the single-role wave of conv_bf16.hip for
+//     ~20 % of its cycles (profiles/r01g_pmc_bf16_conv1b.txt: SQ_WAIT_ANY).  In a separate wave that
+//     cost lands beside the MFMA stream, not inside it.
+//   * one stage per tile: a halo pixel keeps all 64 channels (128 B) in LDS, so a tile is ONE
+//     barrier and 144 MFMAs per consumer wave (4608 matrix cycles) — the time an HBM round trip of
+//     the next tile's loads gets to hide under, twice what a 32-channel stage offered.
+//   * no padding: pixels and weight rows are 128 B, XOR-swizzled in 16-byte pieces
+//     (piece j of halo column c sits in slot j ^ ((c >> 1) & 7); the swizzle is applied by the
+//     producer's choice of source address — free with LDS-direct loads — and by the packed weight
+//     layout).  A halo row is 34 * 128 B = 17 * 256 B, so the bank slot of a fragment depends on the
+//     column only: the 16 lanes of a ds_read_b128 group read 16 distinct columns mod 16 = 16 distinct
+//     16-byte bank slots (conflict-free), and every fragment address is a per-kernel register
+//     (3 dx x 4 k-groups) + immediate.  2 halo buffers (2 x 43,520 B) + the resident 64 x 576
+//     weight block (73,728 B) = 160,768 B of the 160 KiB.
+//   * dynamic tile queue: the producer fetches tile indices from a per-(XCD, channel-block) counter
+//     two tiles ahead, so a workgroup that starts late or shares its CU's issue slots with the
+//     side-stream kernels of the previous batch (SPFE_FLAG_ASYNC_COV) simply takes fewer tiles —
+//     a static split made the slowest workgroup the kernel's duration.
+//   * bias enters as the accumulator's initial value (C operand of the first MFMA), not as adds.
+#include <utility>
+
+#include "spfe_kernels.h"
+
+namespace spfe {
+namespace ws {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(3))) bf16x8 lds_frag;
+
+constexpr unsigned OOB = 0x80000000u;
+constexpr int TH = 8, ROWS = TH + 2, COLS = 34;
+constexpr int ROW_BYTES = COLS * 128;                  // 4352 = 17 * 256
+constexpr int HALO_BYTES = ROWS * ROW_BYTES;           // 43,520
+constexpr int HALO_PIECES = HALO_BYTES / 16;           // 2720
+constexpr int HALO_INSTR = (HALO_PIECES + 63) / 64;    // 43 wave-level LDS-direct passes
+constexpr int HALO_IT = (HALO_INSTR + 3) / 4;          // 11 per producer wave
+constexpr int W_BYTES = 9 * 64 * 128;                  // 73,728: [tap][cout][64 cin], swizzled
+[[maybe_unused]] constexpr int W_INSTR = W_BYTES / 1024;                // 72
+constexpr int LDS_W = 2 * HALO_BYTES;                  // 87,040
+constexpr int LDS_SLOT = LDS_W + W_BYTES;              // 160,768: 3 tile descriptors of 16 B
+constexpr int LDS_TOTAL = LDS_SLOT + 3 * 16;
+constexpr int NSTEP = 36;                              // K steps per tile: 2 chunks x 9 taps x 2
+
+#ifdef WS_PROBE_TIMING
+// probe builds (tools/microbench/conv_ws_probe.hip): cycle counters summed over workgroups
+// [0] consumer wave 0 loop cycles  [1] ... of which at the end-of-tile barrier  [2] tiles
+// [4] producer wave 4 loop cycles  [5] ... issuing passes  [6] ... waiting vmcnt(0)  [7] ... at the barrier
+__device__ unsigned long long ws_dbg[8];
+#define WS_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define WS_ACC(i, v) do { if (lane == 0) atomicAdd(&ws_dbg[i], (unsigned long long)(v)); } while (0)
+#else
+#define WS_T(var)
+#define WS_ACC(i, v)
+#endif
+#ifndef WS_PRIO
+#define WS_PRIO 1
+#endif
+#ifndef WS_ABLATE
+#define WS_ABLATE 0  // probe builds: 1 = producers issue no halo passes in the loop, 2 = consumers issue no MFMAs,
+                     // 3 = every tile loads the same halo (cache hits only), 4 = no fragment reads, 5 = no stores
+#endif
+
+// s_barrier without the vmcnt(0) the fence of a full workgroup sync would add: consumers must not wait
+// for their epilogue stores, producers wait explicitly for what the barrier publishes
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+__device__ __forceinline__ bf16x8 lds_read(lds_char *p, int imm) {
+  return *reinterpret_cast<lds_frag *>(p + imm);
+}
+
+struct Epi {
+  __amdgpu_buffer_rsrc_t rout;
+  unsigned rowoff[2];  // byte offset of this lane's pixel (+ its 4 * hi channels) in output row i (pool: [0]), or OOB
+};
+struct Hold {
+  unsigned h16;
+};
+
+__device__ __forceinline__ float dpp_xor1(float v) {  // the value of lane ^ 1
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+}
+
+// Accumulator layout after mfma(weights, pixels): lane = (pixel column p = lane & 31, hi = lane >> 5),
+// register r <-> output channel j*32 + 8*(r>>2) + 4*hi + (r&3).  Register pair q (r = 2q, 2q+1) <->
+// channels j*32 + 8*(q>>1) + 4*hi + 2*(q&1) + {0,1}; pairs 2g, 2g+1 make a 4-channel group = one 8-byte store.
+// Sub-item E: one register pair (no pool: 2*2*8 = 32 ... of both rows: 64; pool: 16).
+template <bool POOL, int E>
+__device__ __forceinline__ void epi_item(const Epi &e, Hold &hold, const f32x16 (&acc)[2][2]) {
+  constexpr int NEPI = (POOL ? 1 : 2) * 2 * 8;
+  if constexpr (E >= 0 && E < NEPI) {
+    constexpr int q = E % 8, j = (E / 8) % 2, i = POOL ? 0 : E / 16;
+    float v0 = acc[i][j][2 * q], v1 = acc[i][j][2 * q + 1];
+    if constexpr (POOL) {
+      v0 = __builtin_fmaxf(v0, acc[1][j][2 * q]);
+      v1 = __builtin_fmaxf(v1, acc[1][j][2 * q + 1]);
+      v0 = __builtin_fmaxf(__builtin_fmaxf(v0, dpp_xor1(v0)), 0.0f);
+      v1 = __builtin_fmaxf(__builtin_fmaxf(v1, dpp_xor1(v1)), 0.0f);
+    } else {
+      v0 = __builtin_fmaxf(v0, 0.0f);
+      v1 = __builtin_fmaxf(v1, 0.0f);
+    }
+    const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v0, v1}, bf16x2));
+    if constexpr ((q & 1) == 0) {
+      hold.h16 = pk;
+    } else {
+      constexpr unsigned cb = (unsigned)(j * 32 + 8 * (q >> 1)) * 2u;
+      const u32x2 d = {hold.h16, pk};
+      if (WS_ABLATE != 5) __builtin_amdgcn_raw_buffer_store_b64(d, e.rout, e.rowoff[i] + cb, 0, 0);
+      else if (pk == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b64(d, e.rout, e.rowoff[i] + cb, 0, 0);
+    }
+  }
+}
+
+// One consumer K step: MT x NT = 2 x 2 MFMAs; in their shadows the operand fragments of step S + 2
+// (ring of three) and sub-items of the previous tile's epilogue.
+template <int S, bool POOL, int BUF>
+__device__ __forceinline__ void k_steps(bf16x8 (&a)[3][2], bf16x8 (&w)[3][2], f32x16 (&acc)[2][2],
+                                        const f32x16 (&accPrev)[2][2], const f32x16 (&biasfrag)[2],
+                                        lds_char *const (&aptr)[3][4], lds_char *const (&wptr)[2][4],
+                                        const Epi &ePrev, Hold &hold) {
+  if constexpr (S < NSTEP) {
+    constexpr int cur = S % 3, nxt = (S + 2) % 3;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if (m == 0) {
+        if constexpr (S + 2 < NSTEP && WS_ABLATE != 4) {
+          constexpr int s2 = S + 2, chunk = s2 / 18, tap = (s2 % 18) / 2, kk = chunk * 2 + (s2 % 2);
+          constexpr int dy = tap / 3, dx = tap % 3, hiw = tap >= 7 ? 1 : 0;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) a[nxt][i] = lds_read(aptr[dx][kk], BUF * HALO_BYTES + (i + dy) * ROW_BYTES);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) w[nxt][j] = lds_read(wptr[hiw][kk], (tap - 7 * hiw) * 8192 + j * 4096);
+        }
+      }
+      if constexpr (POOL) {  // 16 sub-items: one every second step
+        if (m == 2) {
+          if constexpr (S >= 2 && S % 2 == 0) epi_item<POOL, (S - 2) / 2>(ePrev, hold, accPrev);
+        }
+      } else {               // 64 sub-items: two per step
+        if (m == 1) {
+          if constexpr (S >= 2) epi_item<POOL, (S - 2) * 2>(ePrev, hold, accPrev);
+        }
+        if (m == 3) {
+          if constexpr (S >= 2) epi_item<POOL, (S - 2) * 2 + 1>(ePrev, hold, accPrev);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const int i = m / 2, j = m % 2;
+        if constexpr (S == 0)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[cur][j], a[cur][i], biasfrag[j], 0, 0, 0);
+        else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[cur][j], a[cur][i], acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    k_steps<S + 1, POOL, BUF>(a, w, acc, accPrev, biasfrag, aptr, wptr, ePrev, hold);
+  }
+}
+
+struct TileDesc {
+  int b, ty, tx, valid;
+};
+
+// in: NHWC bf16 [B][H][W][in_stride]; wpack: [nblk][tap 9][cout 64][8 pieces, piece g at slot g ^ ((cout >> 1) & 7)][8 bf16];
+// out: NHWC bf16.  p.tile_ctr: nblk * 8 counters, zeroed before the launch.
+template <bool POOL>
+__global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_ws[];
+  lds_char *const lds = (lds_char *)smem_ws;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xcd = blockIdx.x & 7;
+  const int nb = (int)(blockIdx.x >> 3) % p.nblk;
+  const int per_nb = p.tiles_x * p.tiles_y * p.B;
+  const int t_lo = (int)((long)per_nb * xcd / 8), t_cnt = (int)((long)per_nb * (xcd + 1) / 8) - t_lo;
+  const int Ho = POOL ? p.H >> 1 : p.H, Wo = POOL ? p.W >> 1 : p.W;
+  const unsigned in_pix_bytes = (unsigned)p.in_stride * 2u;
+  [[maybe_unused]] const unsigned frame_in_bytes = (unsigned)p.H * p.W * in_pix_bytes;
+  const unsigned out_pix_bytes = (unsigned)p.out_stride * 2u;
+  const unsigned frame_out_bytes = (unsigned)Ho * Wo * out_pix_bytes;
+
+  auto read_slot = [&](int k) -> TileDesc {
+    const i32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) i32x4 *>(lds + LDS_SLOT + k * 16);
+    TileDesc d;
+    d.b = __builtin_amdgcn_readfirstlane(v.x);
+    d.ty = __builtin_amdgcn_readfirstlane(v.y);
+    d.tx = __builtin_amdgcn_readfirstlane(v.z);
+    d.valid = __builtin_amdgcn_readfirstlane(v.w);
+    return d;
+  };
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ producers
+    const int pw = wave - 4;
+    int *ctr = p.tile_ctr + nb * 8 + xcd;
+    auto fetch = [&]() -> int {  // next tile of this (XCD, block) queue, or -1
+      int v = 0;
+      if (lane == 0) v = atomicAdd(ctr, 1);
+      v = __builtin_amdgcn_readfirstlane(v);
+      return v < t_cnt ? t_lo + v : -1;
+    };
+    auto publish = [&](int k, int tile) {  // decode + write descriptor k (wave 4 only)
+      i32x4 d = {0, 0, 0, 0};
+      if (tile >= 0) {
+        int q = tile;
+        d.z = q % p.tiles_x; q /= p.tiles_x;
+        d.y = q % p.tiles_y; d.x = q / p.tiles_y;
+        d.w = 1;
+      }
+      if (lane == 0) *reinterpret_cast<__attribute__((address_space(3))) i32x4 *>(lds + LDS_SLOT + k * 16) = d;
+    };
+    // per-lane geometry of this wave's halo pieces: pass `it` covers LDS pieces (it * 4 + pw) * 64 + lane
+    int prow[HALO_IT], pcol[HALO_IT];
+    unsigned pj16[HALO_IT];
+#pragma unroll
+    for (int it = 0; it < HALO_IT; ++it) {
+      const int q = (it * 4 + pw) * 64 + lane;
+      const int r = q / (COLS * 8), rem = q % (COLS * 8), c = rem >> 3, slot = rem & 7;
+      prow[it] = q < HALO_PIECES ? r - 1 : (1 << 20);
+      pcol[it] = c - 1;
+      pj16[it] = (unsigned)(slot ^ ((c >> 1) & 7)) * 16u;
+    }
+    auto load_halo = [&](const TileDesc &d, int buf) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      const char *base = reinterpret_cast<const char *>(p.in) + ((size_t)(WS_ABLATE == 3 ? 0 : d.b) * p.H * p.W * p.in_stride + p.in_choff) * 2;
+      const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, frame_in_bytes, 0x00020000);
+      const int y0 = WS_ABLATE == 3 ? 8 : d.ty * TH, x0 = WS_ABLATE == 3 ? 32 : d.tx * 32;
+#pragma unroll
+      for (int it = 0; it < HALO_IT; ++it) {
+        const int k = it * 4 + pw;
+        if (k < HALO_INSTR) {
+          const int gy = y0 + prow[it], gx = x0 + pcol[it];
+          const unsigned voff = ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+                                    ? (unsigned)(gy * p.W + gx) * in_pix_bytes + pj16[it]
+                                    : OOB;
+          if (k * 64 + lane < HALO_PIECES)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void *)(lds + buf * HALO_BYTES + k * 1024), 16, voff, 0, 0, 0);
+        }
+      }
+#endif
+    };
+
+    if (pw == 0) {
+      const int i0 = fetch();
+      const int i1 = i0 >= 0 ? fetch() : -1;
+      publish(0, i0);
+      publish(1, i1);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    wg_barrier();                        // barrier #0: descriptors 0 and 1 are published
+    TileDesc cur = read_slot(0);
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+      const char *wb = reinterpret_cast<const char *>(p.wpack) + (size_t)nb * W_BYTES;
+      const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wb), 0, (unsigned)W_BYTES, 0x00020000);
+      if (cur.valid) {
+#pragma unroll
+        for (int it = 0; it < W_INSTR / 4; ++it) {
+          const int k = it * 4 + pw;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(lds + LDS_W + k * 1024), 16, (unsigned)(k * 1024 + lane * 16), 0, 0, 0);
+        }
+        load_halo(cur, 0);
+      }
+#endif
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    wg_barrier();                        // barrier #1: weights and tile 0 are in LDS
+    int t = 0;
+#ifdef WS_PROBE_TIMING
+    unsigned long long pt_issue = 0, pt_wait = 0, pt_bar = 0;
+    WS_T(pt_begin);
+#endif
+    while (cur.valid) {
+      WS_T(p0);
+      const TileDesc nxt = read_slot((t + 1) % 3);
+      if (WS_ABLATE != 1 && nxt.valid) load_halo(nxt, (t + 1) & 1);
+      int i2 = -1;
+      WS_T(p1);
+      if (pw == 0 && nxt.valid) i2 = fetch();  // behind the passes: its round trip hides under theirs
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the next tile has landed
+      WS_T(p2);
+      if (pw == 0) publish((t + 2) % 3, i2);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      wg_barrier();                      // end of tile t
+      WS_T(p3);
+#ifdef WS_PROBE_TIMING
+      pt_issue += p1 - p0; pt_wait += p2 - p1; pt_bar += p3 - p2;
+#endif
+      cur = nxt;
+      ++t;
+    }
+#ifdef WS_PROBE_TIMING
+    if (pw == 0) {
+      WS_T(pt_end);
+      WS_ACC(4, pt_end - pt_begin); WS_ACC(5, pt_issue); WS_ACC(6, pt_wait); WS_ACC(7, pt_bar);
+    }
+#endif
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumers
+  __builtin_amdgcn_s_setprio(WS_PRIO);
+  const int l31 = lane & 31, hi = lane >> 5, wm = wave;
+  lds_char *aptr[3][4], *wptr[2][4];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int c = dx + l31;
+      aptr[dx][kk] = lds + (wm * 2) * ROW_BYTES + c * 128 + (((kk * 2 + hi) ^ ((c >> 1) & 7)) * 16);
+    }
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    wptr[0][kk] = lds + LDS_W + l31 * 128 + (((kk * 2 + hi) ^ ((l31 >> 1) & 7)) * 16);
+    wptr[1][kk] = wptr[0][kk] + 7 * 8192;
+  }
+  f32x16 biasfrag[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 b4 = *reinterpret_cast<const float4 *>(p.bias + nb * 64 + j * 32 + 8 * g + 4 * hi);
+      biasfrag[j][4 * g] = b4.x; biasfrag[j][4 * g + 1] = b4.y; biasfrag[j][4 * g + 2] = b4.z; biasfrag[j][4 * g + 3] = b4.w;
+    }
+
+  f32x16 accA[2][2], accB[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accA[i][j][r] = 0.0f; accB[i][j][r] = 0.0f; }
+  Epi epiA, epiB;
+  epiA.rout = epiB.rout = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0u, 0x00020000);  // nothing to store yet
+  epiA.rowoff[0] = epiA.rowoff[1] = epiB.rowoff[0] = epiB.rowoff[1] = OOB;
+  Hold hold;
+  hold.h16 = 0u;
+  bf16x8 a[3][2], w[3][2];
+
+  auto aim_epi = [&](const TileDesc &d, Epi &e) {
+    char *obase = reinterpret_cast<char *>(p.out) + ((size_t)d.b * Ho * Wo * p.out_stride + p.out_choff) * 2;
+    e.rout = __builtin_amdgcn_make_buffer_rsrc(obase, 0, frame_out_bytes, 0x00020000);
+    const int y0 = d.ty * TH + wm * 2, x = d.tx * 32 + l31;
+    const unsigned chan = (unsigned)(nb * 64 + 4 * hi) * 2u;
+    if constexpr (POOL) {
+      const bool ok = x < p.W && y0 < p.H && (l31 & 1) == 0;
+      e.rowoff[0] = ok ? (unsigned)((y0 >> 1) * Wo + (x >> 1)) * out_pix_bytes + chan : OOB;
+      e.rowoff[1] = OOB;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        e.rowoff[i] = (x < p.W && y0 + i < p.H) ? (unsigned)((y0 + i) * p.W + x) * out_pix_bytes + chan : OOB;
+    }
+  };
+
+  wg_barrier();  // barrier #0
+  wg_barrier();  // barrier #1: weights and tile 0 are in LDS
+  int t = 0;
+  bool lastA = true, any = false;
+#ifdef WS_PROBE_TIMING
+  unsigned long long ct_bar = 0;
+  WS_T(ct_begin);
+  const unsigned long long wc_begin = wall_clock64();
+#endif
+  auto run_tile = [&]<int BUF>(std::integral_constant<int, BUF>, f32x16(&acc)[2][2], const f32x16(&accPrev)[2][2], Epi &eMine,
+                               const Epi &ePrev) -> bool {
+    const TileDesc d = read_slot(t % 3);
+    if (!d.valid) return false;
+    // K steps 0 and 1: tap 0, k-groups 0 and 1
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[st][i] = lds_read(aptr[0][st], BUF * HALO_BYTES + i * ROW_BYTES);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) w[st][j] = lds_read(wptr[0][st], j * 4096);
+    }
+    aim_epi(d, eMine);
+    if (WS_ABLATE != 2) k_steps<0, POOL, BUF>(a, w, acc, accPrev, biasfrag, aptr, wptr, ePrev, hold);
+    WS_T(c0);
+    wg_barrier();  // end of tile t: every consumer is done with this halo buffer, the next one has landed
+    WS_T(c1);
+#ifdef WS_PROBE_TIMING
+    ct_bar += c1 - c0;
+#endif
+    ++t;
+    return true;
+  };
+  while (true) {
+    if (!run_tile(std::integral_constant<int, 0>{}, accA, accB, epiA, epiB)) break;
+    lastA = true; any = true;
+    if (!run_tile(std::integral_constant<int, 1>{}, accB, accA, epiB, epiA)) break;
+    lastA = false;
+  }
+#ifdef WS_PROBE_TIMING
+  if (wm == 0) {
+    WS_T(ct_end);
+    WS_ACC(0, ct_end - ct_begin); WS_ACC(1, ct_bar); WS_ACC(2, t);
+    WS_ACC(3, wall_clock64() - wc_begin);  // constant-rate counter (100 MHz): [0] / [3] = shader clock
+  }
+#endif
+  if (any) {
+    constexpr int NEPI = (POOL ? 1 : 2) * 16;
+    auto flush = [&](const f32x16(&acc)[2][2], const Epi &e) {
+      [&]<int... E>(std::integer_sequence<int, E...>) {
+        (epi_item<POOL, E>(e, hold, acc), ...);
+      }(std::make_integer_sequence<int, NEPI>{});
+    };
+    if (lastA) flush(accA, epiA); else flush(accB, epiB);
+  }
+}
+
+template <bool POOL>
+static hipError_t launch(const ConvParams &p, hipStream_t s) {
+  static_assert(LDS_TOTAL <= 160 * 1024, "halo double buffer + resident weights must fit the 160 KB LDS");
+  auto k = conv_bf16_ws_kernel<POOL>;
+  static bool attr_done[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64) attr_done[dev] = true;
+  }
+  int grid = p.num_cus > 0 ? p.num_cus : 256;
+  grid &= ~15;  // a multiple of 8 XCDs x (up to) 2 channel blocks
+  if (grid < 16) grid = 16;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), LDS_TOTAL, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace ws
+
+size_t conv_bf16_ws_weight_bytes() { return ws::W_BYTES; }
+
+// cin = 64 only; p.tile_ctr: >= nblk * 8 ints, zero on entry (the kernel leaves them non-zero)
+hipError_t launch_conv_bf16_ws(const ConvParams &p, bool pool, hipStream_t s) {
+  if (!p.tile_ctr || p.nblk < 1 || p.nblk > 2) return hipErrorInvalidValue;
+  return pool ? ws::launch<true>(p, s) : ws::launch<false>(p, s);
+}
+
+}  // namespace spfe

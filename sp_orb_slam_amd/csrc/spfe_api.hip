@@ -116,6 +116,9 @@ struct spfe_handle_s {
   int m_host_cap = 0;              // rows the host-API staging blocks / m_out hold
   unsigned tile16_mask = 0;  // f32 layers (bit i = conv layer i of enqueue()) on 16-row / 8-wave tiles
   bool fuse1a = false;  // f32: conv1a computed inside conv1b (opt-in: SPFE_FUSE_CONV1A=1; measured perf-neutral)
+  unsigned ws_mask = 1u;    // bf16 layers (bit i = conv layer i of enqueue(), Cin = 64 only) on the wave-specialised kernel
+  unsigned char *d_wws[4] = {};  // their weights in conv_bf16_ws.hip's layout
+  int *d_tile_ctr = nullptr;     // [4 layers][16] tile-queue counters, zeroed once per enqueue()
   bool bf16 = false;  // SPFE_PRECISION_BF16: bf16 conv stack (conv1a .. convPa/Da), f32 heads and tail
   // per-stage timing: a ring of event sets, one set per enqueue() call
   bool timing = false;
@@ -260,6 +263,26 @@ int pack_layer_bf16(spfe_handle h, const float *blob, const int *lids, int nl, C
   return SPFE_OK;
 }
 
+// conv_bf16_ws.hip layout: [nblk][tap][cout 64][8 pieces of 8 cin, piece g in slot g ^ ((cout >> 1) & 7)]
+int pack_layer_bf16_ws(spfe_handle h, const float *blob, int lid, unsigned char **out) {
+  const spfe_layer_t &L = SPFE_LAYERS[lid];
+  if (L.cin != 64 || L.ksize != 3 || L.cout % 64) return fail(SPFE_EINVAL, "internal: layer %d is not a Cin = 64 3x3 layer", lid);
+  const size_t blk = spfe::conv_bf16_ws_weight_bytes();
+  std::vector<unsigned char> w((size_t)(L.cout / 64) * blk, 0);
+  const float *W = blob + blob_weight_offset(lid);
+  for (int co = 0; co < L.cout; ++co)
+    for (int ci = 0; ci < 64; ++ci)
+      for (int t = 0; t < 9; ++t) {
+        const unsigned short v = host_bf16_rne(W[((size_t)co * 64 + ci) * 9 + t]);
+        const int j = co % 64, slot = (ci / 8) ^ ((j >> 1) & 7);
+        memcpy(&w[(size_t)(co / 64) * blk + ((size_t)t * 64 + j) * 128 + slot * 16 + (ci % 8) * 2], &v, 2);
+      }
+  int rc;
+  if ((rc = dev_alloc(h, out, w.size()))) return rc;
+  HIP_TRY(hipMemcpy(*out, w.data(), w.size(), hipMemcpyHostToDevice));
+  return SPFE_OK;
+}
+
 int load_blob(const spfe_config *cfg, std::vector<float> *blob) {
   blob->resize(SPFE_NUM_PARAMS);
   if (cfg->weights) {
@@ -311,6 +334,8 @@ int build(spfe_handle h, const spfe_config *cfg) {
     h->fuse1a = fenv && atoi(fenv) != 0;
     const char *menv = getenv("SPFE_TILE16_MASK");
     if (menv) h->tile16_mask = (unsigned)strtoul(menv, nullptr, 0);
+    const char *wenv = getenv("SPFE_BF16_WS_MASK");
+    if (wenv) h->ws_mask = (unsigned)strtoul(wenv, nullptr, 0) & 0xfu;
   }
   const char *tenv = getenv("SPFE_STAGE_TIMING");
   h->timing = tenv && atoi(tenv) != 0;
@@ -418,6 +443,12 @@ int build(spfe_handle h, const spfe_config *cfg) {
     L.in = h->d_head; L.in_stride = 512; L.in_choff = 256;
     L.out = h->d_coarse; L.out_stride = SPFE_DESC_DIM; L.out_choff = 0;
   }
+  if (h->bf16) {  // Cin = 64 layers selected for the wave-specialised kernel (conv1b by default)
+    for (int i = 0; i < 4; ++i)
+      if ((h->ws_mask >> i) & 1)
+        if ((rc = pack_layer_bf16_ws(h, blob.data(), specs[i].l0, &h->d_wws[i]))) return rc;
+    if ((rc = dev_alloc(h, &h->d_tile_ctr, 4 * 16))) return rc;
+  }
   if (h->bf16) {  // descriptor head in bf16: convDa writes bf16, convDb is head_bf16.hip's GEMM
     if ((rc = dev_alloc(h, &h->d_da, (size_t)B * C * 256))) return rc;
     const spfe_layer_t &Ld = SPFE_LAYERS[11];
@@ -453,6 +484,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   if (h->timing) h->ev = h->evpool.data() + (size_t)(h->calls % spfe_handle_s::EVSETS) * (NSTAGE + 1);
   h->calls++;
   STAGE_MARK(0);
+  if (h->bf16 && h->ws_mask) HIP_TRY(hipMemsetAsync(h->d_tile_ctr, 0, 4 * 16 * sizeof(int), s));
   const bool fused = !h->bf16 && h->fuse1a;  // f32: conv1b computes conv1a's outputs itself
   if (h->bf16) HIP_TRY(spfe::launch_conv1a_bf16(d_images, h->d_w1a, h->d_b1a, h->act[0], n, H, W, s));
   else if (!fused) HIP_TRY(spfe::launch_conv1a(d_images, h->d_w1a, h->d_b1a, h->act[0], n, H, W, s));
@@ -467,7 +499,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     p.wpack = L.d_w; p.bias = L.d_b;
     p.out = L.out; p.out_stride = L.out_stride; p.out_choff = L.out_choff; p.cout_real = L.cout_real;
     p.B = n; p.H = L.H; p.W = L.W;
-    p.img = nullptr; p.w1a = nullptr; p.b1a = nullptr;
+    p.img = nullptr; p.w1a = nullptr; p.b1a = nullptr; p.tile_ctr = nullptr;
     if (i == 0 && fused) { p.img = d_images; p.w1a = h->d_w1a; p.b1a = h->d_b1a; }
     // tile height per layer and batch: 8-row tiles do 4 MFMAs per K step and wave
     // (better hidden side work), 4-row tiles give twice the work items; pick the
@@ -476,6 +508,13 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
       // bf16 stack: 8-row tiles only; convPa/Da (i == 7) write f32 for the f32 heads
       p.tiles_x = (L.W + 31) / 32; p.tiles_y = (L.H + 7) / 8; p.nblk = L.nblk;
       p.num_cus = h->num_cus;
+      if (i < 4 && h->d_wws[i]) {
+        p.wpack = reinterpret_cast<const float *>(h->d_wws[i]);
+        p.tile_ctr = h->d_tile_ctr + 16 * i;
+        HIP_TRY(spfe::launch_conv_bf16_ws(p, L.pool, s));
+        STAGE_MARK(2 + i);
+        continue;
+      }
       if (i == 7) {
         // convPa -> f32 (the detector head stays f32), convDa -> bf16 (the descriptor head is bf16 too)
         const size_t half_w = (size_t)4 * (L.cin / 32) * spfe::conv_bf16_slab_bytes();
@@ -773,6 +812,7 @@ long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size
   const size_t C = h->C, HW = (size_t)h->H * h->W;
   const void *src = nullptr;
   size_t bytes = 0;
+  bool bf16_src = false;
   std::string nm(name);
   if (nm == "semi") { src = h->d_semi + frame * C * SPFE_SEMI_CH; bytes = C * SPFE_SEMI_CH * 4; }
   else if (nm == "coarse") { src = h->d_coarse + frame * C * SPFE_DESC_DIM; bytes = C * SPFE_DESC_DIM * 4; }
@@ -782,7 +822,7 @@ long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size
   else if (nm == "heat" && h->d_heat) { src = h->d_heat + frame * HW; bytes = HW * 4; }
   else if (nm == "image") { src = h->d_img + frame * HW; bytes = HW; }
   else if (nm == "cell_score") { src = h->d_cell_score + frame * C; bytes = C * 4; }
-  else if (nm == "feat") { src = h->act[7] + frame * C * 128; bytes = C * 128 * 4; }
+  else if (nm == "feat") { src = h->act[7] + frame * C * 128; bytes = C * 128 * 4; bf16_src = h->bf16; }
   else if (nm.size() == 4 && nm.compare(0, 3, "act") == 0 && nm[3] >= '0' && nm[3] <= '7') {
     const int i = nm[3] - '0';
     if (i == 0 && !h->bf16 && h->fuse1a)
@@ -790,11 +830,27 @@ long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size
     const int lh[8] = {1, 2, 2, 4, 4, 8, 8, 8};
     const int lc[8] = {64, 64, 64, 64, 128, 128, 128, 128};
     const size_t per = (size_t)(h->H / lh[i]) * (h->W / lh[i]) * lc[i];
-    src = h->act[i] + frame * per; bytes = per * 4;
+    src = h->act[i] + frame * per; bytes = per * 4; bf16_src = h->bf16;
   } else return fail(SPFE_EINVAL, "unknown debug buffer '%s'", name);
   if (bytes > cap) return fail(SPFE_EINVAL, "buffer '%s' needs %zu bytes, cap %zu", name, bytes, cap);
+  // both streams: with SPFE_FLAG_ASYNC_COV heat / heat_inv are written on the side stream
   if (hipSetDevice(h->cfg.device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess ||
-      hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+      hipStreamSynchronize(h->side) != hipSuccess)
+    return fail(SPFE_EHIP, "debug read of '%s' failed", name);
+  if (bf16_src) {
+    // bf16 mode keeps the conv stack's activations as bf16 NHWC (half the elements' bytes, the frame offset
+    // in bf16 elements): read them as such and widen to the f32 the caller expects
+    const size_t n = bytes / 4;
+    std::vector<unsigned short> tmp(n);
+    const unsigned short *bsrc = reinterpret_cast<const unsigned short *>(
+        nm == "feat" ? (const void *)h->act[7] : (const void *)h->act[nm[3] - '0']) + (size_t)frame * n;
+    if (hipMemcpy(tmp.data(), bsrc, n * 2, hipMemcpyDeviceToHost) != hipSuccess)
+      return fail(SPFE_EHIP, "debug read of '%s' failed", name);
+    uint32_t *d32 = reinterpret_cast<uint32_t *>(dst);
+    for (size_t k = 0; k < n; ++k) d32[k] = (uint32_t)tmp[k] << 16;
+    return (long)bytes;
+  }
+  if (hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) != hipSuccess)
     return fail(SPFE_EHIP, "debug read of '%s' failed", name);
   return (long)bytes;
 }

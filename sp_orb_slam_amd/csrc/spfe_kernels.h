@@ -24,6 +24,8 @@ struct ConvParams {
   // `in` is then unused
   const uint8_t *img;
   const float *w1a, *b1a;
+  // conv_bf16_ws.hip: nblk * 8 tile counters (one per XCD and 64-channel block), zero before the launch
+  int *tile_ctr;
 };
 
 // cin: 64/128/256; ksize: 3 or 1; pool/relu: fused epilogue; small_tile: 4-row
@@ -38,6 +40,10 @@ int conv_tile_rows(int tile_mode);
 // elements; wpack = bf16 slabs of conv_bf16_slab_bytes() each, [nblk][chunk of 32 ch][tap][64][80 B]
 hipError_t launch_conv_bf16(const ConvParams &p, int cin, bool pool, bool out_f32, hipStream_t s);
 size_t conv_bf16_slab_bytes();
+// wave-specialised variant for the Cin = 64 layers (conv_bf16_ws.hip): wpack = conv_bf16_ws_weight_bytes() per
+// 64-channel block, [nblk][tap][cout 64][8 x 16-byte pieces, piece g in slot g ^ ((cout >> 1) & 7)]
+hipError_t launch_conv_bf16_ws(const ConvParams &p, bool pool, hipStream_t s);
+size_t conv_bf16_ws_weight_bytes();
 hipError_t launch_conv1a_bf16(const uint8_t *img, const float *w9x64, const float *b64, void *out, int B, int H,
                               int W, hipStream_t s);
 

@@ -177,9 +177,12 @@ class ShardedExtractor:
         import torch
 
         if not self._collective:
+            # no gather: `gathered` is this rank's own buffer.  Its completion point still has to be an
+            # event: decode() copies on torch's CURRENT stream, which is not ordered after `stream`
             self.ext.wait_records(ticket, stream.cuda_stream)
-            self.gathered = self.local[k]
-            self._gathered_event = None
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            self.gathered, self._gathered_event = self.local[k], ev
             return
         out = self.all[self._gathers % 2]
         self._gathers += 1

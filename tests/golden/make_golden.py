@@ -18,7 +18,7 @@ missing), so these fixtures are NOT outputs of the reference: parity stays
 (layouts, channel<->pixel mapping, tie rules, sampling coordinates) against
 ATen's implementation of each op.
 
-Usage: python tests/golden/make_golden.py   (writes tests/golden/*.npz)
+Usage: python tests/golden/make_golden.py [case ...]   (writes tests/golden/*.npz)
 """
 import os
 import sys
@@ -36,68 +36,7 @@ torch.set_num_threads(8)
 torch.backends.mkldnn.enabled = True
 
 
-def forward(named, img_u8):
-    """SPFrontend::forward (:79-159) + input conversion (:388), ATen-CPU, NCHW."""
-    H, W = img_u8.shape
-    hc, wc = H // 8, W // 8
-    t = {k: torch.from_numpy(v) for k, v in named.items()}
-    x = torch.from_numpy(img_u8.astype(np.float32) * np.float32(1.0 / 255.0))[None, None]
-
-    def conv(name, x, pad):
-        return F.conv2d(x, t[name + ".weight"], t[name + ".bias"], stride=1, padding=pad)
-
-    x = torch.relu(conv("conv1a", x, 1))
-    x = torch.relu(conv("conv1b", x, 1))
-    x = F.max_pool2d(x, 2, 2)
-    x = torch.relu(conv("conv2a", x, 1))
-    x = torch.relu(conv("conv2b", x, 1))
-    x = F.max_pool2d(x, 2, 2)
-    x = torch.relu(conv("conv3a", x, 1))
-    x = torch.relu(conv("conv3b", x, 1))
-    x = F.max_pool2d(x, 2, 2)
-    x = torch.relu(conv("conv4a", x, 1))
-    x = torch.relu(conv("conv4b", x, 1))
-    cPa = torch.relu(conv("convPa", x, 1))
-    semi = conv("convPb", cPa, 0).squeeze()
-    cDa = torch.relu(conv("convDa", x, 1))
-    coarse_raw = conv("convDb", cDa, 0)
-    dn = torch.norm(coarse_raw, 2, 1)
-    coarse = coarse_raw.div(torch.unsqueeze(dn, 1))
-
-    dense = torch.softmax(semi, 0)
-    semi_dust = semi[-1]
-    dense_dust = dense[-1]
-    nodust = dense[:-1]
-    score, indices = nodust.max(0)
-
-    # `grid` of the SPFrontend ctor (:64-73)
-    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
-    grid_ = torch.cat([xx.unsqueeze(0), yy.unsqueeze(0)])
-    grid = (grid_.contiguous().view(1, 2, H // 8, 8, W // 8, 8)
-            .permute(0, 1, 3, 5, 2, 4).reshape(1, 2, 64, hc, wc))
-    idx = indices.view(1, 1, 1, hc, wc).expand(-1, 2, -1, -1, -1)
-    pixel = torch.gather(grid, 2, idx)
-
-    mask = score >= 0.007
-    pixels_in = torch.masked_select(pixel, mask).reshape(2, -1).type_as(semi)
-    score_sel = torch.masked_select(score, mask)
-
-    heat_log = F.pixel_shuffle(torch.log(torch.clamp(nodust, 0.001)).unsqueeze(0), 8)
-
-    x_s = pixels_in[0].div(W / 2.0) - 1.0
-    y_s = pixels_in[1].div(H / 2.0) - 1.0
-    samp = torch.cat([x_s.unsqueeze(-1), y_s.unsqueeze(-1)], -1).unsqueeze(0).unsqueeze(0)
-    n = pixels_in.shape[1]
-    if n > 0:
-        desc = torch.grid_sampler_2d(coarse, samp, 0, 0, True).squeeze(2).squeeze(0)  # [256, N]
-        desc = desc.div(torch.norm(desc, 2, 0, True))
-    else:
-        desc = torch.zeros(256, 0)
-    return dict(semi=semi.permute(1, 2, 0).contiguous().numpy(),          # [hc,wc,65]
-                coarse_raw=coarse_raw[0].permute(1, 2, 0).contiguous().numpy(),  # [hc,wc,256]
-                semi_dust=semi_dust.numpy().copy(), dense_dust=dense_dust.numpy().copy(),
-                pixels_in=pixels_in.numpy().copy(), score=score_sel.numpy().copy(),
-                desc=desc.numpy().T.copy(), heat_log=heat_log[0, 0].numpy().copy())
+from tools.aten_path import forward  # noqa: E402  (the ATen op sequence; shared with bench.py)
 
 
 def to_heat(heat_log):
@@ -210,11 +149,15 @@ CASES = [
     ("g128x160_sparse", 128, 160, 5, 11, "sparse", 200, True),
     ("g480x752_dense", 480, 752, 100, 7, "dense", 1000, False),
     ("g480x640_sparse", 480, 640, 1, 7, "sparse", 1000, False),
+    ("g720x1280_sparse", 720, 1280, 300, 7, "sparse", 1000, False),   # BASELINE configs[3] size
 ]
 
 
 def main():
+    only = set(sys.argv[1:])   # optional: names of the cases to (re)generate
     for name, H, W, iseed, wseed, det, nf, full in CASES:
+        if only and name not in only:
+            continue
         img = synth.make_image(iseed, H, W)
         blob = weights.synthetic(wseed, det)
         out = extract(weights.to_named_tensors(blob), img, nf)

@@ -35,6 +35,7 @@ class Mat {
     if (dst.rows != rows || dst.cols != cols || dst.type_ != type_ || !dst.data) dst.create(rows, cols, type_);
     for (int y = 0; y < rows; ++y) std::memcpy(dst.data + y * dst.step, data + y * step, (size_t)cols * elemSize_(type_));
   }
+  Mat clone() const { Mat m; copyTo(m); return m; }
   template <class T> T &at(int y, int x) { return *reinterpret_cast<T *>(data + y * step + x * sizeof(T)); }
  private:
   int type_ = 0;
@@ -42,6 +43,10 @@ class Mat {
 };
 
 struct Point2f { float x = 0, y = 0; };
+
+}  // namespace cv
+inline int cvRound(double v) { return (int)__builtin_lrint(v); }
+namespace cv {
 
 class KeyPoint {
  public:

@@ -12,8 +12,13 @@ from sp_orb_slam_amd.extractor import SPExtractor
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_ATOL = 3e-2      # bf16 activations: 8 mantissa bits, 10 layers
-LOGIT_MEAN = 2e-3
+# bf16 activations (8 mantissa bits) through 10 layers.  Measured with tools/bf16_logit_error.py, GPU vs the
+# oracle's bf16 emulation (same rounding points, different summation order inside a dot product): max / scale
+# 0.002-0.004, mean / scale 0.0005-0.0010, and 0.0019-0.0022 on the sparse-detector case whose logit scale is
+# set by the detector bias — against 0.0018-0.0055 for the bf16 emulation vs the f32 network, i.e. the
+# kernel sits well inside the precision step it is allowed.  A wrong tap / channel / tile shows as >= 1e-1.
+LOGIT_ATOL = 1e-2
+LOGIT_MEAN = 3e-3
 DESC_COS_MIN = 0.999   # descriptors of keypoints found by both paths
 
 
@@ -70,6 +75,60 @@ def test_bf16_vs_f32_path_720p():
         x, y = fr.kp_xy[:, 0].astype(int), fr.kp_xy[:, 1].astype(int)
         assert np.all(np.diff(y * W + x) > 0) and fr.K <= nf + 1
         assert np.array_equal(fr.occ_grid.reshape(-1)[(y // 8) * (W // 8) + x // 8], np.arange(fr.K))
+
+
+def test_bf16_720p_batch8_logits_and_invariants():
+    """BASELINE configs[3] as written: 1280x720, batch 8.  Frame 0 and frame 7 of the batch: logits against
+    the oracle's bf16 emulation at 720p; every frame: everything after the network is the f32 code, exact
+    given the GPU's own logits; batch results equal single-frame results."""
+    H, W, nf, B = 720, 1280, 1000, 8
+    blob = weights.synthetic(7, "sparse")
+    imgs = [synth.make_image(300 + i, H, W) for i in range(B)]
+    ext = SPExtractor(nf, H, W, blob, max_batch=B, precision="bf16", with_heat=False)
+    frs = ext.extract_batch(imgs)
+    semis = [ext.debug_read("semi", i) for i in range(B)]
+    coarses = [ext.debug_read("coarse", i) for i in range(B)]
+    ext.close()
+    for i in (0, B - 1):
+        rsemi, rcoarse = oracle.network_bf16(blob, imgs[i])
+        d = np.abs(semis[i] - rsemi)
+        assert d.max() <= LOGIT_ATOL * max(1.0, np.abs(rsemi).max()) and d.mean() <= LOGIT_MEAN * max(1.0, np.abs(rsemi).mean())
+        dc = np.abs(coarses[i] - rcoarse)
+        assert dc.max() <= LOGIT_ATOL * max(1.0, np.abs(rcoarse).max()) and dc.mean() <= LOGIT_MEAN * max(1.0, np.abs(rcoarse).mean())
+    for i in range(B):
+        ref = oracle.postprocess(semis[i], coarses[i], H, W, nf)
+        fr = frs[i]
+        assert fr.K == ref["K"] and np.array_equal(fr.kp_xy, ref["kp_xy"]) and np.array_equal(fr.occ_grid, ref["occ_grid"])
+        assert np.array_equal(fr.descriptors.view(np.uint32), ref["desc"].view(np.uint32))
+        assert np.array_equal(fr.cov2_inv.view(np.uint32), ref["cov2_inv"].view(np.uint32))
+    e1 = SPExtractor(nf, H, W, blob, precision="bf16", with_heat=False)
+    for i in (3, 6):
+        e1(imgs[i], None)
+        assert e1.last.K == frs[i].K and np.array_equal(e1.last.kp_xy, frs[i].kp_xy)
+        assert np.array_equal(e1.last.descriptors, frs[i].descriptors)
+    e1.close()
+
+
+def test_bf16_ws_kernel_equals_single_role_kernel(monkeypatch):
+    """conv_bf16_ws.hip (wave-specialised, the default for conv1b) against conv_bf16.hip's kernel on every
+    Cin = 64 layer: same K order, only the bias enters first, so activations may differ in the last bf16 bit
+    on a handful of outputs — logits agree to 1e-2 of the logit scale and the keypoint sets nearly coincide."""
+    H, W, nf = 240, 376, 400
+    blob = weights.synthetic(7, "dense")
+    imgs = [synth.make_image(80 + i, H, W) for i in range(3)]
+    out = {}
+    for mask in ("0", "15"):
+        monkeypatch.setenv("SPFE_BF16_WS_MASK", mask)
+        ext = SPExtractor(nf, H, W, blob, max_batch=3, precision="bf16", with_heat=False)
+        frs = ext.extract_batch(imgs)
+        out[mask] = (frs, [ext.debug_read("semi", i) for i in range(3)])
+        ext.close()
+    for i in range(3):
+        a, b = out["0"][1][i], out["15"][1][i]
+        assert np.abs(a - b).max() <= 1e-2 * max(1.0, np.abs(a).max())
+        ka = {(int(x), int(y)) for x, y in out["0"][0][i].kp_xy}
+        kb = {(int(x), int(y)) for x, y in out["15"][0][i].kp_xy}
+        assert len(ka & kb) / max(1, len(ka | kb)) >= 0.9
 
 
 def test_bf16_batch_equals_single():

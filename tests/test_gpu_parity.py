@@ -165,7 +165,7 @@ def test_bench_config_752x480_1000_keypoints():
 
 
 @pytest.mark.parametrize("name", ["g64x96_dense", "g64x96_sparse", "g128x160_sparse",
-                                  "g480x752_dense", "g480x640_sparse"])
+                                  "g480x752_dense", "g480x640_sparse", "g720x1280_sparse"])
 def test_against_aten_golden(name, golden_dir):
     """HIP path vs the fixtures generated by the ATen-CPU op sequence."""
     g = np.load("%s/%s.npz" % (golden_dir, name))
@@ -341,6 +341,39 @@ def test_cpp_adaptor_matches_python_path(tmp_path):
     ext.close()
 
 
+def test_cpp_dropin_through_base_pointer_matches_python_path(tmp_path):
+    """orbslam::SPExtractor : BaseExtractor, spfe::ExtractorCV (include/orbslam_sp_extractor.hpp), constructed
+    with the reference's 1-argument constructor and driven through a BaseExtractor* + dynamic_cast exactly as
+    tracker.cpp:131 / frame.cpp:296-311 do (tests/cpp/dropin_main.cpp checks GetLevels() == 1, the scale
+    vectors == {1}, getCov2Inv(), occ_grid_, the empty-image exception): same bits as the ctypes path."""
+    import os
+    import subprocess
+    from test_abi import REF_CV_DIR, _build_dropin
+    H, W, nf = 128, 160, 150
+    blob = weights.synthetic(7, "dense")
+    img = synth.make_image(13, H, W)
+    wpath, ipath, opath = tmp_path / "w.spfw", tmp_path / "im.raw", tmp_path / "out.bin"
+    weights.save(wpath, blob)
+    img.tofile(ipath)
+    exe = _build_dropin(tmp_path, os.path.exists(os.path.join(REF_CV_DIR, "base_extractor.h")))
+    subprocess.check_call([exe, str(wpath), str(ipath), str(H), str(W), str(nf), str(opath)])
+    raw = np.fromfile(opath, np.uint8)
+    K = int(raw[:4].view(np.int32)[0])
+    off = 4
+    kp = raw[off:off + K * 20].view(np.float32).reshape(K, 5); off += K * 20
+    desc = raw[off:off + K * 1024].view(np.float32).reshape(K, 256); off += K * 1024
+    C = (H // 8) * (W // 8)
+    occ = raw[off:off + C * 2].view(np.int16).reshape(H // 8, W // 8); off += C * 2
+    dust = raw[off:off + C * 4].view(np.float32).reshape(H // 8, W // 8); off += C * 4
+    heat = raw[off:off + H * W * 4].view(np.float32).reshape(H, W)
+    ref = oracle.extract(blob, img, nf)
+    assert K == ref["K"] and np.array_equal(kp[:, :2], ref["kp_xy"])
+    assert np.array_equal(kp[:, 3:].view(np.uint32), ref["cov2_inv"].view(np.uint32))
+    assert np.array_equal(desc.view(np.uint32), ref["desc"].view(np.uint32))
+    assert np.array_equal(occ, ref["occ_grid"]) and np.array_equal(dust, ref["dense_dust"])
+    assert np.array_equal(heat, ref["heat"]) and np.array_equal(kp[:, 2], ref["response"])
+
+
 def test_python_record_layout_matches_library():
     from sp_orb_slam_amd import parallel
     for (H, W, nf) in [(64, 96, 30), (480, 752, 1000), (720, 1280, 800)]:
@@ -446,4 +479,63 @@ def test_sharded_driver_comm_stream_and_buffer_rotation():
                 assert g.status == 0 and g.K == e.K and np.array_equal(g.kp_xy, e.kp_xy)
                 assert np.array_equal(g.descriptors, e.descriptors) and np.array_equal(g.cov2_inv, e.cov2_inv)
         assert sh.decode(0).K == expect[(nsteps - 1) % 3][0].K
+        ext.close()
+
+
+def test_bench_workload_b8_async_matches_oracle():
+    """The exact workload bench.py times (BASELINE configs[1] sharded like configs[2]): 8 frames of
+    752x480 per call, num_features 1000, device-resident, covariance overlapped with the next call's
+    convolutions, through ShardedExtractor — every record of a pipelined batch against the oracle:
+    keypoints / occ_grid exact, descriptors / cov2 / response bitwise."""
+    import torch
+    from sp_orb_slam_amd import parallel
+    H, W, nf, B = 480, 752, 1000, 8
+    blob = weights.synthetic(7, "dense")
+    frames = synth.make_batch(200, B, H, W)
+    ext = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=False, async_cov=True)
+    sh = parallel.ShardedExtractor(ext, 1, 0, B)
+    d_img = torch.from_numpy(frames).cuda()
+    stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(3):          # the last completed batch has two younger batches' kernels beside it
+        sh.step(d_img, stream)
+    sh.flush(stream)
+    recs = [sh.decode(i) for i in range(B)]   # no global synchronize: decode() orders itself
+    ext.close()
+    for i in range(B):
+        ref = oracle.extract(blob, frames[i], nf)
+        g = recs[i]
+        assert g.status == 0 and g.K == ref["K"] and g.n_candidates == ref["n_candidates"]
+        assert np.array_equal(g.kp_xy, ref["kp_xy"]) and np.array_equal(g.occ_grid, ref["occ_grid"])
+        assert np.array_equal(g.descriptors.view(np.uint32), ref["desc"].view(np.uint32))
+        assert np.array_equal(g.cov2.view(np.uint32), ref["cov2"].view(np.uint32))
+        assert np.array_equal(g.cov2_inv.view(np.uint32), ref["cov2_inv"].view(np.uint32))
+        assert np.array_equal(g.response.view(np.uint32), ref["response"].view(np.uint32))
+
+
+def test_sharded_decode_orders_itself_after_compute_stream():
+    """world == 1, no gather: decode() right after step() on a non-default stream, with NO
+    torch.cuda.synchronize() in between (the documented use), returns the finished records."""
+    import torch
+    from sp_orb_slam_amd import parallel
+    H, W, nf, B = 240, 320, 300, 4
+    blob = weights.synthetic(7, "dense")
+    frames = synth.make_batch(40, B, H, W)
+    host = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=False)
+    expect = host.extract_batch(list(frames))
+    host.close()
+    for async_cov in (False, True):
+        ext = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=False, async_cov=async_cov)
+        sh = parallel.ShardedExtractor(ext, 1, 0, B)
+        d_img = torch.from_numpy(frames).cuda()
+        stream = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        for rep in range(5):
+            sh.step(d_img, stream)
+            if async_cov:
+                sh.flush(stream)
+            for i in (B - 1, 0):
+                g, e = sh.decode(i), expect[i]
+                assert g.status == 0 and g.K == e.K and np.array_equal(g.kp_xy, e.kp_xy)
+                assert np.array_equal(g.descriptors, e.descriptors) and np.array_equal(g.cov2_inv, e.cov2_inv)
         ext.close()

@@ -1,0 +1,184 @@
+// conv_ws_probe.hip — stand-alone check + timing of the wave-specialised bf16 convolution
+// (sp_orb_slam_amd/csrc/conv_bf16_ws.hip) against the single-role kernel (conv_bf16.hip) and a
+// sampled CPU reference, on random data.  Build (from the repo root):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++20 -ffp-contract=off -Iinclude -Isp_orb_slam_amd/csrc \
+//         tools/microbench/conv_ws_probe.hip -o gpurun_out/conv_ws_probe
+// Run: conv_ws_probe H W B cout(64|128) pool(0|1) iters
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "../../sp_orb_slam_amd/csrc/conv_bf16.hip"
+#include "../../sp_orb_slam_amd/csrc/conv_bf16_ws.hip"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+static unsigned short bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+static float bf16_f(unsigned short h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+int main(int argc, char **argv) {
+  const int H = argc > 1 ? atoi(argv[1]) : 480, W = argc > 2 ? atoi(argv[2]) : 752, B = argc > 3 ? atoi(argv[3]) : 8;
+  const int cout = argc > 4 ? atoi(argv[4]) : 64, pool = argc > 5 ? atoi(argv[5]) : 1, iters = argc > 6 ? atoi(argv[6]) : 20;
+  const int cin = 64, nblk = cout / 64;
+  const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
+  std::mt19937 rng(1234);
+  std::normal_distribution<float> nd(0.f, 1.f);
+  // activations: post-ReLU-like, ~half zeros
+  std::vector<unsigned short> in((size_t)B * H * W * cin);
+  for (auto &v : in) { float x = nd(rng); v = bf16_rne(x > 0 ? x : 0.f); }
+  std::vector<float> wt((size_t)cout * cin * 9), bias(cout);
+  for (auto &v : wt) v = nd(rng) * 0.06f;
+  for (auto &v : bias) v = nd(rng) * 0.1f;
+  std::vector<unsigned short> wb(wt.size());
+  for (size_t i = 0; i < wt.size(); ++i) wb[i] = bf16_rne(wt[i]);
+
+  // old layout: [nb][chunk][tap][64 n][80 B]
+  const size_t slab = spfe::conv_bf16_slab_bytes();
+  std::vector<unsigned char> w_old((size_t)nblk * 2 * slab, 0), w_new((size_t)nblk * spfe::ws::W_BYTES, 0);
+  for (int co = 0; co < cout; ++co)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int t = 0; t < 9; ++t) {
+        const unsigned short v = wb[((size_t)co * cin + ci) * 9 + t];
+        const int nb = co / 64, j = co % 64;
+        memcpy(&w_old[((size_t)nb * 2 + ci / 32) * slab + ((size_t)t * 64 + j) * 80 + (ci % 32) * 2], &v, 2);
+        const int slot = (ci / 8) ^ ((j >> 1) & 7);
+        memcpy(&w_new[(size_t)nb * spfe::ws::W_BYTES + ((size_t)t * 64 + j) * 128 + slot * 16 + (ci % 8) * 2], &v, 2);
+      }
+  std::vector<float> bpad((size_t)nblk * 64);
+  for (int i = 0; i < cout; ++i) bpad[i] = bias[i];
+
+  unsigned short *d_in, *d_o1, *d_o2;
+  unsigned char *d_w1, *d_w2;
+  float *d_b;
+  int *d_ctr;
+  const size_t out_elems = (size_t)B * Ho * Wo * cout;
+  CK(hipMalloc(&d_in, in.size() * 2 + 256));
+  CK(hipMalloc(&d_o1, out_elems * 2 + 256));
+  CK(hipMalloc(&d_o2, out_elems * 2 + 256));
+  CK(hipMalloc(&d_w1, w_old.size()));
+  CK(hipMalloc(&d_w2, w_new.size()));
+  CK(hipMalloc(&d_b, bpad.size() * 4));
+  const int nctr = (iters + 8) * 16;
+  CK(hipMalloc(&d_ctr, nctr * 4));
+  CK(hipMemset(d_ctr, 0, nctr * 4));
+  CK(hipMemcpy(d_in, in.data(), in.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d_w1, w_old.data(), w_old.size(), hipMemcpyHostToDevice));
+  CK(hipMemcpy(d_w2, w_new.data(), w_new.size(), hipMemcpyHostToDevice));
+  CK(hipMemcpy(d_b, bpad.data(), bpad.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemset(d_o1, 0xff, out_elems * 2));
+  CK(hipMemset(d_o2, 0xee, out_elems * 2));
+
+  spfe::ConvParams p{};
+  p.in = reinterpret_cast<const float *>(d_in); p.in_stride = cin; p.in_choff = 0;
+  p.bias = d_b; p.out_stride = cout; p.out_choff = 0; p.cout_real = cout;
+  p.B = B; p.H = H; p.W = W; p.tiles_x = (W + 31) / 32; p.tiles_y = (H + 7) / 8; p.nblk = nblk; p.num_cus = 256;
+  hipStream_t s;
+  CK(hipStreamCreate(&s));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const double flop = 2.0 * B * H * W * cin * cout * 9;
+
+  auto run_old = [&]() { p.wpack = reinterpret_cast<const float *>(d_w1); p.out = reinterpret_cast<float *>(d_o1); CK(spfe::launch_conv_bf16(p, cin, pool, false, s)); };
+  int ctr_set = 0;
+  auto run_new = [&]() { p.wpack = reinterpret_cast<const float *>(d_w2); p.out = reinterpret_cast<float *>(d_o2); p.tile_ctr = d_ctr + 16 * (ctr_set++); CK(spfe::launch_conv_bf16_ws(p, pool, s)); };
+
+  const char *only = getenv("PROBE_ONLY");
+  float ms_old = 0, ms_new = 0;
+  if (!only || !strcmp(only, "old")) {
+    for (int i = 0; i < 3; ++i) run_old();
+    CK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) run_old();
+    CK(hipEventRecord(e1, s));
+    CK(hipStreamSynchronize(s));
+    CK(hipEventElapsedTime(&ms_old, e0, e1));
+    ms_old /= iters;
+  }
+  if (!only || !strcmp(only, "new")) {
+    for (int i = 0; i < 3; ++i) run_new();
+    CK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) run_new();
+    CK(hipEventRecord(e1, s));
+    CK(hipStreamSynchronize(s));
+    CK(hipEventElapsedTime(&ms_new, e0, e1));
+    ms_new /= iters;
+  }
+#ifdef WS_PROBE_TIMING
+  {
+    unsigned long long dbg[8];
+    CK(hipMemcpyFromSymbol(dbg, HIP_SYMBOL(spfe::ws::ws_dbg), sizeof dbg));
+    const double nt = (double)dbg[2], nl = (double)(ctr_set);
+    if (dbg[3] > 0) printf("  shader clock during the consumer loop: %.3f GHz (s_memtime ticks / 100 MHz wall_clock64)\n", (double)dbg[0] / dbg[3] * 0.1);
+    if (nt > 0)
+      printf("  per tile (cycles): consumer %.0f (barrier %.0f) | producer %.0f: issue %.0f, vmcnt wait %.0f, barrier %.0f | tiles/launch %.0f\n",
+             dbg[0] / nt, dbg[1] / nt, dbg[4] / nt, dbg[5] / nt, dbg[6] / nt, dbg[7] / nt, nt / nl);
+  }
+#endif
+  printf("conv %dx%d B=%d cin=64 cout=%d pool=%d: old %.4f ms (%.1f TF/s, %.3f of 2.5 PF)  ws %.4f ms (%.1f TF/s, %.3f of 2.5 PF)\n", W, H, B,
+         cout, pool, ms_old, ms_old > 0 ? flop / ms_old * 1e-9 : 0., ms_old > 0 ? flop / ms_old * 1e-9 / 2500 : 0., ms_new,
+         ms_new > 0 ? flop / ms_new * 1e-9 : 0., ms_new > 0 ? flop / ms_new * 1e-9 / 2500 : 0.);
+
+  std::vector<unsigned short> o1(out_elems), o2(out_elems);
+  CK(hipMemcpy(o1.data(), d_o1, out_elems * 2, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(o2.data(), d_o2, out_elems * 2, hipMemcpyDeviceToHost));
+  int rc = 0;
+  if (!only) {
+    size_t diff = 0, big = 0;
+    for (size_t i = 0; i < out_elems; ++i)
+      if (o1[i] != o2[i]) {
+        ++diff;
+        const float a = bf16_f(o1[i]), b = bf16_f(o2[i]);
+        if (fabsf(a - b) > 0.02f * fmaxf(1.f, fmaxf(fabsf(a), fabsf(b)))) {
+          if (big < 5) printf("  big diff at %zu: old %g ws %g\n", i, a, b);
+          ++big;
+        }
+      }
+    printf("old vs ws: %zu of %zu outputs differ (bias-first accumulation: last-bit flips expected), %zu beyond 2%%\n", diff, out_elems, big);
+    if (big || diff > out_elems / 50) rc = 1;
+  }
+  // sampled CPU reference (double accumulation of the bf16 products) for whichever kernels ran
+  {
+    std::mt19937 r2(99);
+    double worst1 = 0, worst2 = 0;
+    for (int sidx = 0; sidx < 4000; ++sidx) {
+      const int b = r2() % B, oy = r2() % Ho, ox = r2() % Wo, co = r2() % cout;
+      double best = -1e30;
+      for (int py = 0; py < (pool ? 2 : 1); ++py)
+        for (int px = 0; px < (pool ? 2 : 1); ++px) {
+          const int y = pool ? oy * 2 + py : oy, x = pool ? ox * 2 + px : ox;
+          double acc = bias[co];
+          for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+            const unsigned short *ip = &in[(((size_t)b * H + yy) * W + xx) * cin];
+            for (int ci = 0; ci < cin; ++ci) acc += (double)bf16_f(ip[ci]) * bf16_f(wb[((size_t)co * cin + ci) * 9 + t]);
+          }
+          if (acc > best) best = acc;
+        }
+      if (best < 0) best = 0;
+      const size_t oi = (((size_t)b * Ho + oy) * Wo + ox) * cout + co;
+      const double tol = 0.01 * fmax(1.0, fabs(best));
+      const double d1 = fabs(bf16_f(o1[oi]) - best) / tol, d2 = fabs(bf16_f(o2[oi]) - best) / tol;
+      if (d1 > worst1) worst1 = d1;
+      if (d2 > worst2) worst2 = d2;
+    }
+    printf("sampled CPU reference: worst error / tolerance  old %.3f  ws %.3f\n", (!only || !strcmp(only, "old")) ? worst1 : -1., (!only || !strcmp(only, "new")) ? worst2 : -1.);
+    if ((!only || !strcmp(only, "new")) && worst2 > 1.0) rc = 1;
+  }
+  printf(rc ? "PROBE FAIL\n" : "PROBE OK\n");
+  return rc;
+}
