@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--no-match", action="store_true", help="skip the descriptor-matching and input-staging legs (SURVEY 8f-1, 8f-2)")
     ap.add_argument("--no-bf16-leg", action="store_true", help="skip the configs[3] leg (bf16, 1280x720, batch 8)")
     ap.add_argument("--no-aten", action="store_true", help="skip the ATen-CPU baseline")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host-path leg")
     ap.add_argument("--latency-calls", type=int, default=1000)
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
                     help="f32: BASELINE configs[1]/[2] (bit-exact path, the headline); bf16: configs[3] "
@@ -254,6 +255,51 @@ def main():
             out["latency_batch1_ms"] = {"p50": round(lat[len(lat) // 2], 4), "p99": round(lat[int(len(lat) * 0.99) - 1], 4),
                                         "calls": len(lat)}
             ext1.close()
+
+        if not args.no_host_path:
+            # The host boundary of operator() (sp_extractor.cpp:379-390 upload, :427-433 D2H): frames start in
+            # pageable host memory, results end as host views of the records — PCIe inclusive, never `value`.
+            # Pipelined (spfe_submit_batch / spfe_collect_batch: pinned staging, H2D of batch i+1 and D2H of
+            # batch i-1 on copy streams beside the compute of batch i) and synchronous (spfe_extract_batch).
+            exth = SPExtractor(nf, H, W, blob, max_batch=B, device=local, with_heat=False, precision=args.precision)
+            himgs = [np.array(f) for f in frames[:B]]
+            kh = max(10, args.steps)
+            for _ in range(3):
+                exth.extract_batch(himgs)
+            t1 = time.perf_counter()
+            for _ in range(kh):
+                exth.extract_batch(himgs)
+            dt_sync = time.perf_counter() - t1
+            tk = [exth.submit_batch(himgs) for _ in range(2)]
+            for _ in range(3):
+                tk.append(exth.submit_batch(himgs))
+                exth.collect_batch(tk.pop(0), copy=False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(kh):
+                tk.append(exth.submit_batch(himgs))
+                res = exth.collect_batch(tk.pop(0), copy=False)
+            dt_pipe = time.perf_counter() - t1
+            k_ok = all(0 < res[i].K <= nf + 1 and res[i].status == 0 for i in range(B))
+            while tk:
+                exth.collect_batch(tk.pop(0), copy=False)
+            ext1h = SPExtractor(nf, H, W, blob, max_batch=1, device=local, with_heat=False, precision=args.precision)
+            for _ in range(10):
+                ext1h(himgs[0], None)
+            t1 = time.perf_counter()
+            for _ in range(200):
+                ext1h(himgs[0], None)
+            dt_one = (time.perf_counter() - t1) / 200
+            out["host_path"] = {
+                "what": "pageable host frames in -> host views of the records out (C ABI boundary, no heat maps), "
+                        "%d frames per call, %d calls; pipelined = spfe_submit_batch/spfe_collect_batch, 3 in flight" % (B, kh),
+                "fps": round(B * kh / dt_pipe, 2), "ms_per_call": round(dt_pipe / kh * 1e3, 4),
+                "fps_synchronous": round(B * kh / dt_sync, 2), "ms_per_call_synchronous": round(dt_sync / kh * 1e3, 4),
+                "frac_of_device_resident": round(B * kh / dt_pipe / fps * world, 4),
+                "bytes_h2d": int(B * H * W), "bytes_d2h": int(B * rec_bytes),
+                "single_frame_operator_call_ms": round(dt_one * 1e3, 4), "records_ok": bool(k_ok)}
+            exth.close()
+            ext1h.close()
 
         if not args.no_match:
             # SURVEY.md §8(f) rank 1 (outside the timed region): match this step's B frames against

@@ -115,6 +115,19 @@ SPFE_API int spfe_extract(spfe_handle h, const uint8_t *image, int stride, spfe_
 SPFE_API int spfe_extract_batch(spfe_handle h, const uint8_t *const *images, int stride, int n,
                        spfe_result *outs);
 
+/* Pipelined host path.  spfe_extract_batch is synchronous like the reference's operator() (upload
+ * sp_extractor.cpp:379-390, blocking D2H :427-433).  A host that has the next frames while the current ones
+ * are being processed (a dataset player, a multi-camera rig, the batch path) submits instead:
+ *   spfe_submit_batch   copies the frames into pinned staging, enqueues H2D (copy stream), the whole path
+ *                       (compute + side streams) and the D2H of the records (+ heat maps with SPFE_FLAG_HEAT;
+ *                       second copy stream), and returns at once with a ticket;
+ *   spfe_collect_batch  blocks until that batch is back in host memory; outs[i] are valid until three
+ *                       further batches have been submitted.
+ * Up to 3 batches may be in flight (submit fails with SPFE_EINVAL when the oldest has not been collected), so
+ * the H2D of batch i + 1 and the D2H of batch i - 1 overlap the compute of batch i.  Collect in any order. */
+SPFE_API int spfe_submit_batch(spfe_handle h, const uint8_t *const *images, int stride, int n, long *ticket);
+SPFE_API int spfe_collect_batch(spfe_handle h, long ticket, spfe_result *outs);
+
 /* Everything after the network (sp_extractor.cpp:105-148 detector tail and
  * descriptor sampling, :461-514 host glue, nms, computeCovariance) for n frames
  * whose raw head outputs the caller provides as HOST arrays: semi [n][H/8][W/8][65]
@@ -156,6 +169,28 @@ SPFE_API int spfe_extract_batch_device(spfe_handle h, const void *d_images, int 
  * does this and spfe_wait_records is a no-op dependency. */
 SPFE_API long spfe_last_ticket(spfe_handle h);
 SPFE_API int spfe_wait_records(spfe_handle h, long ticket, void *stream);
+
+/* ---- multi-GPU batch path: RCCL all-gather of the records (BASELINE configs[2]) ----------
+ * One process per GPU, one handle per process.  Frames are independent, so a batch shards over ranks with no
+ * collective in the data path; the ONLY exchange is this all-gather of the fixed-stride records (K lives in
+ * the record header, so no count exchange).  The C++ SLAM host uses these directly; no torch involved.
+ *   rank 0: spfe_comm_unique_id(id) -> ship the 128 bytes to every rank (MPI, a socket, a file ...)
+ *   every rank: spfe_comm_init(h, id, rank, world)            [ncclCommInitRank on the handle's device]
+ *   per batch:  spfe_extract_batch_device(h, imgs, n, d_local, stream); t = spfe_last_ticket(h);
+ *               spfe_allgather_records(h, t, d_local, d_all, n);   [d_all: world * n * spfe_record_bytes(h)]
+ *               spfe_comm_wait(h, consumer_stream);                [or hipStreamSynchronize(spfe_comm_stream(h))]
+ * The collective runs on a library-owned communication stream that waits only for the records of call
+ * `ticket` (convolutions, selection and covariance of THAT batch), so the gather of batch i overlaps the
+ * compute of batch i + 1.  d_local / d_all must stay untouched until the gather has completed (order the
+ * next writer with spfe_comm_wait).  librccl is loaded on first use (dlopen), so single-GPU users of
+ * libspfe.so do not need it.  rank-major output: global frame g = rank * n + i. */
+#define SPFE_COMM_ID_BYTES 128
+SPFE_API int spfe_comm_unique_id(void *id, size_t cap);
+SPFE_API int spfe_comm_init(spfe_handle h, const void *id, int rank, int world);
+SPFE_API int spfe_comm_destroy(spfe_handle h);
+SPFE_API int spfe_allgather_records(spfe_handle h, long ticket, const void *d_local, void *d_all, int frames_per_rank);
+SPFE_API int spfe_comm_wait(spfe_handle h, void *stream);
+SPFE_API void *spfe_comm_stream(spfe_handle h); /* hipStream_t of the collective, NULL before spfe_comm_init */
 
 /* Host view of ONE record that the caller copied to host memory. */
 SPFE_API int spfe_view_record(spfe_handle h, const void *host_record, spfe_result *out);

@@ -6,6 +6,8 @@
 // (/root/reference/orb_slam2/src/cv/sp_extractor.cpp:342-359) and whose
 // operator() (:361-514) the extract calls replace.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: librccl is dlopen'ed by spfe_comm_init, not linked
 
 #include <algorithm>
 #include <cfloat>
@@ -116,6 +118,30 @@ struct spfe_handle_s {
   int m_host_cap = 0;              // rows the host-API staging blocks / m_out hold
   unsigned tile16_mask = 0;  // f32 layers (bit i = conv layer i of enqueue()) on 16-row / 8-wave tiles
   bool fuse1a = false;  // f32: conv1a computed inside conv1b (opt-in: SPFE_FUSE_CONV1A=1; measured perf-neutral)
+  // pipelined host path (spfe_submit_batch / spfe_collect_batch): NPIPE batches in flight, each with its own
+  // pinned input / output staging and device frame / record buffers; H2D and D2H on copy streams
+  static constexpr int NPIPE = 3;
+  struct PipeSlot {
+    uint8_t *h_img = nullptr, *d_img = nullptr, *d_rec = nullptr, *h_rec = nullptr;
+    float *h_heat = nullptr, *h_heat_inv = nullptr;
+    hipEvent_t ev_h2d = nullptr, ev_done = nullptr;
+    long ticket = -1;   // records ticket of the batch in this slot, -1 = free
+    int n = 0;
+  } pipe[NPIPE];
+  bool pipe_ready = false, pipe_mode = false;
+  hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+  long pipe_submitted = 0;
+  // RCCL all-gather of the records (spfe_comm_init / spfe_allgather_records): librccl is loaded on demand
+  void *rccl_lib = nullptr;
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_world = 0;
+  hipStream_t comm_stream = nullptr;   // library-owned: the collective never queues behind younger compute
+  hipEvent_t ev_gather = nullptr;      // the last gather on comm_stream is done
+  bool gather_recorded = false;
+  decltype(&ncclCommInitRank) p_ncclCommInitRank = nullptr;
+  decltype(&ncclCommDestroy) p_ncclCommDestroy = nullptr;
+  decltype(&ncclAllGather) p_ncclAllGather = nullptr;
+  decltype(&ncclGetErrorString) p_ncclGetErrorString = nullptr;
   unsigned ws_mask = 1u;    // bf16 layers (bit i = conv layer i of enqueue(), Cin = 64 only) on the wave-specialised kernel
   unsigned char *d_wws[4] = {};  // their weights in conv_bf16_ws.hip's layout
   int *d_tile_ctr = nullptr;     // [4 layers][16] tile-queue counters, zeroed once per enqueue()
@@ -592,7 +618,7 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s) {
   if (h->timing && h->timing_all) HIP_TRY(hipEventRecord(h->ev[14], h->side));
   h->cov_inflight = true;
   h->ticket++;
-  if (!(h->cfg.flags & SPFE_FLAG_ASYNC_COV)) {
+  if (!(h->cfg.flags & SPFE_FLAG_ASYNC_COV) && !h->pipe_mode) {
     // synchronous contract: the records are complete in `s` order when the call returns
     HIP_TRY(hipStreamWaitEvent(s, h->ev_cov[slot], 0));
     h->cov_inflight = false;
@@ -672,6 +698,13 @@ void spfe_destroy(spfe_handle h) {
     if (h->ev_cov[i]) (void)hipEventDestroy(h->ev_cov[i]);
   }
   if (h->ev_desc) (void)hipEventDestroy(h->ev_desc);
+  (void)spfe_comm_destroy(h);
+  for (auto &ps : h->pipe) {
+    if (ps.ev_h2d) (void)hipEventDestroy(ps.ev_h2d);
+    if (ps.ev_done) (void)hipEventDestroy(ps.ev_done);
+  }
+  if (h->s_h2d) { (void)hipStreamSynchronize(h->s_h2d); (void)hipStreamDestroy(h->s_h2d); }
+  if (h->s_d2h) { (void)hipStreamSynchronize(h->s_d2h); (void)hipStreamDestroy(h->s_d2h); }
   if (h->side) (void)hipStreamDestroy(h->side);
   for (void *p : {(void *)h->d_map_x, (void *)h->d_map_y, (void *)h->d_raw})
     if (p) (void)hipFree(p);
@@ -892,6 +925,204 @@ int spfe_stage_times(spfe_handle h, float *ms, int cap) {
   }
   for (int i = 0; i < nst; ++i) ms[i] = (float)(acc[i] / (double)(h->calls - first));
   return nst;
+}
+
+// ---- pipelined host path ------------------------------------------------------------------------
+// The host boundary of SPExtractor::operator() (upload sp_extractor.cpp:379-390, six synchronous D2H copies
+// :427-433) as a depth-NPIPE pipeline: pinned staging, H2D of batch i + 1 and D2H of batch i - 1 on copy
+// streams beside the compute of batch i, covariance on the side stream.
+namespace {
+int pipe_setup(spfe_handle h) {
+  if (h->pipe_ready) return SPFE_OK;
+  const size_t img = (size_t)h->B * h->H * h->W, rec = (size_t)h->B * h->rl.bytes;
+  const bool want = (h->cfg.flags & SPFE_FLAG_HEAT) != 0;
+  int rc;
+  HIP_TRY(hipStreamCreateWithFlags(&h->s_h2d, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&h->s_d2h, hipStreamNonBlocking));
+  for (auto &ps : h->pipe) {
+    if ((rc = host_alloc(h, &ps.h_img, img))) return rc;
+    if ((rc = host_alloc(h, &ps.h_rec, rec))) return rc;
+    if ((rc = dev_alloc(h, &ps.d_img, img))) return rc;
+    if ((rc = dev_alloc(h, &ps.d_rec, rec))) return rc;
+    if (want) {
+      if ((rc = host_alloc(h, &ps.h_heat, img))) return rc;
+      if ((rc = host_alloc(h, &ps.h_heat_inv, img))) return rc;
+    }
+    HIP_TRY(hipEventCreateWithFlags(&ps.ev_h2d, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ps.ev_done, hipEventDisableTiming));
+  }
+  h->pipe_ready = true;
+  return SPFE_OK;
+}
+}  // namespace
+
+int spfe_submit_batch(spfe_handle h, const uint8_t *const *images, int stride, int n, long *ticket) {
+  if (!h || !ticket) return fail(SPFE_EINVAL, "null argument");
+  if (!images) return fail(SPFE_EEMPTY, "input image is empty");
+  if (n < 1 || n > h->B) return fail(SPFE_EINVAL, "batch %d not in [1, %d]", n, h->B);
+  const int H = h->H, W = h->W;
+  if (stride < W) return fail(SPFE_EINVAL, "stride %d smaller than width %d", stride, W);
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  int rc = pipe_setup(h);
+  if (rc) return rc;
+  spfe_handle_s::PipeSlot &ps = h->pipe[h->pipe_submitted % spfe_handle_s::NPIPE];
+  if (ps.ticket >= 0)
+    return fail(SPFE_EINVAL, "pipeline full: %d batches in flight, collect ticket %ld first", spfe_handle_s::NPIPE, ps.ticket);
+  for (int i = 0; i < n; ++i) {
+    if (!images[i]) return fail(SPFE_EEMPTY, "input image is empty");  // sp_extractor.cpp:364-365
+    if (stride == W) memcpy(ps.h_img + (size_t)i * H * W, images[i], (size_t)H * W);
+    else
+      for (int y = 0; y < H; ++y) memcpy(ps.h_img + ((size_t)i * H + y) * W, images[i] + (size_t)y * stride, W);
+  }
+  HIP_TRY(hipMemcpyAsync(ps.d_img, ps.h_img, (size_t)n * H * W, hipMemcpyHostToDevice, h->s_h2d));
+  HIP_TRY(hipEventRecord(ps.ev_h2d, h->s_h2d));
+  hipStream_t s = h->stream;
+  HIP_TRY(hipStreamWaitEvent(s, ps.ev_h2d, 0));
+  const bool want = (h->cfg.flags & SPFE_FLAG_HEAT) != 0;
+  if (want && h->pipe_submitted > 0) {
+    // the heat maps are single buffers: this batch's heat_norm (side stream) must not overwrite them
+    // before the previous batch's copy has left
+    const spfe_handle_s::PipeSlot &pp = h->pipe[(h->pipe_submitted - 1) % spfe_handle_s::NPIPE];
+    if (pp.ticket >= 0) HIP_TRY(hipStreamWaitEvent(h->side, pp.ev_done, 0));
+  }
+  h->pipe_mode = true;
+  rc = enqueue(h, ps.d_img, n, ps.d_rec, s);
+  h->pipe_mode = false;
+  if (rc) return rc;
+  const long t = h->ticket - 1;
+  HIP_TRY(hipStreamWaitEvent(h->s_d2h, h->ev_cov[t % spfe_handle_s::NTICKET], 0));
+  HIP_TRY(hipMemcpyAsync(ps.h_rec, ps.d_rec, (size_t)n * h->rl.bytes, hipMemcpyDeviceToHost, h->s_d2h));
+  if (want) {
+    HIP_TRY(hipMemcpyAsync(ps.h_heat_inv, h->d_heat_inv, (size_t)n * H * W * 4, hipMemcpyDeviceToHost, h->s_d2h));
+    HIP_TRY(hipMemcpyAsync(ps.h_heat, h->d_heat, (size_t)n * H * W * 4, hipMemcpyDeviceToHost, h->s_d2h));
+  }
+  HIP_TRY(hipEventRecord(ps.ev_done, h->s_d2h));
+  ps.ticket = t;
+  ps.n = n;
+  h->pipe_submitted++;
+  *ticket = t;
+  return SPFE_OK;
+}
+
+int spfe_collect_batch(spfe_handle h, long ticket, spfe_result *outs) {
+  if (!h || !outs) return fail(SPFE_EINVAL, "null argument");
+  spfe_handle_s::PipeSlot *ps = nullptr;
+  for (auto &c : h->pipe)
+    if (c.ticket == ticket && ticket >= 0) ps = &c;
+  if (!ps) return fail(SPFE_EINVAL, "ticket %ld is not in flight", ticket);
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  HIP_TRY(hipEventSynchronize(ps->ev_done));
+  const int H = h->H, W = h->W;
+  const bool want = (h->cfg.flags & SPFE_FLAG_HEAT) != 0;
+  for (int i = 0; i < ps->n; ++i) {
+    uint8_t *rec = ps->h_rec + (size_t)i * h->rl.bytes;
+    const int *hdr = reinterpret_cast<const int *>(rec + h->rl.off_hdr);
+    if ((hdr[2] & SPFE_STATUS_COV_OVERFLOW) && want)
+      spfe::covariance_host(ps->h_heat_inv + (size_t)i * H * W, H, W, reinterpret_cast<const float *>(rec + h->rl.off_xy),
+                            hdr[0], reinterpret_cast<float *>(rec + h->rl.off_cov),
+                            reinterpret_cast<float *>(rec + h->rl.off_cinv));
+    view_record(h, rec, want ? ps->h_heat + (size_t)i * H * W : nullptr, want ? ps->h_heat_inv + (size_t)i * H * W : nullptr,
+                &outs[i]);
+  }
+  ps->ticket = -1;   // the views stay valid until NPIPE further submits reuse the slot
+  return SPFE_OK;
+}
+
+// ---- multi-GPU: RCCL all-gather of the records -----------------------------------
+namespace {
+void *open_rccl() {
+  // an already loaded librccl (e.g. the one torch.distributed brought) is reused by soname
+  for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    if (void *l = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) return l;
+  }
+  return nullptr;
+}
+}  // namespace
+
+int spfe_comm_unique_id(void *id, size_t cap) {
+  if (!id || cap < NCCL_UNIQUE_ID_BYTES) return fail(SPFE_EINVAL, "unique id buffer must hold %d bytes", NCCL_UNIQUE_ID_BYTES);
+  void *lib = open_rccl();
+  if (!lib) return fail(SPFE_EHIP, "librccl not found: %s", dlerror());
+  auto get = reinterpret_cast<decltype(&ncclGetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+  auto err = reinterpret_cast<decltype(&ncclGetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+  if (!get || !err) return fail(SPFE_EHIP, "librccl lacks ncclGetUniqueId");
+  ncclUniqueId u;
+  const ncclResult_t r = get(&u);
+  if (r != ncclSuccess) return fail(SPFE_EHIP, "ncclGetUniqueId: %s", err(r));
+  memcpy(id, &u, NCCL_UNIQUE_ID_BYTES);
+  return SPFE_OK;
+}
+
+int spfe_comm_init(spfe_handle h, const void *id, int rank, int world) {
+  if (!h || !id) return fail(SPFE_EINVAL, "null argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(SPFE_EINVAL, "rank %d / world %d", rank, world);
+  if (h->comm) return fail(SPFE_EINVAL, "communicator already initialised (spfe_comm_destroy first)");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  if (!h->rccl_lib) {
+    h->rccl_lib = open_rccl();
+    if (!h->rccl_lib) return fail(SPFE_EHIP, "librccl not found: %s", dlerror());
+    h->p_ncclCommInitRank = reinterpret_cast<decltype(&ncclCommInitRank)>(dlsym(h->rccl_lib, "ncclCommInitRank"));
+    h->p_ncclCommDestroy = reinterpret_cast<decltype(&ncclCommDestroy)>(dlsym(h->rccl_lib, "ncclCommDestroy"));
+    h->p_ncclAllGather = reinterpret_cast<decltype(&ncclAllGather)>(dlsym(h->rccl_lib, "ncclAllGather"));
+    h->p_ncclGetErrorString = reinterpret_cast<decltype(&ncclGetErrorString)>(dlsym(h->rccl_lib, "ncclGetErrorString"));
+    if (!h->p_ncclCommInitRank || !h->p_ncclCommDestroy || !h->p_ncclAllGather || !h->p_ncclGetErrorString)
+      return fail(SPFE_EHIP, "librccl lacks a required entry point");
+  }
+  ncclUniqueId u;
+  memcpy(&u, id, NCCL_UNIQUE_ID_BYTES);
+  const ncclResult_t r = h->p_ncclCommInitRank(&h->comm, world, u, rank);
+  if (r != ncclSuccess) {
+    h->comm = nullptr;
+    return fail(SPFE_EHIP, "ncclCommInitRank(rank %d of %d, device %d): %s", rank, world, h->cfg.device,
+                h->p_ncclGetErrorString(r));
+  }
+  if (!h->comm_stream) HIP_TRY(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+  if (!h->ev_gather) HIP_TRY(hipEventCreateWithFlags(&h->ev_gather, hipEventDisableTiming));
+  h->comm_rank = rank;
+  h->comm_world = world;
+  h->gather_recorded = false;
+  return SPFE_OK;
+}
+
+int spfe_comm_destroy(spfe_handle h) {
+  if (!h) return fail(SPFE_EINVAL, "null handle");
+  if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+  if (h->comm && h->p_ncclCommDestroy) (void)h->p_ncclCommDestroy(h->comm);
+  h->comm = nullptr;
+  if (h->ev_gather) { (void)hipEventDestroy(h->ev_gather); h->ev_gather = nullptr; }
+  if (h->comm_stream) { (void)hipStreamDestroy(h->comm_stream); h->comm_stream = nullptr; }
+  h->comm_world = 0;
+  h->gather_recorded = false;
+  return SPFE_OK;
+}
+
+void *spfe_comm_stream(spfe_handle h) { return h ? reinterpret_cast<void *>(h->comm_stream) : nullptr; }
+
+int spfe_allgather_records(spfe_handle h, long ticket, const void *d_local, void *d_all, int frames_per_rank) {
+  if (!h || !d_local || !d_all) return fail(SPFE_EINVAL, "null argument");
+  if (!h->comm) return fail(SPFE_EINVAL, "spfe_comm_init has not been called");
+  if (frames_per_rank < 1) return fail(SPFE_EINVAL, "frames_per_rank %d", frames_per_rank);
+  if (ticket < 0 || ticket >= h->ticket || ticket + spfe_handle_s::NTICKET <= h->ticket)
+    return fail(SPFE_EINVAL, "ticket %ld is not one of the last %d calls", ticket, spfe_handle_s::NTICKET);
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  // the communication stream waits for exactly this batch's records (covariance included), never for
+  // younger compute: the gather of batch i runs beside the convolutions of batch i + 1
+  HIP_TRY(hipStreamWaitEvent(h->comm_stream, h->ev_cov[ticket % spfe_handle_s::NTICKET], 0));
+  const size_t count = (size_t)frames_per_rank * h->rl.bytes;   // bytes as ncclUint8; RCCL counts are size_t
+  const ncclResult_t r = h->p_ncclAllGather(d_local, d_all, count, ncclUint8, h->comm, h->comm_stream);
+  if (r != ncclSuccess) return fail(SPFE_EHIP, "ncclAllGather(%zu bytes per rank): %s", count, h->p_ncclGetErrorString(r));
+  HIP_TRY(hipEventRecord(h->ev_gather, h->comm_stream));
+  h->gather_recorded = true;
+  return SPFE_OK;
+}
+
+int spfe_comm_wait(spfe_handle h, void *stream) {
+  if (!h) return fail(SPFE_EINVAL, "null handle");
+  if (!h->gather_recorded) return SPFE_OK;
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
+  HIP_TRY(hipStreamWaitEvent(s, h->ev_gather, 0));
+  return SPFE_OK;
 }
 
 // ---- input staging ------------------------------------------------------

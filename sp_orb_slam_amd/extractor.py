@@ -36,6 +36,8 @@ ABI_SYMBOLS = [
     "spfe_match", "spfe_match_records_device", "spfe_match_out_bytes",
     "spfe_match_patches", "spfe_match_patches_record_device",
     "spfe_set_staging", "spfe_extract_staged", "spfe_extract_batch_staged", "spfe_stage_batch_device",
+    "spfe_comm_unique_id", "spfe_comm_init", "spfe_comm_destroy", "spfe_allgather_records", "spfe_comm_wait",
+    "spfe_comm_stream", "spfe_submit_batch", "spfe_collect_batch",
 ]
 
 
@@ -163,6 +165,22 @@ def load_library():
                                             C.c_void_p]
     L.spfe_match_out_bytes.restype = C.c_size_t
     L.spfe_match_out_bytes.argtypes = [C.c_void_p]
+    L.spfe_submit_batch.restype = C.c_int
+    L.spfe_submit_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_long)]
+    L.spfe_collect_batch.restype = C.c_int
+    L.spfe_collect_batch.argtypes = [C.c_void_p, C.c_long, C.POINTER(_Result)]
+    L.spfe_comm_unique_id.restype = C.c_int
+    L.spfe_comm_unique_id.argtypes = [C.c_void_p, C.c_size_t]
+    L.spfe_comm_init.restype = C.c_int
+    L.spfe_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.spfe_comm_destroy.restype = C.c_int
+    L.spfe_comm_destroy.argtypes = [C.c_void_p]
+    L.spfe_allgather_records.restype = C.c_int
+    L.spfe_allgather_records.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_int]
+    L.spfe_comm_wait.restype = C.c_int
+    L.spfe_comm_wait.argtypes = [C.c_void_p, C.c_void_p]
+    L.spfe_comm_stream.restype = C.c_void_p
+    L.spfe_comm_stream.argtypes = [C.c_void_p]
     L.spfe_last_error.restype = C.c_char_p
     L.spfe_version.restype = C.c_char_p
     _lib = L
@@ -337,6 +355,36 @@ class SPExtractor:
         self._publish(out[-1])
         return out
 
+    # -- pipelined host path: up to 3 batches in flight --
+    def submit_batch(self, images):
+        """Copy `images` (list of uint8 [H, W]) into pinned staging, enqueue H2D + the whole path + D2H of the
+        records, return a ticket immediately (spfe_submit_batch)."""
+        imgs = [self._check_image(im) for im in images]
+        n = len(imgs)
+        if n == 0:
+            raise RuntimeError("input image is empty")
+        if len({im.strides[0] for im in imgs}) != 1:
+            imgs = [np.ascontiguousarray(im) for im in imgs]
+        ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+        t = C.c_long(-1)
+        _check(self._lib.spfe_submit_batch(self._h, ptrs, imgs[0].strides[0], n, C.byref(t)))
+        self._pipe_n = getattr(self, "_pipe_n", {})
+        self._pipe_n[t.value] = n
+        return t.value
+
+    def collect_batch(self, ticket, copy=True):
+        """Block until batch `ticket` is back in host memory; list of FrameResult (deep copies).  copy=False
+        returns the raw spfe_result array instead (pointers into the library's pinned buffers, valid until
+        three further submits) — what a C++ caller gets."""
+        n = self._pipe_n.pop(ticket)
+        res = (_Result * n)()
+        _check(self._lib.spfe_collect_batch(self._h, int(ticket), res))
+        if not copy:
+            return res
+        out = [FrameResult(res[i], self.height, self.width, self.with_heat) for i in range(n)]
+        self._publish(out[-1])
+        return out
+
     def postprocess(self, semi, coarse):
         """Tail + selection + descriptors + covariance from host semi/coarse maps
         ([n,hc,wc,65], [n,hc,wc,256], or a single frame without the n axis)."""
@@ -381,6 +429,36 @@ class SPExtractor:
     def wait_records(self, ticket, stream=None):
         """Order `stream` after the covariance stage of call `ticket` (async_cov mode)."""
         _check(self._lib.spfe_wait_records(self._h, int(ticket), C.c_void_p(stream or 0)))
+
+    # -- multi-GPU: RCCL all-gather of the records, inside the library (no torch) --
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL unique id (rank 0 creates it and ships it to every rank)."""
+        buf = (C.c_ubyte * 128)()
+        _check(load_library().spfe_comm_unique_id(buf, 128))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        if len(unique_id) != 128:
+            raise ValueError("unique id must be 128 bytes")
+        _check(self._lib.spfe_comm_init(self._h, C.c_char_p(bytes(unique_id)), int(rank), int(world)))
+
+    def comm_destroy(self):
+        _check(self._lib.spfe_comm_destroy(self._h))
+
+    def comm_stream(self):
+        """hipStream_t (int) of the library's communication stream, 0 before comm_init."""
+        return int(self._lib.spfe_comm_stream(self._h) or 0)
+
+    def allgather_records(self, ticket, d_local, d_all, frames_per_rank):
+        """ncclAllGather of this rank's `frames_per_rank` records (device pointers as ints) on the library's
+        communication stream, ordered after the records of call `ticket`."""
+        _check(self._lib.spfe_allgather_records(self._h, int(ticket), C.c_void_p(d_local), C.c_void_p(d_all),
+                                                int(frames_per_rank)))
+
+    def comm_wait(self, stream=None):
+        """Order `stream` after the last all-gather."""
+        _check(self._lib.spfe_comm_wait(self._h, C.c_void_p(stream or 0)))
 
     def view_record(self, host_record):
         """Decode ONE record (bytes-like / uint8 array copied from the device)."""

@@ -150,23 +150,48 @@ class ShardedExtractor:
     batch i's convolutions); flush() completes the last batch.  `gathered` is the most recently
     completed batch; call sync(stream) (or decode()) before consuming it.
 
-    gather_fn(out, local) defaults to torch.distributed.all_gather_into_tensor; tests inject a
-    single-process stand-in to exercise the stream / buffer logic on one GPU."""
+    The collective itself is the LIBRARY's: spfe_allgather_records (ncclAllGather on a library-owned
+    communication stream, include/spfe.h) — the same entry point the C++ SLAM host uses — set up by
+    `native_comm=True` (the default when world > 1 and the process group is RCCL: the 128-byte unique id is
+    created on rank 0 and broadcast through torch.distributed, the only thing torch still does for the
+    gather).  native_comm=True with world == 1 gives a 1-rank communicator (self-gather; used by tests).
+    gather_fn(out, local) replaces the collective (tests: a device copy, to exercise the stream / buffer
+    logic on one GPU); with neither, torch.distributed.all_gather_into_tensor is the fallback (gloo dry
+    runs on CPU-only / shared-GPU boxes)."""
 
-    def __init__(self, extractor, world, rank, frames_per_rank, gather_fn=None):
+    def __init__(self, extractor, world, rank, frames_per_rank, gather_fn=None, native_comm=None):
         import torch
 
         self.ext, self.world, self.rank, self.fpr = extractor, world, rank, frames_per_rank
         self.rec_bytes = extractor.record_bytes()
         self._gather_fn = gather_fn
-        self._collective = world > 1 or gather_fn is not None
+        if native_comm is None:
+            native_comm = False
+            if world > 1 and gather_fn is None:
+                import torch.distributed as dist
+
+                native_comm = dist.is_initialized() and dist.get_backend() == "nccl"
+        self._native = bool(native_comm) and gather_fn is None
+        self._collective = world > 1 or gather_fn is not None or self._native
         nbuf = 3 if extractor.async_cov else (2 if self._collective else 1)
         nbytes = frames_per_rank * self.rec_bytes
         self.local = [torch.zeros(nbytes, dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
         self._local_free = [None] * nbuf          # event: the gather that last read local[k] is done
         self.all = ([torch.zeros(world * nbytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
                     if self._collective else None)
-        self.comm = torch.cuda.Stream() if self._collective else None
+        if self._native:
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(extractor.comm_unique_id()), dtype=torch.uint8))
+            if world > 1:
+                import torch.distributed as dist
+
+                dist.broadcast(uid, 0)
+            extractor.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+            # the library's communication stream, wrapped so torch events can be recorded on it
+            self.comm = torch.cuda.ExternalStream(extractor.comm_stream())
+        else:
+            self.comm = torch.cuda.Stream() if self._collective else None
         self.gathered = None
         self._gathered_event = None
         self._pending = None
@@ -186,6 +211,15 @@ class ShardedExtractor:
             return
         out = self.all[self._gathers % 2]
         self._gathers += 1
+        if self._native:
+            # spfe_allgather_records: waits (on the communication stream) for exactly this batch's records,
+            # covariance included, then ncclAllGather
+            self.ext.allgather_records(ticket, self.local[k].data_ptr(), out.data_ptr(), self.fpr)
+            ev = torch.cuda.Event()
+            ev.record(self.comm)
+            self._local_free[k] = ev
+            self.gathered, self._gathered_event = out, ev
+            return
         # the communication stream waits for exactly this batch's records (covariance included)
         self.ext.wait_records(ticket, self.comm.cuda_stream)
         with torch.cuda.stream(self.comm):

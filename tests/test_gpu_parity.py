@@ -539,3 +539,98 @@ def test_sharded_decode_orders_itself_after_compute_stream():
                 assert g.status == 0 and g.K == e.K and np.array_equal(g.kp_xy, e.kp_xy)
                 assert np.array_equal(g.descriptors, e.descriptors) and np.array_equal(g.cov2_inv, e.cov2_inv)
         ext.close()
+
+
+def test_rccl_native_allgather_single_rank():
+    """spfe_comm_init / spfe_allgather_records (ncclAllGather inside libspfe.so, librccl dlopen'ed) with a
+    1-rank communicator: the RCCL code path of the multi-GPU batch mode — unique id, ncclCommInitRank on the
+    handle's device, the library's communication stream waiting for the batch's ticket, the gather, the
+    completion event — executed on the one GPU a test box has.  Pipelined driver, many steps, bit-identical
+    to the host-facing call.  (N > 1 needs N GPUs: RCCL refuses two ranks on one device.)"""
+    import torch
+    from sp_orb_slam_amd import parallel
+    H, W, nf, B = 120, 160, 150, 3
+    blob = weights.synthetic(7, "dense")
+    batches = [np.stack([synth.make_image(500 + 10 * s + i, H, W) for i in range(B)]) for s in range(3)]
+    host = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=False)
+    expect = [host.extract_batch(list(b)) for b in batches]
+    host.close()
+    d_batches = [torch.from_numpy(b).cuda() for b in batches]
+    for async_cov in (False, True):
+        ext = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=False, async_cov=async_cov)
+        assert ext.comm_stream() == 0
+        sh = parallel.ShardedExtractor(ext, 1, 0, B, native_comm=True)
+        assert ext.comm_stream() != 0 and sh.comm.cuda_stream == ext.comm_stream()
+        comp = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        done = []
+        for k in range(7):
+            sh.step(d_batches[k % 3], comp)
+            kk = k - 1 if async_cov else k
+            if kk >= 0:
+                done.append((kk, [sh.decode(i) for i in range(B)]))   # decode() waits for the gather's event
+        if async_cov:
+            sh.flush(comp)
+            done.append((6, [sh.decode(i) for i in range(B)]))
+        assert [k for k, _ in done] == list(range(7))
+        for k, got in done:
+            for g, e in zip(got, expect[k % 3]):
+                assert g.status == 0 and g.K == e.K and np.array_equal(g.kp_xy, e.kp_xy)
+                assert np.array_equal(g.descriptors, e.descriptors) and np.array_equal(g.cov2_inv, e.cov2_inv)
+                assert np.array_equal(g.occ_grid, e.occ_grid)
+        # errors: double init, bad ticket
+        with pytest.raises(SpfeError):
+            ext.comm_init(ext.comm_unique_id(), 0, 1)
+        with pytest.raises(SpfeError):
+            ext.allgather_records(10 ** 6, sh.local[0].data_ptr(), sh.all[0].data_ptr(), B)
+        ext.comm_destroy()
+        assert ext.comm_stream() == 0
+        ext.close()
+
+
+def test_pipelined_host_path_submit_collect():
+    """spfe_submit_batch / spfe_collect_batch: three batches in flight, out-of-order collection, strided
+    inputs, heat maps on and off — bit-identical to the synchronous host call; a fourth submit without a
+    collect is refused."""
+    H, W, nf, B = 120, 160, 150, 3
+    blob = weights.synthetic(7, "dense")
+    batches = [[synth.make_image(700 + 10 * s + i, H, W) for i in range(B)] for s in range(5)]
+    for with_heat in (False, True):
+        host = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=with_heat)
+        expect = [host.extract_batch(b) for b in batches]
+        host.close()
+        ext = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=with_heat)
+        wide = np.zeros((H, W + 32), np.uint8)
+        tickets = []
+        for s in range(3):
+            imgs = batches[s]
+            if s == 1:   # strided rows (cv::Mat::step > cols)
+                imgs = []
+                for im in batches[s]:
+                    w2 = wide.copy()
+                    w2[:, :W] = im
+                    imgs.append(w2[:, :W])
+            tickets.append(ext.submit_batch(imgs))
+        with pytest.raises(SpfeError):
+            ext.submit_batch(batches[3])       # pipeline full
+        got = {1: ext.collect_batch(tickets[1])}              # out of order
+        with pytest.raises(SpfeError):
+            ext.submit_batch(batches[3])       # the ring's next slot is the oldest batch's: still in flight
+        got[0] = ext.collect_batch(tickets[0])
+        tickets.append(ext.submit_batch(batches[3]))
+        tickets.append(ext.submit_batch(batches[4][:2]))   # a short batch
+        got[2] = ext.collect_batch(tickets[2])
+        got[3] = ext.collect_batch(tickets[3])
+        got[4] = ext.collect_batch(tickets[4])
+        with pytest.raises((SpfeError, KeyError)):
+            ext.collect_batch(tickets[4])
+        for s in range(5):
+            exp = expect[s][:len(got[s])]
+            assert len(got[s]) == (2 if s == 4 else B)
+            for g, e in zip(got[s], exp):
+                assert g.status == 0 and g.K == e.K and np.array_equal(g.kp_xy, e.kp_xy)
+                assert np.array_equal(g.descriptors, e.descriptors) and np.array_equal(g.cov2_inv, e.cov2_inv)
+                assert np.array_equal(g.occ_grid, e.occ_grid) and np.array_equal(g.response, e.response)
+                if with_heat:
+                    assert np.array_equal(g.heat, e.heat) and np.array_equal(g.heat_inv, e.heat_inv)
+        ext.close()
