@@ -366,6 +366,46 @@ def main():
             extm.close()
 
         if not args.no_match:
+            # SURVEY.md §8(f) rank 3 (outside the timed region): direct dust alignment, 160 map points against the
+            # dense_dust of frame 0's resident record (optimizer_dust.cpp:170-294: 40 LM iterations)
+            from sp_orb_slam_amd import dust_scene
+            from sp_orb_slam_amd.extractor import DUST_OUT_BYTES
+            extd = SPExtractor(nf, H, W, blob, max_batch=1, device=local, with_heat=False)
+            dsc = dust_scene.make_scene(0, H=H, W=W, n_points=160, cx=W / 2 - 8.8, cy=H / 2 + 8.4)
+            d_rec = torch.zeros(rec_bytes, dtype=torch.uint8, device="cuda")
+            dstream = torch.cuda.Stream()
+            extd.extract_batch_device(d_img.data_ptr(), 1, d_rec.data_ptr(), dstream.cuda_stream)
+            # a scene-shaped dust map in the record, so that the solve does real work (synthetic weights give a flat one)
+            lay = parallel.RecordLayout(H, W, nf)
+            d_rec[lay.off_dd:lay.off_dd + dsc["dust"].size * 4] = torch.from_numpy(dsc["dust"].reshape(-1).view(np.uint8)).cuda()
+            d_pts, d_T = torch.from_numpy(dsc["pts"]).cuda(), torch.from_numpy(dsc["Tcw_init"].reshape(16)).cuda()
+            d_do = torch.zeros(DUST_OUT_BYTES, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            def dust_once():
+                extd.align_dust_record_device(d_rec.data_ptr(), d_pts.data_ptr(), 160, d_T.data_ptr(), d_do.data_ptr(),
+                                              dsc["fx"], dsc["fy"], dsc["cx"], dsc["cy"], stream=dstream.cuda_stream)
+            for _ in range(3):
+                dust_once()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(dstream)
+            for _ in range(20):
+                dust_once()
+            e1.record(dstream)
+            torch.cuda.synchronize()
+            gd = extd.decode_dust_out(d_do.cpu().numpy(), 160)
+            out["dust_alignment"] = {"what": "Optimizer::PoseOptimizationDust: 160 map points vs the dense_dust of a resident "
+                                             "record, Huber 0.9, <= 40 LM iterations, one workgroup, f64",
+                                     "us_per_solve": round(e0.elapsed_time(e1) / 20 * 1e3, 1), "iterations": gd["iterations"],
+                                     "n_inlier": gd["n_inlier"]}
+            if world == 1 and not args.no_cpu_baseline:
+                from oracle import oracle as _orc2
+                t1 = time.perf_counter()
+                rd = _orc2.align_dust(dsc["dust"], dsc["pts"], dsc["Tcw_init"], dsc["fx"], dsc["fy"], dsc["cx"], dsc["cy"])
+                out["dust_alignment"]["cpu_oracle_us_per_solve"] = round((time.perf_counter() - t1) * 1e6, 1)
+                out["dust_alignment"]["pose_max_abs_diff_vs_oracle"] = float(np.abs(rd["Tcw"] - gd["Tcw"]).max())
+            extd.close()
+
+        if not args.no_match:
             # SURVEY.md §8(f) rank 2 (outside the timed region): staging kernel on B raw BGR frames
             exts = SPExtractor(nf, H, W, blob, max_batch=B, device=local, with_heat=False)
             vv, uu = np.mgrid[0:H, 0:W].astype(np.float64)

@@ -244,6 +244,42 @@ SPFE_API int spfe_match_patches_record_device(spfe_handle h, const void *d_mp_de
                                               int n_points, const void *d_record, float max_dist, void *d_kp_idx,
                                               void *stream);
 
+/* ---- direct "dust" alignment ------------------------------------------------
+ * Replaces  Optimizer::PoseOptimizationDust(Frame *pFrame, const std::vector<MapPoint *> &mps,
+ *                                           std::vector<bool> &is_visible)
+ * (orb_slam2/src/mapping/optimizer_dust.cpp:170-294, called from Tracker::trackFrameDustKFLocal,
+ * tracker_dust.cpp:91): a 6-DoF Levenberg-Marquardt (g2o: OptimizationAlgorithmLevenberg, one VertexSE3Expmap,
+ * one EdgeSE3ProjectDustOnlyPose per map point — src/optimization/types_dust_tracking.cpp:37-140 — with
+ * RobustKernelHuber(0.9), optimize(40)) that moves the camera pose so that the map points project onto cells
+ * with a low dustbin probability.  dense_dust = Frame::dust_ (the extractor's dense_dust_, [H/8][W/8]);
+ * points_xyz[i] = mps[i]->GetWorldPos() (3 floats); Tcw = Frame::mTcw (CV_32F 4x4, row-major); fx..cy =
+ * Frame::fx.. (full resolution; the /8 and -3.5 of :223-226 are applied inside).
+ * Outputs: Tcw_out (what pFrame->SetPose receives, :287), inlier[i] (is_visible[i] / in_view, :262-266: level 0
+ * and chi2 <= inlier_chi2), proj_uv[i] = (dust_proj_u, dust_proj_v) of the inliers (:267-268), *n_inlier (the
+ * return value), *iterations (optimize()'s).  n <= SPFE_DUST_MAX_POINTS (the tracker keeps 150-200).
+ * g2o is not part of the reference snapshot: its algorithm is restated (include/spfe_dust_math.h) — results
+ * equal the CPU oracle's up to the device's sin / cos in the exponential map. */
+#define SPFE_DUST_MAX_POINTS 512
+typedef struct {
+  float fx, fy, cx, cy;
+  int max_iterations;   /* 40 (:243) */
+  double huber_delta;   /* 0.9 (:221) */
+  double inlier_chi2;   /* 0.9 (:260) */
+} spfe_dust_params;
+SPFE_API int spfe_align_dust(spfe_handle h, const float *dense_dust, const float *points_xyz, int n,
+                             const float *Tcw, const spfe_dust_params *prm, float *Tcw_out, uint8_t *inlier,
+                             float *proj_uv, int *n_inlier, int *iterations);
+/* The same against the dense_dust of ONE record resident in HBM; d_points_xyz / d_Tcw are device arrays; d_out
+ * receives SPFE_DUST_OUT_BYTES: float Tcw_out[16] | int32 n_inlier | int32 iterations | pad to
+ * SPFE_DUST_OFF_UV: float proj_uv[512][2] | SPFE_DUST_OFF_INLIER: uint8 inlier[512].  Enqueued on `stream`
+ * (NULL = the handle's), no host synchronisation; order it after the record with spfe_wait_records. */
+#define SPFE_DUST_OFF_UV 128
+#define SPFE_DUST_OFF_INLIER (128 + SPFE_DUST_MAX_POINTS * 8)
+#define SPFE_DUST_OUT_BYTES (128 + SPFE_DUST_MAX_POINTS * 9)
+SPFE_API int spfe_align_dust_record_device(spfe_handle h, const void *d_record, const void *d_points_xyz, int n,
+                                           const void *d_Tcw, const spfe_dust_params *prm, void *d_out,
+                                           void *stream);
+
 /* ---- input staging -----------------------------------------------------
  * Replaces, per frame, the host OpenCV sequence in front of the extractor:
  *   cv::remap(mono, mono, m1, m2, cv::INTER_LINEAR)       orb_slam2/src/io/data_loader.cc:519-521

@@ -276,3 +276,24 @@ def match_patches(mp_desc, mp_uv, occ_grid, kp_desc, max_dist=0.75):
         lib().oracle_match_patches(m, uv, len(m), occ, occ.shape[0], occ.shape[1],
                                    kd if len(kd) else np.zeros((1, 256), np.float32), len(kd), max_dist, out)
     return out[:len(m)].copy()
+
+
+def align_dust(dust, pts, Tcw, fx, fy, cx, cy, max_iterations=40, delta=0.9, inlier_chi2=0.9):
+    """Optimizer::PoseOptimizationDust (optimizer_dust.cpp:170-294) -> dict(Tcw, inlier, uv, n_inlier, iterations)."""
+    dust = np.ascontiguousarray(dust, np.float32)
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 3)
+    Tin = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+    n = len(pts)
+    Tout = np.zeros(16, np.float32)
+    inl = np.zeros(max(n, 1), np.uint8)
+    uv = np.zeros((max(n, 1), 2), np.float32)
+    it = C.c_int(0)
+    L = lib()
+    L.oracle_align_dust.restype = C.c_int
+    L.oracle_align_dust.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float,
+                                    C.c_float, C.c_float, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.POINTER(C.c_int)]
+    k = L.oracle_align_dust(dust.ctypes.data, dust.shape[0], dust.shape[1], pts.ctypes.data, n, Tin.ctypes.data,
+                            float(fx), float(fy), float(cx), float(cy), int(max_iterations), float(delta),
+                            float(inlier_chi2), Tout.ctypes.data, inl.ctypes.data, uv.ctypes.data, C.byref(it))
+    return dict(Tcw=Tout.reshape(4, 4), inlier=inl[:n].astype(bool), uv=uv[:n], n_inlier=int(k), iterations=it.value)

@@ -780,3 +780,92 @@ EXPORT int oracle_get_max_threads(void) { return 1; }
 EXPORT float oracle_expf(float x) { return spfe_expf(x); }
 EXPORT float oracle_logf(float x) { return spfe_logf(x); }
 EXPORT float oracle_sum256(const float *v) { return spfe_sum256_host(v); }
+
+/* ---- direct "dust" alignment -------------------------------------------------
+ * Optimizer::PoseOptimizationDust(Frame*, const vector<MapPoint*>&, vector<bool>&)
+ *   /root/reference/orb_slam2/src/mapping/optimizer_dust.cpp:170-294
+ * with g2o::EdgeSE3ProjectDustOnlyPose (src/optimization/types_dust_tracking.cpp:37-140) and g2o's
+ * Levenberg-Marquardt driver (SparseOptimizer::optimize(40), OptimizationAlgorithmLevenberg::solve,
+ * BlockSolver_6_3 + LinearSolverDense on the single 6x6 pose block, RobustKernelHuber(0.9)).  g2o is a
+ * catkin dependency that is NOT in /root/reference: PARITY UNPINNED — its published algorithm is restated
+ * (arithmetic in include/spfe_dust_math.h, the control flow here), sequentially, edge by edge, as g2o loops.
+ *
+ * dust [hc][wc] = Frame::dust_ (dense_dust_ of the extractor); pts [n][3] = MapPoint::GetWorldPos() floats;
+ * Tcw_in / Tcw_out = Frame::mTcw, CV_32F 4x4 row-major; fx..cy = Frame::fx.. (floats, full resolution: the
+ * /8 and -3.5 of :223-226 are applied here).  Outputs per map point: inlier (is_visible / in_view, :262-266),
+ * uv = dust_proj_u / dust_proj_v (:267-268; only meaningful for inliers).  Returns n_inlier (:258-270). */
+#include "../include/spfe_dust_math.h"
+
+static double dust_errors(const spfe_se3 *T, const float *pts, int n, double fx, double fy, double cx, double cy,
+                          const float *dust, int wc, int hc, double delta, spfe_dust_edge *ed) {
+  /* computeActiveErrors + activeRobustChi2: sum of rho[0] over the edges in insertion order */
+  double chi = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double Xw[3] = {(double)pts[3 * i], (double)pts[3 * i + 1], (double)pts[3 * i + 2]};
+    spfe_dust_error(T, Xw, fx, fy, cx, cy, dust, wc, hc, &ed[i]);
+    double rho[3];
+    spfe_huber(ed[i].err * ed[i].err, delta, rho);
+    chi += rho[0];
+  }
+  return chi;
+}
+
+EXPORT int oracle_align_dust(const float *dust, int hc, int wc, const float *pts, int n, const float *Tcw_in,
+                             float fxf, float fyf, float cxf, float cyf, int max_iterations, double delta,
+                             double inlier_chi2, float *Tcw_out, uint8_t *inlier, float *uv, int *iterations) {
+  const double fx = (double)(fxf / 8.0f), fy = (double)(fyf / 8.0f);           /* :223-224 */
+  const double cx = ((double)cxf - 3.5) / 8.0f, cy = ((double)cyf - 3.5) / 8.0f; /* :225-226 */
+  spfe_se3 T;
+  spfe_se3_from_f32(Tcw_in, &T);
+  spfe_dust_edge *ed = (spfe_dust_edge *)calloc((size_t)(n > 0 ? n : 1), sizeof(spfe_dust_edge));
+  spfe_lm lm = {0.0, 2.0};
+  int it_done = 0, ok = 1;
+  for (int it = 0; it < max_iterations && ok; ++it) {
+    double currentChi = dust_errors(&T, pts, n, fx, fy, cx, cy, dust, wc, hc, delta, ed);
+    /* buildSystem: linearizeOplus + constructQuadraticForm of every edge */
+    double H[36] = {0}, b[6] = {0};
+    for (int i = 0; i < n; ++i) {
+      const double Xw[3] = {(double)pts[3 * i], (double)pts[3 * i + 1], (double)pts[3 * i + 2]};
+      double J[6], rho[3];
+      spfe_dust_jacobian(&T, Xw, fx, fy, cx, cy, dust, wc, hc, ed[i].level, J);
+      spfe_huber(ed[i].err * ed[i].err, delta, rho);
+      for (int j = 0; j < 6; ++j) {
+        b[j] -= (rho[1] * J[j]) * ed[i].err;
+        for (int k = 0; k < 6; ++k) H[j * 6 + k] += (J[j] * rho[1]) * J[k];
+      }
+    }
+    if (it == 0) {
+      double maxDiagonal = 0;
+      for (int j = 0; j < 6; ++j) maxDiagonal = fabs(H[j * 6 + j]) > maxDiagonal ? fabs(H[j * 6 + j]) : maxDiagonal;
+      lm.lambda = SPFE_LM_TAU * maxDiagonal;
+      lm.ni = 2;
+    }
+    double rho = 0;
+    int qmax = 0;
+    do {
+      const spfe_se3 saved = T;                               /* _optimizer->push() */
+      double x[6] = {0, 0, 0, 0, 0, 0};
+      const int ok2 = spfe_solve6(H, lm.lambda, b, x);
+      if (ok2) spfe_se3_oplus(&T, x);
+      double tempChi = dust_errors(&T, pts, n, fx, fy, cx, cy, dust, wc, hc, delta, ed);
+      if (!ok2) tempChi = DBL_MAX;
+      if (spfe_lm_judge(&lm, currentChi, tempChi, x, b, &rho)) currentChi = tempChi;   /* discardTop */
+      else T = saved;                                                                    /* pop */
+      qmax++;
+    } while (rho < 0 && qmax < SPFE_LM_MAX_TRIALS);
+    it_done++;
+    if (qmax == SPFE_LM_MAX_TRIALS || rho == 0) ok = 0;       /* Terminate */
+  }
+  /* the edges hold the errors of the LAST evaluation (a rejected trial's, if the run ended on one) */
+  int n_inlier = n;
+  for (int i = 0; i < n; ++i) {
+    const int out = ed[i].level == 1 || ed[i].err * ed[i].err > inlier_chi2;
+    if (inlier) inlier[i] = out ? 0 : 1;
+    if (uv) { uv[2 * i] = ed[i].u; uv[2 * i + 1] = ed[i].v; }
+    if (out) n_inlier--;
+  }
+  spfe_se3_to_f32(&T, Tcw_out);
+  if (iterations) *iterations = it_done;
+  free(ed);
+  return n_inlier;
+}

@@ -118,6 +118,8 @@ struct spfe_handle_s {
   int m_host_cap = 0;              // rows the host-API staging blocks / m_out hold
   unsigned tile16_mask = 0;  // f32 layers (bit i = conv layer i of enqueue()) on 16-row / 8-wave tiles
   bool fuse1a = false;  // f32: conv1a computed inside conv1b (opt-in: SPFE_FUSE_CONV1A=1; measured perf-neutral)
+  uint8_t *dust_scratch = nullptr;   // spfe_align_dust: dust map | points | pose | output block (device)
+  uint8_t *dust_host = nullptr;      // pinned mirror of the output block
   // pipelined host path (spfe_submit_batch / spfe_collect_batch): NPIPE batches in flight, each with its own
   // pinned input / output staging and device frame / record buffers; H2D and D2H on copy streams
   static constexpr int NPIPE = 3;
@@ -925,6 +927,73 @@ int spfe_stage_times(spfe_handle h, float *ms, int cap) {
   }
   for (int i = 0; i < nst; ++i) ms[i] = (float)(acc[i] / (double)(h->calls - first));
   return nst;
+}
+
+// ---- direct "dust" alignment (optimizer_dust.cpp:170-294) -----------------
+namespace {
+int dust_check(spfe_handle h, int n, const spfe_dust_params *prm) {
+  if (n < 0 || n > SPFE_DUST_MAX_POINTS) return fail(SPFE_EINVAL, "n_points %d not in [0, %d]", n, SPFE_DUST_MAX_POINTS);
+  if (prm->max_iterations < 0 || prm->max_iterations > 1000) return fail(SPFE_EINVAL, "max_iterations %d", prm->max_iterations);
+  if (!(prm->huber_delta > 0)) return fail(SPFE_EINVAL, "huber_delta must be positive");
+  if (spfe::dust_lds_bytes(h->hc, h->wc) > 160 * 1024) return fail(SPFE_EINVAL, "dust map %dx%d too large for LDS", h->wc, h->hc);
+  return SPFE_OK;
+}
+int dust_launch(spfe_handle h, const float *d_dust, const float *d_pts, int n, const float *d_T,
+                const spfe_dust_params *prm, uint8_t *d_out, hipStream_t s) {
+  spfe::DustArgs a{};
+  a.dust = d_dust; a.hc = h->hc; a.wc = h->wc; a.pts = d_pts; a.n = n; a.Tcw_in = d_T;
+  a.fx = prm->fx; a.fy = prm->fy; a.cx = prm->cx; a.cy = prm->cy;
+  a.max_iterations = prm->max_iterations; a.delta = prm->huber_delta; a.inlier_chi2 = prm->inlier_chi2;
+  a.Tcw_out = reinterpret_cast<float *>(d_out);
+  a.counts = reinterpret_cast<int *>(d_out + 64);
+  a.uv = reinterpret_cast<float *>(d_out + SPFE_DUST_OFF_UV);
+  a.inlier = d_out + SPFE_DUST_OFF_INLIER;
+  HIP_TRY(spfe::launch_dust_align(a, s));
+  return SPFE_OK;
+}
+}  // namespace
+
+int spfe_align_dust_record_device(spfe_handle h, const void *d_record, const void *d_points_xyz, int n,
+                                  const void *d_Tcw, const spfe_dust_params *prm, void *d_out, void *stream) {
+  if (!h || !d_record || !d_Tcw || !prm || !d_out || (n > 0 && !d_points_xyz)) return fail(SPFE_EINVAL, "null argument");
+  int rc = dust_check(h, n, prm);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
+  const float *d_dust = reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(d_record) + h->rl.off_dd);
+  return dust_launch(h, d_dust, reinterpret_cast<const float *>(d_points_xyz), n, reinterpret_cast<const float *>(d_Tcw),
+                     prm, reinterpret_cast<uint8_t *>(d_out), s);
+}
+
+int spfe_align_dust(spfe_handle h, const float *dense_dust, const float *points_xyz, int n, const float *Tcw,
+                    const spfe_dust_params *prm, float *Tcw_out, uint8_t *inlier, float *proj_uv, int *n_inlier,
+                    int *iterations) {
+  if (!h || !dense_dust || !Tcw || !prm || !Tcw_out || (n > 0 && !points_xyz)) return fail(SPFE_EINVAL, "null argument");
+  int rc = dust_check(h, n, prm);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const size_t map_b = (size_t)h->C * 4, pts_b = (size_t)SPFE_DUST_MAX_POINTS * 12, out_off = map_b + pts_b + 64;
+  if (!h->dust_scratch) {
+    if ((rc = dev_alloc(h, &h->dust_scratch, out_off + SPFE_DUST_OUT_BYTES))) return rc;
+    if ((rc = host_alloc(h, &h->dust_host, (size_t)SPFE_DUST_OUT_BYTES))) return rc;
+  }
+  hipStream_t s = h->stream;
+  uint8_t *d = h->dust_scratch;
+  HIP_TRY(hipMemcpyAsync(d, dense_dust, map_b, hipMemcpyHostToDevice, s));
+  if (n > 0) HIP_TRY(hipMemcpyAsync(d + map_b, points_xyz, (size_t)n * 12, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d + map_b + pts_b, Tcw, 64, hipMemcpyHostToDevice, s));
+  rc = dust_launch(h, reinterpret_cast<const float *>(d), reinterpret_cast<const float *>(d + map_b), n,
+                   reinterpret_cast<const float *>(d + map_b + pts_b), prm, d + out_off, s);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(h->dust_host, d + out_off, SPFE_DUST_OUT_BYTES, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  memcpy(Tcw_out, h->dust_host, 64);
+  const int *cnt = reinterpret_cast<const int *>(h->dust_host + 64);
+  if (n_inlier) *n_inlier = cnt[0];
+  if (iterations) *iterations = cnt[1];
+  if (proj_uv && n > 0) memcpy(proj_uv, h->dust_host + SPFE_DUST_OFF_UV, (size_t)n * 8);
+  if (inlier && n > 0) memcpy(inlier, h->dust_host + SPFE_DUST_OFF_INLIER, (size_t)n);
+  return SPFE_OK;
 }
 
 // ---- pipelined host path ------------------------------------------------------------------------

@@ -153,6 +153,25 @@ struct PatchArgs {
 hipError_t launch_match_patches(const PatchArgs &a, int kcap, float max_dist, int *cand_idx, float *cand_dist,
                                 int32_t *out, hipStream_t s);
 
+// direct "dust" alignment (dust.hip; optimizer_dust.cpp:170-294): one workgroup, Levenberg-Marquardt over n points
+constexpr int DUST_MAX_POINTS = 512;
+struct DustArgs {
+  const float *dust;   // [hc][wc] dense_dust (device)
+  int hc, wc;
+  const float *pts;    // [n][3] world positions (device)
+  int n;
+  const float *Tcw_in; // [16] row-major 4x4 (device)
+  float fx, fy, cx, cy;   // full-resolution intrinsics
+  int max_iterations;
+  double delta, inlier_chi2;
+  float *Tcw_out;      // [16]
+  unsigned char *inlier;  // [n]
+  float *uv;           // [n][2]
+  int *counts;         // n_inlier, iterations
+};
+hipError_t launch_dust_align(const DustArgs &a, hipStream_t s);
+size_t dust_lds_bytes(int hc, int wc);
+
 // exact-math probe kernels for tests (device bits vs host bits)
 hipError_t launch_math_probe(const float *in, float *out_exp, float *out_log, int n, hipStream_t s);
 

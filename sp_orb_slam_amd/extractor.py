@@ -38,6 +38,7 @@ ABI_SYMBOLS = [
     "spfe_set_staging", "spfe_extract_staged", "spfe_extract_batch_staged", "spfe_stage_batch_device",
     "spfe_comm_unique_id", "spfe_comm_init", "spfe_comm_destroy", "spfe_allgather_records", "spfe_comm_wait",
     "spfe_comm_stream", "spfe_submit_batch", "spfe_collect_batch",
+    "spfe_align_dust", "spfe_align_dust_record_device",
 ]
 
 
@@ -64,6 +65,17 @@ class RecordLayout(C.Structure):
                 ("off_xy", C.c_size_t), ("off_resp", C.c_size_t), ("off_cov", C.c_size_t),
                 ("off_cinv", C.c_size_t), ("off_desc", C.c_size_t), ("off_occ", C.c_size_t),
                 ("off_dd", C.c_size_t), ("off_sd", C.c_size_t)]
+
+
+class _DustParams(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("max_iterations", C.c_int), ("huber_delta", C.c_double), ("inlier_chi2", C.c_double)]
+
+
+DUST_MAX_POINTS = 512
+DUST_OFF_UV = 128
+DUST_OFF_INLIER = 128 + DUST_MAX_POINTS * 8
+DUST_OUT_BYTES = 128 + DUST_MAX_POINTS * 9
 
 
 class _Staging(C.Structure):
@@ -165,6 +177,12 @@ def load_library():
                                             C.c_void_p]
     L.spfe_match_out_bytes.restype = C.c_size_t
     L.spfe_match_out_bytes.argtypes = [C.c_void_p]
+    L.spfe_align_dust.restype = C.c_int
+    L.spfe_align_dust.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(_DustParams),
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.spfe_align_dust_record_device.restype = C.c_int
+    L.spfe_align_dust_record_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                C.POINTER(_DustParams), C.c_void_p, C.c_void_p]
     L.spfe_submit_batch.restype = C.c_int
     L.spfe_submit_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_long)]
     L.spfe_collect_batch.restype = C.c_int
@@ -354,6 +372,47 @@ class SPExtractor:
         out = [FrameResult(res[i], self.height, self.width, self.with_heat) for i in range(n)]
         self._publish(out[-1])
         return out
+
+    # -- direct "dust" alignment (optimizer_dust.cpp:170-294) --
+    @staticmethod
+    def _dust_params(fx, fy, cx, cy, max_iterations, huber_delta, inlier_chi2):
+        return _DustParams(float(fx), float(fy), float(cx), float(cy), int(max_iterations), float(huber_delta),
+                           float(inlier_chi2))
+
+    def align_dust(self, dense_dust, points_xyz, Tcw, fx, fy, cx, cy, max_iterations=40, huber_delta=0.9,
+                   inlier_chi2=0.9):
+        """Optimizer::PoseOptimizationDust(pFrame, mps, is_visible): -> dict(Tcw [4,4] f32, inlier bool[n],
+        uv f32 [n,2] (dust_proj_u/v), n_inlier, iterations)."""
+        dust = np.ascontiguousarray(dense_dust, np.float32)
+        if dust.shape != (self.height // 8, self.width // 8):
+            raise SpfeError("dense_dust must be [H/8, W/8]")
+        pts = np.ascontiguousarray(points_xyz, np.float32).reshape(-1, 3)
+        T = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+        n = len(pts)
+        Tout = np.zeros(16, np.float32)
+        inl = np.zeros(max(n, 1), np.uint8)
+        uv = np.zeros((max(n, 1), 2), np.float32)
+        ni, it = C.c_int(0), C.c_int(0)
+        prm = self._dust_params(fx, fy, cx, cy, max_iterations, huber_delta, inlier_chi2)
+        _check(self._lib.spfe_align_dust(self._h, dust.ctypes.data, pts.ctypes.data, n, T.ctypes.data, C.byref(prm),
+                                         Tout.ctypes.data, inl.ctypes.data, uv.ctypes.data, C.byref(ni), C.byref(it)))
+        return dict(Tcw=Tout.reshape(4, 4), inlier=inl[:n].astype(bool), uv=uv[:n], n_inlier=ni.value,
+                    iterations=it.value)
+
+    def align_dust_record_device(self, d_record, d_points_xyz, n, d_Tcw, d_out, fx, fy, cx, cy, max_iterations=40,
+                                 huber_delta=0.9, inlier_chi2=0.9, stream=None):
+        prm = self._dust_params(fx, fy, cx, cy, max_iterations, huber_delta, inlier_chi2)
+        _check(self._lib.spfe_align_dust_record_device(self._h, C.c_void_p(d_record), C.c_void_p(d_points_xyz), int(n),
+                                                       C.c_void_p(d_Tcw), C.byref(prm), C.c_void_p(d_out),
+                                                       C.c_void_p(stream or 0)))
+
+    @staticmethod
+    def decode_dust_out(host_block, n):
+        b = np.ascontiguousarray(host_block, np.uint8)
+        cnt = b[64:72].view(np.int32)
+        return dict(Tcw=b[:64].view(np.float32).reshape(4, 4).copy(), n_inlier=int(cnt[0]), iterations=int(cnt[1]),
+                    uv=b[DUST_OFF_UV:DUST_OFF_UV + n * 8].view(np.float32).reshape(n, 2).copy(),
+                    inlier=b[DUST_OFF_INLIER:DUST_OFF_INLIER + n].astype(bool))
 
     # -- pipelined host path: up to 3 batches in flight --
     def submit_batch(self, images):

@@ -1,0 +1,109 @@
+"""GPU: direct "dust" alignment (spfe_align_dust, csrc/dust.hip) against the CPU oracle
+(oracle_align_dust — Optimizer::PoseOptimizationDust, optimizer_dust.cpp:170-294; g2o restated, PARITY UNPINNED).
+
+Both sides evaluate include/spfe_dust_math.h and sum the edges in the same order, so they differ only through
+the device's sin / cos / sqrt / division in the exponential map and the solve (<= 1 ulp each).  Tolerances:
+pose 1e-5 (absolute, 4x4 float), projections 1e-3 cell, inlier flags equal except where chi2 is within 1e-6 of
+the 0.9 threshold, iteration count equal."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from sp_orb_slam_amd import dust_scene, synth, weights
+from sp_orb_slam_amd.extractor import DUST_OUT_BYTES, SPExtractor, SpfeError
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-5
+UV_TOL = 1e-3
+
+
+def _compare(g, r, dust):
+    assert g["iterations"] == r["iterations"]
+    assert np.abs(g["Tcw"] - r["Tcw"]).max() <= POSE_TOL
+    both = g["inlier"] & r["inlier"]
+    assert np.abs(g["uv"][both] - r["uv"][both]).max(initial=0) <= UV_TOL
+    diff = np.flatnonzero(g["inlier"] != r["inlier"])
+    for i in diff:   # only threshold-straddling edges may flip
+        u, v = r["uv"][i]
+        xf, yf = int(np.floor(u)), int(np.floor(v))
+        xx, yy = u - xf, v - yf
+        val = ((1 - xx) * (1 - yy) * dust[yf, xf] + xx * (1 - yy) * dust[yf, xf + 1] + (1 - xx) * yy * dust[yf + 1, xf] +
+               xx * yy * dust[yf + 1, xf + 1])
+        assert abs(val * val - 0.9) < 1e-4, i
+    assert abs(g["n_inlier"] - r["n_inlier"]) <= len(diff)
+    assert g["n_inlier"] == int(g["inlier"].sum())
+
+
+@pytest.mark.parametrize("H,W,n,seed", [(480, 752, 160, 0), (480, 752, 200, 1), (480, 640, 97, 2), (720, 1280, 300, 3),
+                                        (480, 752, 512, 4), (480, 752, 1, 5), (120, 160, 40, 6)])
+def test_align_dust_matches_oracle(H, W, n, seed):
+    sc = dust_scene.make_scene(seed, H=H, W=W, n_points=n, cx=W / 2 - 8.8, cy=H / 2 + 8.4)
+    ext = SPExtractor(100, H, W, weights.synthetic(7, "dense"), with_heat=False)
+    g = ext.align_dust(sc["dust"], sc["pts"], sc["Tcw_init"], sc["fx"], sc["fy"], sc["cx"], sc["cy"])
+    r = oracle.align_dust(sc["dust"], sc["pts"], sc["Tcw_init"], sc["fx"], sc["fy"], sc["cx"], sc["cy"])
+    _compare(g, r, sc["dust"])
+    # the alignment did something: the projections moved towards the keypoints
+    uv_t, _ = dust_scene.project(sc["Tcw_true"], sc["pts"], sc["fx"], sc["fy"], sc["cx"], sc["cy"])
+    uv_0, _ = dust_scene.project(sc["Tcw_init"], sc["pts"], sc["fx"], sc["fy"], sc["cx"], sc["cy"])
+    uv_1, _ = dust_scene.project(g["Tcw"], sc["pts"], sc["fx"], sc["fy"], sc["cx"], sc["cy"])
+    if n >= 40:
+        assert np.abs(uv_1 - uv_t).mean() < np.abs(uv_0 - uv_t).mean()
+    # other iteration caps / kernel parameters
+    for it, delta in ((0, 0.9), (3, 0.9), (40, 0.3)):
+        g2 = ext.align_dust(sc["dust"], sc["pts"], sc["Tcw_init"], sc["fx"], sc["fy"], sc["cx"], sc["cy"],
+                            max_iterations=it, huber_delta=delta)
+        r2 = oracle.align_dust(sc["dust"], sc["pts"], sc["Tcw_init"], sc["fx"], sc["fy"], sc["cx"], sc["cy"],
+                               max_iterations=it, delta=delta)
+        _compare(g2, r2, sc["dust"])
+    ext.close()
+
+
+def test_align_dust_edge_cases():
+    H, W = 480, 752
+    sc = dust_scene.make_scene(11, n_points=64, outlier_frac=0.0)
+    ext = SPExtractor(100, H, W, weights.synthetic(7, "dense"), with_heat=False)
+    # points behind the camera / outside the map, a flat map (H = 0: ten failed trials, Terminate)
+    pts = sc["pts"].copy()
+    T = sc["Tcw_init"].astype(np.float64)
+    pts[0] = (np.array([0.1, -0.2, -3.0]) - T[:3, 3]) @ T[:3, :3]
+    pts[1] = (np.array([-30.0, 0.0, 4.0]) - T[:3, 3]) @ T[:3, :3]
+    for dust in (sc["dust"], np.full_like(sc["dust"], 0.5)):
+        g = ext.align_dust(dust, pts, sc["Tcw_init"], sc["fx"], sc["fy"], sc["cx"], sc["cy"])
+        r = oracle.align_dust(dust, pts, sc["Tcw_init"], sc["fx"], sc["fy"], sc["cx"], sc["cy"])
+        _compare(g, r, dust)
+        assert not g["inlier"][0] and not g["inlier"][1]
+    # n = 0
+    g = ext.align_dust(sc["dust"], np.zeros((0, 3), np.float32), sc["Tcw_init"], sc["fx"], sc["fy"], sc["cx"], sc["cy"])
+    assert g["n_inlier"] == 0 and np.abs(g["Tcw"] - sc["Tcw_init"]).max() < 1e-6
+    with pytest.raises(SpfeError):
+        ext.align_dust(sc["dust"], np.zeros((513, 3), np.float32), sc["Tcw_init"], sc["fx"], sc["fy"], sc["cx"], sc["cy"])
+    with pytest.raises(SpfeError):
+        ext.align_dust(sc["dust"][:-1], sc["pts"], sc["Tcw_init"], sc["fx"], sc["fy"], sc["cx"], sc["cy"])
+    ext.close()
+
+
+def test_align_dust_on_a_resident_record():
+    """The device form: the dust map is the dense_dust of a record that never left HBM (extraction -> alignment)."""
+    import torch
+    H, W, nf = 240, 320, 300
+    blob = weights.synthetic(7, "sparse")
+    img = synth.make_image(21, H, W)
+    ext = SPExtractor(nf, H, W, blob, with_heat=False, async_cov=True)
+    d_img = torch.from_numpy(img[None]).cuda()
+    d_rec = torch.zeros(ext.record_bytes(), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.Stream()
+    t = ext.extract_batch_device(d_img.data_ptr(), 1, d_rec.data_ptr(), stream.cuda_stream)
+    ext.wait_records(t, stream.cuda_stream)
+    sc = dust_scene.make_scene(5, H=H, W=W, n_points=120, fx=200.0, fy=200.0, cx=W / 2 - 3.0, cy=H / 2 + 2.0)
+    d_pts = torch.from_numpy(sc["pts"]).cuda()
+    d_T = torch.from_numpy(sc["Tcw_init"].reshape(16)).cuda()
+    d_out = torch.zeros(DUST_OUT_BYTES, dtype=torch.uint8, device="cuda")
+    ext.align_dust_record_device(d_rec.data_ptr(), d_pts.data_ptr(), 120, d_T.data_ptr(), d_out.data_ptr(), 200.0, 200.0,
+                                 sc["cx"], sc["cy"], stream=stream.cuda_stream)
+    stream.synchronize()
+    rec = ext.view_record(d_rec.cpu().numpy())
+    g = ext.decode_dust_out(d_out.cpu().numpy(), 120)
+    r = oracle.align_dust(rec.dense_dust, sc["pts"], sc["Tcw_init"], 200.0, 200.0, sc["cx"], sc["cy"])
+    _compare(g, r, rec.dense_dust)
+    ext.close()
