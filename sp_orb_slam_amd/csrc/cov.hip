@@ -44,7 +44,8 @@ namespace spfe {
 #define COV_INF 0x7f7f7f7f
 #define COV_LCAP 128     // FIFO entries kept in LDS per wavefront
 #define COV_WIN 16       // the window covers dx,dy in [-16, 15] around the keypoint
-#define COV_WAVES 2      // wavefronts (= walks) per workgroup: 19 KB of LDS, fits beside a conv workgroup (127 KB)
+#define COV_WAVES 2      // wavefronts (= walks) per workgroup: 21 KB of LDS, fits beside a conv workgroup (127 KB)
+#define COV_OW 256       // popped pixels OUTSIDE the window a walk can remember (its visited set out there)
 
 struct WaveMem {         // LDS of one wavefront
   float hv[32 * 32];     // heat_inv window
@@ -52,6 +53,7 @@ struct WaveMem {         // LDS of one wavefront
   int lq[COV_LCAP];
   float lqv[COV_LCAP];
   uint32_t bm[32];       // own-visited bitmap
+  int ow[COV_OW];        // popped pixels outside the window (visited set there), now = count
 };
 
 struct Walk {
@@ -102,13 +104,20 @@ __device__ __forceinline__ void stage_window(const Walk &w, int lane) {
   if (lane < 32) w.m->bm[lane] = 0;
 }
 
+__device__ __attribute__((noinline)) bool ow_seen(const WaveMem *m, int now, int id) {
+  for (int u = 0; u < now; ++u)
+    if (m->ow[u] == id) return true;
+  return false;
+}
+
 // The FIFO walk, run by the whole wavefront in lock step.  All lanes read the
 // popped entry (an LDS broadcast); lanes 0..3 each examine one neighbour (left,
 // up, right, down — :302-313) and the survivors are appended in lane order with a
 // ballot + prefix count, i.e. in the reference's push order.  A pop costs one
 // chain of ~3 dependent LDS reads instead of four.  REPLAY additionally blocks
 // pixels with done[p] < j.  Returns the number of pops, or -1 when the FIFO
-// outgrew qcap.  (head, tail and the result are wave-uniform.)
+// outgrew qcap, -2 when more than COV_OW distinct pixels outside the staged window were popped (a hill wider
+// than the window: reported, not guessed).  (head, tail and the result are wave-uniform.)
 template <bool REPLAY>
 __device__ int walk(const Walk &w, int lane) {
   WaveMem *m = w.m;
@@ -117,7 +126,7 @@ __device__ int walk(const Walk &w, int lane) {
     m->lq[0] = y0 * W + x0;
     m->lqv[0] = m->hv[COV_WIN * 32 + COV_WIN];
   }
-  int head = 0, tail = 1;
+  int head = 0, tail = 1, now = 0;
   const int t = lane & 3;
   const int ox = t == 0 ? -1 : (t == 2 ? 1 : 0), oy = t == 1 ? -1 : (t == 3 ? 1 : 0);
   int id = y0 * W + x0;
@@ -125,8 +134,14 @@ __device__ int walk(const Walk &w, int lane) {
   while (true) {
     const int y = id / W, x = id - y * W;
     const int cdx = x - x0 + COV_WIN, cdy = y - y0 + COV_WIN;
-    // visited at POP (:285)
-    if (lane == 0 && (unsigned)cdx < 32u && (unsigned)cdy < 32u) m->bm[cdy] |= 1u << cdx;
+    // visited at POP (:285): a bitmap inside the window, a short list outside it
+    if ((unsigned)cdx < 32u && (unsigned)cdy < 32u) {
+      if (lane == 0) m->bm[cdy] |= 1u << cdx;
+    } else if (!ow_seen(m, now, id)) {   // wave-uniform branch (id, now are uniform)
+      if (now >= COV_OW) return -2;
+      if (lane == 0) m->ow[now] = id;
+      ++now;
+    }
     ++head;
     const int nx = x + ox, ny = y + oy;
     // bounds as in the reference: xx > 0, yy > 0, xx < w, yy < h
@@ -143,15 +158,11 @@ __device__ int walk(const Walk &w, int lane) {
       const uint32_t row = m->bm[inwin ? dy : 0];
       v = hv;
       take = take && hv > 0.0f && hv < here && !(REPLAY && dstamp < w.j) && !((row >> dx) & 1u);
-    } else {  // a neighbour outside the staged window (rare): global lookups, pop-list search
+    } else {  // a neighbour outside the staged window (rare): global lookups, search of the outside list
       v = slow_ld_f(w.hinv, nid);
       take = v > 0.0f && v < here;
       if (take && REPLAY) take = !(slow_ld_i(w.done, nid) < w.j);
-      if (take) {
-        bool seen = false;
-        for (int u = 0; u < head && !seen; ++u) seen = fifo_id(w, u) == nid;
-        take = !seen;
-      }
+      if (take) take = !ow_seen(m, now, nid);
     }
     const unsigned mask = (unsigned)(__ballot(take) & 0xFull);
     const int pos = tail + __popc(mask & ((1u << t) - 1u));
@@ -218,6 +229,8 @@ struct CovFrame {
   const float *hinv;
   int *claim, *done, *queues, *npop, *dirty, *ndirty, *nxt, *workers, *nworkers;
   float *qvals;
+  int *ovf_slot, *novf, *ovf_q;   // overflow slots: pop lists of the walks that outgrew qcap
+  float *ovf_v;
   int K;
 };
 
@@ -239,9 +252,23 @@ __device__ __forceinline__ CovFrame cov_frame(const FrameBufs &f, const RecordLa
   c.dirty = cs.dirty + (size_t)b * rl.kmax;
   c.nxt = cs.nxt + (size_t)b * rl.kmax;
   c.workers = cs.workers + (size_t)b * rl.kmax;
-  c.ndirty = cs.counters + 2 * b;
-  c.nworkers = cs.counters + 2 * b + 1;
+  c.ndirty = cs.counters + 4 * b;
+  c.nworkers = cs.counters + 4 * b + 1;
+  c.novf = cs.counters + 4 * b + 2;
+  c.ovf_slot = cs.ovf_slot + (size_t)b * rl.kmax;
+  c.ovf_q = cs.ovf_q + (size_t)b * cs.ovf_slots * cs.ovf_cap;
+  c.ovf_v = cs.ovf_v + (size_t)b * cs.ovf_slots * cs.ovf_cap;
   return c;
+}
+
+// where keypoint j's pop list lives: its regular row, or the overflow slot its lone walk took
+__device__ __forceinline__ void pop_list(const CovFrame &c, const CovScratch &cs, int j, int *&q, float *&qv, int &cap) {
+  const int s = c.ovf_slot[j];
+  if (__builtin_expect(s < 0, 1)) {
+    q = c.queues + (size_t)j * cs.qcap; qv = c.qvals + (size_t)j * cs.qcap; cap = cs.qcap;
+  } else {
+    q = c.ovf_q + (size_t)s * cs.ovf_cap; qv = c.ovf_v + (size_t)s * cs.ovf_cap; cap = cs.ovf_cap;
+  }
 }
 
 // ---- A: lone walks, one wavefront per keypoint ----
@@ -256,10 +283,25 @@ __global__ __launch_bounds__(64 * COV_WAVES) void cov_walk_kernel(FrameBufs f, R
   Walk w{&s_mem[wv], c.hinv, nullptr, c.queues + (size_t)j * cs.qcap, c.qvals + (size_t)j * cs.qcap, cs.qcap, W, H,
          (int)c.kp_xy[2 * j], (int)c.kp_xy[2 * j + 1], j};
   stage_window<false>(w, lane);
-  const int n = walk<false>(w, lane);
+  int n = walk<false>(w, lane);
+  if (n == -1) {
+    // The region outgrew the regular FIFO (the reference's visited-at-pop rule multiplies pops on smooth
+    // hills): take one of the frame's overflow slots and walk again from the start, still on the device.
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(c.novf, 1);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    if (slot < cs.ovf_slots) {
+      if (lane == 0) c.ovf_slot[j] = slot;
+      w.gq = c.ovf_q + (size_t)slot * cs.ovf_cap;
+      w.gqv = c.ovf_v + (size_t)slot * cs.ovf_cap;
+      w.qcap = cs.ovf_cap;
+      if (lane < 32) w.m->bm[lane] = 0;
+      n = walk<false>(w, lane);
+    }
+  }
   if (lane == 0) {
     c.npop[j] = n;
-    if (n < 0) atomicOr(&c.hdr[2], 1);  // region outgrew the FIFO: report, do not guess
+    if (n < 0) atomicOr(&c.hdr[2], 1);  // beyond the overflow capacity too: report, do not guess
   }
   if (n < 0) return;
   moments(w, n, lane, c.cov2 + 2 * j, c.cinv + 2 * j);  // final if the keypoint turns out clean
@@ -276,7 +318,8 @@ __global__ __launch_bounds__(64 * COV_WAVES) void cov_classify_kernel(FrameBufs 
   const int j = blockIdx.x * COV_WAVES + (threadIdx.x >> 6);
   const CovFrame c = cov_frame(f, rl, cs, b, H, W);
   if (j >= c.K || (c.hdr[2] & 1)) return;
-  const int *q = c.queues + (size_t)j * cs.qcap;
+  int *q; float *qv; int cap;
+  pop_list(c, cs, j, q, qv, cap);
   const int n = c.npop[j];
   int bad = 0;
   for (int i = 1 + lane; i < n; i += 64) bad |= c.claim[q[i]] < j;  // claims were made by the previous kernel
@@ -316,7 +359,8 @@ __global__ __launch_bounds__(LINK_THREADS) void cov_link_kernel(FrameBufs f, Rec
   const int lane = tid & 63, wv = tid >> 6;
   for (int d = wv; d < nd; d += LINK_THREADS / 64) {
     const int j = c.dirty[d];
-    const int *q = c.queues + (size_t)j * cs.qcap;
+    int *q; float *qv; int cap;
+    pop_list(c, cs, j, q, qv, cap);
     const int n = c.npop[j];
     for (int i = 1 + lane; i < n; i += 64) {
       int a = c.claim[q[i]];
@@ -337,31 +381,38 @@ __global__ __launch_bounds__(LINK_THREADS) void cov_link_kernel(FrameBufs f, Rec
   __syncthreads();
   for (int j = tid; j < K; j += LINK_THREADS) parent[j] = uf_find(parent, j);  // flatten (roots are fixed now)
   __syncthreads();
-  for (int d = tid; d < nd; d += LINK_THREADS) {
-    const int j = c.dirty[d];
-    atomicMin(&leader[parent[j]], j);
-  }
-  __syncthreads();
-  // chain: next dirty member of the same component in ascending index; leaders
-  // become the workers of the replay kernel.  (leader[] doubles as scratch: the
-  // dirty list and each member's root, so the search below stays in LDS.)
-  int *sdirty = smem_i + 2 * K, *sroot = smem_i + 3 * K;
-  for (int d = tid; d < nd; d += LINK_THREADS) {
-    const int j = c.dirty[d];
-    sdirty[d] = j;
-    sroot[d] = parent[j];
-  }
-  __syncthreads();
-  for (int d = tid; d < nd; d += LINK_THREADS) {
-    const int j = sdirty[d];
-    const int root = sroot[d];
-    int best = COV_INF;
-    for (int e = 0; e < nd; ++e) {
-      const int i = sdirty[e];
-      if (i > j && i < best && sroot[e] == root) best = i;
+  // chain: the dirty members of a component in ascending index.  Sort the dirty list by (root, index)
+  // — a bitonic sort in LDS — and the successor / the component's first member (the replay kernel's
+  // worker) are the neighbours in the sorted order.
+  int *key = smem_i + 2 * K;   // [P], P = next power of two >= nd (<= 2 K)
+  int P = 1;
+  while (P < nd) P <<= 1;
+  for (int d = tid; d < P; d += LINK_THREADS) {
+    if (d < nd) {
+      const int j = c.dirty[d];
+      key[d] = (parent[j] << 15) | j;   // K <= 16385 < 2^15 + 1: bounded by spfe_create
+    } else {
+      key[d] = COV_INF;
     }
-    c.nxt[j] = best == COV_INF ? -1 : best;
-    if (leader[root] == j) c.workers[atomicAdd(c.nworkers, 1)] = j;
+  }
+  __syncthreads();
+  for (int k = 2; k <= P; k <<= 1)
+    for (int jj = k >> 1; jj > 0; jj >>= 1) {
+      for (int i = tid; i < P; i += LINK_THREADS) {
+        const int ixj = i ^ jj;
+        if (ixj > i) {
+          const int a = key[i], bq = key[ixj];
+          const bool up = (i & k) == 0;
+          if ((a > bq) == up) { key[i] = bq; key[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int d = tid; d < nd; d += LINK_THREADS) {
+    const int kd = key[d], j = kd & 0x7fff, root = kd >> 15;
+    const int kn = d + 1 < nd ? key[d + 1] : COV_INF;
+    c.nxt[j] = (kn != COV_INF && (kn >> 15) == root) ? (kn & 0x7fff) : -1;
+    if (d == 0 || (key[d - 1] >> 15) != root) c.workers[atomicAdd(c.nworkers, 1)] = j;
   }
 }
 
@@ -378,8 +429,9 @@ __global__ __launch_bounds__(64 * COV_WAVES) void cov_replay_kernel(FrameBufs f,
   while (j >= 0) {
     const int jn = c.nxt[j];  // issued together with the coordinates: one round trip per member
     const float fx = c.kp_xy[2 * j], fy = c.kp_xy[2 * j + 1];
-    Walk w{&s_mem[wv], c.hinv, c.done, c.queues + (size_t)j * cs.qcap, c.qvals + (size_t)j * cs.qcap, cs.qcap, W,
-           H, (int)fx, (int)fy, j};
+    int *q; float *qv; int cap;
+    pop_list(c, cs, j, q, qv, cap);
+    Walk w{&s_mem[wv], c.hinv, c.done, q, qv, cap, W, H, (int)fx, (int)fy, j};
     stage_window<true>(w, lane);
     // a replay's pop list is a subsequence of the lone walk's: it cannot overflow
     const int n = walk<true>(w, lane);
@@ -393,7 +445,7 @@ __global__ __launch_bounds__(64 * COV_WAVES) void cov_replay_kernel(FrameBufs f,
   }
 }
 
-size_t cov_link_lds(int kmax) { return (size_t)kmax * 4 * sizeof(int); }
+size_t cov_link_lds(int kmax) { return (size_t)kmax * 4 * sizeof(int); }   // parent, leader, 2 K sort keys
 
 hipError_t launch_cov(const FrameBufs &f, const RecordLayout &r, const CovScratch &cs, int B, int H, int W,
                       hipStream_t s) {
@@ -401,7 +453,9 @@ hipError_t launch_cov(const FrameBufs &f, const RecordLayout &r, const CovScratc
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(cs.done, 0x7f, (size_t)B * H * W * 4, s);
   if (e != hipSuccess) return e;
-  e = hipMemsetAsync(cs.counters, 0, (size_t)B * 2 * 4, s);
+  e = hipMemsetAsync(cs.counters, 0, (size_t)B * 4 * 4, s);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(cs.ovf_slot, 0xff, (size_t)B * r.kmax * 4, s);
   if (e != hipSuccess) return e;
   const dim3 grid((r.kmax + COV_WAVES - 1) / COV_WAVES, B), block(64 * COV_WAVES);
   hipLaunchKernelGGL(cov_walk_kernel, grid, block, 0, s, f, r, cs, H, W);

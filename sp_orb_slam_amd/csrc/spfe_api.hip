@@ -422,7 +422,15 @@ int build(spfe_handle h, const spfe_config *cfg) {
     if ((rc = dev_alloc(h, &h->cov.dirty, (size_t)B * h->kmax))) return rc;
     if ((rc = dev_alloc(h, &h->cov.nxt, (size_t)B * h->kmax))) return rc;
     if ((rc = dev_alloc(h, &h->cov.workers, (size_t)B * h->kmax))) return rc;
-    if ((rc = dev_alloc(h, &h->cov.counters, (size_t)B * 2))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.counters, (size_t)B * 4))) return rc;
+    const char *oenv = getenv("SPFE_COV_OVF_SLOTS"), *cenv = getenv("SPFE_COV_OVF_CAP");
+    h->cov.ovf_slots = oenv ? atoi(oenv) : 16;
+    h->cov.ovf_cap = cenv ? atoi(cenv) : 16384;
+    if (h->cov.ovf_slots < 0) h->cov.ovf_slots = 0;
+    if (h->cov.ovf_cap < h->cov.qcap) h->cov.ovf_cap = h->cov.qcap;
+    if ((rc = dev_alloc(h, &h->cov.ovf_slot, (size_t)B * h->kmax))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.ovf_q, (size_t)B * h->cov.ovf_slots * h->cov.ovf_cap + 1))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.ovf_v, (size_t)B * h->cov.ovf_slots * h->cov.ovf_cap + 1))) return rc;
   }
   make_layout(h->kmax, C, &h->rl);
   if ((rc = dev_alloc(h, &h->d_records, (size_t)B * h->rl.bytes))) return rc;
@@ -664,8 +672,9 @@ int spfe_create(const spfe_config *cfg, spfe_handle *out) {
                 cfg->width, cfg->height);
   if (cfg->height < 16 || cfg->width < 16)
     return fail(SPFE_EINVAL, "image size %dx%d too small", cfg->width, cfg->height);
-  if (cfg->num_features < 1 || cfg->num_features > 16384)
-    return fail(SPFE_EINVAL, "num_features %d out of range (1..16384)", cfg->num_features);
+  if (cfg->num_features < 1 || cfg->num_features > 10000)
+    return fail(SPFE_EINVAL, "num_features %d out of range (1..10000: the covariance link stage keeps 16 bytes per "
+                             "keypoint in one workgroup's 160 KB of LDS)", cfg->num_features);
   if (cfg->max_batch < 1) return fail(SPFE_EINVAL, "max_batch must be >= 1");
   if (cfg->precision != SPFE_PRECISION_F32 && cfg->precision != SPFE_PRECISION_BF16)
     return fail(SPFE_EINVAL, "unsupported precision %d", cfg->precision);

@@ -92,8 +92,13 @@ struct CovScratch {
   int *dirty;     // [B][kmax] keypoints whose lone region meets a lower keypoint's
   int *nxt;       // [B][kmax] next dirty member of the same component (ascending) or -1
   int *workers;   // [B][kmax] lowest dirty member of each component
-  int *counters;  // [B][2] number of dirty keypoints, number of components
+  int *counters;  // [B][4] number of dirty keypoints, number of components, overflow slots taken
   int qcap;
+  // walks that outgrow qcap redo themselves in one of ovf_slots per-frame slots of ovf_cap entries
+  int *ovf_slot;  // [B][kmax] slot of the keypoint's pop list, or -1
+  int *ovf_q;     // [B][ovf_slots][ovf_cap]
+  float *ovf_v;
+  int ovf_slots, ovf_cap;
 };
 size_t cov_link_lds(int kmax);
 hipError_t launch_cov(const FrameBufs &f, const RecordLayout &r, const CovScratch &cs, int B, int H, int W,

@@ -149,21 +149,56 @@ def test_overlapping_covariance_regions_exact(H, W, sigma, nh, seed):
     assert (lone != ref["cov2"]).any(), "test input has no interacting regions"
 
 
-def test_covariance_queue_overflow_is_reported_and_repaired():
+def test_covariance_queue_overflow_is_handled_on_the_device(monkeypatch):
+    """Walks that outgrow the regular per-keypoint FIFO (forced here: SPFE_COV_QCAP=24) redo themselves in an
+    overflow slot ON THE DEVICE: the record is complete and exact, status stays 0, no host fallback involved."""
     H, W = 128, 160
     semi = _hills(H, W, 1, 10.0, 12)
     coarse = _coarse(H, W, 1)
-    os.environ["SPFE_COV_QCAP"] = "24"
-    try:
-        ext = SPExtractor(1000, H, W, _blob())
-    finally:
-        del os.environ["SPFE_COV_QCAP"]
+    monkeypatch.setenv("SPFE_COV_QCAP", "24")
+    monkeypatch.setenv("SPFE_COV_OVF_SLOTS", "1024")
+    ext = SPExtractor(1000, H, W, _blob())
+    fr = ext.postprocess(semi, coarse)[0]
+    ext.close()
+    ref = oracle.postprocess(semi, coarse, H, W, 1000)
+    assert fr.status == 0
+    assert np.array_equal(_bits(fr.cov2), _bits(ref["cov2"])) and np.array_equal(_bits(fr.cov2_inv), _bits(ref["cov2_inv"]))
+    assert np.array_equal(fr.kp_xy, ref["kp_xy"])
+
+
+def test_covariance_overflow_beyond_capacity_is_reported_and_repaired(monkeypatch):
+    """No overflow slots left (forced: none configured): the frame's status carries SPFE_STATUS_COV_OVERFLOW and
+    the host-facing call repairs cov2 with the host routine, exactly."""
+    H, W = 128, 160
+    semi = _hills(H, W, 1, 10.0, 12)
+    coarse = _coarse(H, W, 1)
+    monkeypatch.setenv("SPFE_COV_QCAP", "24")
+    monkeypatch.setenv("SPFE_COV_OVF_SLOTS", "0")
+    ext = SPExtractor(1000, H, W, _blob())
     fr = ext.postprocess(semi, coarse)[0]
     ext.close()
     ref = oracle.postprocess(semi, coarse, H, W, 1000)
     assert fr.status & 1                                    # SPFE_STATUS_COV_OVERFLOW
     assert np.array_equal(_bits(fr.cov2), _bits(ref["cov2"]))   # host call repaired the frame
     assert np.array_equal(fr.kp_xy, ref["kp_xy"])
+
+
+def test_covariance_wide_hills_leave_the_staged_window(monkeypatch):
+    """Regions wider than the 32x32 window staged in LDS: the walk continues on global lookups and remembers the
+    pixels it popped out there; exact against the sequential oracle."""
+    H, W = 128, 160
+    for sigma, nh, rough in ((30.0, 4, 0.01), (24.0, 5, 0.03), (30.0, 4, 0.05)):
+        semi = _hills(H, W, 1, sigma, nh, rough=rough)
+        coarse = _coarse(H, W, 1)
+        ext = SPExtractor(1000, H, W, _blob())
+        fr = ext.postprocess(semi, coarse)[0]
+        ext.close()
+        ref = oracle.postprocess(semi, coarse, H, W, 1000)
+        assert np.array_equal(fr.kp_xy, ref["kp_xy"])
+        if fr.status == 0:
+            assert np.array_equal(_bits(fr.cov2), _bits(ref["cov2"]))
+        else:   # a hill with more than 256 distinct pixels outside the window: reported and repaired by the host call
+            assert np.array_equal(_bits(fr.cov2), _bits(ref["cov2"]))
 
 
 def test_postprocess_batch():
