@@ -79,29 +79,42 @@ __device__ __forceinline__ float fifo_val(const Walk &w, int i) {
   return slow_ld_f(w.gqv, i);
 }
 
-// all 64 lanes: stage the window (zero outside the image: never read there)
-template <bool REPLAY>
-__device__ __forceinline__ void stage_window(const Walk &w, int lane) {
-  const int wx0 = w.x0 - COV_WIN, wy0 = w.y0 - COV_WIN;
+// all 64 lanes: stage the window (zero outside the image: never read there).  Two halves so that a caller can
+// have the loads of the NEXT window in flight while it walks the current one.
+struct WinRegs {
   float hv[16];
   int dn[16];
+};
+template <bool REPLAY>
+__device__ __forceinline__ void load_window(const float *hinv, const int *done, int W, int H, int x0, int y0, int lane,
+                                            WinRegs &r) {
+  const int wx0 = x0 - COV_WIN, wy0 = y0 - COV_WIN;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {  // all 16 (32) loads in flight together: one round trip
     const int i = lane + 64 * k;
     const int dy = i >> 5, dx = i & 31;
     const int x = wx0 + dx, y = wy0 + dy;
-    const bool in = (unsigned)x < (unsigned)w.W && (unsigned)y < (unsigned)w.H;
-    const size_t g = in ? (size_t)y * w.W + x : 0;
-    hv[k] = w.hinv[g];
-    if (REPLAY) dn[k] = w.done[g];
-    if (!in) { hv[k] = 0.0f; dn[k] = COV_INF; }
+    const bool in = (unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H;
+    const size_t g = in ? (size_t)y * W + x : 0;
+    r.hv[k] = hinv[g];
+    if (REPLAY) r.dn[k] = done[g];
+    if (!in) { r.hv[k] = 0.0f; r.dn[k] = COV_INF; }
   }
+}
+template <bool REPLAY>
+__device__ __forceinline__ void store_window(WaveMem *m, int lane, const WinRegs &r) {
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    w.m->hv[lane + 64 * k] = hv[k];
-    if (REPLAY) w.m->dn[lane + 64 * k] = dn[k];
+    m->hv[lane + 64 * k] = r.hv[k];
+    if (REPLAY) m->dn[lane + 64 * k] = r.dn[k];
   }
-  if (lane < 32) w.m->bm[lane] = 0;
+  if (lane < 32) m->bm[lane] = 0;
+}
+template <bool REPLAY>
+__device__ __forceinline__ void stage_window(const Walk &w, int lane) {
+  WinRegs r;
+  load_window<REPLAY>(w.hinv, w.done, w.W, w.H, w.x0, w.y0, lane, r);
+  store_window<REPLAY>(w.m, lane, r);
 }
 
 __device__ __attribute__((noinline)) bool ow_seen(const WaveMem *m, int now, int id) {
@@ -110,12 +123,15 @@ __device__ __attribute__((noinline)) bool ow_seen(const WaveMem *m, int now, int
   return false;
 }
 
-// The FIFO walk, run by the whole wavefront in lock step.  All lanes read the
-// popped entry (an LDS broadcast); lanes 0..3 each examine one neighbour (left,
-// up, right, down — :302-313) and the survivors are appended in lane order with a
-// ballot + prefix count, i.e. in the reference's push order.  A pop costs one
-// chain of ~3 dependent LDS reads instead of four.  REPLAY additionally blocks
-// pixels with done[p] < j.  Returns the number of pops, or -1 when the FIFO
+// The FIFO walk, run by the whole wavefront in lock step, up to 16 pops at a time.  A group is the next
+// G = min(16, tail - head) FIFO entries; lane = 4 * g + t examines neighbour t (left, up, right, down —
+// :302-313) of the group's g-th entry, and the survivors are appended in lane order with a ballot + prefix
+// count, i.e. in the reference's push order (entry by entry, neighbour by neighbour).  This is the
+// sequential loop exactly: "visited" means POPPED (:285), so entry g must see the pops of entries
+// 0..g-1 of its own group — its candidates are compared with their ids — and must NOT see later ones
+// (the bitmap is updated after the group's lookups); entries pushed by the group are popped by later groups,
+// as a FIFO would.  A walk of n pops takes ~log-ish many LDS round trips (the BFS frontier) instead of n.
+// REPLAY additionally blocks pixels with done[p] < j.  Returns the number of pops, or -1 when the FIFO
 // outgrew qcap, -2 when more than COV_OW distinct pixels outside the staged window were popped (a hill wider
 // than the window: reported, not guessed).  (head, tail and the result are wave-uniform.)
 template <bool REPLAY>
@@ -127,25 +143,20 @@ __device__ int walk(const Walk &w, int lane) {
     m->lqv[0] = m->hv[COV_WIN * 32 + COV_WIN];
   }
   int head = 0, tail = 1, now = 0;
-  const int t = lane & 3;
+  const int t = lane & 3, gi = lane >> 2;
   const int ox = t == 0 ? -1 : (t == 2 ? 1 : 0), oy = t == 1 ? -1 : (t == 3 ? 1 : 0);
-  int id = y0 * W + x0;
-  float here = m->hv[COV_WIN * 32 + COV_WIN];
-  while (true) {
+  while (head < tail) {
+    const int G = tail - head < 16 ? tail - head : 16;
+    const bool act = gi < G;
+    const int e = head + (act ? gi : 0);
+    const int id = fifo_id(w, e);
+    const float here = fifo_val(w, e);
     const int y = id / W, x = id - y * W;
     const int cdx = x - x0 + COV_WIN, cdy = y - y0 + COV_WIN;
-    // visited at POP (:285): a bitmap inside the window, a short list outside it
-    if ((unsigned)cdx < 32u && (unsigned)cdy < 32u) {
-      if (lane == 0) m->bm[cdy] |= 1u << cdx;
-    } else if (!ow_seen(m, now, id)) {   // wave-uniform branch (id, now are uniform)
-      if (now >= COV_OW) return -2;
-      if (lane == 0) m->ow[now] = id;
-      ++now;
-    }
-    ++head;
+    const bool pin = (unsigned)cdx < 32u && (unsigned)cdy < 32u;   // the popped pixel is inside the window
     const int nx = x + ox, ny = y + oy;
     // bounds as in the reference: xx > 0, yy > 0, xx < w, yy < h
-    bool take = lane < 4 && (t == 0 ? nx > 0 : t == 1 ? ny > 0 : t == 2 ? nx < W : ny < H);
+    bool take = act && (t == 0 ? nx > 0 : t == 1 ? ny > 0 : t == 2 ? nx < W : ny < H);
     const int nid = id + oy * W + ox;
     const int dx = cdx + ox, dy = cdy + oy;
     const bool inwin = (unsigned)dx < 32u && (unsigned)dy < 32u;
@@ -164,18 +175,34 @@ __device__ int walk(const Walk &w, int lane) {
       if (take && REPLAY) take = !(slow_ld_i(w.done, nid) < w.j);
       if (take) take = !ow_seen(m, now, nid);
     }
-    const unsigned mask = (unsigned)(__ballot(take) & 0xFull);
-    const int pos = tail + __popc(mask & ((1u << t) - 1u));
-    const int ntail = tail + __popc(mask);
+    // popped earlier in this very group
+    for (int k = 0; k + 1 < G; ++k) {
+      const int idk = __builtin_amdgcn_readlane(id, 4 * k);
+      if (gi > k && nid == idk) take = false;
+    }
+    const unsigned long long mask = __ballot(take);
+    const int pos = tail + __popcll(mask & ((1ull << lane) - 1ull));
+    const int ntail = tail + __popcll(mask);
     if (ntail > w.qcap) return -1;
     if (take) {
       if (pos < COV_LCAP) { m->lq[pos] = nid; m->lqv[pos] = v; }
       else { w.gq[pos] = nid; w.gqv[pos] = v; }
     }
+    // visited at POP (:285): a bitmap inside the window, a short list outside it
+    if (act && t == 0 && pin) atomicOr(&m->bm[cdy], 1u << cdx);
+    if (__ballot(act && !pin) != 0) {   // rare: some popped pixel lies outside the window
+      for (int k = 0; k < G; ++k) {
+        const int idk = __builtin_amdgcn_readlane(id, 4 * k);
+        const int pk = __builtin_amdgcn_readlane(pin ? 1 : 0, 4 * k);
+        if (!pk && !ow_seen(m, now, idk)) {
+          if (now >= COV_OW) return -2;
+          if (lane == 0) m->ow[now] = idk;
+          ++now;
+        }
+      }
+    }
+    head += G;
     tail = ntail;
-    if (head >= tail) break;
-    id = fifo_id(w, head);
-    here = fifo_val(w, head);
   }
   return tail;
 }
@@ -231,6 +258,7 @@ struct CovFrame {
   float *qvals;
   int *ovf_slot, *novf, *ovf_q;   // overflow slots: pop lists of the walks that outgrew qcap
   float *ovf_v;
+  float *nxy;                     // [kmax][2] position of nxt[j] (so that one load yields the next member AND its window)
   int K;
 };
 
@@ -258,6 +286,7 @@ __device__ __forceinline__ CovFrame cov_frame(const FrameBufs &f, const RecordLa
   c.ovf_slot = cs.ovf_slot + (size_t)b * rl.kmax;
   c.ovf_q = cs.ovf_q + (size_t)b * cs.ovf_slots * cs.ovf_cap;
   c.ovf_v = cs.ovf_v + (size_t)b * cs.ovf_slots * cs.ovf_cap;
+  c.nxy = cs.nxy + (size_t)b * rl.kmax * 2;
   return c;
 }
 
@@ -332,7 +361,7 @@ __global__ __launch_bounds__(64 * COV_WAVES) void cov_classify_kernel(FrameBufs 
 
 // ---- C1: link.  One workgroup per frame: union-find over the dirty keypoints'
 // claim edges, then per component the ascending chain of its dirty members. ----
-#define LINK_THREADS 256
+#define LINK_THREADS 1024   // 16 wavefronts: the union phase is a chain of dependent global loads per dirty keypoint
 
 __device__ __forceinline__ int uf_find(volatile int *parent, int x) {
   while (true) {
@@ -411,7 +440,9 @@ __global__ __launch_bounds__(LINK_THREADS) void cov_link_kernel(FrameBufs f, Rec
   for (int d = tid; d < nd; d += LINK_THREADS) {
     const int kd = key[d], j = kd & 0x7fff, root = kd >> 15;
     const int kn = d + 1 < nd ? key[d + 1] : COV_INF;
-    c.nxt[j] = (kn != COV_INF && (kn >> 15) == root) ? (kn & 0x7fff) : -1;
+    const int jn = (kn != COV_INF && (kn >> 15) == root) ? (kn & 0x7fff) : -1;
+    c.nxt[j] = jn;
+    if (jn >= 0) { c.nxy[2 * j] = c.kp_xy[2 * jn]; c.nxy[2 * j + 1] = c.kp_xy[2 * jn + 1]; }
     if (d == 0 || (key[d - 1] >> 15) != root) c.workers[atomicAdd(c.nworkers, 1)] = j;
   }
 }
@@ -426,13 +457,39 @@ __global__ __launch_bounds__(64 * COV_WAVES) void cov_replay_kernel(FrameBufs f,
   const CovFrame c = cov_frame(f, rl, cs, b, H, W);
   if ((c.hdr[2] & 1) || widx >= *c.nworkers) return;
   int j = c.workers[widx];
+  WaveMem *m = &s_mem[wv];
+  const int *prev_q = nullptr;
+  float fx = c.kp_xy[2 * j], fy = c.kp_xy[2 * j + 1];
+  int jn = c.nxt[j];
+  float nfx = c.nxy[2 * j], nfy = c.nxy[2 * j + 1];   // (garbage when jn < 0: never used)
+  WinRegs win;
+  load_window<true>(c.hinv, c.done, W, H, (int)fx, (int)fy, lane, win);
+  int n_prev = 0, j_prev = -1;
   while (j >= 0) {
-    const int jn = c.nxt[j];  // issued together with the coordinates: one round trip per member
-    const float fx = c.kp_xy[2 * j], fy = c.kp_xy[2 * j + 1];
+    const int x0 = (int)fx, y0 = (int)fy;
+    // this member's window goes to LDS; the pixels the previous member just stamped were loaded before its
+    // stamps existed: patch them from its pop list, which still sits in the LDS FIFO (no other wavefront
+    // writes this component's pixels)
+    store_window<true>(m, lane, win);
+    for (int i = lane; i < n_prev; i += 64) {
+      const int id = i < COV_LCAP ? m->lq[i] : slow_ld_i(prev_q, i);
+      const int py = id / W, px = id - py * W;
+      const int dx = px - x0 + COV_WIN, dy = py - y0 + COV_WIN;
+      if ((unsigned)dx < 32u && (unsigned)dy < 32u) m->dn[dy * 32 + dx] = j_prev;
+    }
     int *q; float *qv; int cap;
     pop_list(c, cs, j, q, qv, cap);
-    Walk w{&s_mem[wv], c.hinv, c.done, q, qv, cap, W, H, (int)fx, (int)fy, j};
-    stage_window<true>(w, lane);
+    Walk w{m, c.hinv, c.done, q, qv, cap, W, H, x0, y0, j};
+    // the next member's window and the member after it (index + position): all addresses are known, so the
+    // requests go out now and their round trips pass under this member's walk
+    int jnn = -1;
+    float nnfx = 0.0f, nnfy = 0.0f;
+    if (jn >= 0) {
+      load_window<true>(c.hinv, c.done, W, H, (int)nfx, (int)nfy, lane, win);
+      jnn = c.nxt[jn];
+      nnfx = c.nxy[2 * jn];
+      nnfy = c.nxy[2 * jn + 1];
+    }
     // a replay's pop list is a subsequence of the lone walk's: it cannot overflow
     const int n = walk<true>(w, lane);
     if (n < 0) { if (lane == 0) atomicOr(&c.hdr[2], 1); return; }
@@ -441,7 +498,9 @@ __global__ __launch_bounds__(64 * COV_WAVES) void cov_replay_kernel(FrameBufs f,
     // the only reader of these pixels during the kernel
     for (int i = lane; i < n; i += 64) c.done[fifo_id(w, i)] = j;  // popped => its stamp was >= j
     __threadfence_block();  // same wavefront, same CU: L1 is coherent for it
-    j = jn;
+    n_prev = n; j_prev = j; prev_q = q;
+    j = jn; fx = nfx; fy = nfy;
+    jn = jnn; nfx = nnfx; nfy = nnfy;
   }
 }
 

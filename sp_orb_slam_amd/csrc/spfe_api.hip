@@ -421,6 +421,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
     if ((rc = dev_alloc(h, &h->cov.npop, (size_t)B * h->kmax))) return rc;
     if ((rc = dev_alloc(h, &h->cov.dirty, (size_t)B * h->kmax))) return rc;
     if ((rc = dev_alloc(h, &h->cov.nxt, (size_t)B * h->kmax))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.nxy, (size_t)B * h->kmax * 2))) return rc;
     if ((rc = dev_alloc(h, &h->cov.workers, (size_t)B * h->kmax))) return rc;
     if ((rc = dev_alloc(h, &h->cov.counters, (size_t)B * 4))) return rc;
     const char *oenv = getenv("SPFE_COV_OVF_SLOTS"), *cenv = getenv("SPFE_COV_OVF_CAP");
@@ -866,6 +867,10 @@ long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size
   else if (nm == "heat" && h->d_heat) { src = h->d_heat + frame * HW; bytes = HW * 4; }
   else if (nm == "image") { src = h->d_img + frame * HW; bytes = HW; }
   else if (nm == "cell_score") { src = h->d_cell_score + frame * C; bytes = C * 4; }
+  else if (nm == "cov_counters") { src = h->cov.counters + frame * 4; bytes = 16; }
+  else if (nm == "cov_nxt") { src = h->cov.nxt + (size_t)frame * h->kmax; bytes = (size_t)h->kmax * 4; }
+  else if (nm == "cov_workers") { src = h->cov.workers + (size_t)frame * h->kmax; bytes = (size_t)h->kmax * 4; }
+  else if (nm == "cov_npop") { src = h->cov.npop + (size_t)frame * h->kmax; bytes = (size_t)h->kmax * 4; }
   else if (nm == "feat") { src = h->act[7] + frame * C * 128; bytes = C * 128 * 4; bf16_src = h->bf16; }
   else if (nm.size() == 4 && nm.compare(0, 3, "act") == 0 && nm[3] >= '0' && nm[3] <= '7') {
     const int i = nm[3] - '0';

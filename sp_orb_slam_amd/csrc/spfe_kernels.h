@@ -91,6 +91,7 @@ struct CovScratch {
   int *npop;      // [B][kmax]
   int *dirty;     // [B][kmax] keypoints whose lone region meets a lower keypoint's
   int *nxt;       // [B][kmax] next dirty member of the same component (ascending) or -1
+  float *nxy;     // [B][kmax][2] keypoint position of nxt
   int *workers;   // [B][kmax] lowest dirty member of each component
   int *counters;  // [B][4] number of dirty keypoints, number of components, overflow slots taken
   int qcap;

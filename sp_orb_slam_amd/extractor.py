@@ -639,8 +639,11 @@ class SPExtractor:
         ch = [64, 64, 64, 64, 128, 128, 128, 128]
         for i in range(8):
             shapes["act%d" % i] = (self.height // div[i], self.width // div[i], ch[i])
-        out = (np.empty((self.height, self.width), np.uint8) if name == "image"   # the staged gray frame
-               else np.empty(shapes[name], np.float32))
+        if name.startswith("cov_"):   # covariance scratch (int32): counters [4], nxt / workers / npop [kmax]
+            out = np.empty(4 if name == "cov_counters" else self.nfeatures + 1, np.int32)
+        else:
+            out = (np.empty((self.height, self.width), np.uint8) if name == "image"   # the staged gray frame
+                   else np.empty(shapes[name], np.float32))
         n = self._lib.spfe_debug_read(self._h, name.encode(), frame, out.ctypes.data, out.nbytes)
         if n < 0:
             _check(int(n))
