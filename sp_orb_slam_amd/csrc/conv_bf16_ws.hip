@@ -28,7 +28,8 @@
 //     two tiles ahead, so a workgroup that starts late or shares its CU's issue slots with the
 //     side-stream kernels of the previous batch (SPFE_FLAG_ASYNC_COV) simply takes fewer tiles —
 //     a static split made the slowest workgroup the kernel's duration.
-//   * bias enters as the accumulator's initial value (C operand of the first MFMA), not as adds.
+//   * mfma(pixels, weights): a lane owns an output channel, so stores are 64-byte channel runs and the bias is
+//     one register per accumulator tile.
 #include <utility>
 
 #include "spfe_kernels.h"
@@ -88,45 +89,67 @@ __device__ __forceinline__ bf16x8 lds_read(lds_char *p, int imm) {
   return *reinterpret_cast<lds_frag *>(p + imm);
 }
 
-struct Epi {
-  __amdgpu_buffer_rsrc_t rout;
-  unsigned rowoff[2];  // byte offset of this lane's pixel (+ its 4 * hi channels) in output row i (pool: [0]), or OOB
-};
-struct Hold {
-  unsigned h16;
-};
-
-__device__ __forceinline__ float dpp_xor1(float v) {  // the value of lane ^ 1
-  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+// left edge of tile column tx: the last column of a ragged row ends at the image edge instead of overhanging it
+__device__ __forceinline__ int tile_x0(int tx, int W) {
+  const int x0 = tx * 32;
+  return x0 + 32 > W ? W - 32 : x0;
 }
 
-// Accumulator layout after mfma(weights, pixels): lane = (pixel column p = lane & 31, hi = lane >> 5),
-// register r <-> output channel j*32 + 8*(r>>2) + 4*hi + (r&3).  Register pair q (r = 2q, 2q+1) <->
-// channels j*32 + 8*(q>>1) + 4*hi + 2*(q&1) + {0,1}; pairs 2g, 2g+1 make a 4-channel group = one 8-byte store.
-// Sub-item E: one register pair (no pool: 2*2*8 = 32 ... of both rows: 64; pool: 16).
-template <bool POOL, int E>
-__device__ __forceinline__ void epi_item(const Epi &e, Hold &hold, const f32x16 (&acc)[2][2]) {
-  constexpr int NEPI = (POOL ? 1 : 2) * 2 * 8;
-  if constexpr (E >= 0 && E < NEPI) {
-    constexpr int q = E % 8, j = (E / 8) % 2, i = POOL ? 0 : E / 16;
-    float v0 = acc[i][j][2 * q], v1 = acc[i][j][2 * q + 1];
+struct Epi {
+  __amdgpu_buffer_rsrc_t rout;
+  unsigned rowoff[2];  // byte offset of (row i, column x0 + 4 hi, this lane's channel) in the output frame (pool: [0]), or OOB
+  unsigned pitch;      // bytes per output pixel
+};
+// Accumulator layout after mfma(pixels, weights): lane = (output channel j*32 + (lane & 31), hi = lane >> 5),
+// register r <-> pixel column 8*(r>>2) + 4*hi + (r&3) of the wave's row i.  A store of register r writes, for the
+// 32 lanes of each half, 32 consecutive bf16 channels of ONE pixel: two 64-byte segments per instruction (the
+// transposed form of conv_bf16.hip — a lane owns a pixel — scatters 8-byte pieces over 32-64 cache lines per
+// store, which is what bounds its layers without a pool).  Bias (one value per lane and accumulator tile), ReLU,
+// the 2x2 max (max(a + b, c + b) == max(a, c) + b exactly: rounding is monotonic), RNE to bf16: bit-identical
+// to conv_bf16.hip's epilogue.
+// Item G: the four registers 4g..4g+3 of one accumulator tile (no pool: 16 items; pool: 8 items, two pooled pixels each).
+// No column predicates: when the width is not a multiple of 32, the last tile of a row is shifted left to end at
+// the image edge (x0 = W - 32) and recomputes a few columns of its neighbour — identical values, written twice.
+// max without the canonicalising v_max(x, x) that fmaxf's sNaN rule puts in front of every MFMA result (the
+// instruction itself: v_max_f32 returns the non-NaN operand, as fmaxf does)
+__device__ __forceinline__ float max_nc(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float max3_nc(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float relu_nc(float a) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a));
+  return r;
+}
+
+template <bool POOL, int G>
+__device__ __forceinline__ void epi_item_c(const Epi &e, const float (&bias)[2], const f32x16 (&acc)[2][2]) {
+  constexpr int NITEM = (POOL ? 1 : 2) * 2 * 4;
+  if constexpr (G >= 0 && G < NITEM) {
+    constexpr int g = G % 4, j = (G / 4) % 2, i = POOL ? 0 : G / 8;
+    const unsigned base = e.rowoff[i] + (unsigned)(j * 64);
     if constexpr (POOL) {
-      v0 = __builtin_fmaxf(v0, acc[1][j][2 * q]);
-      v1 = __builtin_fmaxf(v1, acc[1][j][2 * q + 1]);
-      v0 = __builtin_fmaxf(__builtin_fmaxf(v0, dpp_xor1(v0)), 0.0f);
-      v1 = __builtin_fmaxf(__builtin_fmaxf(v1, dpp_xor1(v1)), 0.0f);
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int r = 4 * g + 2 * h2;
+        float v = max3_nc(acc[0][j][r], acc[0][j][r + 1], max_nc(acc[1][j][r], acc[1][j][r + 1]));
+        v = relu_nc(v + bias[j]);
+        const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v, v}, bf16x2));
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)pk, e.rout, base, (unsigned)(4 * g + h2) * e.pitch, 0);
+      }
     } else {
-      v0 = __builtin_fmaxf(v0, 0.0f);
-      v1 = __builtin_fmaxf(v1, 0.0f);
-    }
-    const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v0, v1}, bf16x2));
-    if constexpr ((q & 1) == 0) {
-      hold.h16 = pk;
-    } else {
-      constexpr unsigned cb = (unsigned)(j * 32 + 8 * (q >> 1)) * 2u;
-      const u32x2 d = {hold.h16, pk};
-      if (WS_ABLATE != 5) __builtin_amdgcn_raw_buffer_store_b64(d, e.rout, e.rowoff[i] + cb, 0, 0);
-      else if (pk == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b64(d, e.rout, e.rowoff[i] + cb, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float v = relu_nc(acc[i][j][4 * g + m] + bias[j]);
+        const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v, v}, bf16x2));
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)pk, e.rout, base, (unsigned)(8 * g + m) * e.pitch, 0);
+      }
     }
   }
 }
@@ -135,9 +158,9 @@ __device__ __forceinline__ void epi_item(const Epi &e, Hold &hold, const f32x16 
 // (ring of three) and sub-items of the previous tile's epilogue.
 template <int S, bool POOL, int BUF>
 __device__ __forceinline__ void k_steps(bf16x8 (&a)[3][2], bf16x8 (&w)[3][2], f32x16 (&acc)[2][2],
-                                        const f32x16 (&accPrev)[2][2], const f32x16 (&biasfrag)[2],
+                                        const f32x16 (&accPrev)[2][2], const float (&bias)[2],
                                         lds_char *const (&aptr)[3][4], lds_char *const (&wptr)[2][4],
-                                        const Epi &ePrev, Hold &hold) {
+                                        const Epi &ePrev) {
   if constexpr (S < NSTEP) {
     constexpr int cur = S % 3, nxt = (S + 2) % 3;
 #pragma unroll
@@ -152,29 +175,30 @@ __device__ __forceinline__ void k_steps(bf16x8 (&a)[3][2], bf16x8 (&w)[3][2], f3
           for (int j = 0; j < 2; ++j) w[nxt][j] = lds_read(wptr[hiw][kk], (tap - 7 * hiw) * 8192 + j * 4096);
         }
       }
-      if constexpr (POOL) {  // 16 sub-items: one every second step
+      if constexpr (POOL) {  // 8 items: one every fourth step
         if (m == 2) {
-          if constexpr (S >= 2 && S % 2 == 0) epi_item<POOL, (S - 2) / 2>(ePrev, hold, accPrev);
+          if constexpr (S >= 2 && S % 4 == 2) epi_item_c<POOL, (S - 2) / 4>(ePrev, bias, accPrev);
         }
-      } else {               // 64 sub-items: two per step
-        if (m == 1) {
-          if constexpr (S >= 2) epi_item<POOL, (S - 2) * 2>(ePrev, hold, accPrev);
-        }
-        if (m == 3) {
-          if constexpr (S >= 2) epi_item<POOL, (S - 2) * 2 + 1>(ePrev, hold, accPrev);
+      } else {               // 16 items: one every second step
+        if (m == 2) {
+          if constexpr (S >= 2 && S % 2 == 0) epi_item_c<POOL, (S - 2) / 2>(ePrev, bias, accPrev);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
       {
         const int i = m / 2, j = m % 2;
-        if constexpr (S == 0)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[cur][j], a[cur][i], biasfrag[j], 0, 0, 0);
-        else
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[cur][j], a[cur][i], acc[i][j], 0, 0, 0);
+        if constexpr (S == 0) {
+          f32x16 z;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][i], w[cur][j], z, 0, 0, 0);
+        } else {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][i], w[cur][j], acc[i][j], 0, 0, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    k_steps<S + 1, POOL, BUF>(a, w, acc, accPrev, biasfrag, aptr, wptr, ePrev, hold);
+    k_steps<S + 1, POOL, BUF>(a, w, acc, accPrev, bias, aptr, wptr, ePrev);
   }
 }
 
@@ -194,6 +218,7 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int xcd = blockIdx.x & 7;
   const int nb = (int)(blockIdx.x >> 3) % p.nblk;
+  const int gi = (int)(blockIdx.x >> 3) / p.nblk, gsize = (int)(gridDim.x >> 3) / p.nblk;  // this workgroup in its queue's group
   const int per_nb = p.tiles_x * p.tiles_y * p.B;
   const int t_lo = (int)((long)per_nb * xcd / 8), t_cnt = (int)((long)per_nb * (xcd + 1) / 8) - t_lo;
   const int Ho = POOL ? p.H >> 1 : p.H, Wo = POOL ? p.W >> 1 : p.W;
@@ -219,7 +244,7 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
     auto fetch = [&]() -> int {  // next tile of this (XCD, block) queue, or -1
       int v = 0;
       if (lane == 0) v = atomicAdd(ctr, 1);
-      v = __builtin_amdgcn_readfirstlane(v);
+      v = __builtin_amdgcn_readfirstlane(v) + 2 * gsize;   // the first 2 * gsize tiles are pre-assigned
       return v < t_cnt ? t_lo + v : -1;
     };
     auto publish = [&](int k, int tile) {  // decode + write descriptor k (wave 4 only)
@@ -247,7 +272,7 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
       const char *base = reinterpret_cast<const char *>(p.in) + ((size_t)(WS_ABLATE == 3 ? 0 : d.b) * p.H * p.W * p.in_stride + p.in_choff) * 2;
       const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, frame_in_bytes, 0x00020000);
-      const int y0 = WS_ABLATE == 3 ? 8 : d.ty * TH, x0 = WS_ABLATE == 3 ? 32 : d.tx * 32;
+      const int y0 = WS_ABLATE == 3 ? 8 : d.ty * TH, x0 = WS_ABLATE == 3 ? 32 : tile_x0(d.tx, p.W);
 #pragma unroll
       for (int it = 0; it < HALO_IT; ++it) {
         const int k = it * 4 + pw;
@@ -263,29 +288,30 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
 #endif
     };
 
-    if (pw == 0) {
-      const int i0 = fetch();
-      const int i1 = i0 >= 0 ? fetch() : -1;
-      publish(0, i0);
-      publish(1, i1);
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-    wg_barrier();                        // barrier #0: descriptors 0 and 1 are published
-    TileDesc cur = read_slot(0);
+    // The resident weight block first: nothing it needs has to be fetched or decided.
     {
 #if defined(__HIP_DEVICE_COMPILE__)
       const char *wb = reinterpret_cast<const char *>(p.wpack) + (size_t)nb * W_BYTES;
       const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wb), 0, (unsigned)W_BYTES, 0x00020000);
-      if (cur.valid) {
+      if (gi < t_cnt) {
 #pragma unroll
         for (int it = 0; it < W_INSTR / 4; ++it) {
           const int k = it * 4 + pw;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(lds + LDS_W + k * 1024), 16, (unsigned)(k * 1024 + lane * 16), 0, 0, 0);
         }
-        load_halo(cur, 0);
       }
 #endif
     }
+    // the first two tiles of every workgroup are fixed (its index in the queue's group, and that + the group
+    // size): no atomic round trips before the first loads; the queue hands out the tiles after those
+    if (pw == 0) {
+      publish(0, gi < t_cnt ? t_lo + gi : -1);
+      publish(1, gi + gsize < t_cnt ? t_lo + gi + gsize : -1);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    wg_barrier();                        // barrier #0: descriptors 0 and 1 are published
+    TileDesc cur = read_slot(0);
+    if (cur.valid) load_halo(cur, 0);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     wg_barrier();                        // barrier #1: weights and tile 0 are in LDS
     int t = 0;
@@ -337,14 +363,7 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
     wptr[0][kk] = lds + LDS_W + l31 * 128 + (((kk * 2 + hi) ^ ((l31 >> 1) & 7)) * 16);
     wptr[1][kk] = wptr[0][kk] + 7 * 8192;
   }
-  f32x16 biasfrag[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 b4 = *reinterpret_cast<const float4 *>(p.bias + nb * 64 + j * 32 + 8 * g + 4 * hi);
-      biasfrag[j][4 * g] = b4.x; biasfrag[j][4 * g + 1] = b4.y; biasfrag[j][4 * g + 2] = b4.z; biasfrag[j][4 * g + 3] = b4.w;
-    }
+  const float bias[2] = {p.bias[nb * 64 + l31], p.bias[nb * 64 + 32 + l31]};   // this lane's channel of each accumulator tile
 
   f32x16 accA[2][2], accB[2][2];
 #pragma unroll
@@ -356,23 +375,23 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
   Epi epiA, epiB;
   epiA.rout = epiB.rout = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0u, 0x00020000);  // nothing to store yet
   epiA.rowoff[0] = epiA.rowoff[1] = epiB.rowoff[0] = epiB.rowoff[1] = OOB;
-  Hold hold;
-  hold.h16 = 0u;
+  epiA.pitch = epiB.pitch = out_pix_bytes;
   bf16x8 a[3][2], w[3][2];
 
   auto aim_epi = [&](const TileDesc &d, Epi &e) {
     char *obase = reinterpret_cast<char *>(p.out) + ((size_t)d.b * Ho * Wo * p.out_stride + p.out_choff) * 2;
     e.rout = __builtin_amdgcn_make_buffer_rsrc(obase, 0, frame_out_bytes, 0x00020000);
-    const int y0 = d.ty * TH + wm * 2, x = d.tx * 32 + l31;
-    const unsigned chan = (unsigned)(nb * 64 + 4 * hi) * 2u;
+    const int y0 = d.ty * TH + wm * 2;
+    // this lane's channel nb*64 + l31 (+ 32 j per accumulator tile) of the pixel column x0 + 4 hi (+ the register's)
+    const int x0 = tile_x0(d.tx, p.W);
+    const unsigned ch = (unsigned)(nb * 64 + l31) * 2u;
     if constexpr (POOL) {
-      const bool ok = x < p.W && y0 < p.H && (l31 & 1) == 0;
-      e.rowoff[0] = ok ? (unsigned)((y0 >> 1) * Wo + (x >> 1)) * out_pix_bytes + chan : OOB;
+      e.rowoff[0] = y0 < p.H ? (unsigned)((y0 >> 1) * Wo + (x0 >> 1) + 2 * hi) * out_pix_bytes + ch : OOB;
       e.rowoff[1] = OOB;
     } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        e.rowoff[i] = (x < p.W && y0 + i < p.H) ? (unsigned)((y0 + i) * p.W + x) * out_pix_bytes + chan : OOB;
+        e.rowoff[i] = y0 + i < p.H ? (unsigned)((y0 + i) * p.W + x0 + 4 * hi) * out_pix_bytes + ch : OOB;
     }
   };
 
@@ -398,7 +417,7 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
       for (int j = 0; j < 2; ++j) w[st][j] = lds_read(wptr[0][st], j * 4096);
     }
     aim_epi(d, eMine);
-    if (WS_ABLATE != 2) k_steps<0, POOL, BUF>(a, w, acc, accPrev, biasfrag, aptr, wptr, ePrev, hold);
+    if (WS_ABLATE != 2) k_steps<0, POOL, BUF>(a, w, acc, accPrev, bias, aptr, wptr, ePrev);
     WS_T(c0);
     wg_barrier();  // end of tile t: every consumer is done with this halo buffer, the next one has landed
     WS_T(c1);
@@ -422,10 +441,10 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
   }
 #endif
   if (any) {
-    constexpr int NEPI = (POOL ? 1 : 2) * 16;
+    constexpr int NEPI = (POOL ? 1 : 2) * 8;
     auto flush = [&](const f32x16(&acc)[2][2], const Epi &e) {
       [&]<int... E>(std::integer_sequence<int, E...>) {
-        (epi_item<POOL, E>(e, hold, acc), ...);
+        (epi_item_c<POOL, E>(e, bias, acc), ...);
       }(std::make_integer_sequence<int, NEPI>{});
     };
     if (lastA) flush(accA, epiA); else flush(accB, epiB);
@@ -457,7 +476,7 @@ size_t conv_bf16_ws_weight_bytes() { return ws::W_BYTES; }
 
 // cin = 64 only; p.tile_ctr: >= nblk * 8 ints, zero on entry (the kernel leaves them non-zero)
 hipError_t launch_conv_bf16_ws(const ConvParams &p, bool pool, hipStream_t s) {
-  if (!p.tile_ctr || p.nblk < 1 || p.nblk > 2) return hipErrorInvalidValue;
+  if (!p.tile_ctr || p.nblk < 1 || p.nblk > 2 || p.W < 32 || (p.W & 1)) return hipErrorInvalidValue;
   return pool ? ws::launch<true>(p, s) : ws::launch<false>(p, s);
 }
 

@@ -508,14 +508,8 @@ size_t cov_link_lds(int kmax) { return (size_t)kmax * 4 * sizeof(int); }   // pa
 
 hipError_t launch_cov(const FrameBufs &f, const RecordLayout &r, const CovScratch &cs, int B, int H, int W,
                       hipStream_t s) {
-  hipError_t e = hipMemsetAsync(cs.claim, 0x7f, (size_t)B * H * W * 4, s);
-  if (e != hipSuccess) return e;
-  e = hipMemsetAsync(cs.done, 0x7f, (size_t)B * H * W * 4, s);
-  if (e != hipSuccess) return e;
-  e = hipMemsetAsync(cs.counters, 0, (size_t)B * 4 * 4, s);
-  if (e != hipSuccess) return e;
-  e = hipMemsetAsync(cs.ovf_slot, 0xff, (size_t)B * r.kmax * 4, s);
-  if (e != hipSuccess) return e;
+  // claim / done / counters / ovf_slot were reset by heat_norm_kernel (the kernel in front of this stage)
+  hipError_t e = hipSuccess;
   const dim3 grid((r.kmax + COV_WAVES - 1) / COV_WAVES, B), block(64 * COV_WAVES);
   hipLaunchKernelGGL(cov_walk_kernel, grid, block, 0, s, f, r, cs, H, W);
   hipLaunchKernelGGL(cov_classify_kernel, grid, block, 0, s, f, r, cs, H, W);

@@ -144,7 +144,8 @@ struct spfe_handle_s {
   decltype(&ncclCommDestroy) p_ncclCommDestroy = nullptr;
   decltype(&ncclAllGather) p_ncclAllGather = nullptr;
   decltype(&ncclGetErrorString) p_ncclGetErrorString = nullptr;
-  unsigned ws_mask = 1u;    // bf16 layers (bit i = conv layer i of enqueue(), Cin = 64 only) on the wave-specialised kernel
+  unsigned ws_mask = 15u;   // bf16 layers (bit i = conv layer i of enqueue(), Cin = 64 only) that may use the wave-specialised kernel
+  int ws_min_items = 11;    // ... when the launch has at least this many (tile, 64-channel block) items per workgroup
   unsigned char *d_wws[4] = {};  // their weights in conv_bf16_ws.hip's layout
   int *d_tile_ctr = nullptr;     // [4 layers][16] tile-queue counters, zeroed once per enqueue()
   bool bf16 = false;  // SPFE_PRECISION_BF16: bf16 conv stack (conv1a .. convPa/Da), f32 heads and tail
@@ -364,6 +365,8 @@ int build(spfe_handle h, const spfe_config *cfg) {
     if (menv) h->tile16_mask = (unsigned)strtoul(menv, nullptr, 0);
     const char *wenv = getenv("SPFE_BF16_WS_MASK");
     if (wenv) h->ws_mask = (unsigned)strtoul(wenv, nullptr, 0) & 0xfu;
+    const char *ienv = getenv("SPFE_BF16_WS_MIN_ITEMS");
+    if (ienv) h->ws_min_items = atoi(ienv);
   }
   const char *tenv = getenv("SPFE_STAGE_TIMING");
   h->timing = tenv && atoi(tenv) != 0;
@@ -545,7 +548,11 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
       // bf16 stack: 8-row tiles only; convPa/Da (i == 7) write f32 for the f32 heads
       p.tiles_x = (L.W + 31) / 32; p.tiles_y = (L.H + 7) / 8; p.nblk = L.nblk;
       p.num_cus = h->num_cus;
-      if (i < 4 && h->d_wws[i]) {
+      // the wave-specialised kernel has the higher rate but ~8 us more start-up (512-thread workgroups, two
+      // barriers before the first MFMA): it takes the launches with enough work items per workgroup
+      // (tools/microbench/conv_ws_probe: the crossover is at ~10 items)
+      const int grid_ws = (h->num_cus > 0 ? h->num_cus : 256) & ~15;
+      if (i < 4 && h->d_wws[i] && L.W >= 32 && (long)p.tiles_x * p.tiles_y * n * p.nblk >= (long)h->ws_min_items * (grid_ws < 16 ? 16 : grid_ws)) {
         p.wpack = reinterpret_cast<const float *>(h->d_wws[i]);
         p.tile_ctr = h->d_tile_ctr + 16 * i;
         HIP_TRY(spfe::launch_conv_bf16_ws(p, L.pool, s));
@@ -620,7 +627,7 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s) {
   // selection: small latency-bound kernels that run beside the next call's convolutions.
   HIP_TRY(hipEventRecord(h->ev_post[slot], s));
   HIP_TRY(hipStreamWaitEvent(h->side, h->ev_post[slot], 0));
-  HIP_TRY(spfe::launch_heat_norm(f, n, H, W, h->side));
+  HIP_TRY(spfe::launch_heat_norm(f, h->cov, h->rl.kmax, n, H, W, h->side));
   HIP_TRY(spfe::launch_desc(f, h->rl, n, H, W, h->side));
   HIP_TRY(hipEventRecord(h->ev_desc, h->side));  // d_coarse may be overwritten after this (next call's convDb)
   h->desc_recorded = true;

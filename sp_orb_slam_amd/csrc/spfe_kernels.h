@@ -109,7 +109,8 @@ int tail_parts(int H, int W);  // min/max partials per frame written by the tail
 hipError_t launch_tail(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s);
 hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H, int W,
                          int num_features, hipStream_t s);
-hipError_t launch_heat_norm(const FrameBufs &f, int B, int H, int W, hipStream_t s);
+// (also resets the covariance scratch: launch_cov must follow it)
+hipError_t launch_heat_norm(const FrameBufs &f, const CovScratch &cs, int kmax, int B, int H, int W, hipStream_t s);
 hipError_t launch_desc(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s);
 size_t select_lds_bytes(int H, int W);
 

@@ -174,8 +174,15 @@ hipError_t launch_tail(const FrameBufs &f, const RecordLayout &r, int B, int H, 
 
 // to_heat (:461-474): img = -L, min/max as doubles, one affine map per pixel with
 // float scale/shift, float multiply then float add (oracle_heat has the rule).
-__global__ __launch_bounds__(256) void heat_norm_kernel(FrameBufs f, int H, int W, int nparts) {
+// The same pass also resets the covariance stage's scratch (claim / done maps to "nobody", counters to 0,
+// overflow slots to "none"): it touches every pixel anyway, and four memset launches leave the latency-bound
+// side chain.
+__global__ __launch_bounds__(256) void heat_norm_kernel(FrameBufs f, int H, int W, int nparts, CovScratch cs, int kmax) {
   const int b = blockIdx.y;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < 4) cs.counters[b * 4 + threadIdx.x] = 0;
+    for (int k = threadIdx.x; k < kmax; k += 256) cs.ovf_slot[(size_t)b * kmax + k] = -1;
+  }
   __shared__ float sc[4];
   if (threadIdx.x < 64) {
     const float *part = reinterpret_cast<const float *>(f.minmax) + (size_t)b * nparts * 2;
@@ -206,11 +213,15 @@ __global__ __launch_bounds__(256) void heat_norm_kernel(FrameBufs f, int H, int 
   const float4 *L4 = reinterpret_cast<const float4 *>(f.heat_log + (size_t)b * H * W);
   float4 *hi4 = reinterpret_cast<float4 *>(f.heat_inv + (size_t)b * H * W);
   float4 *h4 = f.heat ? reinterpret_cast<float4 *>(f.heat + (size_t)b * H * W) : nullptr;
+  int4 *cl4 = reinterpret_cast<int4 *>(cs.claim + (size_t)b * H * W), *dn4 = reinterpret_cast<int4 *>(cs.done + (size_t)b * H * W);
+  const int4 none = {0x7f7f7f7f, 0x7f7f7f7f, 0x7f7f7f7f, 0x7f7f7f7f};
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     const float4 L = L4[i];
     float4 o;
     o.x = L.x * a_i + b_i; o.y = L.y * a_i + b_i; o.z = L.z * a_i + b_i; o.w = L.w * a_i + b_i;
     hi4[i] = o;
+    cl4[i] = none;
+    dn4[i] = none;
     if (h4) {
       o.x = L.x * a_h + b_h; o.y = L.y * a_h + b_h; o.z = L.z * a_h + b_h; o.w = L.w * a_h + b_h;
       h4[i] = o;
@@ -218,9 +229,9 @@ __global__ __launch_bounds__(256) void heat_norm_kernel(FrameBufs f, int H, int 
   }
 }
 
-hipError_t launch_heat_norm(const FrameBufs &f, int B, int H, int W, hipStream_t s) {
+hipError_t launch_heat_norm(const FrameBufs &f, const CovScratch &cs, int kmax, int B, int H, int W, hipStream_t s) {
   const int blocks = (int)(((size_t)H * W / 4 + 255) / 256);
-  hipLaunchKernelGGL(heat_norm_kernel, dim3(blocks < 128 ? blocks : 128, B), dim3(256), 0, s, f, H, W, tail_parts(H, W));
+  hipLaunchKernelGGL(heat_norm_kernel, dim3(blocks < 128 ? blocks : 128, B), dim3(256), 0, s, f, H, W, tail_parts(H, W), cs, kmax);
   return hipGetLastError();
 }
 

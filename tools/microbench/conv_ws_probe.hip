@@ -95,6 +95,7 @@ int main(int argc, char **argv) {
 
   auto run_old = [&]() { p.wpack = reinterpret_cast<const float *>(d_w1); p.out = reinterpret_cast<float *>(d_o1); CK(spfe::launch_conv_bf16(p, cin, pool, false, s)); };
   int ctr_set = 0;
+  if (W < 32) { printf("width < 32: the wave-specialised kernel does not apply\nPROBE OK\n"); return 0; }
   auto run_new = [&]() { p.wpack = reinterpret_cast<const float *>(d_w2); p.out = reinterpret_cast<float *>(d_o2); p.tile_ctr = d_ctr + 16 * (ctr_set++); CK(spfe::launch_conv_bf16_ws(p, pool, s)); };
 
   const char *only = getenv("PROBE_ONLY");
@@ -147,8 +148,8 @@ int main(int argc, char **argv) {
           ++big;
         }
       }
-    printf("old vs ws: %zu of %zu outputs differ (bias-first accumulation: last-bit flips expected), %zu beyond 2%%\n", diff, out_elems, big);
-    if (big || diff > out_elems / 50) rc = 1;
+    printf("old vs ws: %zu of %zu outputs differ (the two kernels are bit-identical by construction), %zu beyond 2%%\n", diff, out_elems, big);
+    if (diff) rc = 1;
   }
   // sampled CPU reference (double accumulation of the bf16 products) for whichever kernels ran
   {
