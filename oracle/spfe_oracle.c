@@ -187,9 +187,9 @@ EXPORT int oracle_network(const float *blob, const uint8_t *img, int H, int W, f
 /*
  * The network in the build's bf16 mode: conv1a in f32 with its output rounded to bf16;
  * conv1b..conv4b with bf16 weights and activations (f32 accumulate, bias, ReLU, pool; outputs
- * rounded); convPa with bf16 weights and f32 output, convPb (the detector logits) in f32;
- * convDa with bf16 weights and bf16 output, convDb with bf16 weights, f32 accumulate and f32
- * output; everything after the two heads in f32.  (The MFMA's accumulation order differs from this loop's, so the GPU is
+ * rounded); convPa and convDa with bf16 weights and bf16 output; the 1x1 heads convPb (the detector
+ * logits) and convDb with bf16 weights, f32 accumulate and f32 output; everything after the two
+ * heads in f32.  (The MFMA's accumulation order differs from this loop's, so the GPU is
  * compared with a tolerance in this mode, not bitwise.)
  */
 EXPORT int oracle_network_bf16(const float *blob, const uint8_t *img, int H, int W, float *semi,
@@ -216,8 +216,8 @@ EXPORT int oracle_network_bf16(const float *blob, const uint8_t *img, int H, int
   conv_layer_ex(6, blob, a, h, w, b, 1, 1);
   conv_layer_ex(7, blob, b, h, w, a, 1, 1);
   float *cPa = (float *)malloc((size_t)h * w * 256 * sizeof(float));
-  conv_layer_ex(8, blob, a, h, w, cPa, 1, 0);
-  conv_layer_ex(9, blob, cPa, h, w, semi, 0, 0);
+  conv_layer_ex(8, blob, a, h, w, cPa, 1, 1);        /* convPa: bf16 weights, bf16 output */
+  conv_layer_ex(9, blob, cPa, h, w, semi, 1, 0);     /* convPb: bf16 weights, f32 output */
   conv_layer_ex(10, blob, a, h, w, cPa, 1, 1);       /* convDa: bf16 weights, bf16 output */
   conv_layer_ex(11, blob, cPa, h, w, coarse, 1, 0);  /* convDb: bf16 weights, f32 output */
   free(cPa);

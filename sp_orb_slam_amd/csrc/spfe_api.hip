@@ -52,7 +52,7 @@ int fail(int code, const char *fmt, ...) {
 constexpr int NSTAGE = 15;
 const char *kStageNames[NSTAGE] = {"conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b",
                                    "conv4a", "conv4b", "convPaDa", "convPb", "convDb", "tail",
-                                   "select", "post_side", "total"};  // post_side = heat_norm + desc + cov
+                                   "select", "post_side", "total"};  // post_side = select + heat_norm + desc + cov (side stream)
 
 struct ConvLayer {
   int cin, cout_real, nblk, ks;
@@ -86,8 +86,8 @@ struct spfe_handle_s {
   float *d_w1a = nullptr, *d_b1a = nullptr;
   float *act[8] = {};
   float *d_head = nullptr, *d_semi = nullptr, *d_coarse = nullptr;
-  unsigned short *d_da = nullptr;    // bf16 mode: convDa's output [B][C][256] bf16 (input of the bf16 descriptor head)
-  unsigned char *d_wdb = nullptr;    // bf16 mode: convDb weights, head_bf16.hip layout
+  unsigned short *d_hd = nullptr;    // bf16 mode: ReLU(convPa) | ReLU(convDa), [B][C][512] bf16 (input of the two bf16 heads)
+  unsigned char *d_wdb = nullptr, *d_wpb = nullptr;   // bf16 mode: convDb / convPb weights, head_bf16.hip layout
   float *d_heat_log = nullptr, *d_heat = nullptr, *d_heat_inv = nullptr;
   float *d_minmax = nullptr, *d_cell_score = nullptr, *d_heat_consts = nullptr;
   uint8_t *d_cell_k = nullptr;
@@ -489,18 +489,22 @@ int build(spfe_handle h, const spfe_config *cfg) {
         if ((rc = pack_layer_bf16_ws(h, blob.data(), specs[i].l0, &h->d_wws[i]))) return rc;
     if ((rc = dev_alloc(h, &h->d_tile_ctr, 4 * 16))) return rc;
   }
-  if (h->bf16) {  // descriptor head in bf16: convDa writes bf16, convDb is head_bf16.hip's GEMM
-    if ((rc = dev_alloc(h, &h->d_da, (size_t)B * C * 256))) return rc;
-    const spfe_layer_t &Ld = SPFE_LAYERS[11];
-    const float *Wd = blob.data() + blob_weight_offset(11);
-    std::vector<unsigned char> w(spfe::head_bf16_weight_bytes(), 0);
-    for (int co = 0; co < Ld.cout; ++co)
-      for (int ci = 0; ci < Ld.cin; ++ci) {
-        const unsigned short v = host_bf16_rne(Wd[(size_t)co * Ld.cin + ci]);
-        memcpy(&w[(size_t)(co / 64) * 40960 + ((size_t)(ci / 32) * 64 + co % 64) * 80 + (ci % 32) * 2], &v, 2);
-      }
-    if ((rc = dev_alloc(h, &h->d_wdb, w.size()))) return rc;
-    HIP_TRY(hipMemcpy(h->d_wdb, w.data(), w.size(), hipMemcpyHostToDevice));
+  if (h->bf16) {  // both heads in bf16: convPa | convDa write bf16, convPb and convDb are head_bf16.hip's GEMMs
+    if ((rc = dev_alloc(h, &h->d_hd, (size_t)B * C * 512))) return rc;
+    for (int which = 0; which < 2; ++which) {
+      const int lid = which ? 9 : 11;
+      const spfe_layer_t &Ld = SPFE_LAYERS[lid];
+      const float *Wd = blob.data() + blob_weight_offset(lid);
+      std::vector<unsigned char> w(spfe::head_bf16_weight_bytes(Ld.cout), 0);
+      for (int co = 0; co < Ld.cout; ++co)
+        for (int ci = 0; ci < Ld.cin; ++ci) {
+          const unsigned short v = host_bf16_rne(Wd[(size_t)co * Ld.cin + ci]);
+          memcpy(&w[(size_t)(co / 64) * 40960 + ((size_t)(ci / 32) * 64 + co % 64) * 80 + (ci % 32) * 2], &v, 2);
+        }
+      unsigned char **dst = which ? &h->d_wpb : &h->d_wdb;
+      if ((rc = dev_alloc(h, dst, w.size()))) return rc;
+      HIP_TRY(hipMemcpy(*dst, w.data(), w.size(), hipMemcpyHostToDevice));
+    }
   }
 
   // pinned host mirrors for the host-facing calls
@@ -560,13 +564,8 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
         continue;
       }
       if (i == 7) {
-        // convPa -> f32 (the detector head stays f32), convDa -> bf16 (the descriptor head is bf16 too)
-        const size_t half_w = (size_t)4 * (L.cin / 32) * spfe::conv_bf16_slab_bytes();
-        p.nblk = 4; p.cout_real = 256;
-        HIP_TRY(spfe::launch_conv_bf16(p, L.cin, L.pool, true, s));
-        p.wpack = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(L.d_w) + half_w);
-        p.bias = L.d_b + 256;
-        p.out = reinterpret_cast<float *>(h->d_da); p.out_stride = 256; p.out_choff = 0;
+        // convPa | convDa: one launch, 512 output channels, bf16 (both 1x1 heads are bf16 GEMMs)
+        p.out = reinterpret_cast<float *>(h->d_hd); p.out_stride = 512; p.out_choff = 0;
         HIP_TRY(spfe::launch_conv_bf16(p, L.cin, L.pool, false, s));
       } else {
         HIP_TRY(spfe::launch_conv_bf16(p, L.cin, L.pool, false, s));
@@ -574,8 +573,9 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
       STAGE_MARK(2 + i);
       continue;
     }
-    if (h->bf16 && i == 9) {  // convDb: bf16 GEMM over all cells of the batch
-      HIP_TRY(spfe::launch_head1x1_bf16(h->d_da, h->d_wdb, L.d_b, h->d_coarse, n * h->C, s));
+    if (h->bf16 && i >= 8) {  // convPb (65 logits) and convDb (256 descriptor channels): bf16 GEMMs over all cells of the batch
+      if (i == 8) HIP_TRY(spfe::launch_head1x1_bf16(h->d_hd, h->d_wpb, L.d_b, h->d_semi, n * h->C, 65, s));
+      else HIP_TRY(spfe::launch_head1x1_bf16(h->d_hd, h->d_wdb, L.d_b, h->d_coarse, n * h->C, 256, s));
       STAGE_MARK(2 + i);
       continue;
     }
@@ -620,13 +620,13 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s) {
   }
   HIP_TRY(spfe::launch_tail(f, h->rl, n, H, W, s));
   STAGE_MARK(12);
-  HIP_TRY(spfe::launch_select(f, h->rl, n, H, W, h->cfg.num_features, s));
-  STAGE_MARK(13);
-  // Everything that only the finished record needs — heat normalisation (input of the covariance),
-  // descriptor sampling, covariance — goes to the side stream, ordered after this call's
-  // selection: small latency-bound kernels that run beside the next call's convolutions.
+  // Everything that only the finished record needs — selection (one latency-bound workgroup per frame), heat
+  // normalisation (input of the covariance), descriptor sampling, covariance — goes to the side stream, ordered
+  // after this call's detector tail: small kernels that run beside the next call's convolutions.
   HIP_TRY(hipEventRecord(h->ev_post[slot], s));
   HIP_TRY(hipStreamWaitEvent(h->side, h->ev_post[slot], 0));
+  STAGE_MARK(13);   // ("select" reads 0 on the launch stream: it is part of post_side)
+  HIP_TRY(spfe::launch_select(f, h->rl, n, H, W, h->cfg.num_features, h->side));
   HIP_TRY(spfe::launch_heat_norm(f, h->cov, h->rl.kmax, n, H, W, h->side));
   HIP_TRY(spfe::launch_desc(f, h->rl, n, H, W, h->side));
   HIP_TRY(hipEventRecord(h->ev_desc, h->side));  // d_coarse may be overwritten after this (next call's convDb)
@@ -868,7 +868,10 @@ long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size
   std::string nm(name);
   if (nm == "semi") { src = h->d_semi + frame * C * SPFE_SEMI_CH; bytes = C * SPFE_SEMI_CH * 4; }
   else if (nm == "coarse") { src = h->d_coarse + frame * C * SPFE_DESC_DIM; bytes = C * SPFE_DESC_DIM * 4; }
-  else if (nm == "head") { src = h->d_head + frame * C * 512; bytes = C * 512 * 4; }
+  else if (nm == "head") {
+    if (h->bf16) return fail(SPFE_EINVAL, "'head' is f32 only: the bf16 mode keeps ReLU(convPa) | ReLU(convDa) as bf16");
+    src = h->d_head + frame * C * 512; bytes = C * 512 * 4;
+  }
   else if (nm == "heat_log") { src = h->d_heat_log + frame * HW; bytes = HW * 4; }
   else if (nm == "heat_inv") { src = h->d_heat_inv + frame * HW; bytes = HW * 4; }
   else if (nm == "heat" && h->d_heat) { src = h->d_heat + frame * HW; bytes = HW * 4; }

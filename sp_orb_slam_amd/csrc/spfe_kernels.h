@@ -47,11 +47,12 @@ size_t conv_bf16_ws_weight_bytes();
 hipError_t launch_conv1a_bf16(const uint8_t *img, const float *w9x64, const float *b64, void *out, int B, int H,
                               int W, hipStream_t s);
 
-// bf16 mode, descriptor head (head_bf16.hip): coarse[npix][256] f32 = in[npix][256] bf16 x W^T + bias;
-// wpack: head_bf16_weight_bytes() bytes, [nb 4][chunk 8][64 couts][80 B: 32 channels bf16 + pad]
-hipError_t launch_head1x1_bf16(const void *in_bf16, const void *wpack, const float *bias, float *out, int npix,
+// bf16 mode, the 1x1 heads (head_bf16.hip): out[npix][cout] f32 = in[npix][512] bf16 (channels 0..255 for the
+// detector head, cout = 65; 256..511 for the descriptor head, cout = 256) x W^T + bias;
+// wpack: head_bf16_weight_bytes(cout) bytes, [nb][chunk 8][64 couts][80 B: 32 channels bf16 + pad]
+hipError_t launch_head1x1_bf16(const void *in_bf16, const void *wpack, const float *bias, float *out, int npix, int cout,
                                hipStream_t s);
-size_t head_bf16_weight_bytes();
+size_t head_bf16_weight_bytes(int cout);
 
 // conv1a: u8 image -> (x * 1/255) -> 3x3 conv 1->64 + bias + relu, NHWC out.
 // w: [9][64] (tap-major), b: [64]

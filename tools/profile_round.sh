@@ -1,0 +1,34 @@
+#!/bin/bash
+# One round's profiles (GPU box, via gpurun): kernel-trace summaries of the bench commands the numbers in
+# DESIGN.md come from, and PMC passes (their own runs, --kernel-trace --pmc only) for the dominant kernel of
+# each precision.  usage: tools/profile_round.sh <tag>  -> gpurun_out/round_<tag>/...
+tag=$1
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/round_$tag
+mkdir -p $out
+common="--no-cpu-baseline --no-bf16-leg --no-host-path --no-match --no-latency --no-stage-table"
+trace() {   # name, bench args
+  name=$1; shift
+  rocprofv3 --kernel-trace --stats -d $out/kt_$name -o trace -- python bench.py $common --steps 10 "$@" > $out/kt_$name.log 2>&1
+  python tools/rocpd_summary.py $out/kt_$name/*.db > $out/kernel_stats_$name.txt 2>&1
+  grep '^{' $out/kt_$name.log | tail -1 > $out/bench_under_trace_$name.json
+}
+trace f32_async
+trace f32_sync --sync-cov
+trace bf16_720p_async --precision bf16 --height 720 --width 1280
+trace bf16_720p_sync --precision bf16 --height 720 --width 1280 --sync-cov
+trace bf16_752_async --precision bf16
+pmc() {   # name, counters, bench args
+  name=$1; ctrs=$2; shift; shift
+  timeout 600 rocprofv3 --kernel-trace --pmc $ctrs -d $out/pmc_$name -o pmc -- python bench.py $common --steps 2 --warmup 1 --sync-cov "$@" > $out/pmc_$name.log 2>&1 || echo "pmc $name failed"
+}
+for cfg in "f32:" "bf16_720p:--precision bf16 --height 720 --width 1280" "bf16_752:--precision bf16"; do
+  n=${cfg%%:*}; a=${cfg#*:}
+  pmc ${n}_fetch "FETCH_SIZE" $a
+  pmc ${n}_write "WRITE_SIZE" $a
+  pmc ${n}_sq "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VALU" $a
+  pmc ${n}_grbm "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE TCC_HIT_sum TCC_MISS_sum" $a
+  python tools/rocpd_summary.py $out/pmc_${n}_*/*.db > $out/pmc_summary_$n.txt 2>&1
+done
+rm -rf $out/kt_*/ $out/pmc_*/   # the databases are large; the summaries are what is kept
+ls -la $out
