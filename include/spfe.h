@@ -215,6 +215,15 @@ SPFE_API long spfe_debug_read(spfe_handle h, const char *name, int frame, void *
  * NaN / infinite distances never match.  n_query or n_train == 0: all -1, SPFE_OK. */
 SPFE_API int spfe_match(spfe_handle h, const float *query, int n_query, const float *train, int n_train,
                         int cross_check, int32_t *train_idx, float *distance);
+/* Replaces  matcher->knnMatch(desc_query, matches, 2)  on a cv::FlannBasedMatcher that holds desc_train — the k = 2
+ * search behind the ratio tests of KeyFrame::matchMps (orb_slam2/src/type/keyframe.cpp:447-470, index built in
+ * buildIndexesMps :421-445) and SPMatcher's keyframe matching (src/cv/sp_matcher.cpp:195-215, :264-280) — by the
+ * EXACT two nearest train rows (the reference's randomised kd-trees, matching::ntree / nchecks, are approximate:
+ * this returns what they approximate, so it has no bit-parity target, only the exact-search oracle's).
+ * train_idx / distance: [n_query][2], nearest first; ties -> lower train index; -1 / FLT_MAX when n_train < 2
+ * (or a distance is NaN / infinite).  Distances as in spfe_match. */
+SPFE_API int spfe_match_knn2(spfe_handle h, const float *query, int n_query, const float *train, int n_train,
+                             int32_t *train_idx, float *distance);
 /* Device-resident form: matches the descriptors of n_pairs query records against n_pairs train
  * records (both arrays of spfe_record_bytes()-strided records in HBM, e.g. the outputs of two
  * spfe_extract_batch_device calls), reading K from the record headers on the device; no host

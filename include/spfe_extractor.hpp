@@ -154,6 +154,61 @@ class ExtractorCV {
       if (idx[i] >= 0) matches.push_back(cv::DMatch(i, idx[i], 0, dist[i]));
   }
 
+  // Replaces  flann->knnMatch(desc_query, matches, 2)  on the cv::FlannBasedMatcher that holds desc_train
+  // (KeyFrame::matchMps keyframe.cpp:447-448 on the index of buildIndexesMps :421-445; SPMatcher sp_matcher.cpp:200,
+  // :269) by the exact two nearest neighbours; the ratio test that follows (0.7, keyframe.cpp:462) is unchanged.
+  // matches[i] holds 0, 1 or 2 DMatch for query i, nearest first, like OpenCV's knnMatch.
+  void knnMatch2(const cv::Mat &desc_query, const cv::Mat &desc_train, std::vector<std::vector<cv::DMatch>> &matches) {
+    matches.assign(static_cast<size_t>(desc_query.rows), std::vector<cv::DMatch>());
+    if (desc_query.empty() || desc_train.empty()) return;
+    if (desc_query.cols != 256 || desc_train.cols != 256 || desc_query.type() != CV_32FC1 ||
+        desc_train.type() != CV_32FC1 || desc_query.step != 256 * sizeof(float) ||
+        desc_train.step != 256 * sizeof(float))
+      throw std::runtime_error("knnMatch2: descriptors must be contiguous K x 256 CV_32FC1");
+    std::vector<int32_t> idx(2 * static_cast<size_t>(desc_query.rows));
+    std::vector<float> dist(2 * static_cast<size_t>(desc_query.rows));
+    if (spfe_match_knn2(h_, reinterpret_cast<const float *>(desc_query.data), desc_query.rows,
+                        reinterpret_cast<const float *>(desc_train.data), desc_train.rows, idx.data(),
+                        dist.data()) != SPFE_OK)
+      throw std::runtime_error(spfe_last_error());
+    for (int i = 0; i < desc_query.rows; ++i)
+      for (int k = 0; k < 2; ++k)
+        if (idx[2 * i + k] >= 0) matches[i].push_back(cv::DMatch(i, idx[2 * i + k], 0, dist[2 * i + k]));
+  }
+
+  // Direct "dust" alignment: Optimizer::PoseOptimizationDust(pFrame, mps, is_visible) (optimizer_dust.cpp:170-294) on
+  // the dust map of the frame extracted last.  Tcw: CV_32F 4x4 (Frame::mTcw), updated in place (SetPose, :287);
+  // points: N x 3 CV_32F world positions (MapPoint::GetWorldPos); fx..cy: Frame::fx.. at full resolution.
+  // Returns n_inlier; inlier[i] = is_visible / in_view, proj_uv[i] = (dust_proj_u, dust_proj_v).
+  int alignDust(cv::Mat &Tcw, const cv::Mat &points, float fx, float fy, float cx, float cy, std::vector<bool> &inlier,
+                std::vector<cv::Point2f> &proj_uv, int max_iterations = 40) {
+    if (Tcw.rows != 4 || Tcw.cols != 4 || Tcw.type() != CV_32FC1 || Tcw.step != 4 * sizeof(float))
+      throw std::runtime_error("alignDust: Tcw must be a contiguous 4 x 4 CV_32F matrix");
+    const int n = points.rows;
+    if (n > 0 && (points.cols != 3 || points.type() != CV_32FC1 || points.step != 3 * sizeof(float)))
+      throw std::runtime_error("alignDust: points must be contiguous N x 3 CV_32F");
+    if (dense_dust_.empty()) throw std::runtime_error("alignDust: no frame has been extracted yet");
+    spfe_dust_params prm{fx, fy, cx, cy, max_iterations, 0.9, 0.9};
+    std::vector<uint8_t> inl(n > 0 ? n : 1);
+    std::vector<float> uv(2 * static_cast<size_t>(n > 0 ? n : 1));
+    float out[16];
+    int n_inlier = 0, iters = 0;
+    if (spfe_align_dust(h_, reinterpret_cast<const float *>(dense_dust_.data),
+                        n > 0 ? reinterpret_cast<const float *>(points.data) : nullptr, n,
+                        reinterpret_cast<const float *>(Tcw.data), &prm, out, inl.data(), uv.data(), &n_inlier,
+                        &iters) != SPFE_OK)
+      throw std::runtime_error(spfe_last_error());
+    for (int k = 0; k < 16; ++k) reinterpret_cast<float *>(Tcw.data)[k] = out[k];
+    inlier.assign(n, false);
+    proj_uv.assign(n, cv::Point2f());
+    for (int i = 0; i < n; ++i) {
+      inlier[i] = inl[i] != 0;
+      proj_uv[i].x = uv[2 * i];
+      proj_uv[i].y = uv[2 * i + 1];
+    }
+    return n_inlier;
+  }
+
   // The association loop of Tracker::trackFrameDustKFLocal (tracker_dust.cpp:113-172) against the frame
   // extracted last: map point i (descriptor row i, projected dust-map position uv[i] in cells —
   // dust_proj_u / dust_proj_v) takes the nearest keypoint of its 2 x 2 cells below max_dist, earlier map

@@ -297,3 +297,18 @@ def align_dust(dust, pts, Tcw, fx, fy, cx, cy, max_iterations=40, delta=0.9, inl
                             float(fx), float(fy), float(cx), float(cy), int(max_iterations), float(delta),
                             float(inlier_chi2), Tout.ctypes.data, inl.ctypes.data, uv.ctypes.data, C.byref(it))
     return dict(Tcw=Tout.reshape(4, 4), inlier=inl[:n].astype(bool), uv=uv[:n], n_inlier=int(k), iterations=it.value)
+
+
+def match_knn2(query, train):
+    """Exact 2-nearest-neighbour search (what flann->knnMatch(query, matches, 2) approximates)."""
+    q = np.ascontiguousarray(query, np.float32).reshape(-1, 256)
+    t = np.ascontiguousarray(train, np.float32).reshape(-1, 256)
+    idx = np.full((max(len(q), 1), 2), -1, np.int32)
+    dist = np.full((max(len(q), 1), 2), np.finfo(np.float32).max, np.float32)
+    L = lib()
+    L.oracle_match_knn2.restype = None
+    L.oracle_match_knn2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    if len(q):
+        L.oracle_match_knn2(q.ctypes.data, len(q), (t if len(t) else np.zeros((1, 256), np.float32)).ctypes.data, len(t),
+                            idx.ctypes.data, dist.ctypes.data)
+    return idx[:len(q)], dist[:len(q)]

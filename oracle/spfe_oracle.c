@@ -869,3 +869,24 @@ EXPORT int oracle_align_dust(const float *dust, int hc, int wc, const float *pts
   free(ed);
   return n_inlier;
 }
+
+/* k = 2 nearest train rows per query — the EXACT search that the reference's
+ * flann->knnMatch(query, matches, 2) approximates (keyframe.cpp:447-470, sp_matcher.cpp:195-215, :264-280;
+ * cv::FlannBasedMatcher with randomised kd-trees: no bit-parity target).  OpenCV's brute-force k-NN
+ * (batchDistance, K = 2) is the statement followed: a sorted insertion with strict `<`, so the earlier train
+ * row stays in front on ties; NaN / infinite distances never enter.  train_idx / distance: [nq][2]. */
+EXPORT void oracle_match_knn2(const float *query, int nq, const float *train, int nt, int32_t *train_idx,
+                              float *distance) {
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < nq; ++i) {
+    float d0 = FLT_MAX, d1 = FLT_MAX;
+    int i0 = -1, i1 = -1;
+    for (int j = 0; j < nt; ++j) {
+      const float d = match_dist(query + (size_t)i * 256, train + (size_t)j * 256);
+      if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = j; }
+      else if (d < d1) { d1 = d; i1 = j; }
+    }
+    train_idx[2 * i] = i0; train_idx[2 * i + 1] = i1;
+    distance[2 * i] = d0; distance[2 * i + 1] = d1;
+  }
+}

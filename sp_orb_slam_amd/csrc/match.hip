@@ -46,8 +46,11 @@ __device__ __forceinline__ const float *side_desc(const MatchSide &s, int pair) 
 }
 }  // namespace
 
+// excl (may be null): per row, only candidates with a (dist, column) key ABOVE excl[row] compete — with excl =
+// the nearest neighbours of a first pass this finds the second nearest (k = 2 of cv::DescriptorMatcher::knnMatch).
 __global__ __launch_bounds__(256) void match_nn_kernel(MatchSide rows, MatchSide cols,
-                                                       unsigned long long *__restrict__ best) {
+                                                       unsigned long long *__restrict__ best,
+                                                       const unsigned long long *__restrict__ excl) {
   const int pair = blockIdx.z;
   const int nr = side_count(rows, pair), nc = side_count(cols, pair);
   const int r0 = blockIdx.y * M_TILE, c0 = blockIdx.x * M_TILE;
@@ -112,13 +115,15 @@ __global__ __launch_bounds__(256) void match_nn_kernel(MatchSide rows, MatchSide
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     unsigned long long p = M_NONE;
+    const int row_r = r0 + ty * 4 + r;
+    const unsigned long long floor_key = (excl && row_r < nr) ? excl[(size_t)pair * rows.cap + row_r] : 0ull;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int col = c0 + tx + 16 * c;
       const float dist = __builtin_sqrtf(acc[r][c]);  // correctly rounded (v_sqrt_f32 + the fma fix-up), unlike __fsqrt_rn
       if (col < nc && dist < FLT_MAX) {  // NaN / inf distances are never "nearer" (OpenCV: d < FLT_MAX start)
         const unsigned long long cand = ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned)col;
-        p = cand < p ? cand : p;
+        if (!excl || (floor_key != M_NONE && cand > floor_key)) p = cand < p ? cand : p;
       }
     }
 #pragma unroll
@@ -163,15 +168,32 @@ hipError_t launch_match(const MatchSide &query, const MatchSide &train, int pair
   if (cross_check) {
     if ((e = hipMemsetAsync(best_t, 0xff, (size_t)pairs * train.cap * 8, s)) != hipSuccess) return e;
     dim3 g((query.cap + M_TILE - 1) / M_TILE, (train.cap + M_TILE - 1) / M_TILE, pairs);
-    hipLaunchKernelGGL(match_nn_kernel, g, dim3(256), 0, s, train, query, best_t);
+    hipLaunchKernelGGL(match_nn_kernel, g, dim3(256), 0, s, train, query, best_t, (const unsigned long long *)nullptr);
     hipLaunchKernelGGL(match_resolve_kernel, dim3((train.cap + 255) / 256, pairs), dim3(256), 0, s, best_t,
                        train.cap, best_q, query.cap);
   } else {
     dim3 g((train.cap + M_TILE - 1) / M_TILE, (query.cap + M_TILE - 1) / M_TILE, pairs);
-    hipLaunchKernelGGL(match_nn_kernel, g, dim3(256), 0, s, query, train, best_q);
+    hipLaunchKernelGGL(match_nn_kernel, g, dim3(256), 0, s, query, train, best_q, (const unsigned long long *)nullptr);
   }
   hipLaunchKernelGGL(match_emit_kernel, dim3((query.cap + 255) / 256, pairs), dim3(256), 0, s, best_q, query.cap,
                      out, out_stride);
+  return hipGetLastError();
+}
+
+// k = 2 nearest train rows per query (no cross-check): two passes of the distance kernel, the second restricted
+// to keys above the first's.  out: [first: idx[cap] | dist[cap]] [second: idx[cap] | dist[cap]] per pair.
+// best1 / best2: [pairs][query.cap] scratch.
+hipError_t launch_match_knn2(const MatchSide &query, const MatchSide &train, int pairs, unsigned long long *best1,
+                             unsigned long long *best2, uint8_t *out, size_t out_stride, hipStream_t s) {
+  hipError_t e;
+  if ((e = hipMemsetAsync(best1, 0xff, (size_t)pairs * query.cap * 8, s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(best2, 0xff, (size_t)pairs * query.cap * 8, s)) != hipSuccess) return e;
+  dim3 g((train.cap + M_TILE - 1) / M_TILE, (query.cap + M_TILE - 1) / M_TILE, pairs);
+  hipLaunchKernelGGL(match_nn_kernel, g, dim3(256), 0, s, query, train, best1, (const unsigned long long *)nullptr);
+  hipLaunchKernelGGL(match_nn_kernel, g, dim3(256), 0, s, query, train, best2, (const unsigned long long *)best1);
+  const dim3 ge((query.cap + 255) / 256, pairs);
+  hipLaunchKernelGGL(match_emit_kernel, ge, dim3(256), 0, s, best1, query.cap, out, out_stride);
+  hipLaunchKernelGGL(match_emit_kernel, ge, dim3(256), 0, s, best2, query.cap, out + (size_t)query.cap * 8, out_stride);
   return hipGetLastError();
 }
 
@@ -315,6 +337,12 @@ hipError_t launch_match_patches(const PatchArgs &a, int kcap, float max_dist, in
   if (a.n_points > 4096) return hipErrorInvalidValue;
   hipLaunchKernelGGL(patch_dist_kernel, dim3((a.n_points + 3) / 4), dim3(256), 0, s, a, cand_idx, cand_dist);
   const size_t lds = (size_t)kcap * 5 + 16;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (lds > 48 * 1024) {   // beyond the default dynamic-LDS limit (kcap > ~9800): raise it
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(patch_resolve_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL(patch_resolve_kernel, dim3(1), dim3(1024), lds, s, cand_idx, cand_dist, a.n_points, kcap,
                      max_dist, out);
   return hipGetLastError();

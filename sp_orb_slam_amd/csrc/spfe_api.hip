@@ -109,7 +109,7 @@ struct spfe_handle_s {
   uint8_t *d_raw = nullptr, *h_raw = nullptr;
   // descriptor matching (spfe_match*): scratch grown on demand
   unsigned long long *m_best_t = nullptr, *m_best_q = nullptr;
-  uint8_t *m_stage_q = nullptr, *m_stage_t = nullptr, *m_out = nullptr;
+  uint8_t *m_stage_q = nullptr, *m_stage_t = nullptr, *m_out = nullptr, *m_out2 = nullptr;
   int *p_cidx = nullptr;           // patch association scratch: [4096][4] candidates, distances, host staging
   float *p_cdist = nullptr;
   uint8_t *p_stage = nullptr;
@@ -731,7 +731,7 @@ void spfe_destroy(spfe_handle h) {
   for (void *p : {(void *)h->p_cidx, (void *)h->p_cdist, (void *)h->p_stage})
     if (p) (void)hipFree(p);
   for (void *p : {(void *)h->m_best_t, (void *)h->m_best_q, (void *)h->m_stage_q, (void *)h->m_stage_t,
-                  (void *)h->m_out})
+                  (void *)h->m_out, (void *)h->m_out2})
     if (p) (void)hipFree(p);
   for (void *p : h->dev_allocs) (void)hipFree(p);
   for (void *p : h->host_allocs) (void)hipHostFree(p);
@@ -1440,7 +1440,7 @@ int spfe_match(spfe_handle h, const float *query, int n_query, const float *trai
   const int cap = std::max(n_query, n_train);
   if (cap > h->m_host_cap) {
     HIP_TRY(hipDeviceSynchronize());
-    for (uint8_t **p : {&h->m_stage_q, &h->m_stage_t, &h->m_out})
+    for (uint8_t **p : {&h->m_stage_q, &h->m_stage_t, &h->m_out, &h->m_out2})
       if (*p) { (void)hipFree(*p); *p = nullptr; }
     h->m_host_cap = 0;
     const int want = std::max(cap, h->kmax);
@@ -1464,6 +1464,57 @@ int spfe_match(spfe_handle h, const float *query, int n_query, const float *trai
   HIP_TRY(hipMemcpyAsync(train_idx, h->m_out, (size_t)n_query * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(distance, h->m_out + (size_t)n_query * 4, (size_t)n_query * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  return SPFE_OK;
+}
+
+// knnMatch(query, matches, 2): the two nearest train rows of every query, exactly (the FLANN kd-tree the
+// reference builds for this is approximate and randomised)
+int spfe_match_knn2(spfe_handle h, const float *query, int n_query, const float *train, int n_train,
+                    int32_t *train_idx, float *distance) {
+  if (!h || !train_idx || !distance) return fail(SPFE_EINVAL, "null argument");
+  if (n_query < 0 || n_train < 0) return fail(SPFE_EINVAL, "negative descriptor count");
+  if ((n_query && !query) || (n_train && !train)) return fail(SPFE_EINVAL, "null descriptor array");
+  for (int i = 0; i < 2 * n_query; ++i) { train_idx[i] = -1; distance[i] = FLT_MAX; }
+  if (n_query == 0 || n_train == 0) return SPFE_OK;
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const int cap = std::max(n_query, n_train);
+  if (cap > h->m_host_cap || !h->m_out2) {
+    HIP_TRY(hipDeviceSynchronize());
+    for (uint8_t **p : {&h->m_stage_q, &h->m_stage_t, &h->m_out, &h->m_out2})
+      if (*p) { (void)hipFree(*p); *p = nullptr; }
+    h->m_host_cap = 0;
+    const int want = std::max(cap, h->kmax);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->m_stage_q), kMatchHdr + (size_t)want * 1024));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->m_stage_t), kMatchHdr + (size_t)want * 1024));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->m_out), (size_t)want * 8));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->m_out2), (size_t)want * 16));
+    h->m_host_cap = want;
+  }
+  int rc = match_scratch(h, 1, std::max(cap, h->kmax));
+  if (rc) return rc;
+  hipStream_t s = h->stream;
+  const int32_t hq[4] = {n_query, 0, 0, 0}, ht[4] = {n_train, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(h->m_stage_q, hq, 16, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->m_stage_t, ht, 16, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->m_stage_q + kMatchHdr, query, (size_t)n_query * 1024, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->m_stage_t + kMatchHdr, train, (size_t)n_train * 1024, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));  // hq / ht live on this frame
+  spfe::MatchSide q{h->m_stage_q, 0, 0, kMatchHdr, n_query};
+  spfe::MatchSide t{h->m_stage_t, 0, 0, kMatchHdr, n_train};
+  // scratch: best_q holds the first neighbours, best_t (>= cap entries) the second
+  HIP_TRY(spfe::launch_match_knn2(q, t, 1, h->m_best_q, h->m_best_t, h->m_out2, 0, s));
+  // device layout idx1 | dist1 | idx2 | dist2 -> host layout [n_query][2]
+  std::vector<int32_t> hi(2 * (size_t)n_query);
+  std::vector<float> hd(2 * (size_t)n_query);
+  HIP_TRY(hipMemcpyAsync(hi.data(), h->m_out2, (size_t)n_query * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(hd.data(), h->m_out2 + (size_t)n_query * 4, (size_t)n_query * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(hi.data() + n_query, h->m_out2 + (size_t)n_query * 8, (size_t)n_query * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(hd.data() + n_query, h->m_out2 + (size_t)n_query * 12, (size_t)n_query * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (int i = 0; i < n_query; ++i) {
+    train_idx[2 * i] = hi[i]; train_idx[2 * i + 1] = hi[n_query + i];
+    distance[2 * i] = hd[i]; distance[2 * i + 1] = hd[n_query + i];
+  }
   return SPFE_OK;
 }
 

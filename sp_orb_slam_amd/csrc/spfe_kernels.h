@@ -132,6 +132,11 @@ hipError_t launch_match(const MatchSide &query, const MatchSide &train, int pair
                         unsigned long long *best_t, unsigned long long *best_q, uint8_t *out, size_t out_stride,
                         hipStream_t s);
 
+// the two nearest train rows per query (cv::DescriptorMatcher::knnMatch(query, matches, 2)); out per pair:
+// idx1[query.cap] | dist1[query.cap] | idx2[query.cap] | dist2[query.cap]
+hipError_t launch_match_knn2(const MatchSide &query, const MatchSide &train, int pairs, unsigned long long *best1,
+                             unsigned long long *best2, uint8_t *out, size_t out_stride, hipStream_t s);
+
 // ---------------------------------------------------------------------------
 // input staging (stage_input.hip): raw camera frames -> cropped gray u8 frames
 // ---------------------------------------------------------------------------

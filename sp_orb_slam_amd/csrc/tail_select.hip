@@ -321,7 +321,9 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
     sMask[c] = (uint8_t)m;
   }
   __syncthreads();
-  for (int round = 0; round < 4096; ++round) {
+  // every round decides at least the best-ranked undecided candidate, so C rounds always suffice (a strictly
+  // rank-ordered staircase across the cells is the worst case); real frames need a handful
+  for (int round = 0; round < C; ++round) {
     if (tid == 0) sCnt[0] = 0;
     __syncthreads();
     int pending = 0;

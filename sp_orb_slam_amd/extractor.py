@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "spfe_set_staging", "spfe_extract_staged", "spfe_extract_batch_staged", "spfe_stage_batch_device",
     "spfe_comm_unique_id", "spfe_comm_init", "spfe_comm_destroy", "spfe_allgather_records", "spfe_comm_wait",
     "spfe_comm_stream", "spfe_submit_batch", "spfe_collect_batch",
-    "spfe_align_dust", "spfe_align_dust_record_device",
+    "spfe_align_dust", "spfe_align_dust_record_device", "spfe_match_knn2",
 ]
 
 
@@ -172,6 +172,8 @@ def load_library():
     L.spfe_match.restype = C.c_int
     L.spfe_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                              C.c_void_p]
+    L.spfe_match_knn2.restype = C.c_int
+    L.spfe_match_knn2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.spfe_match_records_device.restype = C.c_int
     L.spfe_match_records_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                             C.c_void_p]
@@ -586,6 +588,16 @@ class SPExtractor:
                                     t.ctypes.data if len(t) else None, len(t), 1 if cross_check else 0,
                                     idx.ctypes.data, dist.ctypes.data))
         return idx, dist
+
+    def match_knn2(self, query, train):
+        """knnMatch(query, matches, 2) against `train`, exact: -> (train_idx [nq, 2] int32, distance [nq, 2] f32)."""
+        q = np.ascontiguousarray(query, np.float32).reshape(-1, 256)
+        t = np.ascontiguousarray(train, np.float32).reshape(-1, 256)
+        idx = np.full((max(len(q), 1), 2), -1, np.int32)
+        dist = np.zeros((max(len(q), 1), 2), np.float32)
+        _check(self._lib.spfe_match_knn2(self._h, q.ctypes.data, len(q), t.ctypes.data, len(t), idx.ctypes.data,
+                                         dist.ctypes.data))
+        return idx[:len(q)], dist[:len(q)]
 
     def match_patches(self, mp_desc, mp_uv, occ_grid, kp_desc, max_dist=0.75):
         """Patch-wise association of projected map points (tracker_dust.cpp:113-172): map point i at

@@ -106,3 +106,27 @@ def test_match_records_on_device(ext):
                 m = idx[:fb.K] >= 0
                 d = fb.kp_xy[m] - fa.kp_xy[idx[:fb.K][m]]
                 assert np.mean((d[:, 0] == 16) & (d[:, 1] == 8)) > 0.5
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (5, 2), (64, 64), (65, 63), (300, 1001), (1001, 700), (2, 2300)])
+def test_match_knn2_exact(ext, nq, nt):
+    """spfe_match_knn2 = knnMatch(query, matches, 2), exact: indices and distances bit-identical to the oracle,
+    including duplicated train rows (ties -> lower index first), a single train row (second = none) and NaNs."""
+    rng = np.random.default_rng(nq * 13 + nt)
+    q, t = _unit(rng, nq), _unit(rng, nt)
+    if nt >= 8:
+        t[5] = t[2]                       # exact duplicate: tie between train rows 2 and 5
+        q[0] = t[2]
+        t[7, 3] = np.nan                  # never a neighbour
+    idx, dist = ext.match_knn2(q, t)
+    ridx, rdist = oracle.match_knn2(q, t)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(dist.view(np.uint32), rdist.view(np.uint32))
+    if nt >= 8:
+        assert tuple(idx[0]) == (2, 5) and dist[0, 0] == dist[0, 1] == 0.0
+        assert not (idx == 7).any()
+    if nt == 1:
+        assert (idx[:, 1] == -1).all() and (dist[:, 1] == FMAX).all()
+    # the ratio test of KeyFrame::matchMps (keyframe.cpp:462): well defined on the exact neighbours
+    good = dist[:, 0] < 0.7 * dist[:, 1]
+    assert good.dtype == bool

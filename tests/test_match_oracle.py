@@ -83,3 +83,21 @@ def test_empty_and_nan():
     for cross in (True, False):
         idx, _ = oracle.match_bruteforce(q, t, cross)
         assert idx.tolist() == [0, 1, -1 if cross else idx[2], 3, 4] and idx[2] != 2
+
+
+def test_knn2_oracle_against_numpy_sort():
+    """oracle_match_knn2 (exact 2-NN, what the reference's FLANN knnMatch(.., 2) approximates) against a literal
+    numpy statement: sort the distances of every query stably, take the first two."""
+    rng = np.random.default_rng(11)
+    q = rng.standard_normal((40, 256)).astype(np.float32)
+    t = rng.standard_normal((90, 256)).astype(np.float32)
+    t[10] = t[3]
+    q[0] = t[3]
+    idx, dist = oracle.match_knn2(q, t)
+    full = np.stack([oracle.match_bruteforce(q, t[j:j + 1], False)[1] for j in range(len(t))], 1)   # [nq, nt] distances
+    order = np.argsort(full, axis=1, kind="stable")[:, :2]
+    assert np.array_equal(idx, order.astype(np.int32))
+    assert np.array_equal(dist, np.take_along_axis(full, order, 1))
+    assert tuple(idx[0]) == (3, 10)
+    i1, d1 = oracle.match_knn2(q, t[:1])
+    assert (i1[:, 0] == 0).all() and (i1[:, 1] == -1).all()
