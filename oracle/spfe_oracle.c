@@ -185,13 +185,41 @@ EXPORT int oracle_network(const float *blob, const uint8_t *img, int H, int W, f
 }
 
 /*
- * The network in the build's bf16 mode: conv1a in f32 with its output rounded to bf16;
+ * The network in the build's bf16 mode: conv1a as conv1a_bf16() below (bf16 weights, exact u8 inputs, the 1/255
+ * applied to the sum, output rounded to bf16);
  * conv1b..conv4b with bf16 weights and activations (f32 accumulate, bias, ReLU, pool; outputs
  * rounded); convPa and convDa with bf16 weights and bf16 output; the 1x1 heads convPb (the detector
  * logits) and convDb with bf16 weights, f32 accumulate and f32 output; everything after the two
  * heads in f32.  (The MFMA's accumulation order differs from this loop's, so the GPU is
  * compared with a tolerance in this mode, not bitwise.)
  */
+/* conv1a of the bf16 mode (sp_orb_slam_amd/csrc/conv1a_mfma.h): the u8 pixels enter the product unscaled (exact
+ * in bf16), the weights rounded to bf16, the 1/255 of convertTo (:388) applied to the f32 sum:
+ *   a0[c] = bf16( max( fmaf( sum_t float(u8_t) * bf16(w[c][t]), 1/255, b[c] ), 0 ) ),  zero padding. */
+static void conv1a_bf16(const float *blob, const uint8_t *img, int H, int W, float *out) {
+  const float *w = blob + oracle_weight_offset(0); /* [64][1][3][3] */
+  const float *b = blob + oracle_bias_offset(0);
+  float wb[64 * 9];
+  for (int i = 0; i < 64 * 9; ++i) wb[i] = bf16_round(w[i]);
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      float px[9];
+      for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        px[t] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (float)img[(size_t)yy * W + xx] : 0.0f;
+      }
+      float *o = out + ((size_t)y * W + x) * 64;
+      for (int c = 0; c < 64; ++c) {
+        float s = 0.0f;
+        for (int t = 0; t < 9; ++t) s = __builtin_fmaf(px[t], wb[c * 9 + t], s);
+        float v = __builtin_fmaf(s, 1.0f / 255.0f, b[c]);
+        v = v > 0.0f ? v : 0.0f;
+        o[c] = bf16_round(v);
+      }
+    }
+}
+
 EXPORT int oracle_network_bf16(const float *blob, const uint8_t *img, int H, int W, float *semi,
                                float *coarse) {
   if (H % 8 || W % 8 || H <= 0 || W <= 0) return -1;
@@ -201,7 +229,7 @@ EXPORT int oracle_network_bf16(const float *blob, const uint8_t *img, int H, int
   float *x0 = (float *)malloc((size_t)H * W * sizeof(float));
   for (size_t i = 0; i < (size_t)H * W; ++i) x0[i] = spfe_pixel_to_float(img[i]);
   int h = H, w = W;
-  conv_layer_ex(0, blob, x0, h, w, a, 0, 1);
+  conv1a_bf16(blob, img, h, w, a);
   conv_layer_ex(1, blob, a, h, w, b, 1, 1);
   maxpool2(b, h, w, 64, a);
   h /= 2, w /= 2;

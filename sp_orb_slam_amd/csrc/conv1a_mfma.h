@@ -1,0 +1,91 @@
+// conv1a_mfma.h — the first convolution of the bf16 mode (conv1a, 1 -> 64 channels, 3 x 3;
+// /root/reference/orb_slam2/src/cv/sp_extractor.cpp:81 after the input conversion :388) as a K = 16 matrix
+// product on v_mfma_f32_32x32x16_bf16, shared by the two places that compute it so that they produce the same bits:
+//   * conv_bf16_ws.hip, TAG 2: the producer waves of conv1b make conv1b's halo tile instead of loading it;
+//   * conv_bf16.hip, conv1a_bf16_kernel: the stand-alone layer (launches too small for the wave-specialised kernel).
+//
+// Definition (the oracle's oracle_network_bf16 restates it):
+//   s[c]  = sum over the 9 taps of  float(u8 pixel) * bf16(w[c][tap])          (f32 accumulate; the products are exact)
+//   a0[c] = bf16( max( fmaf(s[c], 1/255, bias[c]), 0 ) )
+// i.e. the 1/255 of convertTo(CV_32F, 1.f/255.f) is applied to the sum, so the matrix operands are exact: u8 values are
+// integers below 2^8 (exact in bf16) and the weights are rounded to bf16 like every other layer's of this mode.
+// As VALU code (9 taps x 64 channels of f32 FMAs per pixel) this layer cost 0.27 ms per eight 1280x720 frames on its own,
+// and ~950 instructions per tile and wave when fused — more issue slots than the MFMA stream beside it leaves; as a
+// matrix product it is 2 MFMAs per 32 pixels.
+//
+// Operands of one 32-pixel group (lane = (l31 = lane & 31, hi = lane >> 5)):
+//   A (weights, per channel tile j): row m = l31 <-> channel 32 j + l31, k = 8 hi + e <-> tap k (zero for k >= 9): the
+//     packed table `wtab` [2][64 lanes][8 bf16] built by the host;
+//   B (pixels): column n = l31 <-> the group's pixel l31, k = 8 hi + e <-> its tap k, read from a bf16 patch in LDS;
+//   D[channel][pixel]: the lane owns one pixel, register r <-> channel 32 j + 8 (r >> 2) + 4 hi + (r & 3): four
+//     consecutive channels per (r >> 2) = 8 bytes of bf16 = half of a 16-byte piece of the NHWC activation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace spfe {
+namespace c1a {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) unsigned short lds_u16;
+
+constexpr int PATCH_PITCH = 40;   // bf16 elements per patch row (36 used)
+
+// the bf16 bit pattern of an integer 0..255 (exact: 8 significant bits)
+__device__ __forceinline__ unsigned short u8_to_bf16(unsigned v) { return (unsigned short)(__float_as_uint((float)v) >> 16); }
+
+// B operand of a lane: `tap0` = LDS address of its pixel's tap (0, 0) in a bf16 patch of pitch PATCH_PITCH
+__device__ __forceinline__ bf16x8 pixel_operand(lds_u16 *tap0, int hi) {
+  unsigned t[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) t[k] = tap0[(k / 3) * PATCH_PITCH + k % 3];
+  u32x4 d;
+  d.x = hi ? t[8] : (t[0] | (t[1] << 16));
+  d.y = hi ? 0u : (t[2] | (t[3] << 16));
+  d.z = hi ? 0u : (t[4] | (t[5] << 16));
+  d.w = hi ? 0u : (t[6] | (t[7] << 16));
+  return __builtin_bit_cast(bf16x8, d);
+}
+
+// the two accumulator tiles of a 32-pixel group
+__device__ __forceinline__ void product(const bf16x8 (&wA)[2], bf16x8 px, f32x16 (&acc)[2]) {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+  acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA[0], px, z, 0, 0, 0);
+  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA[1], px, z, 0, 0, 0);
+}
+
+// epilogue of one (channel tile j, q = r >> 2): channels 32 j + 8 q + 4 hi + 0..3 of the lane's pixel, as 8 bytes of bf16
+__device__ __forceinline__ u32x2 finish4(const f32x16 &acc, int q, const float (&bias)[16]) {
+  float v[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    v[m] = __builtin_fmaf(acc[4 * q + m], 1.0f / 255.0f, bias[4 * q + m]);
+    v[m] = __builtin_fmaxf(v[m], 0.0f);
+  }
+  u32x2 o;
+  o.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v[0], v[1]}, bf16x2));
+  o.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v[2], v[3]}, bf16x2));
+  return o;
+}
+
+// per-lane constants: A operands from the host table, the lane's 2 x 16 biases (register r of tile j <-> channel
+// 32 j + 8 (r >> 2) + 4 hi + (r & 3))
+__device__ __forceinline__ void load_constants(const void *wtab, const float *b64, int lane, bf16x8 (&wA)[2], float (&bias)[2][16]) {
+  const int hi = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    wA[j] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4 *>(wtab)[j * 64 + lane]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias[j][r] = b64[32 * j + 8 * (r >> 2) + 4 * hi + (r & 3)];
+  }
+}
+
+}  // namespace c1a
+}  // namespace spfe

@@ -32,6 +32,7 @@
 //    swizzle, and every fragment address is base + immediate.
 #include <utility>
 
+#include "conv1a_mfma.h"
 #include "spfe_kernels.h"
 
 namespace spfe {
@@ -554,16 +555,16 @@ hipError_t launch_conv_bf16(const ConvParams &p, int cin, bool pool, bool out_f3
   return hipErrorInvalidValue;
 }
 
-// conv1a for the bf16 path: same arithmetic as conv1a_kernel (f32 VALU, K = 9), output
-// rounded to bf16: 16 lanes per pixel, 4 channels (8 bytes) each.
-__global__ __launch_bounds__(256) void conv1a_bf16_kernel(const uint8_t *__restrict__ img,
-                                                          const float *__restrict__ w9x64,
+// conv1a for the bf16 path, stand-alone (launches the wave-specialised conv1b does not take — it computes conv1a
+// itself otherwise): the arithmetic of conv1a_mfma.h, 2 MFMAs per 32 pixels of an image row.  One workgroup =
+// an 8 x 32 pixel tile, one wavefront = two of its rows; the tile's u8 pixels (+ 1 border) sit in LDS as bf16.
+__global__ __launch_bounds__(256) void conv1a_bf16_kernel(const uint8_t *__restrict__ img, const void *__restrict__ wtab,
                                                           const float *__restrict__ b64,
                                                           unsigned short *__restrict__ out, int B, int H,
                                                           int W, int tiles_x, int tiles_y) {
   constexpr int TH = 8, TW = 32;
-  __shared__ float sI[(TH + 2) * (TW + 2)];
-  const int tid = threadIdx.x;
+  __shared__ unsigned short sP[(TH + 2) * c1a::PATCH_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int wg = blockIdx.x;
   const int tx = wg % tiles_x;
   wg /= tiles_x;
@@ -574,55 +575,41 @@ __global__ __launch_bounds__(256) void conv1a_bf16_kernel(const uint8_t *__restr
   for (int i = tid; i < (TH + 2) * (TW + 2); i += 256) {
     const int row = i / (TW + 2), col = i % (TW + 2);
     const int gy = ty0 + row - 1, gx = tx0 + col - 1;
-    float v = 0.0f;
-    if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-      v = (float)ib[(size_t)gy * W + gx] * (1.0f / 255.0f);
-    sI[i] = v;
+    unsigned v = 0;
+    if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = ib[(size_t)gy * W + gx];
+    sP[row * c1a::PATCH_PITCH + col] = c1a::u8_to_bf16(v);
   }
-  // this kernel is VALU bound (9 fma + bias + ReLU + rounding per output, 185 M outputs per batch),
-  // so the channels go two to a register pair: v_pk_fma_f32 / v_pk_add_f32 and v_cvt_pk_bf16_f32
-  const int c4 = tid & 15;
-  f32x2 w01[9], w23[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const float4 wv = *reinterpret_cast<const float4 *>(w9x64 + t * 64 + c4 * 4);
-    w01[t] = (f32x2){wv.x, wv.y};
-    w23[t] = (f32x2){wv.z, wv.w};
-  }
-  const float4 bias = *reinterpret_cast<const float4 *>(b64 + c4 * 4);
-  const f32x2 b01 = {bias.x, bias.y}, b23 = {bias.z, bias.w};
+  c1a::bf16x8 wA[2];
+  float bias[2][16];
+  c1a::load_constants(wtab, b64, lane, wA, bias);
   __syncthreads();
-  const int psub = tid >> 4;
-#pragma unroll 4
-  for (int it = 0; it < 16; ++it) {
-    const int pix = it * 16 + psub;
-    const int row = pix >> 5, col = pix & 31;
-    f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+  const int l31 = lane & 31, hi = lane >> 5;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const float x = sI[(row + t / 3) * (TW + 2) + col + t % 3];
-      const f32x2 xx = {x, x};
-      a01 = __builtin_elementwise_fma(xx, w01[t], a01);
-      a23 = __builtin_elementwise_fma(xx, w23[t], a23);
-    }
-    a01 = a01 + b01;
-    a23 = a23 + b23;
-    a01 = __builtin_elementwise_max(a01, (f32x2){0.f, 0.f});
-    a23 = __builtin_elementwise_max(a23, (f32x2){0.f, 0.f});
-    const int gy = ty0 + row, gx = tx0 + col;
+  for (int rr = 0; rr < 2; ++rr) {
+    const int row = wave * 2 + rr;
+    const c1a::bf16x8 px = c1a::pixel_operand(
+        (c1a::lds_u16 *)sP + row * c1a::PATCH_PITCH + l31, hi);
+    c1a::f32x16 acc[2];
+    c1a::product(wA, px, acc);
+    const int gy = ty0 + row, gx = tx0 + l31;
     if (gy < H && gx < W) {
-      uint2 o;
-      o.x = __builtin_bit_cast(unsigned, __builtin_convertvector(a01, bf16x2));
-      o.y = __builtin_bit_cast(unsigned, __builtin_convertvector(a23, bf16x2));
-      *reinterpret_cast<uint2 *>(out + (((size_t)b * H + gy) * W + gx) * 64 + c4 * 4) = o;
+      unsigned short *o = out + (((size_t)b * H + gy) * W + gx) * 64 + 4 * hi;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const c1a::u32x2 v = c1a::finish4(acc[j], q, bias[j]);
+          *reinterpret_cast<uint2 *>(o + 32 * j + 8 * q) = make_uint2(v.x, v.y);
+        }
     }
   }
 }
 
-hipError_t launch_conv1a_bf16(const uint8_t *img, const float *w9x64, const float *b64, void *out, int B, int H,
+// wtab: the bf16 operand table of conv1a_mfma.h ([2][64 lanes][8 bf16]); b64: bias
+hipError_t launch_conv1a_bf16(const uint8_t *img, const void *wtab, const float *b64, void *out, int B, int H,
                               int W, hipStream_t s) {
   const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
-  hipLaunchKernelGGL(conv1a_bf16_kernel, dim3(tiles_x * tiles_y * B), dim3(256), 0, s, img, w9x64, b64,
+  hipLaunchKernelGGL(conv1a_bf16_kernel, dim3(tiles_x * tiles_y * B), dim3(256), 0, s, img, wtab, b64,
                      reinterpret_cast<unsigned short *>(out), B, H, W, tiles_x, tiles_y);
   return hipGetLastError();
 }

@@ -32,6 +32,7 @@
 //     one register per accumulator tile.
 #include <utility>
 
+#include "conv1a_mfma.h"
 #include "spfe_kernels.h"
 
 namespace spfe {
@@ -59,7 +60,8 @@ constexpr int W_BYTES = 9 * 64 * 128;                  // 73,728: [tap][cout][64
 [[maybe_unused]] constexpr int W_INSTR = W_BYTES / 1024;                // 72
 constexpr int LDS_W = 2 * HALO_BYTES;                  // 87,040
 constexpr int LDS_SLOT = LDS_W + W_BYTES;              // 160,768: 3 tile descriptors of 16 B
-constexpr int LDS_TOTAL = LDS_SLOT + 3 * 16;
+constexpr int LDS_PATCH = LDS_SLOT + 64;               // TAG 2: per producer wave a 4 x 40 bf16 patch of the frame (320 B)
+constexpr int LDS_TOTAL = LDS_PATCH + 4 * 320;         // 162,112 of the 163,840 bytes
 constexpr int NSTEP = 36;                              // K steps per tile: 2 chunks x 9 taps x 2
 
 #ifdef WS_PROBE_TIMING
@@ -208,7 +210,17 @@ struct TileDesc {
 
 // in: NHWC bf16 [B][H][W][in_stride]; wpack: [nblk][tap 9][cout 64][8 pieces, piece g at slot g ^ ((cout >> 1) & 7)][8 bf16];
 // out: NHWC bf16.  p.tile_ctr: nblk * 8 counters, zeroed before the launch.
-template <bool POOL>
+// TAG 1 only names the instantiation (conv1b, the dominant kernel): profiler rows of conv1b and conv2b — same
+// template arguments otherwise, same grid — stay apart.
+// TAG 2 = conv1b with conv1a INSIDE (sp_extractor.cpp:81-82 as one kernel): the producer waves do not load the
+// halo tile, they compute it — conv1a of the u8 frame (p.img; p.w1a = the bf16 operand table, p.b1a = the bias) as
+// 2 MFMAs per 32 pixels, the arithmetic of conv1a_mfma.h that the stand-alone conv1a_bf16_kernel shares (bit-identical
+// activations) — and write it into the swizzled LDS layout the consumers read.  The 64-channel activation of the
+// first layer (118 MB per 1280x720 frame) never exists in HBM: conv1a's launch, its writes and conv1b's reads
+// of them are gone; what remains of the first two layers' HBM traffic is the u8 frame in and conv1b's pooled
+// output.  (As VALU code — 9 taps x 64 channels of f32 FMAs per pixel — the producers needed ~950 instructions per tile
+// and wave, more issue slots than the consumers' MFMA stream leaves: 12.3 k cycles per tile instead of 5.9 k.)
+template <bool POOL, int TAG>
 __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_ws[];
   lds_char *const lds = (lds_char *)smem_ws;
@@ -288,6 +300,91 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
 #endif
     };
 
+    // ---- TAG 2: conv1a computed here, as a K = 16 matrix product (conv1a_mfma.h).  The 340 halo pixels are 11 groups
+    // of 32 (linear index P = 34 r + c); this wave makes groups pw, pw + 4, pw + 8.  A group's u8 pixels (4 rows x 40
+    // columns: it can straddle two halo rows) go through a wave-private bf16 patch in LDS, one group at a time.
+    constexpr int NGRP = (ROWS * COLS + 31) / 32;   // 11
+    [[maybe_unused]] bf16x8 wA[2];
+    [[maybe_unused]] float bias1[2][16];
+    [[maybe_unused]] unsigned tap0[3], hdst[3][8], pdst[3];
+    [[maybe_unused]] int hrc[3], prel[3];
+    if constexpr (TAG == 2) {
+      c1a::load_constants(p.w1a, p.b1a, lane, wA, bias1);
+      const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+      for (int gi = 0; gi < 3; ++gi) {
+        const int g = pw + 4 * gi, P = 32 * g + l31, r = P / COLS, c = P % COLS, r0 = (32 * g) / COLS;
+        tap0[gi] = (unsigned)(((r - r0) * c1a::PATCH_PITCH + c + 2) * 2);   // patch column 0 <-> image column x0 - 4
+        hrc[gi] = (g < NGRP && P < ROWS * COLS) ? (int)(((unsigned)(r - 1) << 16) | ((unsigned)(c - 1) & 0xffffu)) : (int)0x80000000;
+#pragma unroll
+        for (int pi = 0; pi < 8; ++pi) hdst[gi][pi] = (unsigned)(P * 128 + ((pi ^ ((c >> 1) & 7)) * 16) + 8 * hi);
+        // the group's patch: 4 rows x 40 bytes starting at image column x0 - 4 (4-byte aligned; widths are multiples of
+        // 8, so a dword is entirely inside the frame or entirely outside): lane < 40 loads one dword = 4 pixels
+        const int prow = lane / 10, pdw = lane % 10;
+        pdst[gi] = (unsigned)((prow * c1a::PATCH_PITCH + 4 * pdw) * 2);
+        prel[gi] = (g < NGRP && lane < 40) ? (int)(((unsigned)(r0 - 2 + prow) << 16) | ((unsigned)(4 * pdw - 4) & 0xffffu)) : (int)0x80000000;
+      }
+    }
+    // (fetch_next: wave 4 also asks the tile queue for the tile after this one — the atomic goes out behind the
+    // patch loads and returns while the matrix products run; the raw counter value comes back through *fetched)
+    auto make_halo = [&](const TileDesc &d, int buf, bool fetch_next, int *fetched) {
+      // the frame as a buffer: out-of-range offsets read 0 — conv1a's own zero padding — and nothing is conditional,
+      // so the tile's patch bytes leave as ONE burst of loads
+      const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<uint8_t *>(p.img) + (size_t)d.b * p.H * p.W, 0, (unsigned)(p.H * p.W), 0x00020000);
+      const int y0 = d.ty * TH, x0 = tile_x0(d.tx, p.W);
+      lds_char *patch = lds + LDS_PATCH + pw * 320;
+      const int hi = lane >> 5;
+      unsigned px[3];
+#pragma unroll
+      for (int gi = 0; gi < 3; ++gi) {
+        const int gy = y0 + (prel[gi] >> 16), gx = x0 + (int)(short)(prel[gi] & 0xffff);
+        const bool in = prel[gi] != (int)0x80000000 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        px[gi] = __builtin_amdgcn_raw_buffer_load_b32(rimg, in ? (unsigned)(gy * p.W + gx) : OOB, 0, 0);
+      }
+      if (fetch_next) {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(ctr, 1);
+        *fetched = v;   // (consumed by the caller after its vmcnt(0))
+      }
+      // border tiles only: some halo pixel lies outside the frame (conv1b's zero padding)
+      const bool border = y0 == 0 || x0 == 0 || y0 + TH + 1 > p.H || x0 + 33 > p.W;
+#pragma unroll
+      for (int gi = 0; gi < 3; ++gi) {
+        if (pw + 4 * gi >= NGRP) break;   // (wave-uniform)
+        if (prel[gi] != (int)0x80000000) {
+          u32x2 pb;   // 4 pixels -> 4 bf16
+          pb.x = c1a::u8_to_bf16(px[gi] & 0xffu) | ((unsigned)c1a::u8_to_bf16((px[gi] >> 8) & 0xffu) << 16);
+          pb.y = c1a::u8_to_bf16((px[gi] >> 16) & 0xffu) | ((unsigned)c1a::u8_to_bf16(px[gi] >> 24) << 16);
+          *reinterpret_cast<__attribute__((address_space(3))) u32x2 *>(patch + pdst[gi]) = pb;
+        }
+        const bf16x8 pxop = c1a::pixel_operand(reinterpret_cast<c1a::lds_u16 *>(patch + tap0[gi]), hi);
+        f32x16 acc1[2];
+        c1a::product(wA, pxop, acc1);
+        if (hrc[gi] != (int)0x80000000) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              *reinterpret_cast<__attribute__((address_space(3))) u32x2 *>(lds + buf * HALO_BYTES + hdst[gi][4 * j + q]) =
+                  c1a::finish4(acc1[j], q, bias1[j]);
+          if (border) {
+            // conv1b's own zero padding: halo pixels outside the frame are zeros, not conv1a evaluated out there
+            const int hy = y0 + (hrc[gi] >> 16), hx = x0 + (int)(short)(hrc[gi] & 0xffff);
+            if (!((unsigned)hy < (unsigned)p.H && (unsigned)hx < (unsigned)p.W)) {
+#pragma unroll
+              for (int pi = 0; pi < 8; ++pi)
+                *reinterpret_cast<__attribute__((address_space(3))) u32x2 *>(lds + buf * HALO_BYTES + hdst[gi][pi]) = (u32x2){0u, 0u};
+            }
+          }
+        }
+      }
+    };
+    auto fill_halo = [&](const TileDesc &d, int buf) {
+      if constexpr (TAG == 2) { int unused = 0; make_halo(d, buf, false, &unused); }
+      else load_halo(d, buf);
+    };
+
     // The resident weight block first: nothing it needs has to be fetched or decided.
     {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -311,7 +408,7 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
     wg_barrier();                        // barrier #0: descriptors 0 and 1 are published
     TileDesc cur = read_slot(0);
-    if (cur.valid) load_halo(cur, 0);
+    if (cur.valid) fill_halo(cur, 0);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     wg_barrier();                        // barrier #1: weights and tile 0 are in LDS
     int t = 0;
@@ -322,10 +419,19 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
     while (cur.valid) {
       WS_T(p0);
       const TileDesc nxt = read_slot((t + 1) % 3);
-      if (WS_ABLATE != 1 && nxt.valid) load_halo(nxt, (t + 1) & 1);
       int i2 = -1;
+      if constexpr (TAG == 2) {
+        int raw = 0;
+        if (nxt.valid) make_halo(nxt, (t + 1) & 1, pw == 0, &raw);
+        if (pw == 0 && nxt.valid) {
+          raw = __builtin_amdgcn_readfirstlane(raw) + 2 * gsize;
+          i2 = raw < t_cnt ? t_lo + raw : -1;
+        }
+      } else if (WS_ABLATE != 1 && nxt.valid) {
+        fill_halo(nxt, (t + 1) & 1);
+      }
       WS_T(p1);
-      if (pw == 0 && nxt.valid) i2 = fetch();  // behind the passes: its round trip hides under theirs
+      if (TAG != 2 && pw == 0 && nxt.valid) i2 = fetch();  // behind the passes: its round trip hides under theirs
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the next tile has landed
       WS_T(p2);
       if (pw == 0) publish((t + 2) % 3, i2);
@@ -451,10 +557,10 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
   }
 }
 
-template <bool POOL>
+template <bool POOL, int TAG>
 static hipError_t launch(const ConvParams &p, hipStream_t s) {
   static_assert(LDS_TOTAL <= 160 * 1024, "halo double buffer + resident weights must fit the 160 KB LDS");
-  auto k = conv_bf16_ws_kernel<POOL>;
+  auto k = conv_bf16_ws_kernel<POOL, TAG>;
   static bool attr_done[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -475,9 +581,14 @@ static hipError_t launch(const ConvParams &p, hipStream_t s) {
 size_t conv_bf16_ws_weight_bytes() { return ws::W_BYTES; }
 
 // cin = 64 only; p.tile_ctr: >= nblk * 8 ints, zero on entry (the kernel leaves them non-zero)
-hipError_t launch_conv_bf16_ws(const ConvParams &p, bool pool, hipStream_t s) {
+hipError_t launch_conv_bf16_ws(const ConvParams &p, bool pool, int layer_tag, hipStream_t s) {
   if (!p.tile_ctr || p.nblk < 1 || p.nblk > 2 || p.W < 32 || (p.W & 1)) return hipErrorInvalidValue;
-  return pool ? ws::launch<true>(p, s) : ws::launch<false>(p, s);
+  if (layer_tag == 2) {   // conv1a fused: the u8 frames, conv1a's taps and bias instead of an input activation
+    if (!pool || p.nblk != 1 || !p.img || !p.w1a || !p.b1a) return hipErrorInvalidValue;
+    return ws::launch<true, 2>(p, s);
+  }
+  if (layer_tag == 1 && pool) return ws::launch<true, 1>(p, s);
+  return pool ? ws::launch<true, 0>(p, s) : ws::launch<false, 0>(p, s);
 }
 
 }  // namespace spfe

@@ -84,6 +84,7 @@ struct spfe_handle_s {
   std::vector<void *> host_allocs;
   uint8_t *d_img = nullptr;
   float *d_w1a = nullptr, *d_b1a = nullptr;
+  unsigned short *d_w1a_tab = nullptr;   // bf16 mode: conv1a's weights as the MFMA operand table of conv1a_mfma.h
   float *act[8] = {};
   float *d_head = nullptr, *d_semi = nullptr, *d_coarse = nullptr;
   unsigned short *d_hd = nullptr;    // bf16 mode: ReLU(convPa) | ReLU(convDa), [B][C][512] bf16 (input of the two bf16 heads)
@@ -118,6 +119,7 @@ struct spfe_handle_s {
   int m_host_cap = 0;              // rows the host-API staging blocks / m_out hold
   unsigned tile16_mask = 0;  // f32 layers (bit i = conv layer i of enqueue()) on 16-row / 8-wave tiles
   bool fuse1a = false;  // f32: conv1a computed inside conv1b (opt-in: SPFE_FUSE_CONV1A=1; measured perf-neutral)
+  bool fuse1a_bf16 = true;  // bf16: conv1a computed by the producer waves of the wave-specialised conv1b (SPFE_BF16_FUSE_CONV1A=0 to split)
   uint8_t *dust_scratch = nullptr;   // spfe_align_dust: dust map | points | pose | output block (device)
   uint8_t *dust_host = nullptr;      // pinned mirror of the output block
   // pipelined host path (spfe_submit_batch / spfe_collect_batch): NPIPE batches in flight, each with its own
@@ -148,6 +150,7 @@ struct spfe_handle_s {
   int ws_min_items = 11;    // ... when the launch has at least this many (tile, 64-channel block) items per workgroup
   unsigned char *d_wws[4] = {};  // their weights in conv_bf16_ws.hip's layout
   int *d_tile_ctr = nullptr;     // [4 layers][16] tile-queue counters, zeroed once per enqueue()
+  bool act0_missing = false;  // the last call computed conv1a inside conv1b
   bool bf16 = false;  // SPFE_PRECISION_BF16: bf16 conv stack (conv1a .. convPa/Da), f32 heads and tail
   // per-stage timing: a ring of event sets, one set per enqueue() call
   bool timing = false;
@@ -365,6 +368,8 @@ int build(spfe_handle h, const spfe_config *cfg) {
     if (menv) h->tile16_mask = (unsigned)strtoul(menv, nullptr, 0);
     const char *wenv = getenv("SPFE_BF16_WS_MASK");
     if (wenv) h->ws_mask = (unsigned)strtoul(wenv, nullptr, 0) & 0xfu;
+    const char *f16env = getenv("SPFE_BF16_FUSE_CONV1A");
+    if (f16env) h->fuse1a_bf16 = atoi(f16env) != 0;
     const char *ienv = getenv("SPFE_BF16_WS_MIN_ITEMS");
     if (ienv) h->ws_min_items = atoi(ienv);
   }
@@ -392,6 +397,18 @@ int build(spfe_handle h, const spfe_config *cfg) {
     if ((rc = dev_alloc(h, &h->d_b1a, bv.size()))) return rc;
     HIP_TRY(hipMemcpy(h->d_w1a, w.data(), w.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->d_b1a, bv.data(), bv.size() * 4, hipMemcpyHostToDevice));
+    if (h->bf16) {
+      // conv1a_mfma.h: [j 2][lane 64][e 8] = bf16(w[channel 32 j + (lane & 31)][tap 8 (lane >> 5) + e]), 0 for taps >= 9
+      std::vector<unsigned short> tab(2 * 64 * 8, 0);
+      for (int j = 0; j < 2; ++j)
+        for (int ln = 0; ln < 64; ++ln)
+          for (int e = 0; e < 8; ++e) {
+            const int t = 8 * (ln >> 5) + e, co = 32 * j + (ln & 31);
+            if (t < 9) tab[(j * 64 + ln) * 8 + e] = host_bf16_rne(Wt[co * 9 + t]);
+          }
+      if ((rc = dev_alloc(h, &h->d_w1a_tab, tab.size()))) return rc;
+      HIP_TRY(hipMemcpy(h->d_w1a_tab, tab.data(), tab.size() * 2, hipMemcpyHostToDevice));
+    }
   }
 
   // activations (NHWC f32).  act[0]=conv1a .. act[7]=conv4b
@@ -530,8 +547,14 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   STAGE_MARK(0);
   if (h->bf16 && h->ws_mask) HIP_TRY(hipMemsetAsync(h->d_tile_ctr, 0, 4 * 16 * sizeof(int), s));
   const bool fused = !h->bf16 && h->fuse1a;  // f32: conv1b computes conv1a's outputs itself
-  if (h->bf16) HIP_TRY(spfe::launch_conv1a_bf16(d_images, h->d_w1a, h->d_b1a, h->act[0], n, H, W, s));
-  else if (!fused) HIP_TRY(spfe::launch_conv1a(d_images, h->d_w1a, h->d_b1a, h->act[0], n, H, W, s));
+  // bf16: when conv1b takes the wave-specialised kernel, its producer waves compute conv1a (no conv1a launch, no act0)
+  const int grid_ws0 = std::max(16, (h->num_cus > 0 ? h->num_cus : 256) & ~15);
+  const bool ws_layer0 = h->bf16 && h->d_wws[0] && W >= 32 &&
+                         (long)((W + 31) / 32) * ((H + 7) / 8) * n >= (long)h->ws_min_items * grid_ws0;
+  const bool fused16 = ws_layer0 && h->fuse1a_bf16;
+  h->act0_missing = fused || fused16;
+  if (h->bf16 && !fused16) HIP_TRY(spfe::launch_conv1a_bf16(d_images, h->d_w1a_tab, h->d_b1a, h->act[0], n, H, W, s));
+  else if (!h->bf16 && !fused) HIP_TRY(spfe::launch_conv1a(d_images, h->d_w1a, h->d_b1a, h->act[0], n, H, W, s));
   STAGE_MARK(1);
   for (int i = 0; i < 10; ++i) {
     const ConvLayer &L = h->layers[i];
@@ -559,7 +582,8 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
       if (i < 4 && h->d_wws[i] && L.W >= 32 && (long)p.tiles_x * p.tiles_y * n * p.nblk >= (long)h->ws_min_items * (grid_ws < 16 ? 16 : grid_ws)) {
         p.wpack = reinterpret_cast<const float *>(h->d_wws[i]);
         p.tile_ctr = h->d_tile_ctr + 16 * i;
-        HIP_TRY(spfe::launch_conv_bf16_ws(p, L.pool, s));
+        if (i == 0 && fused16) { p.img = d_images; p.w1a = reinterpret_cast<const float *>(h->d_w1a_tab); p.b1a = h->d_b1a; }
+        HIP_TRY(spfe::launch_conv_bf16_ws(p, L.pool, i == 0 ? (fused16 ? 2 : 1) : 0, s));
         STAGE_MARK(2 + i);
         continue;
       }
@@ -884,8 +908,8 @@ long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size
   else if (nm == "feat") { src = h->act[7] + frame * C * 128; bytes = C * 128 * 4; bf16_src = h->bf16; }
   else if (nm.size() == 4 && nm.compare(0, 3, "act") == 0 && nm[3] >= '0' && nm[3] <= '7') {
     const int i = nm[3] - '0';
-    if (i == 0 && !h->bf16 && h->fuse1a)
-      return fail(SPFE_EINVAL, "act0 is not materialised: conv1a is fused into conv1b (SPFE_FUSE_CONV1A=1)");
+    if (i == 0 && h->act0_missing)
+      return fail(SPFE_EINVAL, "act0 is not materialised: conv1a was fused into conv1b in the last call");
     const int lh[8] = {1, 2, 2, 4, 4, 8, 8, 8};
     const int lc[8] = {64, 64, 64, 64, 128, 128, 128, 128};
     const size_t per = (size_t)(h->H / lh[i]) * (h->W / lh[i]) * lc[i];

@@ -42,10 +42,12 @@ hipError_t launch_conv_bf16(const ConvParams &p, int cin, bool pool, bool out_f3
 size_t conv_bf16_slab_bytes();
 // wave-specialised variant for the Cin = 64 layers (conv_bf16_ws.hip): wpack = conv_bf16_ws_weight_bytes() per
 // 64-channel block, [nblk][tap][cout 64][8 x 16-byte pieces, piece g in slot g ^ ((cout >> 1) & 7)]
-hipError_t launch_conv_bf16_ws(const ConvParams &p, bool pool, hipStream_t s);
+hipError_t launch_conv_bf16_ws(const ConvParams &p, bool pool, int layer_tag /* 1 = conv1b, 2 = conv1b with conv1a fused in (p.img / p.w1a / p.b1a) */, hipStream_t s);
 size_t conv_bf16_ws_weight_bytes();
-hipError_t launch_conv1a_bf16(const uint8_t *img, const float *w9x64, const float *b64, void *out, int B, int H,
+// conv1a of the bf16 mode (conv1a_mfma.h): wtab = the bf16 operand table [2][64][8] (conv1a_bf16_table_bytes()), b64 = bias
+hipError_t launch_conv1a_bf16(const uint8_t *img, const void *wtab, const float *b64, void *out, int B, int H,
                               int W, hipStream_t s);
+inline size_t conv1a_bf16_table_bytes() { return 2 * 64 * 8 * 2; }
 
 // bf16 mode, the 1x1 heads (head_bf16.hip): out[npix][cout] f32 = in[npix][512] bf16 (channels 0..255 for the
 // detector head, cout = 65; 256..511 for the descriptor head, cout = 256) x W^T + bias;

@@ -113,19 +113,24 @@ def test_bf16_ws_kernel_equals_single_role_kernel(monkeypatch):
     """conv_bf16_ws.hip (wave-specialised; taken by the Cin = 64 layers when a launch has enough tiles per
     workgroup) against conv_bf16.hip's kernel on the same layers: same K order, same epilogue arithmetic —
     bit-identical activations, hence identical logits, keypoints and descriptors, whichever kernel a batch
-    size selects."""
+    size selects; the same with conv1a computed inside conv1b (the default when conv1b takes the
+    wave-specialised kernel) against the stand-alone conv1a kernel: both run conv1a_mfma.h."""
     H, W, nf = 240, 376, 400
     blob = weights.synthetic(7, "dense")
     imgs = [synth.make_image(80 + i, H, W) for i in range(3)]
     out = {}
-    for mask, items in (("0", "11"), ("15", "0"), ("5", "0")):
-        monkeypatch.setenv("SPFE_BF16_WS_MASK", mask)
+    for mask, items, fuse in (("0", "11", "0"), ("15", "0", "0"), ("5", "0", "0"), ("15f", "0", "1")):
+        monkeypatch.setenv("SPFE_BF16_WS_MASK", mask.rstrip("f"))
         monkeypatch.setenv("SPFE_BF16_WS_MIN_ITEMS", items)
+        monkeypatch.setenv("SPFE_BF16_FUSE_CONV1A", fuse)   # "15f": conv1a computed by conv1b's producer waves
         ext = SPExtractor(nf, H, W, blob, max_batch=3, precision="bf16", with_heat=False)
         frs = ext.extract_batch(imgs)
         out[mask] = (frs, [ext.debug_read("semi", i) for i in range(3)], [ext.debug_read("act%d" % k, 1) for k in (1, 2, 3, 4)])
+        if fuse == "1":
+            with pytest.raises(Exception):
+                ext.debug_read("act0", 0)       # never materialised
         ext.close()
-    for other in ("15", "5"):
+    for other in ("15", "5", "15f"):
         for i in range(3):
             assert np.array_equal(out["0"][1][i].view(np.uint32), out[other][1][i].view(np.uint32))
             assert np.array_equal(out["0"][0][i].kp_xy, out[other][0][i].kp_xy)

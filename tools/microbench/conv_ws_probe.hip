@@ -3,7 +3,9 @@
 // sampled CPU reference, on random data.  Build (from the repo root):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++20 -ffp-contract=off -Iinclude -Isp_orb_slam_amd/csrc \
 //         tools/microbench/conv_ws_probe.hip -o gpurun_out/conv_ws_probe
-// Run: conv_ws_probe H W B cout(64|128) pool(0|1) iters
+// Run: conv_ws_probe H W B cout(64|128) pool(0|1) iters [fuse]
+//   fuse: the input activation is conv1a of a random u8 frame (launch_conv1a_bf16), the reference is conv1a followed by the
+//   single-role kernel, and the wave-specialised kernel runs with conv1a fused in (layer_tag 2) on the u8 frame
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -34,6 +36,7 @@ static float bf16_f(unsigned short h) {
 int main(int argc, char **argv) {
   const int H = argc > 1 ? atoi(argv[1]) : 480, W = argc > 2 ? atoi(argv[2]) : 752, B = argc > 3 ? atoi(argv[3]) : 8;
   const int cout = argc > 4 ? atoi(argv[4]) : 64, pool = argc > 5 ? atoi(argv[5]) : 1, iters = argc > 6 ? atoi(argv[6]) : 20;
+  const bool fuse = argc > 7 && !strcmp(argv[7], "fuse");
   const int cin = 64, nblk = cout / 64;
   const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
   std::mt19937 rng(1234);
@@ -62,6 +65,14 @@ int main(int argc, char **argv) {
   std::vector<float> bpad((size_t)nblk * 64);
   for (int i = 0; i < cout; ++i) bpad[i] = bias[i];
 
+  // fuse mode: a random u8 frame batch and conv1a parameters; d_in becomes conv1a's output
+  std::vector<uint8_t> img((size_t)B * H * W);
+  for (auto &v : img) v = (uint8_t)(rng() & 0xff);
+  std::vector<float> w1a(9 * 64), b1a(64);
+  for (auto &v : w1a) v = nd(rng) * 0.5f;
+  for (auto &v : b1a) v = nd(rng) * 0.1f;
+  uint8_t *d_img = nullptr;
+  float *d_w1a = nullptr, *d_b1a = nullptr;
   unsigned short *d_in, *d_o1, *d_o2;
   unsigned char *d_w1, *d_w2;
   float *d_b;
@@ -83,6 +94,26 @@ int main(int argc, char **argv) {
   CK(hipMemset(d_o1, 0xff, out_elems * 2));
   CK(hipMemset(d_o2, 0xee, out_elems * 2));
 
+  if (fuse) {
+    if (!pool || cout != 64) { printf("fuse needs pool = 1, cout = 64\n"); return 2; }
+    CK(hipMalloc(&d_img, img.size()));
+    // conv1a_mfma.h operand table: [j][lane][e] = bf16(w[tap 8 (lane >> 5) + e][channel 32 j + (lane & 31)])  (w1a is [tap][64] here)
+    std::vector<unsigned short> tab(2 * 64 * 8, 0);
+    for (int j = 0; j < 2; ++j)
+      for (int ln = 0; ln < 64; ++ln)
+        for (int e = 0; e < 8; ++e) {
+          const int t = 8 * (ln >> 5) + e, co = 32 * j + (ln & 31);
+          if (t < 9) tab[(j * 64 + ln) * 8 + e] = bf16_rne(w1a[t * 64 + co]);
+        }
+    CK(hipMalloc(&d_w1a, tab.size() * 2));
+    CK(hipMalloc(&d_b1a, b1a.size() * 4));
+    CK(hipMemcpy(d_img, img.data(), img.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_w1a, tab.data(), tab.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_b1a, b1a.data(), b1a.size() * 4, hipMemcpyHostToDevice));
+    CK(spfe::launch_conv1a_bf16(d_img, d_w1a, d_b1a, d_in, B, H, W, nullptr));
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(in.data(), d_in, in.size() * 2, hipMemcpyDeviceToHost));   // the sampled CPU reference reads it
+  }
   spfe::ConvParams p{};
   p.in = reinterpret_cast<const float *>(d_in); p.in_stride = cin; p.in_choff = 0;
   p.bias = d_b; p.out_stride = cout; p.out_choff = 0; p.cout_real = cout;
@@ -96,14 +127,20 @@ int main(int argc, char **argv) {
   auto run_old = [&]() { p.wpack = reinterpret_cast<const float *>(d_w1); p.out = reinterpret_cast<float *>(d_o1); CK(spfe::launch_conv_bf16(p, cin, pool, false, s)); };
   int ctr_set = 0;
   if (W < 32) { printf("width < 32: the wave-specialised kernel does not apply\nPROBE OK\n"); return 0; }
-  auto run_new = [&]() { p.wpack = reinterpret_cast<const float *>(d_w2); p.out = reinterpret_cast<float *>(d_o2); p.tile_ctr = d_ctr + 16 * (ctr_set++); CK(spfe::launch_conv_bf16_ws(p, pool, s)); };
+  auto run_old_1a = [&]() { CK(spfe::launch_conv1a_bf16(d_img, d_w1a, d_b1a, d_in, B, H, W, s)); };
+  auto run_new = [&]() {
+    p.wpack = reinterpret_cast<const float *>(d_w2); p.out = reinterpret_cast<float *>(d_o2); p.tile_ctr = d_ctr + 16 * (ctr_set++);
+    if (fuse) { p.img = d_img; p.w1a = d_w1a; p.b1a = d_b1a; }
+    CK(spfe::launch_conv_bf16_ws(p, pool, fuse ? 2 : 0, s));
+    p.img = nullptr;
+  };
 
   const char *only = getenv("PROBE_ONLY");
   float ms_old = 0, ms_new = 0;
   if (!only || !strcmp(only, "old")) {
     for (int i = 0; i < 3; ++i) run_old();
     CK(hipEventRecord(e0, s));
-    for (int i = 0; i < iters; ++i) run_old();
+    for (int i = 0; i < iters; ++i) { if (fuse) run_old_1a(); run_old(); }
     CK(hipEventRecord(e1, s));
     CK(hipStreamSynchronize(s));
     CK(hipEventElapsedTime(&ms_old, e0, e1));
@@ -129,6 +166,7 @@ int main(int argc, char **argv) {
              dbg[0] / nt, dbg[1] / nt, dbg[4] / nt, dbg[5] / nt, dbg[6] / nt, dbg[7] / nt, nt / nl);
   }
 #endif
+  if (fuse) printf("(fuse: 'old' = conv1a kernel + single-role conv1b, 'ws' = one kernel on the u8 frames)\n");
   printf("conv %dx%d B=%d cin=64 cout=%d pool=%d: old %.4f ms (%.1f TF/s, %.3f of 2.5 PF)  ws %.4f ms (%.1f TF/s, %.3f of 2.5 PF)\n", W, H, B,
          cout, pool, ms_old, ms_old > 0 ? flop / ms_old * 1e-9 : 0., ms_old > 0 ? flop / ms_old * 1e-9 / 2500 : 0., ms_new,
          ms_new > 0 ? flop / ms_new * 1e-9 : 0., ms_new > 0 ? flop / ms_new * 1e-9 / 2500 : 0.);
