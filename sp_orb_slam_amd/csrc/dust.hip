@@ -81,7 +81,7 @@ __global__ __launch_bounds__(DUST_THREADS) void dust_align_kernel(DustArgs a) {
       }
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0) {   // (a lane-order readlane fold was tried: SGPR round trips make it slower than these pipelined LDS reads)
       double chi = 0.0;
       for (int i = 0; i < n; ++i) chi += s_rho0[i];
       *chi_out = chi;
