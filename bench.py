@@ -177,7 +177,7 @@ def main():
         flop_frame = FLOP_PER_FRAME.get((H, W))
         # dominant kernel: conv1b (43.5 % of the FLOPs), one launch covers B frames
         bf16 = args.precision == "bf16"
-        traffic = (stamped_traffic("conv1b_bf16_traffic.json", ["conv_bf16_ws.hip"], H, W, B) if bf16 else
+        traffic = (stamped_traffic("conv1b_bf16_traffic.json", ["conv_bf16_ws.hip", "conv1a_mfma.h"], H, W, B) if bf16 else
                    stamped_traffic("conv1b_traffic.json", ["conv_f32.hip"], H, W, B))
         out = {
             "metric": "frames/sec SuperPoint extract (%dx%d, %s kpts)" % (W, H, "1k" if nf == 1000 else str(nf)),
@@ -235,7 +235,7 @@ def main():
                         "f32 detector head / NMS / descriptors / covariance, 1 GPU, %d timed steps" % k3,
                 "value": round(fps3, 2), "unit": "frames/s", "ms_per_step": round(dt3 / k3 * 1e3, 4), "dtype": "bf16",
                 "roofline": roofline_of("bf16", st3, H3, W3, B3,
-                                        stamped_traffic("conv1b_bf16_720p_traffic.json", ["conv_bf16_ws.hip"], H3, W3, B3)),
+                                        stamped_traffic("conv1b_bf16_720p_traffic.json", ["conv_bf16_ws.hip", "conv1a_mfma.h"], H3, W3, B3)),
                 "whole_path_tflops": round(fps3 * FLOP_PER_FRAME[(H3, W3)] / 1e12, 2)}
             ext3.close()
             del d3

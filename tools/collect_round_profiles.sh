@@ -17,11 +17,11 @@ for n in f32 bf16_720p bf16_752; do
   {
     echo "# profiles/${pre}_pmc_$n.txt — rocprofv3 PMC passes (tools/profile_round.sh: separate runs, --kernel-trace --pmc <ctrs> only; bench.py --steps 2 --warmup 1 --sync-cov)"
     echo "# rows: kernel, counter, sum over dispatches, dispatches x instances, min, max per dispatch-instance (SQ_*: one per shader engine, x32 for the chip; GRBM: one per XCD)"
-    grep -E "conv_f32_kernel<1,64|conv_bf16_ws_kernel<true,1>|conv1a|cov_replay" $R/pmc_summary_$n.txt | grep -v "^#" | grep -E "FETCH|WRITE|SQ_|GRBM|TCC|LDS" | cut -c1-175
+    grep -E "conv_f32_kernel<1,64|conv_bf16_ws_kernel<true,2>|conv1a|cov_replay" $R/pmc_summary_$n.txt | grep -v "^#" | grep -E "FETCH|WRITE|SQ_|GRBM|TCC|LDS" | cut -c1-175
   } > profiles/${pre}_pmc_$n.txt
 done
 for f in $R/bench_*.json; do b=$(basename $f); case $b in bench_under_trace*) ;; *) cp $f profiles/${pre}_$b;; esac; done
 python tools/make_traffic_json.py profiles/${pre}_pmc_f32.txt "conv_f32_kernel<1,64,3,16,4,1,2,2,true,true>" 480 752 8 conv_f32.hip > profiles/conv1b_traffic.json
-python tools/make_traffic_json.py profiles/${pre}_pmc_bf16_752.txt "conv_bf16_ws_kernel<true,1>" 480 752 8 conv_bf16_ws.hip > profiles/conv1b_bf16_traffic.json
-python tools/make_traffic_json.py profiles/${pre}_pmc_bf16_720p.txt "conv_bf16_ws_kernel<true,1>" 720 1280 8 conv_bf16_ws.hip > profiles/conv1b_bf16_720p_traffic.json
+python tools/make_traffic_json.py profiles/${pre}_pmc_bf16_752.txt "conv_bf16_ws_kernel<true,2>" 480 752 8 conv_bf16_ws.hip conv1a_mfma.h > profiles/conv1b_bf16_traffic.json
+python tools/make_traffic_json.py profiles/${pre}_pmc_bf16_720p.txt "conv_bf16_ws_kernel<true,2>" 720 1280 8 conv_bf16_ws.hip conv1a_mfma.h > profiles/conv1b_bf16_720p_traffic.json
 ls profiles | grep "^$pre" | wc -l

@@ -23,7 +23,10 @@ for line in open(summ):
             vals[m.group(1)] = float(m.group(5))
 fetch_kb, write_kb = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
 el = 4 if "f32" in kern else 2
-alg = B * (H * W * 64 * el + (H // 2) * (W // 2) * 64 * el) + 64 * 576 * el
+if "true,2" in kern:   # conv1a fused into the producers: the kernel reads the u8 image, not conv1a's activation
+    alg = B * (H * W + (H // 2) * (W // 2) * 64 * el) + 64 * 576 * el + 64 * 16 * 2 + 64 * 4
+else:
+    alg = B * (H * W * 64 * el + (H // 2) * (W // 2) * 64 * el) + 64 * 576 * el
 out = {
     "kernel": "%s (conv1b), %d frames %dx%d per launch" % (kern, B, W, H),
     "workload_hwb": [H, W, B],

@@ -16,7 +16,7 @@ def short(name):
     if m:
         args = m.group(2).replace(" ", "")
         tag = " [conv1b]" if (m.group(1).endswith("conv_f32_kernel") and args.startswith("1,")) or \
-            (m.group(1).endswith("conv_bf16_ws_kernel") and args.endswith(",1")) else ""
+            (m.group(1).endswith("conv_bf16_ws_kernel") and args.endswith((",1", ",2"))) else ""
         return "%s<%s>%s" % (m.group(1), args, tag)
     return name.split("(")[0][:90]
 
