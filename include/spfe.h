@@ -53,10 +53,12 @@ extern "C" {
                                   convolutions of batch i+1.  Pass a different record buffer to consecutive calls. */
 
 /* spfe_result.status / record header word 2 */
-#define SPFE_STATUS_COV_OVERFLOW 1 /* a covariance region outgrew the device FIFO (SPFE_COV_QCAP, default
-                                      1024 pixels per keypoint).  Device records: cov2/cov2_inv of that frame
-                                      are not valid.  Host calls: the frame's covariance was recomputed by
-                                      the host routine, values are valid. */
+#define SPFE_STATUS_COV_OVERFLOW 1 /* a covariance region outgrew even the device-side overflow lists (a walk longer
+                                      than SPFE_COV_QCAP = 1024 pops reruns in one of SPFE_COV_OVF_SLOTS = 16
+                                      lists of SPFE_COV_OVF_CAP = 16384 pops per frame, on the device, exactly,
+                                      status stays 0; this bit means those ran out too).  Device records:
+                                      cov2/cov2_inv of that frame are not valid.  Host calls: the frame's
+                                      covariance was recomputed by the host routine, values are valid. */
 
 #define SPFE_DESC_DIM 256
 #define SPFE_NUM_PARAMS 1300865 /* sp_extractor.cpp:16-43; order = register_module order :46-62 */
