@@ -68,7 +68,7 @@ constexpr int NSTEP = 36;                              // K steps per tile: 2 ch
 // probe builds (tools/microbench/conv_ws_probe.hip): cycle counters summed over workgroups
 // [0] consumer wave 0 loop cycles  [1] ... of which at the end-of-tile barrier  [2] tiles
 // [4] producer wave 4 loop cycles  [5] ... issuing passes  [6] ... waiting vmcnt(0)  [7] ... at the barrier
-__device__ unsigned long long ws_dbg[8];
+__device__ unsigned long long ws_dbg[10];
 #define WS_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define WS_ACC(i, v) do { if (lane == 0) atomicAdd(&ws_dbg[i], (unsigned long long)(v)); } while (0)
 #else
@@ -77,6 +77,12 @@ __device__ unsigned long long ws_dbg[8];
 #endif
 #ifndef WS_PRIO
 #define WS_PRIO 1
+#endif
+#ifndef WS_EPI_MICRO
+#define WS_EPI_MICRO -1  // probe builds: force the epilogue form (1 = single instructions in every gap, 0 = one item per burst)
+#endif
+#ifndef WS_EPI_GAP
+#define WS_EPI_GAP 2     // the gap (0..3) of a K step that carries the epilogue item
 #endif
 #ifndef WS_ABLATE
 #define WS_ABLATE 0  // probe builds: 1 = producers issue no halo passes in the loop, 2 = consumers issue no MFMAs,
@@ -156,35 +162,119 @@ __device__ __forceinline__ void epi_item_c(const Epi &e, const float (&bias)[2],
   }
 }
 
-// One consumer K step: MT x NT = 2 x 2 MFMAs; in their shadows the operand fragments of step S + 2
-// (ring of three) and sub-items of the previous tile's epilogue.
-template <int S, bool POOL, int BUF>
+struct TileDesc {
+  int b, ty, tx, valid;
+};
+
+// the consumer's per-tile side work that needs runtime state, placed at fixed K steps (see k_steps)
+template <typename Aim>
+struct TileHooks {
+  Aim &aim;
+  lds_char *lds;
+  TileDesc dc, dn;     // this tile, the next one
+  Epi *eMine;
+  i32x4 raw;
+  int t;
+  unsigned long long bar;
+  template <int S, int M>
+  __device__ __forceinline__ void at() {
+    if constexpr (S == 3 && M == 1) aim(dc, *eMine);
+    if constexpr (S == 24 && M == 1)
+      raw = *reinterpret_cast<const __attribute__((address_space(3))) i32x4 *>(lds + LDS_SLOT + ((t + 1) % 3) * 16);
+    if constexpr (S == 28 && M == 1) {
+      dn.b = __builtin_amdgcn_readfirstlane(raw.x);
+      dn.ty = __builtin_amdgcn_readfirstlane(raw.y);
+      dn.tx = __builtin_amdgcn_readfirstlane(raw.z);
+      dn.valid = __builtin_amdgcn_readfirstlane(raw.w);
+    }
+  }
+};
+
+// The previous tile's epilogue as single instructions, one (pool) or two (no pool) per MFMA gap of K steps 2..33
+// instead of bursts of 12: a burst delays the next MFMA by its whole issue time (measured: ~600 cycles per tile), a
+// single instruction fits the gap.  Same operations on the same values as epi_item_c, which still flushes the last tile.
+// pool: value vI = 0..15 <-> (item G = vI / 2: g = G % 4, j = G / 4; h2 = vI % 2) takes steps 2 + 2 vI, 3 + 2 vI.
+// no pool: value u = 0..63 <-> (item G = u / 4: g = G % 4, j = (G / 4) % 2, i = G / 8; m = u % 4), two per step.
+struct EpiTmp {
+  float v[2];
+  unsigned pk[2];
+};
+template <bool POOL, int S, int M>
+__device__ __forceinline__ void epi_micro(const Epi &e, const float (&bias)[2], const f32x16 (&acc)[2][2], EpiTmp &t) {
+  if constexpr (WS_ABLATE != 5 && S >= 2 && S < 34) {
+    if constexpr (POOL) {
+      constexpr int vI = (S - 2) / 2, k = ((S - 2) % 2) * 4 + M;
+      constexpr int G = vI / 2, g = G % 4, j = G / 4, h2 = vI % 2, r = 4 * g + 2 * h2;
+      if constexpr (k == 0) t.v[1] = max_nc(acc[1][j][r], acc[1][j][r + 1]);
+      if constexpr (k == 1) t.v[0] = max3_nc(acc[0][j][r], acc[0][j][r + 1], t.v[1]);
+      if constexpr (k == 2) t.v[0] = t.v[0] + bias[j];
+      if constexpr (k == 3) t.v[0] = relu_nc(t.v[0]);
+      if constexpr (k == 4) t.pk[0] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){t.v[0], t.v[0]}, bf16x2));
+      if constexpr (k == 5)
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)t.pk[0], e.rout, e.rowoff[0] + (unsigned)(j * 64),
+                                              (unsigned)(4 * g + h2) * e.pitch, 0);
+    } else {
+      [&]<int... Q>(std::integer_sequence<int, Q...>) {
+        ([&] {
+          constexpr int u = (S - 2) * 2 + Q, G = u / 4, g = G % 4, j = (G / 4) % 2, i = G / 8, m = u % 4;
+          if constexpr (M == 0) t.v[Q] = acc[i][j][4 * g + m] + bias[j];
+          if constexpr (M == 1) t.v[Q] = relu_nc(t.v[Q]);
+          if constexpr (M == 2) t.pk[Q] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){t.v[Q], t.v[Q]}, bf16x2));
+          if constexpr (M == 3)
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)t.pk[Q], e.rout, e.rowoff[i] + (unsigned)(j * 64),
+                                                  (unsigned)(8 * g + m) * e.pitch, 0);
+        }(), ...);
+      }(std::integer_sequence<int, 0, 1>{});
+    }
+  }
+}
+
+// One consumer K step: MT x NT = 2 x 2 MFMAs; in their shadows the operand fragments of step S + 2 (ring of three) and
+// the previous tile's epilogue.  The ring runs THROUGH the tile boundary: steps 34 and 35 prefetch steps 0 and 1 of the
+// next tile from the other halo buffer, so the matrix pipe never waits for a tile's first fragments (the ~400-cycle head
+// of every tile before).  That moves the end-of-tile barrier to the start of step 34: by then this wave has issued — and
+// waits for — its last reads of this tile's buffer (step 35's, issued at step 33), which is all the barrier has to say to the
+// producers ("the buffer is free") and all it has to hear from them ("the next halo is in LDS").
+// hooks.at<S, M>() — the caller's side work that needs runtime state (next tile's descriptor, epilogue geometry).
+template <int S, bool POOL, int BUF, bool MICRO, typename Hooks>
 __device__ __forceinline__ void k_steps(bf16x8 (&a)[3][2], bf16x8 (&w)[3][2], f32x16 (&acc)[2][2],
                                         const f32x16 (&accPrev)[2][2], const float (&bias)[2],
                                         lds_char *const (&aptr)[3][4], lds_char *const (&wptr)[2][4],
-                                        const Epi &ePrev) {
+                                        const Epi &ePrev, EpiTmp &et, Hooks &hooks) {
   if constexpr (S < NSTEP) {
     constexpr int cur = S % 3, nxt = (S + 2) % 3;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       if (m == 0) {
-        if constexpr (S + 2 < NSTEP && WS_ABLATE != 4) {
-          constexpr int s2 = S + 2, chunk = s2 / 18, tap = (s2 % 18) / 2, kk = chunk * 2 + (s2 % 2);
+        if constexpr (S == NSTEP - 2) {
+          __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's last reads of the tile's halo buffer are back
+          wg_barrier();                        // end of tile: the buffer is free, the next halo has landed
+        }
+        if constexpr (WS_ABLATE != 4) {
+          constexpr int s2 = (S + 2) % NSTEP, chunk = s2 / 18, tap = (s2 % 18) / 2, kk = chunk * 2 + (s2 % 2);
           constexpr int dy = tap / 3, dx = tap % 3, hiw = tap >= 7 ? 1 : 0;
+          constexpr int buf = S + 2 < NSTEP ? BUF : BUF ^ 1;
 #pragma unroll
-          for (int i = 0; i < 2; ++i) a[nxt][i] = lds_read(aptr[dx][kk], BUF * HALO_BYTES + (i + dy) * ROW_BYTES);
+          for (int i = 0; i < 2; ++i) a[nxt][i] = lds_read(aptr[dx][kk], buf * HALO_BYTES + (i + dy) * ROW_BYTES);
 #pragma unroll
           for (int j = 0; j < 2; ++j) w[nxt][j] = lds_read(wptr[hiw][kk], (tap - 7 * hiw) * 8192 + j * 4096);
         }
       }
-      if constexpr (POOL) {  // 8 items: one every fourth step
-        if (m == 2) {
-          if constexpr (S >= 2 && S % 4 == 2) epi_item_c<POOL, (S - 2) / 4>(ePrev, bias, accPrev);
+      if constexpr (MICRO) {
+      if (m == 0) { epi_micro<POOL, S, 0>(ePrev, bias, accPrev, et); hooks.template at<S, 0>(); }
+      if (m == 1) { epi_micro<POOL, S, 1>(ePrev, bias, accPrev, et); hooks.template at<S, 1>(); }
+      if (m == 2) { epi_micro<POOL, S, 2>(ePrev, bias, accPrev, et); hooks.template at<S, 2>(); }
+      if (m == 3) { epi_micro<POOL, S, 3>(ePrev, bias, accPrev, et); hooks.template at<S, 3>(); }
+      } else {
+      // one epilogue item (12-16 instructions) in one gap every second / fourth step
+      if (m == WS_EPI_GAP) {
+        if constexpr (POOL) {  // 8 items: one every fourth step
+          if constexpr (S >= 2 && S % 4 == 2 && WS_ABLATE != 5) epi_item_c<POOL, (S - 2) / 4>(ePrev, bias, accPrev);
+        } else {               // 16 items: one every second step
+          if constexpr (S >= 2 && S % 2 == 0 && WS_ABLATE != 5) epi_item_c<POOL, (S - 2) / 2>(ePrev, bias, accPrev);
         }
-      } else {               // 16 items: one every second step
-        if (m == 2) {
-          if constexpr (S >= 2 && S % 2 == 0) epi_item_c<POOL, (S - 2) / 2>(ePrev, bias, accPrev);
-        }
+        hooks.template at<S, 1>();
+      }
       }
       __builtin_amdgcn_sched_barrier(0);
       {
@@ -200,13 +290,10 @@ __device__ __forceinline__ void k_steps(bf16x8 (&a)[3][2], bf16x8 (&w)[3][2], f3
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    k_steps<S + 1, POOL, BUF>(a, w, acc, accPrev, bias, aptr, wptr, ePrev);
+    k_steps<S + 1, POOL, BUF, MICRO>(a, w, acc, accPrev, bias, aptr, wptr, ePrev, et, hooks);
   }
 }
 
-struct TileDesc {
-  int b, ty, tx, valid;
-};
 
 // in: NHWC bf16 [B][H][W][in_stride]; wpack: [nblk][tap 9][cout 64][8 pieces, piece g at slot g ^ ((cout >> 1) & 7)][8 bf16];
 // out: NHWC bf16.  p.tile_ctr: nblk * 8 counters, zeroed before the launch.
@@ -325,8 +412,8 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
         prel[gi] = (g < NGRP && lane < 40) ? (int)(((unsigned)(r0 - 2 + prow) << 16) | ((unsigned)(4 * pdw - 4) & 0xffffu)) : (int)0x80000000;
       }
     }
-    // (fetch_next: wave 4 also asks the tile queue for the tile after this one — the atomic goes out behind the
-    // patch loads and returns while the matrix products run; the raw counter value comes back through *fetched)
+    // (fetch_next: the queue-keeping wave also asks the tile queue for the tile after this one — the atomic goes out behind
+    // the patch loads and returns while the matrix products run; the raw counter value comes back through *fetched)
     auto make_halo = [&](const TileDesc &d, int buf, bool fetch_next, int *fetched) {
       // the frame as a buffer: out-of-range offsets read 0 — conv1a's own zero padding — and nothing is conditional,
       // so the tile's patch bytes leave as ONE burst of loads
@@ -343,9 +430,11 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
         px[gi] = __builtin_amdgcn_raw_buffer_load_b32(rimg, in ? (unsigned)(gy * p.W + gx) : OOB, 0, 0);
       }
       if (fetch_next) {
+        // (the compiler's atomic optimiser waits for the return right here — vmcnt(0) + readfirstlane — which is why this
+        // duty belongs to the wave with a group less to make: measured on wave 4, it added ~2000 cycles to the 3500 of its groups)
         int v = 0;
         if (lane == 0) v = atomicAdd(ctr, 1);
-        *fetched = v;   // (consumed by the caller after its vmcnt(0))
+        *fetched = v;
       }
       // border tiles only: some halo pixel lies outside the frame (conv1b's zero padding)
       const bool border = y0 == 0 || x0 == 0 || y0 + TH + 1 > p.H || x0 + 33 > p.W;
@@ -401,7 +490,11 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
     }
     // the first two tiles of every workgroup are fixed (its index in the queue's group, and that + the group
     // size): no atomic round trips before the first loads; the queue hands out the tiles after those
-    if (pw == 0) {
+    // the wave that keeps the tile queue: with conv1a inside (TAG 2), wave 7 — it makes two groups of halo pixels per tile,
+    // the others three, so the atomic's round trip (1-2 us under load) hides in its slack instead of adding to the
+    // longest producer
+    constexpr int QW = TAG == 2 ? 3 : 0;
+    if (pw == QW) {
       publish(0, gi < t_cnt ? t_lo + gi : -1);
       publish(1, gi + gsize < t_cnt ? t_lo + gi + gsize : -1);
     }
@@ -422,8 +515,8 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
       int i2 = -1;
       if constexpr (TAG == 2) {
         int raw = 0;
-        if (nxt.valid) make_halo(nxt, (t + 1) & 1, pw == 0, &raw);
-        if (pw == 0 && nxt.valid) {
+        if (nxt.valid) make_halo(nxt, (t + 1) & 1, pw == QW, &raw);
+        if (pw == QW && nxt.valid) {
           raw = __builtin_amdgcn_readfirstlane(raw) + 2 * gsize;
           i2 = raw < t_cnt ? t_lo + raw : -1;
         }
@@ -431,10 +524,10 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
         fill_halo(nxt, (t + 1) & 1);
       }
       WS_T(p1);
-      if (TAG != 2 && pw == 0 && nxt.valid) i2 = fetch();  // behind the passes: its round trip hides under theirs
+      if (TAG != 2 && pw == QW && nxt.valid) i2 = fetch();  // behind the passes: its round trip hides under theirs
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the next tile has landed
       WS_T(p2);
-      if (pw == 0) publish((t + 2) % 3, i2);
+      if (pw == QW) publish((t + 2) % 3, i2);
       __builtin_amdgcn_s_waitcnt(0xC07F);
       wg_barrier();                      // end of tile t
       WS_T(p3);
@@ -506,43 +599,59 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
   int t = 0;
   bool lastA = true, any = false;
 #ifdef WS_PROBE_TIMING
-  unsigned long long ct_bar = 0;
+  unsigned long long ct_head = 0;
   WS_T(ct_begin);
   const unsigned long long wc_begin = wall_clock64();
 #endif
+  // Per tile, in the MFMA shadows: the epilogue geometry of THIS tile (used while the next one computes), the
+  // descriptor of the NEXT tile (published by the producers a tile ahead), and — inside k_steps — the barrier and the
+  // next tile's first fragments.
+  TileHooks<decltype(aim_epi)> hooks{aim_epi, lds, {}, {}, nullptr, {}, 0, 0ull};
+  // The epilogue as single instructions spread over all MFMA gaps wins where the producers only issue LDS-direct passes
+  // (-4 % conv1b-shaped, -9 % without a pool: a burst of 12-16 instructions delays the MFMA behind it); with conv1a in the
+  // producers their VALU stream already sits in those gaps and the burst form is the faster one (+1.5 % otherwise).
+  // (wall-clock A/B of non-instrumented builds, tools/microbench/run_probe12.sh)
+  constexpr bool EPI_MICRO = WS_EPI_MICRO >= 0 ? WS_EPI_MICRO != 0 : TAG != 2;
+  EpiTmp et;
+  et.v[0] = et.v[1] = 0.0f; et.pk[0] = et.pk[1] = 0u;
+
   auto run_tile = [&]<int BUF>(std::integral_constant<int, BUF>, f32x16(&acc)[2][2], const f32x16(&accPrev)[2][2], Epi &eMine,
                                const Epi &ePrev) -> bool {
-    const TileDesc d = read_slot(t % 3);
-    if (!d.valid) return false;
-    // K steps 0 and 1: tap 0, k-groups 0 and 1
+    WS_T(ch0);
+    hooks.eMine = &eMine;
+    hooks.t = t;
+    if (WS_ABLATE != 2) k_steps<0, POOL, BUF, EPI_MICRO>(a, w, acc, accPrev, bias, aptr, wptr, ePrev, et, hooks);
+    else { hooks.template at<3, 1>(); hooks.template at<24, 1>(); hooks.template at<28, 1>(); __builtin_amdgcn_s_waitcnt(0xC07F); wg_barrier(); }
+    WS_T(c1);
+#ifdef WS_PROBE_TIMING
+    ct_head += c1 - ch0;   // (whole tile, for the probe's per-tile figure)
+#endif
+    ++t;
+    hooks.dc = hooks.dn;
+    return hooks.dn.valid != 0;
+  };
+  hooks.dc = read_slot(0);
+  if (hooks.dc.valid) {
+    // K steps 0 and 1 of the first tile: tap 0, k-groups 0 and 1 (every later tile's come from steps 34 / 35 of its predecessor)
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[st][i] = lds_read(aptr[0][st], BUF * HALO_BYTES + i * ROW_BYTES);
+      for (int i = 0; i < 2; ++i) a[st][i] = lds_read(aptr[0][st], i * ROW_BYTES);
 #pragma unroll
       for (int j = 0; j < 2; ++j) w[st][j] = lds_read(wptr[0][st], j * 4096);
     }
-    aim_epi(d, eMine);
-    if (WS_ABLATE != 2) k_steps<0, POOL, BUF>(a, w, acc, accPrev, bias, aptr, wptr, ePrev);
-    WS_T(c0);
-    wg_barrier();  // end of tile t: every consumer is done with this halo buffer, the next one has landed
-    WS_T(c1);
-#ifdef WS_PROBE_TIMING
-    ct_bar += c1 - c0;
-#endif
-    ++t;
-    return true;
-  };
-  while (true) {
-    if (!run_tile(std::integral_constant<int, 0>{}, accA, accB, epiA, epiB)) break;
-    lastA = true; any = true;
-    if (!run_tile(std::integral_constant<int, 1>{}, accB, accA, epiB, epiA)) break;
-    lastA = false;
+    while (true) {
+      any = true;
+      lastA = true;
+      if (!run_tile(std::integral_constant<int, 0>{}, accA, accB, epiA, epiB)) break;
+      lastA = false;
+      if (!run_tile(std::integral_constant<int, 1>{}, accB, accA, epiB, epiA)) break;
+    }
   }
 #ifdef WS_PROBE_TIMING
   if (wm == 0) {
     WS_T(ct_end);
-    WS_ACC(0, ct_end - ct_begin); WS_ACC(1, ct_bar); WS_ACC(2, t);
+    WS_ACC(0, ct_end - ct_begin); WS_ACC(1, hooks.bar); WS_ACC(2, t); WS_ACC(8, ct_head);
     WS_ACC(3, wall_clock64() - wc_begin);  // constant-rate counter (100 MHz): [0] / [3] = shader clock
   }
 #endif
