@@ -108,14 +108,17 @@ struct Epi {
   unsigned rowoff[2];  // byte offset of (row i, column x0 + 4 hi, this lane's channel) in the output frame (pool: [0]), or OOB
   unsigned pitch;      // bytes per output pixel
 };
-// Accumulator layout after mfma(pixels, weights): lane = (output channel j*32 + (lane & 31), hi = lane >> 5),
-// register r <-> pixel column 8*(r>>2) + 4*hi + (r&3) of the wave's row i.  A store of register r writes, for the
-// 32 lanes of each half, 32 consecutive bf16 channels of ONE pixel: two 64-byte segments per instruction (the
-// transposed form of conv_bf16.hip — a lane owns a pixel — scatters 8-byte pieces over 32-64 cache lines per
-// store, which is what bounds its layers without a pool).  Bias (one value per lane and accumulator tile), ReLU,
-// the 2x2 max (max(a + b, c + b) == max(a, c) + b exactly: rounding is monotonic), RNE to bf16: bit-identical
-// to conv_bf16.hip's epilogue.
-// Item G: the four registers 4g..4g+3 of one accumulator tile (no pool: 16 items; pool: 8 items, two pooled pixels each).
+// Accumulator layout after mfma(pixels, weights): lane = (output channel, hi = lane >> 5), register r <-> pixel
+// column 8*(r>>2) + 4*hi + (r&3) of the wave's row i.  The packed weights put the block's EVEN channels in accumulator
+// tile j = 0 and the ODD ones in tile j = 1 (row m of tile j <-> channel 2 m + j), so a lane holds the adjacent channels
+// 2 l31, 2 l31 + 1 of every pixel it has: one v_cvt_pk_bf16_f32 packs them and one dword store per register writes, for
+// the 32 lanes of each half, the 64 consecutive bf16 channels (128 B) of ONE pixel — half the conversions and half the
+// store instructions of a channel-per-tile layout (2-byte stores), which is what bounds the layers without a pool.
+// (The transposed form of conv_bf16.hip — a lane owns a pixel — scatters 8-byte pieces over 32-64 cache lines per store.)
+// Bias (one value per lane and accumulator tile), ReLU, the 2x2 max (max(a + b, c + b) == max(a, c) + b exactly:
+// rounding is monotonic), RNE to bf16: bit-identical to conv_bf16.hip's epilogue.
+// Item G: pool: 8 items (g = G / 2, h2 = G % 2: one pooled pixel, both channels); no pool: 16 items (i = G / 8,
+// g = (G / 2) % 4, two of the four registers 4g..4g+3 each).
 // No column predicates: when the width is not a multiple of 32, the last tile of a row is shifted left to end at
 // the image edge (x0 = W - 32) and recomputes a few columns of its neighbour — identical values, written twice.
 // max without the canonicalising v_max(x, x) that fmaxf's sNaN rule puts in front of every MFMA result (the
@@ -136,27 +139,30 @@ __device__ __forceinline__ float relu_nc(float a) {
   return r;
 }
 
+__device__ __forceinline__ unsigned pack2(float v0, float v1) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v0, v1}, bf16x2));
+}
+
 template <bool POOL, int G>
 __device__ __forceinline__ void epi_item_c(const Epi &e, const float (&bias)[2], const f32x16 (&acc)[2][2]) {
-  constexpr int NITEM = (POOL ? 1 : 2) * 2 * 4;
+  constexpr int NITEM = POOL ? 8 : 16;
   if constexpr (G >= 0 && G < NITEM) {
-    constexpr int g = G % 4, j = (G / 4) % 2, i = POOL ? 0 : G / 8;
-    const unsigned base = e.rowoff[i] + (unsigned)(j * 64);
     if constexpr (POOL) {
+      constexpr int g = G / 2, h2 = G % 2, r = 4 * g + 2 * h2;
+      float v[2];
 #pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2) {
-        const int r = 4 * g + 2 * h2;
-        float v = max3_nc(acc[0][j][r], acc[0][j][r + 1], max_nc(acc[1][j][r], acc[1][j][r + 1]));
-        v = relu_nc(v + bias[j]);
-        const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v, v}, bf16x2));
-        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)pk, e.rout, base, (unsigned)(4 * g + h2) * e.pitch, 0);
+      for (int j = 0; j < 2; ++j) {
+        v[j] = max3_nc(acc[0][j][r], acc[0][j][r + 1], max_nc(acc[1][j][r], acc[1][j][r + 1]));
+        v[j] = relu_nc(v[j] + bias[j]);
       }
+      __builtin_amdgcn_raw_buffer_store_b32(pack2(v[0], v[1]), e.rout, e.rowoff[0], (unsigned)(4 * g + h2) * e.pitch, 0);
     } else {
+      constexpr int i = G / 8, g = (G / 2) % 4, mh = G % 2;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const float v = relu_nc(acc[i][j][4 * g + m] + bias[j]);
-        const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v, v}, bf16x2));
-        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)pk, e.rout, base, (unsigned)(8 * g + m) * e.pitch, 0);
+      for (int mm = 0; mm < 2; ++mm) {
+        const int m = 2 * mh + mm;
+        const float v0 = relu_nc(acc[i][0][4 * g + m] + bias[0]), v1 = relu_nc(acc[i][1][4 * g + m] + bias[1]);
+        __builtin_amdgcn_raw_buffer_store_b32(pack2(v0, v1), e.rout, e.rowoff[i], (unsigned)(8 * g + m) * e.pitch, 0);
       }
     }
   }
@@ -190,41 +196,37 @@ struct TileHooks {
   }
 };
 
-// The previous tile's epilogue as single instructions, one (pool) or two (no pool) per MFMA gap of K steps 2..33
-// instead of bursts of 12: a burst delays the next MFMA by its whole issue time (measured: ~600 cycles per tile), a
-// single instruction fits the gap.  Same operations on the same values as epi_item_c, which still flushes the last tile.
-// pool: value vI = 0..15 <-> (item G = vI / 2: g = G % 4, j = G / 4; h2 = vI % 2) takes steps 2 + 2 vI, 3 + 2 vI.
-// no pool: value u = 0..63 <-> (item G = u / 4: g = G % 4, j = (G / 4) % 2, i = G / 8; m = u % 4), two per step.
+// The previous tile's epilogue as single instructions in the MFMA gaps of K steps 2..33 instead of bursts: a burst
+// delays the MFMA behind it by its whole issue time.  Same operations on the same values as epi_item_c, which still
+// flushes the last tile.
+// pool: pooled pixel vI = 0..7 (g = vI / 2, h2 = vI % 2) takes the 16 gaps of steps 2 + 4 vI .. 5 + 4 vI (10 used).
+// no pool: register u = 0..31 (i = u / 16, g = (u / 4) % 4, m = u % 4) takes the 4 gaps of step 2 + u.
 struct EpiTmp {
-  float v[2];
-  unsigned pk[2];
+  float v[2], t[2];
+  unsigned pk;
 };
 template <bool POOL, int S, int M>
 __device__ __forceinline__ void epi_micro(const Epi &e, const float (&bias)[2], const f32x16 (&acc)[2][2], EpiTmp &t) {
   if constexpr (WS_ABLATE != 5 && S >= 2 && S < 34) {
     if constexpr (POOL) {
-      constexpr int vI = (S - 2) / 2, k = ((S - 2) % 2) * 4 + M;
-      constexpr int G = vI / 2, g = G % 4, j = G / 4, h2 = vI % 2, r = 4 * g + 2 * h2;
-      if constexpr (k == 0) t.v[1] = max_nc(acc[1][j][r], acc[1][j][r + 1]);
-      if constexpr (k == 1) t.v[0] = max3_nc(acc[0][j][r], acc[0][j][r + 1], t.v[1]);
-      if constexpr (k == 2) t.v[0] = t.v[0] + bias[j];
-      if constexpr (k == 3) t.v[0] = relu_nc(t.v[0]);
-      if constexpr (k == 4) t.pk[0] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){t.v[0], t.v[0]}, bf16x2));
-      if constexpr (k == 5)
-        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)t.pk[0], e.rout, e.rowoff[0] + (unsigned)(j * 64),
-                                              (unsigned)(4 * g + h2) * e.pitch, 0);
+      constexpr int vI = (S - 2) / 4, k = ((S - 2) % 4) * 4 + M;
+      constexpr int g = vI / 2, h2 = vI % 2, r = 4 * g + 2 * h2;
+      if constexpr (k == 0) t.t[0] = max_nc(acc[1][0][r], acc[1][0][r + 1]);
+      if constexpr (k == 1) t.t[1] = max_nc(acc[1][1][r], acc[1][1][r + 1]);
+      if constexpr (k == 2) t.v[0] = max3_nc(acc[0][0][r], acc[0][0][r + 1], t.t[0]);
+      if constexpr (k == 3) t.v[1] = max3_nc(acc[0][1][r], acc[0][1][r + 1], t.t[1]);
+      if constexpr (k == 4) t.v[0] = t.v[0] + bias[0];
+      if constexpr (k == 5) t.v[1] = t.v[1] + bias[1];
+      if constexpr (k == 6) t.v[0] = relu_nc(t.v[0]);
+      if constexpr (k == 7) t.v[1] = relu_nc(t.v[1]);
+      if constexpr (k == 8) t.pk = pack2(t.v[0], t.v[1]);
+      if constexpr (k == 9) __builtin_amdgcn_raw_buffer_store_b32(t.pk, e.rout, e.rowoff[0], (unsigned)(4 * g + h2) * e.pitch, 0);
     } else {
-      [&]<int... Q>(std::integer_sequence<int, Q...>) {
-        ([&] {
-          constexpr int u = (S - 2) * 2 + Q, G = u / 4, g = G % 4, j = (G / 4) % 2, i = G / 8, m = u % 4;
-          if constexpr (M == 0) t.v[Q] = acc[i][j][4 * g + m] + bias[j];
-          if constexpr (M == 1) t.v[Q] = relu_nc(t.v[Q]);
-          if constexpr (M == 2) t.pk[Q] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){t.v[Q], t.v[Q]}, bf16x2));
-          if constexpr (M == 3)
-            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)t.pk[Q], e.rout, e.rowoff[i] + (unsigned)(j * 64),
-                                                  (unsigned)(8 * g + m) * e.pitch, 0);
-        }(), ...);
-      }(std::integer_sequence<int, 0, 1>{});
+      constexpr int u = S - 2, i = u / 16, g = (u / 4) % 4, m = u % 4;
+      if constexpr (M == 0) { t.v[0] = acc[i][0][4 * g + m] + bias[0]; t.v[1] = acc[i][1][4 * g + m] + bias[1]; }
+      if constexpr (M == 1) { t.v[0] = relu_nc(t.v[0]); t.v[1] = relu_nc(t.v[1]); }
+      if constexpr (M == 2) t.pk = pack2(t.v[0], t.v[1]);
+      if constexpr (M == 3) __builtin_amdgcn_raw_buffer_store_b32(t.pk, e.rout, e.rowoff[i], (unsigned)(8 * g + m) * e.pitch, 0);
     }
   }
 }
@@ -295,7 +297,8 @@ __device__ __forceinline__ void k_steps(bf16x8 (&a)[3][2], bf16x8 (&w)[3][2], f3
 }
 
 
-// in: NHWC bf16 [B][H][W][in_stride]; wpack: [nblk][tap 9][cout 64][8 pieces, piece g at slot g ^ ((cout >> 1) & 7)][8 bf16];
+// in: NHWC bf16 [B][H][W][in_stride]; wpack: [nblk][tap 9][row 64][8 pieces, piece g at slot g ^ ((row >> 1) & 7)][8 bf16],
+// row 32 j + m <-> output channel 2 m + j of the block (even channels first: see the epilogue);
 // out: NHWC bf16.  p.tile_ctr: nblk * 8 counters, zeroed before the launch.
 // TAG 1 only names the instantiation (conv1b, the dominant kernel): profiler rows of conv1b and conv2b — same
 // template arguments otherwise, same grid — stay apart.
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
     wptr[0][kk] = lds + LDS_W + l31 * 128 + (((kk * 2 + hi) ^ ((l31 >> 1) & 7)) * 16);
     wptr[1][kk] = wptr[0][kk] + 7 * 8192;
   }
-  const float bias[2] = {p.bias[nb * 64 + l31], p.bias[nb * 64 + 32 + l31]};   // this lane's channel of each accumulator tile
+  const float bias[2] = {p.bias[nb * 64 + 2 * l31], p.bias[nb * 64 + 2 * l31 + 1]};   // this lane's channel of each accumulator tile (even | odd)
 
   f32x16 accA[2][2], accB[2][2];
 #pragma unroll
@@ -581,9 +584,9 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
     char *obase = reinterpret_cast<char *>(p.out) + ((size_t)d.b * Ho * Wo * p.out_stride + p.out_choff) * 2;
     e.rout = __builtin_amdgcn_make_buffer_rsrc(obase, 0, frame_out_bytes, 0x00020000);
     const int y0 = d.ty * TH + wm * 2;
-    // this lane's channel nb*64 + l31 (+ 32 j per accumulator tile) of the pixel column x0 + 4 hi (+ the register's)
+    // this lane's channel pair nb*64 + 2 l31 (+ j per accumulator tile) of the pixel column x0 + 4 hi (+ the register's)
     const int x0 = tile_x0(d.tx, p.W);
-    const unsigned ch = (unsigned)(nb * 64 + l31) * 2u;
+    const unsigned ch = (unsigned)(nb * 64 + 2 * l31) * 2u;
     if constexpr (POOL) {
       e.rowoff[0] = y0 < p.H ? (unsigned)((y0 >> 1) * Wo + (x0 >> 1) + 2 * hi) * out_pix_bytes + ch : OOB;
       e.rowoff[1] = OOB;
@@ -613,7 +616,7 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
   // (wall-clock A/B of non-instrumented builds, tools/microbench/run_probe12.sh)
   constexpr bool EPI_MICRO = WS_EPI_MICRO >= 0 ? WS_EPI_MICRO != 0 : TAG != 2;
   EpiTmp et;
-  et.v[0] = et.v[1] = 0.0f; et.pk[0] = et.pk[1] = 0u;
+  et.v[0] = et.v[1] = et.t[0] = et.t[1] = 0.0f; et.pk = 0u;
 
   auto run_tile = [&]<int BUF>(std::integral_constant<int, BUF>, f32x16(&acc)[2][2], const f32x16(&accPrev)[2][2], Epi &eMine,
                                const Epi &ePrev) -> bool {
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
   }
 #endif
   if (any) {
-    constexpr int NEPI = (POOL ? 1 : 2) * 8;
+    constexpr int NEPI = POOL ? 8 : 16;
     auto flush = [&](const f32x16(&acc)[2][2], const Epi &e) {
       [&]<int... E>(std::integer_sequence<int, E...>) {
         (epi_item_c<POOL, E>(e, bias, acc), ...);

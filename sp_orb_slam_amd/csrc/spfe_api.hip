@@ -306,7 +306,9 @@ int pack_layer_bf16_ws(spfe_handle h, const float *blob, int lid, unsigned char 
     for (int ci = 0; ci < 64; ++ci)
       for (int t = 0; t < 9; ++t) {
         const unsigned short v = host_bf16_rne(W[((size_t)co * 64 + ci) * 9 + t]);
-        const int j = co % 64, slot = (ci / 8) ^ ((j >> 1) & 7);
+        // row of the block: even channels fill accumulator tile 0, odd ones tile 1 (conv_bf16_ws.hip's epilogue
+        // packs a lane's channel pair into one dword store)
+        const int c64 = co % 64, j = (c64 & 1) * 32 + (c64 >> 1), slot = (ci / 8) ^ ((j >> 1) & 7);
         memcpy(&w[(size_t)(co / 64) * blk + ((size_t)t * 64 + j) * 128 + slot * 16 + (ci % 8) * 2], &v, 2);
       }
   int rc;
@@ -355,7 +357,16 @@ int build(spfe_handle h, const spfe_config *cfg) {
     if (genv) h->num_cus = atoi(genv);
   }
   HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+  {
+    // SPFE_SIDE_PRIORITY (probe knob): -1 = the side stream at the device's highest priority, 1 = lowest, unset / 0 = default
+    const char *pe = getenv("SPFE_SIDE_PRIORITY");
+    const int want = pe ? atoi(pe) : 0;
+    int lo = 0, hi = 0;   // (numerically: greatest priority = lowest value)
+    if (want && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+      HIP_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, want < 0 ? hi : lo));
+    else
+      HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+  }
   for (int i = 0; i < spfe_handle_s::NTICKET; ++i) {
     HIP_TRY(hipEventCreateWithFlags(&h->ev_post[i], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_cov[i], hipEventDisableTiming));
