@@ -399,6 +399,34 @@ def main():
                                              "record, Huber 0.9, <= 40 LM iterations, one workgroup, f64",
                                      "us_per_solve": round(e0.elapsed_time(e1) / 20 * 1e3, 1), "iterations": gd["iterations"],
                                      "n_inlier": gd["n_inlier"]}
+            # the batch path's form: one workgroup per frame, 64 independent solves (each its own record, points and start
+            # pose) in one launch — a solve is a latency chain, so they take about as long as one
+            from sp_orb_slam_amd.extractor import DUST_MAX_POINTS
+            NB = 64
+            d_recs = d_rec.repeat(NB, 1).contiguous()
+            pts_b = np.zeros((NB, DUST_MAX_POINTS, 3), np.float32)
+            T_b = np.zeros((NB, 16), np.float32)
+            for f in range(NB):
+                scf = dust_scene.make_scene(f, H=H, W=W, n_points=160, cx=W / 2 - 8.8, cy=H / 2 + 8.4)
+                pts_b[f, :160] = scf["pts"]; T_b[f] = scf["Tcw_init"].reshape(16)
+                d_recs[f, lay.off_dd:lay.off_dd + scf["dust"].size * 4] = torch.from_numpy(scf["dust"].reshape(-1).view(np.uint8)).cuda()
+            d_pb, d_Tb = torch.from_numpy(pts_b).cuda(), torch.from_numpy(T_b).cuda()
+            d_nb = torch.full((NB,), 160, dtype=torch.int32, device="cuda")
+            d_ob = torch.zeros((NB, DUST_OUT_BYTES), dtype=torch.uint8, device="cuda")
+            def dust_batch():
+                extd.align_dust_batch_device(d_recs.data_ptr(), NB, d_pb.data_ptr(), d_nb.data_ptr(), d_Tb.data_ptr(), d_ob.data_ptr(),
+                                             dsc["fx"], dsc["fy"], dsc["cx"], dsc["cy"], stream=dstream.cuda_stream)
+            for _ in range(2):
+                dust_batch()
+            e0.record(dstream)
+            for _ in range(10):
+                dust_batch()
+            e1.record(dstream)
+            torch.cuda.synchronize()
+            ob = d_ob.cpu().numpy()
+            out["dust_alignment"]["batch64_us_per_launch"] = round(e0.elapsed_time(e1) / 10 * 1e3, 1)
+            out["dust_alignment"]["batch64_us_per_solve"] = round(e0.elapsed_time(e1) / 10 / NB * 1e3, 2)
+            out["dust_alignment"]["batch64_frame0_equals_single"] = bool(np.array_equal(ob[0][:64], d_do.cpu().numpy()[:64]))
             if world == 1 and not args.no_cpu_baseline:
                 from oracle import oracle as _orc2
                 t1 = time.perf_counter()

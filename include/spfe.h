@@ -291,6 +291,16 @@ SPFE_API int spfe_align_dust_record_device(spfe_handle h, const void *d_record, 
                                            const void *d_Tcw, const spfe_dust_params *prm, void *d_out,
                                            void *stream);
 
+/* The batch path's form: n_frames independent solves in ONE launch, one workgroup each (a single solve is a chain of
+ * dependent double-precision operations — latency, not throughput: 256 of them side by side take as long as one).
+ * Frame f aligns d_n_points[f] points at d_points_xyz + f * SPFE_DUST_MAX_POINTS * 3 floats, starting from the pose
+ * d_Tcw + 16 f, against the dense_dust of record f of d_records (spfe_record_bytes() strided, e.g. the output of
+ * spfe_extract_batch_device or the all-gathered array); d_out + f * SPFE_DUST_OUT_BYTES receives the block described
+ * above.  All arrays in device memory; enqueued on `stream`, no host synchronisation. */
+SPFE_API int spfe_align_dust_batch_device(spfe_handle h, const void *d_records, int n_frames, const void *d_points_xyz,
+                                          const void *d_n_points, const void *d_Tcw, const spfe_dust_params *prm,
+                                          void *d_out, void *stream);
+
 /* ---- input staging -----------------------------------------------------
  * Replaces, per frame, the host OpenCV sequence in front of the extractor:
  *   cv::remap(mono, mono, m1, m2, cv::INTER_LINEAR)       orb_slam2/src/io/data_loader.cc:519-521

@@ -36,6 +36,17 @@ struct Shared {
 
 __global__ __launch_bounds__(DUST_THREADS) void dust_align_kernel(DustArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_d[];
+  {  // this workgroup's frame: independent solves side by side (the batch path: one record per frame)
+    const size_t f = blockIdx.x;
+    a.dust = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.dust) + f * a.dust_stride);
+    a.pts = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.pts) + f * a.pts_stride);
+    a.Tcw_in = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.Tcw_in) + f * a.pose_stride);
+    a.Tcw_out = reinterpret_cast<float *>(reinterpret_cast<char *>(a.Tcw_out) + f * a.out_stride);
+    a.inlier = a.inlier + f * a.out_stride;
+    a.uv = reinterpret_cast<float *>(reinterpret_cast<char *>(a.uv) + f * a.out_stride);
+    a.counts = reinterpret_cast<int *>(reinterpret_cast<char *>(a.counts) + f * a.out_stride);
+    if (a.n_dev) a.n = min(max(a.n_dev[f], 0), DUST_MAX_POINTS);
+  }
   // LDS: control block | per-point err, rho0, w (rho1) | per-point J[6] | dust map
   Shared *sh = reinterpret_cast<Shared *>(smem_d);
   double *s_err = reinterpret_cast<double *>(smem_d + 1024);
@@ -202,7 +213,7 @@ hipError_t launch_dust_align(const DustArgs &a, hipStream_t s) {
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64) attr_done[dev] = true;
   }
-  hipLaunchKernelGGL(dust_align_kernel, dim3(1), dim3(DUST_THREADS), lds, s, a);
+  hipLaunchKernelGGL(dust_align_kernel, dim3(a.nframes > 0 ? a.nframes : 1), dim3(DUST_THREADS), lds, s, a);
   return hipGetLastError();
 }
 

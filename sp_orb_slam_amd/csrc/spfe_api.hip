@@ -998,8 +998,11 @@ int dust_check(spfe_handle h, int n, const spfe_dust_params *prm) {
   return SPFE_OK;
 }
 int dust_launch(spfe_handle h, const float *d_dust, const float *d_pts, int n, const float *d_T,
-                const spfe_dust_params *prm, uint8_t *d_out, hipStream_t s) {
+                const spfe_dust_params *prm, uint8_t *d_out, hipStream_t s, int nframes = 1, size_t dust_stride = 0,
+                const int *d_n = nullptr) {
   spfe::DustArgs a{};
+  a.nframes = nframes; a.dust_stride = dust_stride; a.pts_stride = (size_t)SPFE_DUST_MAX_POINTS * 12; a.pose_stride = 64;
+  a.out_stride = SPFE_DUST_OUT_BYTES; a.n_dev = d_n;
   a.dust = d_dust; a.hc = h->hc; a.wc = h->wc; a.pts = d_pts; a.n = n; a.Tcw_in = d_T;
   a.fx = prm->fx; a.fy = prm->fy; a.cx = prm->cx; a.cy = prm->cy;
   a.max_iterations = prm->max_iterations; a.delta = prm->huber_delta; a.inlier_chi2 = prm->inlier_chi2;
@@ -1022,6 +1025,20 @@ int spfe_align_dust_record_device(spfe_handle h, const void *d_record, const voi
   const float *d_dust = reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(d_record) + h->rl.off_dd);
   return dust_launch(h, d_dust, reinterpret_cast<const float *>(d_points_xyz), n, reinterpret_cast<const float *>(d_Tcw),
                      prm, reinterpret_cast<uint8_t *>(d_out), s);
+}
+
+int spfe_align_dust_batch_device(spfe_handle h, const void *d_records, int n_frames, const void *d_points_xyz,
+                                 const void *d_n_points, const void *d_Tcw, const spfe_dust_params *prm, void *d_out,
+                                 void *stream) {
+  if (!h || !d_records || !d_Tcw || !prm || !d_out || !d_points_xyz || !d_n_points) return fail(SPFE_EINVAL, "null argument");
+  if (n_frames < 1 || n_frames > 65535) return fail(SPFE_EINVAL, "n_frames %d", n_frames);
+  int rc = dust_check(h, 0, prm);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
+  const float *d_dust = reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(d_records) + h->rl.off_dd);
+  return dust_launch(h, d_dust, reinterpret_cast<const float *>(d_points_xyz), 0, reinterpret_cast<const float *>(d_Tcw), prm,
+                     reinterpret_cast<uint8_t *>(d_out), s, n_frames, h->rl.bytes, reinterpret_cast<const int *>(d_n_points));
 }
 
 int spfe_align_dust(spfe_handle h, const float *dense_dust, const float *points_xyz, int n, const float *Tcw,

@@ -183,6 +183,11 @@ struct DustArgs {
   unsigned char *inlier;  // [n]
   float *uv;           // [n][2]
   int *counts;         // n_inlier, iterations
+  // batched form (one workgroup per frame f = blockIdx.x): byte strides added to dust / pts+Tcw_in / the four outputs;
+  // n_dev (or null) = per-frame point counts on the device
+  int nframes;
+  size_t dust_stride, pts_stride, pose_stride, out_stride;
+  const int *n_dev;
 };
 hipError_t launch_dust_align(const DustArgs &a, hipStream_t s);
 size_t dust_lds_bytes(int hc, int wc);

@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "spfe_set_staging", "spfe_extract_staged", "spfe_extract_batch_staged", "spfe_stage_batch_device",
     "spfe_comm_unique_id", "spfe_comm_init", "spfe_comm_destroy", "spfe_allgather_records", "spfe_comm_wait",
     "spfe_comm_stream", "spfe_submit_batch", "spfe_collect_batch",
-    "spfe_align_dust", "spfe_align_dust_record_device", "spfe_match_knn2",
+    "spfe_align_dust", "spfe_align_dust_record_device", "spfe_align_dust_batch_device", "spfe_match_knn2",
 ]
 
 
@@ -185,6 +185,9 @@ def load_library():
     L.spfe_align_dust_record_device.restype = C.c_int
     L.spfe_align_dust_record_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                 C.POINTER(_DustParams), C.c_void_p, C.c_void_p]
+    L.spfe_align_dust_batch_device.restype = C.c_int
+    L.spfe_align_dust_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.POINTER(_DustParams), C.c_void_p, C.c_void_p]
     L.spfe_submit_batch.restype = C.c_int
     L.spfe_submit_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_long)]
     L.spfe_collect_batch.restype = C.c_int
@@ -407,6 +410,16 @@ class SPExtractor:
         _check(self._lib.spfe_align_dust_record_device(self._h, C.c_void_p(d_record), C.c_void_p(d_points_xyz), int(n),
                                                        C.c_void_p(d_Tcw), C.byref(prm), C.c_void_p(d_out),
                                                        C.c_void_p(stream or 0)))
+
+    def align_dust_batch_device(self, d_records, n_frames, d_points_xyz, d_n_points, d_Tcw, d_out, fx, fy, cx, cy,
+                                max_iterations=40, huber_delta=0.9, inlier_chi2=0.9, stream=None):
+        """n_frames independent solves in one launch (spfe_align_dust_batch_device): frame f uses record f of `d_records`,
+        the points at d_points_xyz + f * DUST_MAX_POINTS * 3 floats (d_n_points[f] of them), pose d_Tcw + 16 f, and writes
+        d_out + f * DUST_OUT_BYTES."""
+        prm = self._dust_params(fx, fy, cx, cy, max_iterations, huber_delta, inlier_chi2)
+        _check(self._lib.spfe_align_dust_batch_device(self._h, C.c_void_p(d_records), int(n_frames), C.c_void_p(d_points_xyz),
+                                                      C.c_void_p(d_n_points), C.c_void_p(d_Tcw), C.byref(prm),
+                                                      C.c_void_p(d_out), C.c_void_p(stream or 0)))
 
     @staticmethod
     def decode_dust_out(host_block, n):

@@ -107,3 +107,43 @@ def test_align_dust_on_a_resident_record():
     r = oracle.align_dust(rec.dense_dust, sc["pts"], sc["Tcw_init"], 200.0, 200.0, sc["cx"], sc["cy"])
     _compare(g, r, rec.dense_dust)
     ext.close()
+
+
+def test_align_dust_batch_of_records():
+    """spfe_align_dust_batch_device: independent solves side by side, one workgroup per frame — each equals the oracle on its
+    own record / points / start pose, including frames with 0 and 1 points."""
+    import torch
+    from sp_orb_slam_amd import parallel
+    from sp_orb_slam_amd.extractor import DUST_MAX_POINTS
+    H, W, nf, NB = 240, 320, 300, 6
+    blob = weights.synthetic(7, "sparse")
+    ext = SPExtractor(nf, H, W, blob, with_heat=False)
+    lay = parallel.RecordLayout(H, W, nf)
+    recs = np.zeros((NB, ext.record_bytes()), np.uint8)
+    pts = np.zeros((NB, DUST_MAX_POINTS, 3), np.float32)
+    T = np.zeros((NB, 16), np.float32)
+    npts = np.array([120, 0, 1, 200, 64, 512], np.int32)
+    scenes = []
+    for f in range(NB):
+        sc = dust_scene.make_scene(30 + f, H=H, W=W, n_points=max(int(npts[f]), 1), fx=200.0, fy=200.0, cx=W / 2 - 3.0, cy=H / 2 + 2.0)
+        scenes.append(sc)
+        recs[f, lay.off_dd:lay.off_dd + sc["dust"].size * 4] = sc["dust"].reshape(-1).view(np.uint8)
+        pts[f, :npts[f]] = sc["pts"][:npts[f]]
+        T[f] = sc["Tcw_init"].reshape(16)
+    d_recs, d_pts, d_T = torch.from_numpy(recs).cuda(), torch.from_numpy(pts).cuda(), torch.from_numpy(T).cuda()
+    d_n = torch.from_numpy(npts).cuda()
+    d_out = torch.zeros((NB, DUST_OUT_BYTES), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.Stream()
+    ext.align_dust_batch_device(d_recs.data_ptr(), NB, d_pts.data_ptr(), d_n.data_ptr(), d_T.data_ptr(), d_out.data_ptr(),
+                                200.0, 200.0, scenes[0]["cx"], scenes[0]["cy"], stream=stream.cuda_stream)
+    stream.synchronize()
+    out = d_out.cpu().numpy()
+    for f in range(NB):
+        n = int(npts[f])
+        g = ext.decode_dust_out(out[f], n)
+        r = oracle.align_dust(scenes[f]["dust"], pts[f, :n], scenes[f]["Tcw_init"], 200.0, 200.0, scenes[f]["cx"], scenes[f]["cy"])
+        if n == 0:
+            assert g["n_inlier"] == 0 and np.abs(g["Tcw"] - scenes[f]["Tcw_init"]).max() < 1e-6
+        else:
+            _compare(g, r, scenes[f]["dust"])
+    ext.close()
