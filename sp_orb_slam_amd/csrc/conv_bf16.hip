@@ -155,6 +155,15 @@ struct CtlB {
   int i_nb, i_tx, i_ty, i_b, n_nb, n_tx, n_ty, n_b, d_nb, d_tx, d_ty, d_b;
   int w, gper, hi_w;
   bool have_next;
+  // dynamic order (streamed-weight layers, ConvParams::tile_ctr set): items after a workgroup's first come from a per-XCD
+  // atomic counter, so a workgroup that shares its CU with the side-stream kernels of the previous batch (SPFE_FLAG_ASYNC_COV)
+  // takes fewer items instead of making the whole launch wait for its static share (conv3b at 1280x720: 0.128 ms alone,
+  // 0.200 ms beside the covariance kernels).  lo = first item of this XCD; w_n = the next item; slot = the LDS word
+  // through which wave 0 hands the fetched counter value to the other waves.
+  bool dyn;
+  int lo, w_n;
+  float rcp_nblk, rcp_tx, rcp_ty;
+  const __attribute__((address_space(3))) int *slot;
   int chunk;  // K chunk the current stage computes
   // constants
   int H, W, Ho, Wo, wm, l31, hi;
@@ -182,14 +191,32 @@ __device__ __forceinline__ void aim_piece_b(PipeB<NITER, NWITER> &c, const CtlB<
   }
 }
 
+// q / d for q < 2^20 with rcp = 1.0f / d: (q + 0.5) / d is at least 0.5 / d away from an integer, i.e. 2^-21 relative,
+// four times the rounding error of the two float operations
+__device__ __forceinline__ int udiv_small(int q, float rcp) { return (int)(((float)q + 0.5f) * rcp); }
+
 template <int NITER, int NT>
 __device__ __forceinline__ void next_item_b(const ConvParams &p, CtlB<NITER, NT> &t) {
+  if (t.dyn) {
+    const int wn = t.lo + t.gper + __builtin_amdgcn_readfirstlane(*t.slot);
+    t.w_n = wn;
+    t.have_next = wn < t.hi_w;
+    int q = wn;
+    int d = __builtin_amdgcn_readfirstlane(udiv_small(q, t.rcp_nblk));
+    t.n_nb = q - d * p.nblk; q = d;
+    d = __builtin_amdgcn_readfirstlane(udiv_small(q, t.rcp_tx));
+    t.n_tx = q - d * p.tiles_x; q = d;
+    d = __builtin_amdgcn_readfirstlane(udiv_small(q, t.rcp_ty));
+    t.n_ty = q - d * p.tiles_y; t.n_b = d;
+    return;
+  }
   int n_nb = t.i_nb + t.d_nb, n_tx = t.i_tx + t.d_tx, n_ty = t.i_ty + t.d_ty, n_b = t.i_b + t.d_b;
   if (n_nb >= p.nblk) { n_nb -= p.nblk; ++n_tx; }
   if (n_tx >= p.tiles_x) { n_tx -= p.tiles_x; ++n_ty; }
   if (n_ty >= p.tiles_y) { n_ty -= p.tiles_y; ++n_b; }
   t.n_nb = n_nb; t.n_tx = n_tx; t.n_ty = n_ty; t.n_b = n_b;
-  t.have_next = t.w + t.gper < t.hi_w;
+  t.w_n = t.w + t.gper;
+  t.have_next = t.w_n < t.hi_w;
 }
 
 // epilogue context of the CURRENT tile (used one tile later), in two pieces
@@ -373,6 +400,14 @@ __global__ __launch_bounds__(256, 1) void conv_bf16_kernel(ConvParams p) {
   t.n_nb = t.n_tx = t.n_ty = t.n_b = 0;
   t.have_next = false;
   t.chunk = 0;
+  // dynamic order only where weights stream with the tile (a resident 64-channel block would have to be re-loaded
+  // whenever the queue hands out another block) and the index arithmetic of udiv_small is exact
+  t.dyn = !RESW && p.tile_ctr != nullptr && total < (1 << 20);
+  t.lo = lo; t.w_n = 0;
+  t.rcp_nblk = 1.0f / (float)p.nblk; t.rcp_tx = 1.0f / (float)p.tiles_x; t.rcp_ty = 1.0f / (float)p.tiles_y;
+  t.slot = (const __attribute__((address_space(3))) int *)(smem_b + 2 * G::BUF_BYTES);
+  int *const qctr = p.tile_ctr ? p.tile_ctr + xcd : nullptr;
+  int fetched = 0;   // (lane 0 of wave 0: the counter value its atomic returned)
 #pragma unroll
   for (int it = 0; it < NITER; ++it) {
     const int i = tid + it * 256;
@@ -462,13 +497,25 @@ __global__ __launch_bounds__(256, 1) void conv_bf16_kernel(ConvParams p) {
     __syncthreads();
     buf ^= 1;
   };
+  // first stage of a tile, dynamic order: wave 0 asked the queue at the start of the stage; the value is back with the
+  // stage's loads and goes to the other waves through LDS under the same barrier
+  auto end_stage_publish = [&]() {
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (t.dyn && tid == 0) *(__attribute__((address_space(3))) int *)(smem_b + 2 * G::BUF_BYTES) = fetched;
+    __syncthreads();
+    buf ^= 1;
+  };
 
   auto run_tile = [&](f32x16(&acc)[MT][NT], const f32x16(&accPrev)[MT][NT], EpiB<NT> &eMine, const EpiB<NT> &ePrev) {
     t.chunk = 0;
+    if constexpr (!RESW) {
+      // (compiled with the atomic optimiser off, see the Makefile: the plain instruction, waited for where it is used)
+      if (t.dyn && tid == 0) fetched = atomicAdd(qctr, 1);
+    }
     begin_stage();
     k_steps_b<0, NSTEP, true, NCHUNK == 2 ? 1 : 0, CIN, TH, MT, NT, NITER, NWITER, POOL, OUT_F32>(
         p, a, bb, acc, accPrev, c, t, eMine, ePrev, hold);
-    end_stage();
+    if constexpr (!RESW) end_stage_publish(); else end_stage();
     if constexpr (NCHUNK > 2) {
 #pragma unroll 1
       for (int ch = 1; ch < NCHUNK - 2; ++ch) {
@@ -498,7 +545,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16_kernel(ConvParams p) {
         __syncthreads();
       }
     }
-    t.w += t.gper;
+    t.w = t.w_n;
     t.i_nb = t.n_nb; t.i_tx = t.n_tx; t.i_ty = t.n_ty; t.i_b = t.n_b;
   };
 
@@ -525,7 +572,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16_kernel(ConvParams p) {
 template <int CIN, bool POOL, bool OUT_F32>
 static hipError_t launch_b(const ConvParams &p, hipStream_t s) {
   using G = GeoB<8>;
-  constexpr size_t lds = 2 * (size_t)G::BUF_BYTES;
+  constexpr size_t lds = 2 * (size_t)G::BUF_BYTES + 16;   // + the queue slot
   static_assert(lds <= 160 * 1024, "double buffer must fit the 160 KB LDS");
   auto k = conv_bf16_kernel<CIN, POOL, OUT_F32>;
   static bool attr_done[64] = {};  // per instantiation and device: one process may hold handles on several GPUs

@@ -149,7 +149,8 @@ struct spfe_handle_s {
   unsigned ws_mask = 15u;   // bf16 layers (bit i = conv layer i of enqueue(), Cin = 64 only) that may use the wave-specialised kernel
   int ws_min_items = 11;    // ... when the launch has at least this many (tile, 64-channel block) items per workgroup
   unsigned char *d_wws[4] = {};  // their weights in conv_bf16_ws.hip's layout
-  int *d_tile_ctr = nullptr;     // [4 layers][16] tile-queue counters, zeroed once per enqueue()
+  bool bf16_dyn = true;          // SPFE_BF16_DYN_QUEUE
+  int *d_tile_ctr = nullptr;     // [8 layers][16] tile-queue counters, zeroed once per enqueue()
   bool act0_missing = false;  // the last call computed conv1a inside conv1b
   bool bf16 = false;  // SPFE_PRECISION_BF16: bf16 conv stack (conv1a .. convPa/Da), f32 heads and tail
   // per-stage timing: a ring of event sets, one set per enqueue() call
@@ -383,6 +384,8 @@ int build(spfe_handle h, const spfe_config *cfg) {
     if (f16env) h->fuse1a_bf16 = atoi(f16env) != 0;
     const char *ienv = getenv("SPFE_BF16_WS_MIN_ITEMS");
     if (ienv) h->ws_min_items = atoi(ienv);
+    const char *denv = getenv("SPFE_BF16_DYN_QUEUE");
+    if (denv) h->bf16_dyn = atoi(denv) != 0;
   }
   const char *tenv = getenv("SPFE_STAGE_TIMING");
   h->timing = tenv && atoi(tenv) != 0;
@@ -515,7 +518,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
     for (int i = 0; i < 4; ++i)
       if ((h->ws_mask >> i) & 1)
         if ((rc = pack_layer_bf16_ws(h, blob.data(), specs[i].l0, &h->d_wws[i]))) return rc;
-    if ((rc = dev_alloc(h, &h->d_tile_ctr, 4 * 16))) return rc;
+    if ((rc = dev_alloc(h, &h->d_tile_ctr, 8 * 16))) return rc;
   }
   if (h->bf16) {  // both heads in bf16: convPa | convDa write bf16, convPb and convDb are head_bf16.hip's GEMMs
     if ((rc = dev_alloc(h, &h->d_hd, (size_t)B * C * 512))) return rc;
@@ -556,7 +559,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   if (h->timing) h->ev = h->evpool.data() + (size_t)(h->calls % spfe_handle_s::EVSETS) * (NSTAGE + 1);
   h->calls++;
   STAGE_MARK(0);
-  if (h->bf16 && h->ws_mask) HIP_TRY(hipMemsetAsync(h->d_tile_ctr, 0, 4 * 16 * sizeof(int), s));
+  if (h->d_tile_ctr) HIP_TRY(hipMemsetAsync(h->d_tile_ctr, 0, 8 * 16 * sizeof(int), s));
   const bool fused = !h->bf16 && h->fuse1a;  // f32: conv1b computes conv1a's outputs itself
   // bf16: when conv1b takes the wave-specialised kernel, its producer waves compute conv1a (no conv1a launch, no act0)
   const int grid_ws0 = std::max(16, (h->num_cus > 0 ? h->num_cus : 256) & ~15);
@@ -598,6 +601,10 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
         STAGE_MARK(2 + i);
         continue;
       }
+      // streamed-weight layers (Cin = 128): work items in queue order (conv_bf16.hip, CtlB::dyn); SPFE_BF16_DYN_QUEUE=0: static
+      // (launches with a handful of items per workgroup stay static: the queue costs them more than it balances)
+      if (L.cin == 128 && h->bf16_dyn && (long)p.tiles_x * p.tiles_y * n * p.nblk >= 5L * (grid_ws < 8 ? 8 : grid_ws))
+        p.tile_ctr = h->d_tile_ctr + 16 * i;
       if (i == 7) {
         // convPa | convDa: one launch, 512 output channels, bf16 (both 1x1 heads are bf16 GEMMs)
         p.out = reinterpret_cast<float *>(h->d_hd); p.out_stride = 512; p.out_choff = 0;
