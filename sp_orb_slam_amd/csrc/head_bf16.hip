@@ -1,14 +1,21 @@
 // head_bf16.hip — the two 1x1 head convolutions of the bf16 mode (no ReLU; /root/reference/orb_slam2/src/cv/
 // sp_extractor.cpp:96-100): convDb (256 -> 256) and convPb (256 -> 65), plain GEMMs
 //   out[P][COUT] (f32) = in[P][256 of the 512 head channels] (bf16) x W^T (bf16) + bias,  P = frames x cells,
-// on v_mfma_f32_32x32x16_bf16.  As f32 kernels they were 70-100 us each of a ~1.7 ms bf16 step at 1280x720.
+// on v_mfma_f32_32x32x16_bf16.
 //
-// One workgroup = 64 pixels x all 256 output channels: the pixel tile (all 256 input channels, 40 KB
-// with the 80-byte row pitch of conv_bf16.hip) is loaded once and stays; the weights stream through a
-// double buffer one 64-channel block (40 KB) at a time, everything with LDS-direct buffer loads.
-// Wave w computes the 32 x 32 block (pixels 32*(w&1).., channels 32*(w>>1)..) of each block: 16 MFMAs.
-// Pixels are the A operand, so lanes are channels and every store is whole 128-byte pixel rows.
-// convPb's 65 outputs are two blocks (the second holds the dustbin channel and 63 zero rows).
+// These are HBM-bound (convDb at 1280x720 x 8: 59 MB in, 118 MB of f32 out = 0.03 ms at 6 TB/s, against 0.01 ms of
+// matrix time), so the design removes everything that is not the pixel stream:
+//   * WEIGHTS LIVE IN REGISTERS: a wave owns 64 (convDb) or 32 (convPb) output channels for the whole kernel — 16 K steps
+//     x 2 tiles x 4 VGPRs = 128 registers, loaded once from a table packed in fragment order.  (The first version
+//     streamed all 128 KB of weights through LDS for every 64 pixels: 230 MB of L2 -> LDS traffic per launch, 0.068 ms.)
+//   * persistent workgroups (two per CU, so one computes while the other waits for memory) walk 32-pixel tiles; a
+//     tile's 16 KB come HBM -> LDS with LDS-direct loads into a double buffer, XOR-swizzled by the pixel on the
+//     source side (conflict-free 16-byte fragment reads), and are read as the A operand by all four waves;
+//   * mfma(pixels, weights): a lane owns output channels, and the even / odd channels of a wave's block sit in its two
+//     accumulator tiles, so one 8-byte store per register writes 256 contiguous bytes of a pixel's row (convPb: 4-byte
+//     stores, 128-byte runs); a tile's stores go out while the next tile computes.
+// K order: the 16 MFMA steps ascend through the input channels, as in the first version: same bits.
+#include <cstring>
 #include <utility>
 
 #include "spfe_kernels.h"
@@ -17,106 +24,161 @@ namespace spfe {
 
 namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2v __attribute__((__vector_size__(2 * sizeof(unsigned))));
 typedef __attribute__((address_space(3))) void lds_void;
-constexpr int HP = 80;                       // bytes per (row, 32-channel chunk) in LDS and in the packed weights
-constexpr int H_TILE = 64;                   // pixels per workgroup
-constexpr int H_BLOCK = 8 * 64 * HP;         // one operand block: 8 chunks x 64 rows x 80 B = 40960
-constexpr int H_PASSES = H_BLOCK / 16 / 256; // LDS-direct passes per block (10)
-constexpr unsigned H_OOB = 0x80000000u;
+typedef __attribute__((address_space(3))) char lds_char;
+constexpr int HT = 32;                 // pixels per tile
+constexpr int HT_BYTES = HT * 512;     // 256 input channels (bf16) per pixel
+constexpr int H_KSTEPS = 16;
+constexpr int H_WG_PER_CU = 2;
 }  // namespace
 
 // in: [npix][IN_STRIDE] bf16, the head reads channels [in_choff, in_choff + 256); out: [npix][COUT] f32
-template <int NBLK, int COUT, int IN_STRIDE>
-__global__ __launch_bounds__(256, 1) void head1x1_bf16_kernel(const unsigned short *__restrict__ in, int in_choff,
-                                                              const unsigned char *__restrict__ wpack,
-                                                              const float *__restrict__ bias,
-                                                              float *__restrict__ out, int npix) {
+// wpack: [wave 4][tile NTW][K step 16][lane 64][8 bf16] (head_bf16_pack_weights)
+template <int COUT, int IN_STRIDE>
+__global__ __launch_bounds__(256, H_WG_PER_CU) void head1x1_bf16_kernel(const unsigned short *__restrict__ in, int in_choff,
+                                                                        const unsigned char *__restrict__ wpack,
+                                                                        const float *__restrict__ bias,
+                                                                        float *__restrict__ out, int npix) {
+  constexpr int NTW = COUT == 256 ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) char sm_h[];
-  char *sA = sm_h, *sW0 = sm_h + H_BLOCK, *sW1 = sm_h + 2 * H_BLOCK;
+  lds_char *const lds = (lds_char *)sm_h;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
-  const int p0 = blockIdx.x * H_TILE;
-  const unsigned wslot = (unsigned)wave * 1024u;
+  const int ntiles = (npix + HT - 1) / HT;
 
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<unsigned short *>(in) + in_choff, 0, (unsigned)((size_t)npix * IN_STRIDE * 2 - (size_t)in_choff * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rout =
       __builtin_amdgcn_make_buffer_rsrc(out, 0, (unsigned)((size_t)npix * COUT * 4), 0x00020000);
 
-  // pixel tile: piece i -> (chunk, row, q): LDS offset 16 i; global (p0 + row) * 512 + chunk * 64 + q * 16
-#if defined(__HIP_DEVICE_COMPILE__)
+  // this wave's weights, for the whole kernel
+  bf16x8 wreg[NTW][H_KSTEPS];
 #pragma unroll
-  for (int ps = 0; ps < H_PASSES; ++ps) {
-    const int i = tid + ps * 256;
-    const int q = i % 5, row = (i / 5) % 64, chunk = i / 320;
-    const unsigned voff = q < 4 ? (unsigned)(p0 + row) * (unsigned)(IN_STRIDE * 2) + (unsigned)chunk * 64u + (unsigned)q * 16u : H_OOB;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void *)(sA + ps * 4096 + wslot), 16, voff, 0, 0, 0);
-  }
-  auto load_w = [&](int nb, char *dst) {
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned char *>(wpack) + (size_t)nb * H_BLOCK, 0, (unsigned)H_BLOCK, 0x00020000);
+  for (int j = 0; j < NTW; ++j)
 #pragma unroll
-    for (int ps = 0; ps < H_PASSES; ++ps)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(dst + ps * 4096 + wslot), 16, (unsigned)tid * 16u,
-                                               ps * 4096, 0, 0);
-  };
-  load_w(0, sW0);
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  __syncthreads();
+    for (int kk = 0; kk < H_KSTEPS; ++kk)
+      wreg[j][kk] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4 *>(wpack)[((wave * NTW + j) * H_KSTEPS + kk) * 64 + lane]);
+  // output channel(s) of this lane: convDb 64 wave + 2 l31 + j; convPb 32 wave + l31
+  const int co = COUT == 256 ? wave * 64 + 2 * l31 : wave * 32 + l31;
+  float bv[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) bv[j] = co + j < COUT ? bias[co + j] : 0.0f;
+  const bool lane_out = co < COUT;
 
-  const int pr = (wave & 1) * 32, cr = (wave >> 1) * 32;
-  const char *aBase = sA + (pr + l31) * HP + hi * 16;
-#pragma unroll 1
-  for (int nb = 0; nb < NBLK; ++nb) {
-    char *wcur = (nb & 1) ? sW1 : sW0;
-    if (nb + 1 < NBLK) load_w(nb + 1, (nb & 1) ? sW0 : sW1);
-    const char *bBase = wcur + (cr + l31) * HP + hi * 16;
-    f32x16 acc;
+  // a tile's 1024 16-byte pieces = 16 LDS-direct passes, 4 per wave: pass p, lane l -> LDS piece q = 64 p + l = (pixel
+  // q >> 5, slot q & 31), which holds the pixel's piece slot ^ (pixel & 31)
+  unsigned dsrc[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  for (int i = 0; i < 4; ++i) {
+    const int q = (4 * i + wave) * 64 + lane, px = q >> 5, slot = q & 31;
+    dsrc[i] = (unsigned)px * (unsigned)(IN_STRIDE * 2) + (unsigned)((slot ^ (px & 31)) * 16);
+  }
+  auto dma = [&](int tile, int buf) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned base = (unsigned)tile * (unsigned)(HT * IN_STRIDE * 2);   // (past the last pixel: out of range -> zeros)
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void *)(lds + buf * HT_BYTES + (4 * i + wave) * 1024), 16, base + dsrc[i], 0, 0, 0);
+#endif
+  };
+  // A fragment of K step kk: piece 2 kk + hi of pixel l31
+  unsigned aoff[H_KSTEPS];
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(aBase + c * 64 * HP + kk * 32);
-        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(bBase + c * 64 * HP + kk * 32);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-      }
-    // D[pixel][channel]: lane & 31 = channel, register r = pixel (r&3) + 8*(r>>2) + 4*hi
-    const int co = nb * 64 + cr + l31;
-    const float bv = co < COUT ? bias[co] : 0.0f;
+  for (int kk = 0; kk < H_KSTEPS; ++kk) aoff[kk] = (unsigned)(l31 * 512 + (((2 * kk + hi) ^ l31) & 31) * 16);
+
+  // D[pixel][channel]: register r = pixel (r & 3) + 8 (r >> 2) + 4 hi of the tile
+  auto store_tile = [&](const f32x16 (&acc)[NTW], int tile) {
+    const unsigned base = (unsigned)tile * (unsigned)(HT * COUT * 4) + (unsigned)co * 4u;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int p = p0 + pr + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const unsigned off = co < COUT ? (unsigned)p * (unsigned)(COUT * 4) + (unsigned)co * 4u : H_OOB;   // (pixels past npix: out of range too)
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r] + bv), rout, off, 0, 0);
+      const unsigned off = lane_out ? base + (unsigned)(((r & 3) + 8 * (r >> 2) + 4 * hi) * COUT * 4) : 0x80000000u;
+      if constexpr (NTW == 2) {
+        const f32x2 v = {acc[0][r] + bv[0], acc[1][r] + bv[1]};
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, v), rout, off, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[0][r] + bv[0]), rout, off, 0, 0);
+      }
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // the next block of weights has landed
-    __syncthreads();
+  };
+
+  f32x16 accA[NTW], accB[NTW];
+  int tile = blockIdx.x, prev = -1;
+  if (tile < ntiles) dma(tile, 0);
+  int buf = 0;
+  auto run = [&](f32x16 (&acc)[NTW], const f32x16 (&accPrev)[NTW]) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this tile has landed (and the stores of the tile before the previous one are out)
+    __syncthreads();                      // ... for every wave; and every wave is done reading the other buffer
+    const int nxt = tile + (int)gridDim.x;
+    if (nxt < ntiles) dma(nxt, buf ^ 1);
+    if (prev >= 0) store_tile(accPrev, prev);   // the previous tile's outputs leave while this one computes
+    lds_char *const a0 = lds + buf * HT_BYTES;
+    bf16x8 a[3];
+    a[0] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8 *>(a0 + aoff[0]);
+    a[1] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8 *>(a0 + aoff[1]);
+#pragma unroll
+    for (int kk = 0; kk < H_KSTEPS; ++kk) {
+      if (kk + 2 < H_KSTEPS) a[(kk + 2) % 3] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8 *>(a0 + aoff[kk + 2]);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        if (kk == 0) {
+          f32x16 z;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk % 3], wreg[j][kk], z, 0, 0, 0);
+        } else {
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk % 3], wreg[j][kk], acc[j], 0, 0, 0);
+        }
+      }
+    }
+    prev = tile;
+    tile = nxt;
+    buf ^= 1;
+  };
+  bool lastA = true;
+  while (tile < ntiles) {
+    run(accA, accB);
+    lastA = true;
+    if (tile >= ntiles) break;
+    run(accB, accA);
+    lastA = false;
   }
-#endif
+  if (prev >= 0) { if (lastA) store_tile(accA, prev); else store_tile(accB, prev); }
 }
 
-size_t head_bf16_weight_bytes(int cout) { return (size_t)((cout + 63) / 64) * H_BLOCK; }
+size_t head_bf16_weight_bytes(int cout) { return (size_t)4 * (cout == 256 ? 2 : 1) * H_KSTEPS * 64 * 16; }
 
-template <int NBLK, int COUT>
+// Wb: [cout][256] bf16 bit patterns -> the fragment-order table the kernel's waves load once
+void head_bf16_pack_weights(const unsigned short *Wb, int cout, unsigned char *dst) {
+  const int ntw = cout == 256 ? 2 : 1;
+  memset(dst, 0, head_bf16_weight_bytes(cout));
+  for (int w = 0; w < 4; ++w)
+    for (int j = 0; j < ntw; ++j)
+      for (int kk = 0; kk < H_KSTEPS; ++kk)
+        for (int ln = 0; ln < 64; ++ln) {
+          const int l31 = ln & 31, hi = ln >> 5;
+          const int co = cout == 256 ? w * 64 + 2 * l31 + j : w * 32 + l31;
+          if (co >= cout) continue;
+          unsigned char *o = dst + ((((size_t)w * ntw + j) * H_KSTEPS + kk) * 64 + ln) * 16;
+          memcpy(o, Wb + (size_t)co * 256 + 16 * kk + 8 * hi, 16);
+        }
+}
+
+template <int COUT>
 static hipError_t launch_head(const void *in_bf16, int in_choff, const void *wpack, const float *bias, float *out, int npix,
-                              hipStream_t s) {
-  constexpr size_t lds = 3 * (size_t)H_BLOCK;
-  auto k = head1x1_bf16_kernel<NBLK, COUT, 512>;
-  static bool attr_done[64] = {};  // per instantiation and device: one process may hold handles on several GPUs
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    if (dev >= 0 && dev < 64) attr_done[dev] = true;
-  }
+                              int num_cus, hipStream_t s) {
+  constexpr size_t lds = 2 * (size_t)HT_BYTES;
+  auto k = head1x1_bf16_kernel<COUT, 512>;
   if (npix <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k, dim3((npix + H_TILE - 1) / H_TILE), dim3(256), lds, s, reinterpret_cast<const unsigned short *>(in_bf16),
-                     in_choff, reinterpret_cast<const unsigned char *>(wpack), bias, out, npix);
+  const int ntiles = (npix + HT - 1) / HT;
+  int grid = (num_cus > 0 ? num_cus : 256) * H_WG_PER_CU;
+  if (grid > ntiles) grid = ntiles;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, reinterpret_cast<const unsigned short *>(in_bf16), in_choff,
+                     reinterpret_cast<const unsigned char *>(wpack), bias, out, npix);
   return hipGetLastError();
 }
 
@@ -124,8 +186,8 @@ static hipError_t launch_head(const void *in_bf16, int in_choff, const void *wpa
 // cout 65: the detector head on channels 0..255
 hipError_t launch_head1x1_bf16(const void *in_bf16, const void *wpack, const float *bias, float *out, int npix, int cout,
                                hipStream_t s) {
-  if (cout == 256) return launch_head<4, 256>(in_bf16, 256, wpack, bias, out, npix, s);
-  if (cout == 65) return launch_head<2, 65>(in_bf16, 0, wpack, bias, out, npix, s);
+  if (cout == 256) return launch_head<256>(in_bf16, 256, wpack, bias, out, npix, 0, s);
+  if (cout == 65) return launch_head<65>(in_bf16, 0, wpack, bias, out, npix, 0, s);
   return hipErrorInvalidValue;
 }
 

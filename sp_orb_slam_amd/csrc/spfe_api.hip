@@ -527,11 +527,9 @@ int build(spfe_handle h, const spfe_config *cfg) {
       const spfe_layer_t &Ld = SPFE_LAYERS[lid];
       const float *Wd = blob.data() + blob_weight_offset(lid);
       std::vector<unsigned char> w(spfe::head_bf16_weight_bytes(Ld.cout), 0);
-      for (int co = 0; co < Ld.cout; ++co)
-        for (int ci = 0; ci < Ld.cin; ++ci) {
-          const unsigned short v = host_bf16_rne(Wd[(size_t)co * Ld.cin + ci]);
-          memcpy(&w[(size_t)(co / 64) * 40960 + ((size_t)(ci / 32) * 64 + co % 64) * 80 + (ci % 32) * 2], &v, 2);
-        }
+      std::vector<unsigned short> wb((size_t)Ld.cout * Ld.cin);
+      for (size_t k = 0; k < wb.size(); ++k) wb[k] = host_bf16_rne(Wd[k]);
+      spfe::head_bf16_pack_weights(wb.data(), Ld.cout, w.data());
       unsigned char **dst = which ? &h->d_wpb : &h->d_wdb;
       if ((rc = dev_alloc(h, dst, w.size()))) return rc;
       HIP_TRY(hipMemcpy(*dst, w.data(), w.size(), hipMemcpyHostToDevice));

@@ -51,10 +51,11 @@ inline size_t conv1a_bf16_table_bytes() { return 2 * 64 * 8 * 2; }
 
 // bf16 mode, the 1x1 heads (head_bf16.hip): out[npix][cout] f32 = in[npix][512] bf16 (channels 0..255 for the
 // detector head, cout = 65; 256..511 for the descriptor head, cout = 256) x W^T + bias;
-// wpack: head_bf16_weight_bytes(cout) bytes, [nb][chunk 8][64 couts][80 B: 32 channels bf16 + pad]
+// wpack: head_bf16_weight_bytes(cout) bytes in MFMA fragment order, made by head_bf16_pack_weights from Wb = [cout][256] bf16
 hipError_t launch_head1x1_bf16(const void *in_bf16, const void *wpack, const float *bias, float *out, int npix, int cout,
                                hipStream_t s);
 size_t head_bf16_weight_bytes(int cout);
+void head_bf16_pack_weights(const unsigned short *Wb, int cout, unsigned char *dst);
 
 // conv1a: u8 image -> (x * 1/255) -> 3x3 conv 1->64 + bias + relu, NHWC out.
 // w: [9][64] (tap-major), b: [64]
