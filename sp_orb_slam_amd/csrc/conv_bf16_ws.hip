@@ -81,6 +81,9 @@ __device__ unsigned long long ws_dbg[10];
 #ifndef WS_EPI_MICRO
 #define WS_EPI_MICRO -1  // probe builds: force the epilogue form (1 = single instructions in every gap, 0 = one item per burst)
 #endif
+#ifndef WS_READ_SPREAD
+#define WS_READ_SPREAD -1
+#endif
 #ifndef WS_EPI_GAP
 #define WS_EPI_GAP 2     // the gap (0..3) of a K step that carries the epilogue item
 #endif
@@ -252,15 +255,18 @@ __device__ __forceinline__ void k_steps(bf16x8 (&a)[3][2], bf16x8 (&w)[3][2], f3
           __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's last reads of the tile's halo buffer are back
           wg_barrier();                        // end of tile: the buffer is free, the next halo has landed
         }
-        if constexpr (WS_ABLATE != 4) {
-          constexpr int s2 = (S + 2) % NSTEP, chunk = s2 / 18, tap = (s2 % 18) / 2, kk = chunk * 2 + (s2 % 2);
-          constexpr int dy = tap / 3, dx = tap % 3, hiw = tap >= 7 ? 1 : 0;
-          constexpr int buf = S + 2 < NSTEP ? BUF : BUF ^ 1;
-#pragma unroll
-          for (int i = 0; i < 2; ++i) a[nxt][i] = lds_read(aptr[dx][kk], buf * HALO_BYTES + (i + dy) * ROW_BYTES);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) w[nxt][j] = lds_read(wptr[hiw][kk], (tap - 7 * hiw) * 8192 + j * 4096);
-        }
+      }
+      if constexpr (WS_ABLATE != 4) {
+        // the operand fragments of step S + 2: one per gap where the epilogue is spread too (+1 %), else all four behind the
+        // first MFMA (probe builds: WS_READ_SPREAD forces either)
+        constexpr int s2 = (S + 2) % NSTEP, chunk = s2 / 18, tap = (s2 % 18) / 2, kk = chunk * 2 + (s2 % 2);
+        constexpr int dy = tap / 3, dx = tap % 3, hiw = tap >= 7 ? 1 : 0;
+        constexpr int buf = S + 2 < NSTEP ? BUF : BUF ^ 1;
+        constexpr bool SPREAD = WS_READ_SPREAD >= 0 ? WS_READ_SPREAD != 0 : MICRO;
+        if (SPREAD ? m == 0 : m == 0) a[nxt][0] = lds_read(aptr[dx][kk], buf * HALO_BYTES + (0 + dy) * ROW_BYTES);
+        if (SPREAD ? m == 1 : m == 0) a[nxt][1] = lds_read(aptr[dx][kk], buf * HALO_BYTES + (1 + dy) * ROW_BYTES);
+        if (SPREAD ? m == 2 : m == 0) w[nxt][0] = lds_read(wptr[hiw][kk], (tap - 7 * hiw) * 8192 + 0 * 4096);
+        if (SPREAD ? m == 3 : m == 0) w[nxt][1] = lds_read(wptr[hiw][kk], (tap - 7 * hiw) * 8192 + 1 * 4096);
       }
       if constexpr (MICRO) {
       if (m == 0) { epi_micro<POOL, S, 0>(ePrev, bias, accPrev, et); hooks.template at<S, 0>(); }

@@ -153,3 +153,24 @@ def test_bf16_batch_equals_single():
         assert a.K == b.K and np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.descriptors, b.descriptors)
     e1.close()
     eb.close()
+
+
+def test_bf16_queue_order_equals_static_order(monkeypatch):
+    """The Cin = 128 layers take their work items from a per-XCD queue when a launch has >= 5 items per workgroup
+    (conv_bf16.hip, CtlB::dyn; SPFE_BF16_DYN_QUEUE=0 = the static split): which workgroup computes a tile must
+    not change a bit.  1280x720 x 8 puts conv3b and convPa|Da on the queue."""
+    H, W, nf, B = 720, 1280, 1000, 8
+    blob = weights.synthetic(7, "sparse")
+    imgs = [synth.make_image(300 + i, H, W) for i in range(B)]
+    out = {}
+    for dyn in ("1", "0"):
+        monkeypatch.setenv("SPFE_BF16_DYN_QUEUE", dyn)
+        ext = SPExtractor(nf, H, W, blob, max_batch=B, precision="bf16", with_heat=False)
+        frs = ext.extract_batch(imgs)
+        out[dyn] = (frs, [ext.debug_read("semi", i) for i in (0, 3, 7)], [ext.debug_read("coarse", i) for i in (0, 7)])
+        ext.close()
+    for a, b in zip(out["1"][1] + out["1"][2], out["0"][1] + out["0"][2]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for a, b in zip(out["1"][0], out["0"][0]):
+        assert a.K == b.K and np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.descriptors, b.descriptors)
+        assert np.array_equal(a.cov2, b.cov2)
