@@ -187,12 +187,15 @@ def main():
             "config": {"workload": "%dx%d u8 frames, num_features=%d, %s, %d frames/GPU/step, "
                                    "%s synthetic detector weights; records all-gathered over RCCL when n_gpus>1; %s"
                                    % (W, H, nf,
-                                      "bf16 MFMA convolutions (f32 accumulate), f32 heads and post-processing"
+                                      "bf16 MFMA convolutions and heads (f32 accumulate), f32 post-processing"
                                       if bf16 else "f32 MFMA", B, args.detector,
                                       "covariance stage on the device, synchronous" if args.sync_cov else
                                       "covariance of step i overlapped with the convolutions of step i+1 (depth-2 pipeline)"),
                        "frames_per_gpu": B, "height": H, "width": W, "num_features": nf,
-                       "parallelism": "dp%d" % world},
+                       "parallelism": "dp%d" % world,
+                       "gather": ("none (1 GPU)" if world == 1 else
+                                  "ncclAllGather inside libspfe (spfe_allgather_records)" if getattr(sharded, "_native", False)
+                                  else "torch.distributed all_gather_into_tensor")},
             "roofline": roofline_of(args.precision, stages, H, W, B, traffic),
             "whole_path_tflops": round(fps * flop_frame / 1e12, 2) if flop_frame else None,
         }

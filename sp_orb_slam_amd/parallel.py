@@ -171,6 +171,10 @@ class ShardedExtractor:
                 import torch.distributed as dist
 
                 native_comm = dist.is_initialized() and dist.get_backend() == "nccl"
+        import os
+
+        if os.environ.get("SPFE_NATIVE_COMM") == "0":   # force torch.distributed's all-gather
+            native_comm = False
         self._native = bool(native_comm) and gather_fn is None
         self._collective = world > 1 or gather_fn is not None or self._native
         nbuf = 3 if extractor.async_cov else (2 if self._collective else 1)
@@ -187,7 +191,25 @@ class ShardedExtractor:
                 import torch.distributed as dist
 
                 dist.broadcast(uid, 0)
-            extractor.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+            ok = 1
+            try:
+                extractor.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+            except Exception as e:   # RCCL missing / init failure on this rank
+                ok, self.native_comm_error = 0, str(e)
+            if world > 1:
+                # every rank takes the same path: one failed communicator sends all of them to torch's all-gather
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if not ok:
+                try:
+                    extractor.comm_destroy()
+                except Exception:
+                    pass
+                if world == 1:
+                    raise RuntimeError("spfe_comm_init failed: %s" % getattr(self, "native_comm_error", "?"))
+                self._native = False
+        if self._native:
             # the library's communication stream, wrapped so torch events can be recorded on it
             self.comm = torch.cuda.ExternalStream(extractor.comm_stream())
         else:
