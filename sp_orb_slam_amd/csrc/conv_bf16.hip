@@ -256,7 +256,7 @@ __device__ __forceinline__ void aim_epi_bias_b(const ConvParams &p, const CtlB<N
 //   m2, m3: sub-items of the PREVIOUS tile's epilogue (first stage of a tile only)
 template <int STEP, int NSTEP, bool FIRST, int PREP, int CIN, int TH, int MT, int NT, int NITER, int NWITER,
           bool POOL, bool OUT_F32>
-__device__ __forceinline__ void k_steps_b(const ConvParams &p, bf16x8 (&a)[3][MT], bf16x8 (&bb)[3][NT],
+__device__ __forceinline__ void k_steps_b(const ConvParams &p, bf16x8 (&a)[2][MT + 2], bf16x8 (&bb)[3][NT],
                                           f32x16 (&acc)[MT][NT], const f32x16 (&accPrev)[MT][NT],
                                           PipeB<NITER, NWITER> &c, CtlB<NITER, NT> &t, EpiB<NT> &eMine,
                                           const EpiB<NT> &ePrev, EpiHold &hold) {
@@ -268,19 +268,27 @@ __device__ __forceinline__ void k_steps_b(const ConvParams &p, bf16x8 (&a)[3][MT
     constexpr int DPS = NLD > 10 ? 2 : 1;        // LDS-direct passes per step
     constexpr int S0 = (NLD + DPS - 1) / DPS;    // first step without passes
     static_assert(S0 + 1 + NITER <= NSTEP, "side work does not fit the stage");
-    // operand fragments live in a ring of three K steps: a step's MFMAs take 4 x 32 cycles, less than
-    // an LDS round trip under load, so the fragments of step s + 2 are requested during step s
+    // operand fragments are requested two K steps ahead (a step's MFMAs take 4 x 32 cycles, less than an LDS round trip
+    // under load): weights in a ring of three steps, halo rows per K group (below)
     constexpr int cur = STEP % 3, nxt = (STEP + 2) % 3;
     constexpr int M = MT * NT;
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       if (m == 0) {
         if constexpr (STEP + 2 < NSTEP) {
-          constexpr int tap = (STEP + 2) / 2, kk = (STEP + 2) % 2;
-          constexpr int dy = tap / 3, dx = tap % 3;
+          // K order inside the 32-channel chunk: dx -> 16-channel group -> dy (conv_bf16_ws.hip shares fragments across
+          // the three vertical taps; the order is the same here so that the two kernels stay bit-identical)
+          constexpr int s2 = STEP + 2, dx = s2 / 6, kk = (s2 % 6) / 3, dy = s2 % 3, tap = dy * 3 + dx;
+          // halo rows of K group g = step / 3 live in a[g % 2][0 .. MT + 1]: rows 0 .. MT - 1 are read for dy = 0,
+          // row MT - 1 + dy for the two taps below — the three vertical taps share them
+          constexpr int gp = (s2 / 3) % 2;
+          if constexpr (dy == 0) {
 #pragma unroll
-          for (int i = 0; i < MT; ++i)
-            a[nxt][i] = *reinterpret_cast<const bf16x8 *>(c.aBase + ((i + dy) * 34 + dx) * BPITCH + kk * 32);
+            for (int i = 0; i < MT; ++i)
+              a[gp][i] = *reinterpret_cast<const bf16x8 *>(c.aBase + (i * 34 + dx) * BPITCH + kk * 32);
+          } else {
+            a[gp][MT - 1 + dy] = *reinterpret_cast<const bf16x8 *>(c.aBase + ((MT - 1 + dy) * 34 + dx) * BPITCH + kk * 32);
+          }
 #pragma unroll
           for (int j = 0; j < NT; ++j)
             bb[nxt][j] = *reinterpret_cast<const bf16x8 *>(c.bBase + (tap * 64 + j * 32) * BPITCH + kk * 32);
@@ -330,9 +338,9 @@ __device__ __forceinline__ void k_steps_b(const ConvParams &p, bf16x8 (&a)[3][MT
           f32x16 z;
 #pragma unroll
           for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb[cur][j], a[cur][i], z, 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb[cur][j], a[(STEP / 3) % 2][i + STEP % 3], z, 0, 0, 0);
         } else {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb[cur][j], a[cur][i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb[cur][j], a[(STEP / 3) % 2][i + STEP % 3], acc[i][j], 0, 0, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -478,18 +486,19 @@ __global__ __launch_bounds__(256, 1) void conv_bf16_kernel(ConvParams p) {
     for (int q = 0; q < 8; ++q) epiA.bias[j][q] = epiB.bias[j][q] = (f32x2){0.0f, 0.0f};
 
   int buf = 0;
-  bf16x8 a[3][MT], bb[3][NT];
+  bf16x8 a[2][MT + 2], bb[3][NT];
   auto begin_stage = [&]() {  // operand bases of the stage in `buf`, DMA targets in the other buffer, first fragments
     c.nA = lds_a(buf ^ 1) + wave_slot;
     c.nW = lds_w(buf ^ 1) + wave_slot;  // (unused with resident weights)
     c.aBase = lds_a(buf) + ((t.wm * MT) * 34 + t.l31) * BPITCH + t.hi * 16;
     c.bBase = lds_w(RESW ? t.chunk : buf) + t.l31 * BPITCH + t.hi * 16;
+    // K steps 0 and 1: taps (dy = 0, dx = 0) and (1, 0), channels 0-15: halo rows 0 .. MT of group 0
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {  // K steps 0 and 1: tap 0, channels 0-15 and 16-31
+    for (int i = 0; i <= MT; ++i) a[0][i] = *reinterpret_cast<const bf16x8 *>(c.aBase + (i * 34) * BPITCH);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a[st][i] = *reinterpret_cast<const bf16x8 *>(c.aBase + (i * 34) * BPITCH + st * 32);
+    for (int st = 0; st < 2; ++st) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bb[st][j] = *reinterpret_cast<const bf16x8 *>(c.bBase + (j * 32) * BPITCH + st * 32);
+      for (int j = 0; j < NT; ++j) bb[st][j] = *reinterpret_cast<const bf16x8 *>(c.bBase + (st * 3 * 64 + j * 32) * BPITCH);
     }
   };
   auto end_stage = [&]() {

@@ -241,13 +241,45 @@ __device__ __forceinline__ void epi_micro(const Epi &e, const float (&bias)[2], 
 // waits for — its last reads of this tile's buffer (step 35's, issued at step 33), which is all the barrier has to say to the
 // producers ("the buffer is free") and all it has to hear from them ("the next halo is in LDS").
 // hooks.at<S, M>() — the caller's side work that needs runtime state (next tile's descriptor, epilogue geometry).
+// K order (both bf16 kernels, so that they stay bit-identical): 32-channel chunk -> dx -> 16-channel group -> dy, i.e. the three
+// VERTICAL taps of a column are consecutive steps.  Step (group g = (chunk, dx, k-group), dy) multiplies halo rows i + dy
+// (i = 0, 1: the wave's two output rows) with the weights of tap (dy, dx): the four halo rows of a group are read ONCE
+// (2 + 1 + 1 fragments over its three steps) instead of 2 per step — 120 LDS fragment reads per tile instead of 144.  The
+// LDS operand traffic is what costs this kernel its clock.
+struct KStep {
+  int chunk, dx, k2, dy, kk, tap, hiw, g;
+};
+__device__ constexpr KStep kstep_of(int s) {
+  const int chunk = s / 18, r = s % 18, dx = r / 6, k2 = (r % 6) / 3, dy = r % 3;
+  return KStep{chunk, dx, k2, dy, chunk * 2 + k2, dy * 3 + dx, dy * 3 + dx >= 7 ? 1 : 0, s / 3};
+}
+// the fragments step T (0..35 of this tile; 36, 37 = steps 0, 1 of the next one, other halo buffer) needs and no earlier
+// step of its group has read: halo rows 0, 1 at dy = 0, row dy + 1 after that; the step's two weight fragments
+template <int T, int BUF, int PART>
+__device__ __forceinline__ void read_frags(bf16x8 (&ah)[2][4], bf16x8 (&w)[3][2], lds_char *const (&aptr)[3][4],
+                                           lds_char *const (&wptr)[2][4]) {
+  constexpr KStep k = kstep_of(T % NSTEP);
+  constexpr int buf = T < NSTEP ? BUF : BUF ^ 1, gp = (T / 3) % 2, ws = T % 3;
+  // PART: 0..3 = one fragment each (spread over the gaps), -1 = all of them
+  if constexpr (PART == 0 || PART < 0) {
+    if constexpr (k.dy == 0) ah[gp][0] = lds_read(aptr[k.dx][k.kk], buf * HALO_BYTES + 0 * ROW_BYTES);
+    else ah[gp][k.dy + 1] = lds_read(aptr[k.dx][k.kk], buf * HALO_BYTES + (k.dy + 1) * ROW_BYTES);
+  }
+  if constexpr (PART == 1 || PART < 0) w[ws][0] = lds_read(wptr[k.hiw][k.kk], (k.tap - 7 * k.hiw) * 8192 + 0 * 4096);
+  if constexpr (PART == 2 || PART < 0) w[ws][1] = lds_read(wptr[k.hiw][k.kk], (k.tap - 7 * k.hiw) * 8192 + 1 * 4096);
+  if constexpr (PART == 3 || PART < 0) {
+    if constexpr (k.dy == 0) ah[gp][1] = lds_read(aptr[k.dx][k.kk], buf * HALO_BYTES + 1 * ROW_BYTES);
+  }
+}
+
 template <int S, bool POOL, int BUF, bool MICRO, typename Hooks>
-__device__ __forceinline__ void k_steps(bf16x8 (&a)[3][2], bf16x8 (&w)[3][2], f32x16 (&acc)[2][2],
+__device__ __forceinline__ void k_steps(bf16x8 (&ah)[2][4], bf16x8 (&w)[3][2], f32x16 (&acc)[2][2],
                                         const f32x16 (&accPrev)[2][2], const float (&bias)[2],
                                         lds_char *const (&aptr)[3][4], lds_char *const (&wptr)[2][4],
                                         const Epi &ePrev, EpiTmp &et, Hooks &hooks) {
   if constexpr (S < NSTEP) {
-    constexpr int cur = S % 3, nxt = (S + 2) % 3;
+    constexpr KStep ks = kstep_of(S);
+    constexpr int gp = ks.g % 2, cur = S % 3;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       if (m == 0) {
@@ -257,16 +289,17 @@ __device__ __forceinline__ void k_steps(bf16x8 (&a)[3][2], bf16x8 (&w)[3][2], f3
         }
       }
       if constexpr (WS_ABLATE != 4) {
-        // the operand fragments of step S + 2: one per gap where the epilogue is spread too (+1 %), else all four behind the
+        // the operand fragments of step S + 2: one per gap where the epilogue is spread too (+1 %), else all behind the
         // first MFMA (probe builds: WS_READ_SPREAD forces either)
-        constexpr int s2 = (S + 2) % NSTEP, chunk = s2 / 18, tap = (s2 % 18) / 2, kk = chunk * 2 + (s2 % 2);
-        constexpr int dy = tap / 3, dx = tap % 3, hiw = tap >= 7 ? 1 : 0;
-        constexpr int buf = S + 2 < NSTEP ? BUF : BUF ^ 1;
         constexpr bool SPREAD = WS_READ_SPREAD >= 0 ? WS_READ_SPREAD != 0 : MICRO;
-        if (SPREAD ? m == 0 : m == 0) a[nxt][0] = lds_read(aptr[dx][kk], buf * HALO_BYTES + (0 + dy) * ROW_BYTES);
-        if (SPREAD ? m == 1 : m == 0) a[nxt][1] = lds_read(aptr[dx][kk], buf * HALO_BYTES + (1 + dy) * ROW_BYTES);
-        if (SPREAD ? m == 2 : m == 0) w[nxt][0] = lds_read(wptr[hiw][kk], (tap - 7 * hiw) * 8192 + 0 * 4096);
-        if (SPREAD ? m == 3 : m == 0) w[nxt][1] = lds_read(wptr[hiw][kk], (tap - 7 * hiw) * 8192 + 1 * 4096);
+        if constexpr (SPREAD) {
+          if (m == 0) read_frags<S + 2, BUF, 0>(ah, w, aptr, wptr);
+          if (m == 1) read_frags<S + 2, BUF, 1>(ah, w, aptr, wptr);
+          if (m == 2) read_frags<S + 2, BUF, 2>(ah, w, aptr, wptr);
+          if (m == 3) read_frags<S + 2, BUF, 3>(ah, w, aptr, wptr);
+        } else {
+          if (m == 0) read_frags<S + 2, BUF, -1>(ah, w, aptr, wptr);
+        }
       }
       if constexpr (MICRO) {
       if (m == 0) { epi_micro<POOL, S, 0>(ePrev, bias, accPrev, et); hooks.template at<S, 0>(); }
@@ -291,14 +324,14 @@ __device__ __forceinline__ void k_steps(bf16x8 (&a)[3][2], bf16x8 (&w)[3][2], f3
           f32x16 z;
 #pragma unroll
           for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][i], w[cur][j], z, 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[gp][i + ks.dy], w[cur][j], z, 0, 0, 0);
         } else {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][i], w[cur][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[gp][i + ks.dy], w[cur][j], acc[i][j], 0, 0, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    k_steps<S + 1, POOL, BUF, MICRO>(a, w, acc, accPrev, bias, aptr, wptr, ePrev, et, hooks);
+    k_steps<S + 1, POOL, BUF, MICRO>(ah, w, acc, accPrev, bias, aptr, wptr, ePrev, et, hooks);
   }
 }
 
@@ -584,7 +617,7 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
   epiA.rout = epiB.rout = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0u, 0x00020000);  // nothing to store yet
   epiA.rowoff[0] = epiA.rowoff[1] = epiB.rowoff[0] = epiB.rowoff[1] = OOB;
   epiA.pitch = epiB.pitch = out_pix_bytes;
-  bf16x8 a[3][2], w[3][2];
+  bf16x8 ah[2][4], w[3][2];   // halo-row fragments of two K groups, weight fragments of three steps
 
   auto aim_epi = [&](const TileDesc &d, Epi &e) {
     char *obase = reinterpret_cast<char *>(p.out) + ((size_t)d.b * Ho * Wo * p.out_stride + p.out_choff) * 2;
@@ -629,7 +662,7 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
     WS_T(ch0);
     hooks.eMine = &eMine;
     hooks.t = t;
-    if (WS_ABLATE != 2) k_steps<0, POOL, BUF, EPI_MICRO>(a, w, acc, accPrev, bias, aptr, wptr, ePrev, et, hooks);
+    if (WS_ABLATE != 2) k_steps<0, POOL, BUF, EPI_MICRO>(ah, w, acc, accPrev, bias, aptr, wptr, ePrev, et, hooks);
     else { hooks.template at<3, 1>(); hooks.template at<24, 1>(); hooks.template at<28, 1>(); __builtin_amdgcn_s_waitcnt(0xC07F); wg_barrier(); }
     WS_T(c1);
 #ifdef WS_PROBE_TIMING
@@ -641,14 +674,9 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
   };
   hooks.dc = read_slot(0);
   if (hooks.dc.valid) {
-    // K steps 0 and 1 of the first tile: tap 0, k-groups 0 and 1 (every later tile's come from steps 34 / 35 of its predecessor)
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) a[st][i] = lds_read(aptr[0][st], i * ROW_BYTES);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) w[st][j] = lds_read(wptr[0][st], j * 4096);
-    }
+    // K steps 0 and 1 of the first tile (every later tile's come from steps 34 / 35 of its predecessor)
+    read_frags<0, 0, -1>(ah, w, aptr, wptr);
+    read_frags<1, 0, -1>(ah, w, aptr, wptr);
     while (true) {
       any = true;
       lastA = true;
