@@ -382,6 +382,11 @@ int build(spfe_handle h, const spfe_config *cfg) {
     if (wenv) h->ws_mask = (unsigned)strtoul(wenv, nullptr, 0) & 0xfu;
     const char *f16env = getenv("SPFE_BF16_FUSE_CONV1A");
     if (f16env) h->fuse1a_bf16 = atoi(f16env) != 0;
+    // Synchronous calls (latency): the wave-specialised kernel wins from ~5 items per workgroup (batch 1 at 752x480: 0.43 ->
+    // 0.385 ms, conv1a fused).  Pipelined calls (SPFE_FLAG_ASYNC_COV): it holds all of a CU's LDS, the side-stream kernels of
+    // the previous batch cannot start beside it, and at 752x480 x 8 (0.65 ms steps) their chain becomes the critical path
+    // when the quarter-resolution layers take it too (12,450 -> 12,050 frames/s): those keep the higher bar.
+    h->ws_min_items = (cfg->flags & SPFE_FLAG_ASYNC_COV) ? 11 : 5;
     const char *ienv = getenv("SPFE_BF16_WS_MIN_ITEMS");
     if (ienv) h->ws_min_items = atoi(ienv);
     const char *denv = getenv("SPFE_BF16_DYN_QUEUE");

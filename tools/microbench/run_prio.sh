@@ -1,3 +1,3 @@
-python bench.py --frames-per-gpu 1 --sync-cov --no-cpu-baseline --no-bf16-leg --no-host-path --no-match --no-aten --latency-calls 200 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['latency_batch1_ms'], d.get('stage_ms'))"
-python bench.py --frames-per-gpu 1 --sync-cov --precision bf16 --no-cpu-baseline --no-bf16-leg --no-host-path --no-match --no-aten --latency-calls 200 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['latency_batch1_ms'], d.get('stage_ms'))"
-python bench.py --frames-per-gpu 1 --sync-cov --detector sparse --no-cpu-baseline --no-bf16-leg --no-host-path --no-match --no-aten --latency-calls 200 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['latency_batch1_ms'], d.get('stage_ms'))"
+for m in "" "--height 720 --width 1280" "--sync-cov" "--sync-cov --height 720 --width 1280"; do
+  python bench.py --precision bf16 $m --no-cpu-baseline --no-bf16-leg --no-host-path --no-match --no-aten --no-stage-table --latency-calls 300 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$m', d['value'], d['ms_per_step'], d['latency_batch1_ms']['p50'], d['roofline']['frac'])"
+done
