@@ -52,14 +52,15 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
 }
 
 constexpr int BKC = 32;       // channels per K chunk
-constexpr int BPITCH = 80;    // bytes per pixel / weight row in LDS and in the packed slabs (64 + 16 pad)
+constexpr int BPITCH = 64;    // bytes per pixel / weight row in LDS and in the packed slabs: 32 channels, no padding;
+                              // piece g (16 B) of column / row c sits in slot g ^ ((c >> 2) & 3)
 
 template <int TH>
 struct GeoB {
   static constexpr int ROWS = TH + 2, COLS = 34;
-  static constexpr int A_PIECES = ROWS * COLS * (BPITCH / 16);  // 16-byte pieces, the pad piece included
+  static constexpr int A_PIECES = ROWS * COLS * (BPITCH / 16);  // 16-byte pieces
   static constexpr int A_BYTES = (A_PIECES + 255) / 256 * 256 * 16;  // whole 256-lane passes
-  static constexpr int W_BYTES = 12 * 256 * 16;  // 9 * 64 * BPITCH = 46080, padded to whole 256-thread passes
+  static constexpr int W_BYTES = 9 * 64 * BPITCH;  // 36,864 = 9 whole 256-thread passes
   static constexpr int BUF_BYTES = A_BYTES + W_BYTES;
 };
 
@@ -70,7 +71,8 @@ struct PipeB {
   unsigned voff[NITER];    // byte offset of each input piece inside the input frame, or SPFE_OOB
   unsigned woff;           // tid * 16: byte offset inside the weight slab (== LDS offset) of pass 0
   __amdgpu_buffer_rsrc_t rin, rw;
-  const char *aBase, *bBase;  // this stage's operands (LDS)
+  const char *aBase, *bBase;  // this stage's operands (LDS): buffer bases; + the per-lane offsets below + immediates
+  unsigned aofs[3][2], bofs[2];   // [dx][16-channel group]: this lane's pixel column / weight row and its swizzled piece
   char *nA, *nW;              // the other LDS buffer, at this wave's 1 KiB slot of pass 0
 
   // one direct-to-LDS pass: 256 lanes x 16 bytes; pass IT lands at +4096 * IT
@@ -139,7 +141,11 @@ __device__ __forceinline__ void epi_item(const EpiB<NT> &e, EpiHold &hold, const
         __builtin_amdgcn_raw_buffer_store_b128(d, e.rout, e.rowoff[i] + cb, 0, 0);
       } else {
         const u32x2 d = {hold.h16, __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2))};
+#ifndef B_NO_STORES   // (ablation builds)
         __builtin_amdgcn_raw_buffer_store_b64(d, e.rout, e.rowoff[i] + cb, 0, 0);
+#else
+        if (d.x == 0x12345678u && d.y == 0x9abcdef0u) __builtin_amdgcn_raw_buffer_store_b64(d, e.rout, e.rowoff[i] + cb, 0, 0);
+#endif
       }
     }
   }
@@ -285,13 +291,13 @@ __device__ __forceinline__ void k_steps_b(const ConvParams &p, bf16x8 (&a)[2][MT
           if constexpr (dy == 0) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
-              a[gp][i] = *reinterpret_cast<const bf16x8 *>(c.aBase + (i * 34 + dx) * BPITCH + kk * 32);
+              a[gp][i] = *reinterpret_cast<const bf16x8 *>(c.aBase + c.aofs[dx][kk] + (i * 34) * BPITCH);
           } else {
-            a[gp][MT - 1 + dy] = *reinterpret_cast<const bf16x8 *>(c.aBase + ((MT - 1 + dy) * 34 + dx) * BPITCH + kk * 32);
+            a[gp][MT - 1 + dy] = *reinterpret_cast<const bf16x8 *>(c.aBase + c.aofs[dx][kk] + ((MT - 1 + dy) * 34) * BPITCH);
           }
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            bb[nxt][j] = *reinterpret_cast<const bf16x8 *>(c.bBase + (tap * 64 + j * 32) * BPITCH + kk * 32);
+            bb[nxt][j] = *reinterpret_cast<const bf16x8 *>(c.bBase + c.bofs[kk] + (tap * 64 + j * 32) * BPITCH);
         }
         if constexpr (PREP == 2 && STEP < NT * 2) {  // this tile's bias (early: they are vmcnt loads too)
           aim_epi_bias_b<NT, NITER, STEP * 2>(p, t, eMine);
@@ -419,15 +425,24 @@ __global__ __launch_bounds__(256, 1) void conv_bf16_kernel(ConvParams p) {
 #pragma unroll
   for (int it = 0; it < NITER; ++it) {
     const int i = tid + it * 256;
-    const int qq = i % 5, pix = i / 5;
-    // the pad piece of a pixel and the pieces past the tile read out of range (-> zeros)
-    t.prow[it] = (i < NITEM && qq < 4) ? pix / G::COLS - 1 : (1 << 20);
-    t.pcol[it] = pix % G::COLS - 1;
-    t.pqb[it] = qq * 16;
+    const int slot = i % 4, pix = i / 4, col = pix % G::COLS;
+    // pieces past the tile read out of range (-> zeros); the source piece is the slot's un-swizzled index
+    t.prow[it] = i < NITEM ? pix / G::COLS - 1 : (1 << 20);
+    t.pcol[it] = col - 1;
+    t.pqb[it] = (unsigned)((slot ^ ((col >> 2) & 3)) * 16);
   }
 
   PipeB<NITER, NWITER> c;
   c.woff = (unsigned)tid * 16u;
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int col = t.l31 + dx;
+      c.aofs[dx][kk] = (unsigned)(((t.wm * MT) * 34 + col) * BPITCH + (((2 * kk + t.hi) ^ ((col >> 2) & 3)) * 16));
+    }
+    c.bofs[kk] = (unsigned)(t.l31 * BPITCH + (((2 * kk + t.hi) ^ ((t.l31 >> 2) & 3)) * 16));
+  }
   const unsigned wave_slot = (unsigned)wave * 1024u;
 
   // LDS map.  streaming weights: [A0 | W0 | A1 | W1]; resident weights: [W chunk 0 | W chunk 1 | A0 | A1]
@@ -490,15 +505,15 @@ __global__ __launch_bounds__(256, 1) void conv_bf16_kernel(ConvParams p) {
   auto begin_stage = [&]() {  // operand bases of the stage in `buf`, DMA targets in the other buffer, first fragments
     c.nA = lds_a(buf ^ 1) + wave_slot;
     c.nW = lds_w(buf ^ 1) + wave_slot;  // (unused with resident weights)
-    c.aBase = lds_a(buf) + ((t.wm * MT) * 34 + t.l31) * BPITCH + t.hi * 16;
-    c.bBase = lds_w(RESW ? t.chunk : buf) + t.l31 * BPITCH + t.hi * 16;
+    c.aBase = lds_a(buf);
+    c.bBase = lds_w(RESW ? t.chunk : buf);
     // K steps 0 and 1: taps (dy = 0, dx = 0) and (1, 0), channels 0-15: halo rows 0 .. MT of group 0
 #pragma unroll
-    for (int i = 0; i <= MT; ++i) a[0][i] = *reinterpret_cast<const bf16x8 *>(c.aBase + (i * 34) * BPITCH);
+    for (int i = 0; i <= MT; ++i) a[0][i] = *reinterpret_cast<const bf16x8 *>(c.aBase + c.aofs[0][0] + (i * 34) * BPITCH);
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bb[st][j] = *reinterpret_cast<const bf16x8 *>(c.bBase + (st * 3 * 64 + j * 32) * BPITCH);
+      for (int j = 0; j < NT; ++j) bb[st][j] = *reinterpret_cast<const bf16x8 *>(c.bBase + c.bofs[0] + (st * 3 * 64 + j * 32) * BPITCH);
     }
   };
   auto end_stage = [&]() {

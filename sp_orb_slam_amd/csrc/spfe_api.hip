@@ -276,7 +276,8 @@ int pack_layer_bf16(spfe_handle h, const float *blob, const int *lids, int nl, C
         const int ch = ci / 32, c = ci % 32;
         for (int t = 0; t < taps; ++t) {
           const unsigned short v = host_bf16_rne(W[((size_t)co * cin + ci) * taps + t]);
-          memcpy(&w[((size_t)nb * nchunk + ch) * slab + ((size_t)t * 64 + j) * 80 + c * 2], &v, 2);
+          // row (tap, cout) = 64 B: 4 pieces of 8 channels, piece g in slot g ^ ((cout >> 2) & 3) (conv_bf16.hip's LDS layout)
+          memcpy(&w[((size_t)nb * nchunk + ch) * slab + ((size_t)t * 64 + j) * 64 + (((c / 8) ^ ((j >> 2) & 3)) * 16) + (c % 8) * 2], &v, 2);
         }
       }
     }
