@@ -94,59 +94,68 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// Accumulator layout after mfma(weights, pixels): lane = (pixel column p = lane & 31, hi = lane >> 5),
-// register r <-> output channel j*32 + 8*(r>>2) + 4*hi + (r&3).  Register PAIR q (r = 2q, 2q+1) <->
-// channels j*32 + 8*(q>>1) + 4*hi + 2*(q&1) + {0,1}; pairs 2g, 2g+1 make the 4-channel group g.
-template <int NT>
+// Accumulator layout after mfma(pixels, weights): lane = (output channel, hi = lane >> 5), register r <-> pixel column
+// 8*(r>>2) + 4*hi + (r&3) of the wave's row i.  The packed weights put the block's EVEN channels in accumulator tile
+// j = 0 and the ODD ones in tile j = 1 (row m of tile j <-> channel 2 m + j), so a lane holds the adjacent channels
+// 2 l31, 2 l31 + 1 of every pixel it has: one v_cvt_pk_bf16_f32 packs them and one dword store per register writes, for
+// the 32 lanes of each half, the 64 consecutive bf16 channels (128 B) of ONE pixel — as in conv_bf16_ws.hip.  (The
+// transposed form this kernel had — a lane owns a pixel, 8-byte pieces scattered over 32-64 cache lines per store —
+// cost convPa|Da 0.024 of its 0.153 ms, and its per-register bias took 64 VGPRs that the 16-row tiles need.)
+// Columns past the image (ragged last tile, images narrower than 32) are predicated per store: wlim = W - x0 - 4 hi.
+template <int MT>
 struct EpiB {
   __amdgpu_buffer_rsrc_t rout;
-  unsigned rowoff[2];  // byte offset of this lane's pixel (+ its 4*hi channels) in output row i (pool: [0]), or OOB
-  f32x2 bias[NT][8];   // bias of pair q
+  unsigned rowoff[MT];  // byte offset of (row i [pool: pooled row i], column x0 + 4 hi [pool: its half], this lane's
+                        // channel pair) in the output frame, or OOB
+  unsigned pitch;       // bytes per output pixel
+  int wlim;             // valid pixel columns of this lane's half: register column cc = 8 (r >> 2) + (r & 3) < wlim
+  float bias[2];        // this lane's even / odd channel
 };
-struct EpiHold {       // first pair of a 4-channel group, waiting for the second
-  unsigned h16;
-  f32x2 h32;
-};
+struct EpiHold {};      // (kept for the signatures)
 
-__device__ __forceinline__ float dpp_xor1(float v) {  // the value of lane ^ 1
-  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+__device__ __forceinline__ float bmax_nc(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float bmax3_nc(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float brelu_nc(float a) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a));
+  return r;
+}
+__device__ __forceinline__ unsigned bpack2(float v0, float v1) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v0, v1}, bf16x2));
 }
 
-// Sub-item E of the epilogue: one register pair of one accumulator tile (no pool: MT*NT*8 of them;
-// pool: NT*8, each folding the wave's two rows and the neighbouring pixel column).
+// Sub-item E of the epilogue.  pool: (MT / 2) * 8 items — pooled row ip = E / 8, g = (E / 2) % 4, h2 = E % 2: one pooled
+// pixel, both channels.  no pool: MT * 16 items — row i = E / 16, g = (E / 4) % 4, m = E % 4: one pixel.
+// Bias last (max(a + b, c + b) == max(a, c) + b exactly): the bits of conv_bf16_ws.hip's epilogue.
 template <int MT, int NT, bool POOL, bool OUT_F32, int E>
-__device__ __forceinline__ void epi_item(const EpiB<NT> &e, EpiHold &hold, const f32x16 (&acc)[MT][NT]) {
-  constexpr int NEPI_ = (POOL ? 1 : MT) * NT * 8;
+__device__ __forceinline__ void epi_item(const EpiB<MT> &e, EpiHold &, const f32x16 (&acc)[MT][NT]) {
+  static_assert(NT == 2 && !OUT_F32, "bf16 outputs, channel pairs across the two accumulator tiles");
+  constexpr int NEPI_ = POOL ? (MT / 2) * 8 : MT * 16;
   if constexpr (E < NEPI_) {
-    constexpr int q = E % 8, j = (E / 8) % NT, i = POOL ? 0 : E / (8 * NT);
-    constexpr unsigned OEL = OUT_F32 ? 4u : 2u;
-    f32x2 v = (f32x2){acc[i][j][2 * q], acc[i][j][2 * q + 1]} + e.bias[j][q];
     if constexpr (POOL) {
-      static_assert(MT == 2, "pool folds the wave's two rows");
-      const f32x2 w = (f32x2){acc[1][j][2 * q], acc[1][j][2 * q + 1]} + e.bias[j][q];
-      v = __builtin_elementwise_max(v, w);
-      v.x = __builtin_fmaxf(__builtin_fmaxf(v.x, dpp_xor1(v.x)), 0.0f);
-      v.y = __builtin_fmaxf(__builtin_fmaxf(v.y, dpp_xor1(v.y)), 0.0f);
-    } else {
-      v = __builtin_elementwise_max(v, (f32x2){0.0f, 0.0f});
-    }
-    if constexpr ((q & 1) == 0) {
-      if constexpr (OUT_F32) hold.h32 = v;
-      else hold.h16 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-    } else {
-      constexpr unsigned cb = (unsigned)(j * 32 + 8 * (q >> 1)) * OEL;
-      if constexpr (OUT_F32) {
-        const u32x4 d = {__float_as_uint(hold.h32.x), __float_as_uint(hold.h32.y), __float_as_uint(v.x),
-                         __float_as_uint(v.y)};
-        __builtin_amdgcn_raw_buffer_store_b128(d, e.rout, e.rowoff[i] + cb, 0, 0);
-      } else {
-        const u32x2 d = {hold.h16, __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2))};
-#ifndef B_NO_STORES   // (ablation builds)
-        __builtin_amdgcn_raw_buffer_store_b64(d, e.rout, e.rowoff[i] + cb, 0, 0);
-#else
-        if (d.x == 0x12345678u && d.y == 0x9abcdef0u) __builtin_amdgcn_raw_buffer_store_b64(d, e.rout, e.rowoff[i] + cb, 0, 0);
-#endif
+      constexpr int ip = E / 8, g = (E / 2) % 4, h2 = E % 2, r = 4 * g + 2 * h2, i0 = 2 * ip;
+      float v[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        v[j] = bmax3_nc(acc[i0][j][r], acc[i0][j][r + 1], bmax_nc(acc[i0 + 1][j][r], acc[i0 + 1][j][r + 1]));
+        v[j] = brelu_nc(v[j] + e.bias[j]);
       }
+      constexpr int cc = 8 * g + 2 * h2;   // first of the two input columns of this pooled pixel (widths are even)
+      const unsigned off = cc < e.wlim ? e.rowoff[ip] : SPFE_OOB;
+      __builtin_amdgcn_raw_buffer_store_b32(bpack2(v[0], v[1]), e.rout, off, (unsigned)(4 * g + h2) * e.pitch, 0);
+    } else {
+      constexpr int i = E / 16, g = (E / 4) % 4, m = E % 4, cc = 8 * g + m;
+      const float v0 = brelu_nc(acc[i][0][4 * g + m] + e.bias[0]), v1 = brelu_nc(acc[i][1][4 * g + m] + e.bias[1]);
+      const unsigned off = cc < e.wlim ? e.rowoff[i] : SPFE_OOB;
+      __builtin_amdgcn_raw_buffer_store_b32(bpack2(v0, v1), e.rout, off, (unsigned)cc * e.pitch, 0);
     }
   }
 }
@@ -155,8 +164,8 @@ __device__ __forceinline__ void epi_item(const EpiB<NT> &e, EpiHold &hold, const
 template <int NITER, int NT>
 struct CtlB {
   // per-lane geometry of the staging pieces (fixed for the kernel)
-  int prow[NITER], pcol[NITER];
-  unsigned pqb[NITER];
+  int prc[NITER];   // halo (row << 8 | column) of this lane's piece in pass it, or a row far outside
+  int pslot;        // ... and its 16-byte slot in the pixel: tid & 3
   // work items: current, next, and the per-step increment (workgroups stride through an XCD-local range)
   int i_nb, i_tx, i_ty, i_b, n_nb, n_tx, n_ty, n_b, d_nb, d_tx, d_ty, d_b;
   int w, gper, hi_w;
@@ -190,9 +199,10 @@ __device__ __forceinline__ void aim_stage_b(const ConvParams &p, PipeB<NITER, NW
 template <int TH, int NITER, int NWITER, int NT, int IT>
 __device__ __forceinline__ void aim_piece_b(PipeB<NITER, NWITER> &c, const CtlB<NITER, NT> &t, int tx, int ty) {
   if constexpr (IT < NITER) {
-    const int gy = ty * TH + t.prow[IT], gx = tx * 32 + t.pcol[IT];
+    const int col = t.prc[IT] & 0xff;
+    const int gy = ty * TH + (t.prc[IT] >> 8) - 1, gx = tx * 32 + col - 1;
     c.voff[IT] = ((unsigned)gy < (unsigned)t.H && (unsigned)gx < (unsigned)t.W)
-                     ? (unsigned)(gy * t.W + gx) * t.in_pix_bytes + t.pqb[IT]
+                     ? (unsigned)(gy * t.W + gx) * t.in_pix_bytes + (unsigned)((t.pslot ^ ((col >> 2) & 3)) * 16)
                      : SPFE_OOB;
   }
 }
@@ -225,32 +235,30 @@ __device__ __forceinline__ void next_item_b(const ConvParams &p, CtlB<NITER, NT>
   t.have_next = t.w_n < t.hi_w;
 }
 
-// epilogue context of the CURRENT tile (used one tile later), in two pieces
+// epilogue context of the CURRENT tile (used one tile later)
 template <int TH, int MT, int NT, bool POOL, bool OUT_F32, int NITER>
-__device__ __forceinline__ void aim_epi_geom_b(const ConvParams &p, const CtlB<NITER, NT> &t, EpiB<NT> &e) {
-  constexpr unsigned OEL = OUT_F32 ? 4u : 2u;
-  char *obase = reinterpret_cast<char *>(p.out) + ((size_t)t.i_b * t.Ho * t.Wo * p.out_stride + p.out_choff) * OEL;
+__device__ __forceinline__ void aim_epi_geom_b(const ConvParams &p, const CtlB<NITER, NT> &t, EpiB<MT> &e) {
+  char *obase = reinterpret_cast<char *>(p.out) + ((size_t)t.i_b * t.Ho * t.Wo * p.out_stride + p.out_choff) * 2;
   e.rout = __builtin_amdgcn_make_buffer_rsrc(obase, 0, t.frame_out_bytes, 0x00020000);
-  const int y0 = t.i_ty * TH + t.wm * MT, x = t.i_tx * 32 + t.l31;
-  const unsigned chan = (unsigned)(t.i_nb * 64 + 4 * t.hi) * OEL;
+  e.pitch = t.out_pix_bytes;
+  const int y0 = t.i_ty * TH + t.wm * MT, x0 = t.i_tx * 32;
+  e.wlim = t.W - x0 - 4 * t.hi;
+  const unsigned chan = (unsigned)(t.i_nb * 64 + 2 * t.l31) * 2u;
   if constexpr (POOL) {
-    const bool ok = x < t.W && y0 < t.H && (t.l31 & 1) == 0;
-    e.rowoff[0] = ok ? (unsigned)((y0 >> 1) * t.Wo + (x >> 1)) * t.out_pix_bytes + chan : SPFE_OOB;
-    e.rowoff[1] = SPFE_OOB;
+#pragma unroll
+    for (int ip = 0; ip < MT / 2; ++ip)
+      e.rowoff[ip] = y0 + 2 * ip < t.H ? (unsigned)(((y0 >> 1) + ip) * t.Wo + (x0 >> 1) + 2 * t.hi) * t.out_pix_bytes + chan : SPFE_OOB;
   } else {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
-      e.rowoff[i] = (x < t.W && y0 + i < t.H) ? (unsigned)((y0 + i) * t.W + x) * t.out_pix_bytes + chan : SPFE_OOB;
+      e.rowoff[i] = y0 + i < t.H ? (unsigned)((y0 + i) * t.W + x0 + 4 * t.hi) * t.out_pix_bytes + chan : SPFE_OOB;
   }
 }
-template <int NT, int NITER, int G4>
-__device__ __forceinline__ void aim_epi_bias_b(const ConvParams &p, const CtlB<NITER, NT> &t, EpiB<NT> &e) {
-  if constexpr (G4 < NT * 4) {
-    constexpr int j = G4 / 4, g = G4 % 4;
-    const float4 b4 = *reinterpret_cast<const float4 *>(p.bias + t.i_nb * 64 + 4 * t.hi + j * 32 + 8 * g);
-    e.bias[j][2 * g] = (f32x2){b4.x, b4.y};
-    e.bias[j][2 * g + 1] = (f32x2){b4.z, b4.w};
-  }
+template <int MT, int NT, int NITER>
+__device__ __forceinline__ void aim_epi_bias_b(const ConvParams &p, const CtlB<NITER, NT> &t, EpiB<MT> &e) {
+  const float2 b2 = *reinterpret_cast<const float2 *>(p.bias + t.i_nb * 64 + 2 * t.l31);
+  e.bias[0] = b2.x;
+  e.bias[1] = b2.y;
 }
 
 // One stage = NSTEP K steps of MT x NT MFMAs; all side work sits in the MFMA shadows:
@@ -264,14 +272,14 @@ template <int STEP, int NSTEP, bool FIRST, int PREP, int CIN, int TH, int MT, in
           bool POOL, bool OUT_F32>
 __device__ __forceinline__ void k_steps_b(const ConvParams &p, bf16x8 (&a)[2][MT + 2], bf16x8 (&bb)[3][NT],
                                           f32x16 (&acc)[MT][NT], const f32x16 (&accPrev)[MT][NT],
-                                          PipeB<NITER, NWITER> &c, CtlB<NITER, NT> &t, EpiB<NT> &eMine,
-                                          const EpiB<NT> &ePrev, EpiHold &hold) {
+                                          PipeB<NITER, NWITER> &c, CtlB<NITER, NT> &t, EpiB<MT> &eMine,
+                                          const EpiB<MT> &ePrev, EpiHold &hold) {
   if constexpr (STEP < NSTEP) {
-    constexpr int NEPI = (POOL ? 1 : MT) * NT * 8;             // epilogue sub-items of the previous tile
+    constexpr int NEPI = POOL ? (MT / 2) * 8 : MT * 16;        // epilogue sub-items of the previous tile
     constexpr int ES = 8;                                      // ... spread over steps 1..ES,
-    constexpr int HALF = (NEPI + 2 * ES - 1) / (2 * ES);       // HALF of them in each of the m2 / m3 shadows
+    constexpr int HALF = (NEPI + 2 * ES - 1) / (2 * ES);       // HALF of them in each of two shadows
     constexpr int NLD = NITER + NWITER;
-    constexpr int DPS = NLD > 10 ? 2 : 1;        // LDS-direct passes per step
+    constexpr int DPS = NLD > 14 ? 3 : NLD > 10 ? 2 : 1;   // LDS-direct passes per step
     constexpr int S0 = (NLD + DPS - 1) / DPS;    // first step without passes
     static_assert(S0 + 1 + NITER <= NSTEP, "side work does not fit the stage");
     // operand fragments are requested two K steps ahead (a step's MFMAs take 4 x 32 cycles, less than an LDS round trip
@@ -299,15 +307,18 @@ __device__ __forceinline__ void k_steps_b(const ConvParams &p, bf16x8 (&a)[2][MT
           for (int j = 0; j < NT; ++j)
             bb[nxt][j] = *reinterpret_cast<const bf16x8 *>(c.bBase + c.bofs[kk] + (tap * 64 + j * 32) * BPITCH);
         }
-        if constexpr (PREP == 2 && STEP < NT * 2) {  // this tile's bias (early: they are vmcnt loads too)
-          aim_epi_bias_b<NT, NITER, STEP * 2>(p, t, eMine);
-          aim_epi_bias_b<NT, NITER, STEP * 2 + 1>(p, t, eMine);
-        }
+        if constexpr (PREP == 2 && STEP == 0) aim_epi_bias_b<MT, NT, NITER>(p, t, eMine);  // this tile's bias (early: a vmcnt load too)
+      }
+      // (16-row tiles: 8 MFMAs per step, the passes one per gap at m = 1, 3, 5)
+      if constexpr (M == 8 && STEP < S0) {
+        if (m == 3) { if constexpr (DPS >= 2) c.template dma<STEP * DPS + 1>(); }
+        if (m == 5) { if constexpr (DPS >= 3) c.template dma<STEP * DPS + 2>(); }
       }
       if (m == 1 % M) {
         if constexpr (STEP < S0) {
           c.template dma<STEP * DPS>();
-          if constexpr (DPS == 2) c.template dma<STEP * DPS + 1>();
+          if constexpr (M != 8 && DPS >= 2) c.template dma<STEP * DPS + 1>();
+          if constexpr (M != 8 && DPS >= 3) c.template dma<STEP * DPS + 2>();
         } else if constexpr (PREP == 0) {
           if constexpr (STEP == S0) aim_stage_b<CIN, TH>(p, c, t.frame_in_bytes, t.i_nb, t.i_b, t.chunk + 2, true);
         } else if constexpr (PREP == 1) {
@@ -330,7 +341,7 @@ __device__ __forceinline__ void k_steps_b(const ConvParams &p, bf16x8 (&a)[2][MT
           }(std::make_integer_sequence<int, HALF>{});
         }
       }
-      if (m == 3 % M) {
+      if (m == (M == 8 ? 6 : 3 % M)) {
         if constexpr (FIRST && STEP >= 1 && STEP <= ES) {
           [&]<int... Q>(std::integer_sequence<int, Q...>) {
             (epi_item<MT, NT, POOL, OUT_F32, (STEP - 1) * 2 * HALF + HALF + Q>(ePrev, hold, accPrev), ...);
@@ -344,9 +355,9 @@ __device__ __forceinline__ void k_steps_b(const ConvParams &p, bf16x8 (&a)[2][MT
           f32x16 z;
 #pragma unroll
           for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb[cur][j], a[(STEP / 3) % 2][i + STEP % 3], z, 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(STEP / 3) % 2][i + STEP % 3], bb[cur][j], z, 0, 0, 0);
         } else {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb[cur][j], a[(STEP / 3) % 2][i + STEP % 3], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(STEP / 3) % 2][i + STEP % 3], bb[cur][j], acc[i][j], 0, 0, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -358,9 +369,11 @@ __device__ __forceinline__ void k_steps_b(const ConvParams &p, bf16x8 (&a)[2][MT
 
 // in: NHWC bf16 [B][H][W][in_stride]; wpack: bf16 slabs [nblk][chunk][tap][64 n][BPITCH bytes];
 // out: NHWC bf16 (or f32 when OUT_F32) — strides in ConvParams are in ELEMENTS.
-template <int CIN, bool POOL, bool OUT_F32>
+// MT = output rows per wave: 2 (8-row tiles) or 4 (16-row tiles: a stage's weight chunk feeds twice the MFMAs — the
+// streamed-weight layers run at the chip's LDS-DMA fill rate, and 19 passes per 144 MFMAs per wave beat 15 per 72)
+template <int CIN, bool POOL, bool OUT_F32, int MT>
 __global__ __launch_bounds__(256, 1) void conv_bf16_kernel(ConvParams p) {
-  constexpr int WM = 4, MT = 2, NT = 2, TH = WM * MT;
+  constexpr int WM = 4, NT = 2, TH = WM * MT;
   using G = GeoB<TH>;
   constexpr int NCHUNK = CIN / BKC;
   static_assert(NCHUNK >= 2, "first and last stage of a tile are different stages");
@@ -427,10 +440,10 @@ __global__ __launch_bounds__(256, 1) void conv_bf16_kernel(ConvParams p) {
     const int i = tid + it * 256;
     const int slot = i % 4, pix = i / 4, col = pix % G::COLS;
     // pieces past the tile read out of range (-> zeros); the source piece is the slot's un-swizzled index
-    t.prow[it] = i < NITEM ? pix / G::COLS - 1 : (1 << 20);
-    t.pcol[it] = col - 1;
-    t.pqb[it] = (unsigned)((slot ^ ((col >> 2) & 3)) * 16);
+    t.prc[it] = ((i < NITEM ? pix / G::COLS : (1 << 16)) << 8) | col;
+    (void)slot;
   }
+  t.pslot = tid & 3;   // (256 lanes per pass: a lane keeps its slot)
 
   PipeB<NITER, NWITER> c;
   c.woff = (unsigned)tid * 16u;
@@ -489,16 +502,14 @@ __global__ __launch_bounds__(256, 1) void conv_bf16_kernel(ConvParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { accA[i][j][r] = 0.0f; accB[i][j][r] = 0.0f; }
 
-  EpiB<NT> epiA, epiB;
+  EpiB<MT> epiA, epiB;
   EpiHold hold;
-  hold.h16 = 0u;
-  hold.h32 = (f32x2){0.0f, 0.0f};
   epiA.rout = epiB.rout = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0u, 0x00020000);  // nothing to store yet
-  epiA.rowoff[0] = epiA.rowoff[1] = epiB.rowoff[0] = epiB.rowoff[1] = SPFE_OOB;
 #pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int q = 0; q < 8; ++q) epiA.bias[j][q] = epiB.bias[j][q] = (f32x2){0.0f, 0.0f};
+  for (int i = 0; i < MT; ++i) epiA.rowoff[i] = epiB.rowoff[i] = SPFE_OOB;
+  epiA.pitch = epiB.pitch = 0u;
+  epiA.wlim = epiB.wlim = 0;
+  epiA.bias[0] = epiA.bias[1] = epiB.bias[0] = epiB.bias[1] = 0.0f;
 
   int buf = 0;
   bf16x8 a[2][MT + 2], bb[3][NT];
@@ -530,7 +541,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16_kernel(ConvParams p) {
     buf ^= 1;
   };
 
-  auto run_tile = [&](f32x16(&acc)[MT][NT], const f32x16(&accPrev)[MT][NT], EpiB<NT> &eMine, const EpiB<NT> &ePrev) {
+  auto run_tile = [&](f32x16(&acc)[MT][NT], const f32x16(&accPrev)[MT][NT], EpiB<MT> &eMine, const EpiB<MT> &ePrev) {
     t.chunk = 0;
     if constexpr (!RESW) {
       // (compiled with the atomic optimiser off, see the Makefile: the plain instruction, waited for where it is used)
@@ -583,8 +594,8 @@ __global__ __launch_bounds__(256, 1) void conv_bf16_kernel(ConvParams p) {
     if (!t.have_next) break;
   }
   {
-    constexpr int NEPI = (POOL ? 1 : MT) * NT * 8;
-    auto flush = [&](const f32x16(&acc)[MT][NT], const EpiB<NT> &e) {
+    constexpr int NEPI = POOL ? (MT / 2) * 8 : MT * 16;
+    auto flush = [&](const f32x16(&acc)[MT][NT], const EpiB<MT> &e) {
       [&]<int... E>(std::integer_sequence<int, E...>) {
         (epi_item<MT, NT, POOL, OUT_F32, E>(e, hold, acc), ...);
       }(std::make_integer_sequence<int, NEPI>{});
@@ -593,12 +604,12 @@ __global__ __launch_bounds__(256, 1) void conv_bf16_kernel(ConvParams p) {
   }
 }
 
-template <int CIN, bool POOL, bool OUT_F32>
+template <int CIN, bool POOL, bool OUT_F32, int MT = 2>
 static hipError_t launch_b(const ConvParams &p, hipStream_t s) {
-  using G = GeoB<8>;
+  using G = GeoB<4 * MT>;
   constexpr size_t lds = 2 * (size_t)G::BUF_BYTES + 16;   // + the queue slot
   static_assert(lds <= 160 * 1024, "double buffer must fit the 160 KB LDS");
-  auto k = conv_bf16_kernel<CIN, POOL, OUT_F32>;
+  auto k = conv_bf16_kernel<CIN, POOL, OUT_F32, MT>;
   static bool attr_done[64] = {};  // per instantiation and device: one process may hold handles on several GPUs
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -617,12 +628,17 @@ static hipError_t launch_b(const ConvParams &p, hipStream_t s) {
 
 size_t conv_bf16_slab_bytes() { return GeoB<8>::W_BYTES; }
 
-hipError_t launch_conv_bf16(const ConvParams &p, int cin, bool pool, bool out_f32, hipStream_t s) {
+// tile_rows: 8, or 16 (cin = 128, bf16 out only): p.tiles_y must count tiles of that height
+hipError_t launch_conv_bf16(const ConvParams &p, int cin, bool pool, bool out_f32, hipStream_t s, int tile_rows) {
+  if (tile_rows == 16) {
+    if (cin == 128 && pool && !out_f32) return launch_b<128, true, false, 4>(p, s);
+    if (cin == 128 && !pool && !out_f32) return launch_b<128, false, false, 4>(p, s);
+    return hipErrorInvalidValue;
+  }
   if (cin == 64 && pool && !out_f32) return launch_b<64, true, false>(p, s);
   if (cin == 64 && !pool && !out_f32) return launch_b<64, false, false>(p, s);
   if (cin == 128 && pool && !out_f32) return launch_b<128, true, false>(p, s);
   if (cin == 128 && !pool && !out_f32) return launch_b<128, false, false>(p, s);
-  if (cin == 128 && !pool && out_f32) return launch_b<128, false, true>(p, s);
   return hipErrorInvalidValue;
 }
 

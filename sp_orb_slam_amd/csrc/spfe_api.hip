@@ -270,7 +270,9 @@ int pack_layer_bf16(spfe_handle h, const float *blob, const int *lids, int nl, C
     const float *W = blob + blob_weight_offset(lids[i]);
     const float *Bv = W + (size_t)L.cout * L.cin * taps;
     for (int co = 0; co < L.cout; ++co) {
-      const int g = co_base + co, nb = g / 64, j = g % 64;
+      // row of the 64-channel block: even channels fill accumulator tile 0, odd ones tile 1 (the kernels pack a lane's
+      // channel pair into one dword store); the bias stays in channel order
+      const int g = co_base + co, nb = g / 64, c64 = g % 64, j = (c64 & 1) * 32 + (c64 >> 1);
       bia[g] = Bv[co];
       for (int ci = 0; ci < cin; ++ci) {
         const int ch = ci / 32, c = ci % 32;

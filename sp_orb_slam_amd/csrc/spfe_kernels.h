@@ -38,7 +38,7 @@ int conv_tile_rows(int tile_mode);
 
 // bf16 3x3 convolutions (conv_bf16.hip): in/out NHWC bf16 (out f32 when out_f32), strides in
 // elements; wpack = bf16 slabs of conv_bf16_slab_bytes() each, [nblk][chunk of 32 ch][tap][64][80 B]
-hipError_t launch_conv_bf16(const ConvParams &p, int cin, bool pool, bool out_f32, hipStream_t s);
+hipError_t launch_conv_bf16(const ConvParams &p, int cin, bool pool, bool out_f32, hipStream_t s, int tile_rows = 8);
 size_t conv_bf16_slab_bytes();
 // wave-specialised variant for the Cin = 64 layers (conv_bf16_ws.hip): wpack = conv_bf16_ws_weight_bytes() per
 // 64-channel block, [nblk][tap][cout 64][8 x 16-byte pieces, piece g in slot g ^ ((cout >> 1) & 7)]

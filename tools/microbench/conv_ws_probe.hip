@@ -65,7 +65,8 @@ int main(int argc, char **argv) {
       for (int t = 0; t < 9; ++t) {
         const unsigned short v = wb[((size_t)co * cin + ci) * 9 + t];
         const int nb = co / 64, j = co % 64;
-        memcpy(&w_old[((size_t)nb * 2 + ci / 32) * slab + ((size_t)t * 64 + j) * 64 + ((((ci % 32) / 8) ^ ((j >> 2) & 3)) * 16) + (ci % 8) * 2], &v, 2);
+        { const int jo = (j & 1) * 32 + (j >> 1);   // even channels first
+          memcpy(&w_old[((size_t)nb * 2 + ci / 32) * slab + ((size_t)t * 64 + jo) * 64 + ((((ci % 32) / 8) ^ ((jo >> 2) & 3)) * 16) + (ci % 8) * 2], &v, 2); }
         const int jr = (j & 1) * 32 + (j >> 1), slot = (ci / 8) ^ ((jr >> 1) & 7);   // even channels first
         memcpy(&w_new[(size_t)nb * spfe::ws::W_BYTES + ((size_t)t * 64 + jr) * 128 + slot * 16 + (ci % 8) * 2], &v, 2);
       }
