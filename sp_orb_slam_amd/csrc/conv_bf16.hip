@@ -628,11 +628,15 @@ static hipError_t launch_b(const ConvParams &p, hipStream_t s) {
 
 size_t conv_bf16_slab_bytes() { return GeoB<8>::W_BYTES; }
 
-// tile_rows: 8, or 16 (cin = 128, bf16 out only): p.tiles_y must count tiles of that height
+// tile_rows: 8, or 12 (cin = 128, no pool) / 16 (cin = 128): p.tiles_y must count tiles of that height
 hipError_t launch_conv_bf16(const ConvParams &p, int cin, bool pool, bool out_f32, hipStream_t s, int tile_rows) {
   if (tile_rows == 16) {
     if (cin == 128 && pool && !out_f32) return launch_b<128, true, false, 4>(p, s);
     if (cin == 128 && !pool && !out_f32) return launch_b<128, false, false, 4>(p, s);
+    return hipErrorInvalidValue;
+  }
+  if (tile_rows == 12) {
+    if (cin == 128 && !pool && !out_f32) return launch_b<128, false, false, 3>(p, s);
     return hipErrorInvalidValue;
   }
   if (cin == 64 && pool && !out_f32) return launch_b<64, true, false>(p, s);

@@ -150,6 +150,8 @@ struct spfe_handle_s {
   int ws_min_items = 11;    // ... when the launch has at least this many (tile, 64-channel block) items per workgroup
   unsigned char *d_wws[4] = {};  // their weights in conv_bf16_ws.hip's layout
   bool bf16_dyn = true;          // SPFE_BF16_DYN_QUEUE
+  int tile16_min_items = 3;      // SPFE_BF16_TILE16_MIN_ITEMS (0 = 8-row tiles only)
+  int tile_rows_big = 12;        // SPFE_BF16_TILE_ROWS (12 | 16)
   int *d_tile_ctr = nullptr;     // [8 layers][16] tile-queue counters, zeroed once per enqueue()
   bool act0_missing = false;  // the last call computed conv1a inside conv1b
   bool bf16 = false;  // SPFE_PRECISION_BF16: bf16 conv stack (conv1a .. convPa/Da), f32 heads and tail
@@ -392,6 +394,10 @@ int build(spfe_handle h, const spfe_config *cfg) {
     h->ws_min_items = (cfg->flags & SPFE_FLAG_ASYNC_COV) ? 11 : 5;
     const char *ienv = getenv("SPFE_BF16_WS_MIN_ITEMS");
     if (ienv) h->ws_min_items = atoi(ienv);
+    const char *t16env = getenv("SPFE_BF16_TILE16_MIN_ITEMS");
+    if (t16env) h->tile16_min_items = atoi(t16env);
+    const char *trenv = getenv("SPFE_BF16_TILE_ROWS");
+    if (trenv) h->tile_rows_big = atoi(trenv);
     const char *denv = getenv("SPFE_BF16_DYN_QUEUE");
     if (denv) h->bf16_dyn = atoi(denv) != 0;
   }
@@ -609,15 +615,24 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
       }
       // streamed-weight layers (Cin = 128): work items in queue order (conv_bf16.hip, CtlB::dyn); SPFE_BF16_DYN_QUEUE=0: static
       // (launches with a handful of items per workgroup stay static: the queue costs them more than it balances)
+      // taller tiles for the streamed-weight layers when that still leaves every workgroup >= tile16_min_items items
+      // (conv_bf16.hip, MT = 3 / 4: a stage's weight chunk feeds 1.5x / 2x the MFMAs).  Measured: 12-row tiles (layers
+      // without a pool) -3...5 % on convPa|Da; 16-row tiles need 512 VGPRs + spills and lose 35 %: not the default.
+      int tile_rows = 8;
+      if (L.cin == 128 && h->tile16_min_items > 0) {
+        const int tr = h->tile_rows_big > 0 ? h->tile_rows_big : 16;
+        if ((tr == 16 || !L.pool) &&
+            (long)p.tiles_x * ((L.H + tr - 1) / tr) * n * p.nblk >= (long)h->tile16_min_items * (grid_ws < 8 ? 8 : grid_ws)) {
+          tile_rows = tr;
+          p.tiles_y = (L.H + tr - 1) / tr;
+        }
+      }
       if (L.cin == 128 && h->bf16_dyn && (long)p.tiles_x * p.tiles_y * n * p.nblk >= 5L * (grid_ws < 8 ? 8 : grid_ws))
         p.tile_ctr = h->d_tile_ctr + 16 * i;
-      if (i == 7) {
-        // convPa | convDa: one launch, 512 output channels, bf16 (both 1x1 heads are bf16 GEMMs)
+      if (i == 7) {   // convPa | convDa: one launch, 512 output channels, bf16 (both 1x1 heads are bf16 GEMMs)
         p.out = reinterpret_cast<float *>(h->d_hd); p.out_stride = 512; p.out_choff = 0;
-        HIP_TRY(spfe::launch_conv_bf16(p, L.cin, L.pool, false, s));
-      } else {
-        HIP_TRY(spfe::launch_conv_bf16(p, L.cin, L.pool, false, s));
       }
+      HIP_TRY(spfe::launch_conv_bf16(p, L.cin, L.pool, false, s, tile_rows));
       STAGE_MARK(2 + i);
       continue;
     }
