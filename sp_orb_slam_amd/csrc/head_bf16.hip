@@ -122,7 +122,9 @@ __global__ __launch_bounds__(256, H_WG_PER_CU) void head1x1_bf16_kernel(const un
     a[1] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8 *>(a0 + aoff[1]);
 #pragma unroll
     for (int kk = 0; kk < H_KSTEPS; ++kk) {
+      // (pinned: left alone, the scheduler sinks the read to its first use)
       if (kk + 2 < H_KSTEPS) a[(kk + 2) % 3] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8 *>(a0 + aoff[kk + 2]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
         if (kk == 0) {
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(256, H_WG_PER_CU) void head1x1_bf16_kernel(const un
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk % 3], wreg[j][kk], acc[j], 0, 0, 0);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     prev = tile;
     tile = nxt;

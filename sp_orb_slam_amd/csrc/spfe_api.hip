@@ -89,6 +89,8 @@ struct spfe_handle_s {
   float *d_head = nullptr, *d_semi = nullptr, *d_coarse = nullptr;
   unsigned short *d_hd = nullptr;    // bf16 mode: ReLU(convPa) | ReLU(convDa), [B][C][512] bf16 (input of the two bf16 heads)
   unsigned char *d_wdb = nullptr, *d_wpb = nullptr;   // bf16 mode: convDb / convPb weights, head_bf16.hip layout
+  float *d_wdb32 = nullptr, *d_wpb32 = nullptr;       // f32 mode: the same for head_f32.hip (SPFE_F32_HEADS=1; default: generic kernel)
+  bool f32_heads = false;
   float *d_heat_log = nullptr, *d_heat = nullptr, *d_heat_inv = nullptr;
   float *d_minmax = nullptr, *d_cell_score = nullptr, *d_heat_consts = nullptr;
   uint8_t *d_cell_k = nullptr;
@@ -534,6 +536,20 @@ int build(spfe_handle h, const spfe_config *cfg) {
         if ((rc = pack_layer_bf16_ws(h, blob.data(), specs[i].l0, &h->d_wws[i]))) return rc;
     if ((rc = dev_alloc(h, &h->d_tile_ctr, 8 * 16))) return rc;
   }
+  if (!h->bf16) {  // f32 heads with register-resident weights (head_f32.hip), bit-identical to the generic kernel — opt-in:
+    // measured 66 + 38 us per eight 752x480 frames against 74 + 35 for the generic kernel (matrix-bound: 47 us at the peak)
+    const char *fe = getenv("SPFE_F32_HEADS");
+    if (fe) h->f32_heads = atoi(fe) != 0;
+    for (int which = 0; which < 2 && h->f32_heads; ++which) {
+      const int lid = which ? 9 : 11;
+      const spfe_layer_t &Ld = SPFE_LAYERS[lid];
+      std::vector<float> w(spfe::head_f32_weight_bytes(Ld.cout) / 4, 0.0f);
+      spfe::head_f32_pack_weights(blob.data() + blob_weight_offset(lid), Ld.cout, w.data());
+      float **dst = which ? &h->d_wpb32 : &h->d_wdb32;
+      if ((rc = dev_alloc(h, dst, w.size()))) return rc;
+      HIP_TRY(hipMemcpy(*dst, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    }
+  }
   if (h->bf16) {  // both heads in bf16: convPa | convDa write bf16, convPb and convDb are head_bf16.hip's GEMMs
     if ((rc = dev_alloc(h, &h->d_hd, (size_t)B * C * 512))) return rc;
     for (int which = 0; which < 2; ++which) {
@@ -639,6 +655,12 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     if (h->bf16 && i >= 8) {  // convPb (65 logits) and convDb (256 descriptor channels): bf16 GEMMs over all cells of the batch
       if (i == 8) HIP_TRY(spfe::launch_head1x1_bf16(h->d_hd, h->d_wpb, L.d_b, h->d_semi, n * h->C, 65, s));
       else HIP_TRY(spfe::launch_head1x1_bf16(h->d_hd, h->d_wdb, L.d_b, h->d_coarse, n * h->C, 256, s));
+      STAGE_MARK(2 + i);
+      continue;
+    }
+    if (!h->bf16 && i >= 8 && h->f32_heads) {  // convPb / convDb in f32: head_f32.hip (weights in registers)
+      if (i == 8) HIP_TRY(spfe::launch_head1x1_f32(h->d_head, h->d_wpb32, L.d_b, h->d_semi, n * h->C, 65, s));
+      else HIP_TRY(spfe::launch_head1x1_f32(h->d_head, h->d_wdb32, L.d_b, h->d_coarse, n * h->C, 256, s));
       STAGE_MARK(2 + i);
       continue;
     }

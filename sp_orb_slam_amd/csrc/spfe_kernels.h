@@ -57,6 +57,12 @@ hipError_t launch_head1x1_bf16(const void *in_bf16, const void *wpack, const flo
 size_t head_bf16_weight_bytes(int cout);
 void head_bf16_pack_weights(const unsigned short *Wb, int cout, unsigned char *dst);
 
+// f32 mode, the 1x1 heads (head_f32.hip): same shapes, in / out f32, bit-identical to conv_f32.hip's 1x1 path
+hipError_t launch_head1x1_f32(const float *in, const float *wpack, const float *bias, float *out, int npix, int cout,
+                              hipStream_t s);
+size_t head_f32_weight_bytes(int cout);
+void head_f32_pack_weights(const float *W, int cout, float *dst);
+
 // conv1a: u8 image -> (x * 1/255) -> 3x3 conv 1->64 + bias + relu, NHWC out.
 // w: [9][64] (tap-major), b: [64]
 hipError_t launch_conv1a(const uint8_t *img, const float *w9x64, const float *b64, float *out, int B,

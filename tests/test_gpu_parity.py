@@ -634,3 +634,22 @@ def test_pipelined_host_path_submit_collect():
                 if with_heat:
                     assert np.array_equal(g.heat, e.heat) and np.array_equal(g.heat_inv, e.heat_inv)
         ext.close()
+
+
+def test_f32_heads_with_register_resident_weights_are_bit_identical(monkeypatch):
+    """head_f32.hip (SPFE_F32_HEADS=1: convPb / convDb with the weights in registers) against the generic 1x1 path: the
+    same k-ordered fmaf chain, so semi and coarse — and with them everything downstream — are the same bits."""
+    H, W, nf = 240, 376, 500
+    blob = weights.synthetic(7, "dense")
+    imgs = [synth.make_image(60 + i, H, W) for i in range(3)]
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SPFE_F32_HEADS", flag)
+        ext = SPExtractor(nf, H, W, blob, max_batch=3, with_heat=False)
+        frs = ext.extract_batch(imgs)
+        out[flag] = (frs, [ext.debug_read("semi", i) for i in range(3)], [ext.debug_read("coarse", i) for i in range(3)])
+        ext.close()
+    for a, b in zip(out["0"][1] + out["0"][2], out["1"][1] + out["1"][2]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for a, b in zip(out["0"][0], out["1"][0]):
+        assert np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.descriptors, b.descriptors)

@@ -1,6 +1,9 @@
-for t16 in "0 0" "3 12" "0 0" "3 12" "2 12"; do
-set -- $t16
-for m in "--height 720 --width 1280 --sync-cov"; do SPFE_BF16_TILE16_MIN_ITEMS=$1 SPFE_BF16_TILE_ROWS=$2 python bench.py --precision bf16 $m --no-cpu-baseline --no-bf16-leg --no-host-path --no-match --no-latency --no-aten 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('min=$1 rows=$2', d['value'], d['ms_per_step'], {k:v for k,v in d.get('stage_ms',{}).items() if k in ('conv3b','conv4a','conv4b','convPaDa')})"; done
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+rm -rf gpurun_out/hf && mkdir -p gpurun_out/hf
+for prec in f32 bf16; do
+rocprofv3 --kernel-trace --stats -d gpurun_out/hf/kt -o trace -- python bench.py --precision $prec --no-cpu-baseline --no-bf16-leg --no-host-path --no-match --no-latency --no-stage-table --no-aten --steps 6 --sync-cov > gpurun_out/hf/log.txt 2>&1
+python tools/rocpd_summary.py gpurun_out/hf/kt/*.db > gpurun_out/hf/stats_$prec.txt 2>&1
+grep -i "head" gpurun_out/hf/stats_$prec.txt | cut -c1-150
+rm -rf gpurun_out/hf/kt
 done
-SPFE_BF16_TILE16_MIN_ITEMS=3 SPFE_BF16_TILE_ROWS=12 python bench.py --precision bf16 --sync-cov --no-cpu-baseline --no-bf16-leg --no-host-path --no-match --no-latency --no-aten 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('752 rows12', d['value'], d['ms_per_step'], {k:v for k,v in d.get('stage_ms',{}).items() if k in ('conv3b','conv4a','conv4b','convPaDa')})"
-python bench.py --precision bf16 --sync-cov --no-cpu-baseline --no-bf16-leg --no-host-path --no-match --no-latency --no-aten 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('752 rows8', d['value'], d['ms_per_step'], {k:v for k,v in d.get('stage_ms',{}).items() if k in ('conv3b','conv4a','conv4b','convPaDa')})"
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_bf16.py -x -q 2>&1 | grep -E "passed|failed"
