@@ -151,6 +151,7 @@ struct spfe_handle_s {
   unsigned ws_mask = 15u;   // bf16 layers (bit i = conv layer i of enqueue(), Cin = 64 only) that may use the wave-specialised kernel
   int ws_min_items = 11;    // ... when the launch has at least this many (tile, 64-channel block) items per workgroup
   unsigned char *d_wws[4] = {};  // their weights in conv_bf16_ws.hip's layout
+  int side_cus_default = 0;      // SPFE_SIDE_CUS
   bool bf16_dyn = true;          // SPFE_BF16_DYN_QUEUE
   int tile16_min_items = 3;      // SPFE_BF16_TILE16_MIN_ITEMS (0 = 8-row tiles only)
   int tile_rows_big = 12;        // SPFE_BF16_TILE_ROWS (12 | 16)
@@ -370,7 +371,21 @@ int build(spfe_handle h, const spfe_config *cfg) {
     const char *pe = getenv("SPFE_SIDE_PRIORITY");
     const int want = pe ? atoi(pe) : 0;
     int lo = 0, hi = 0;   // (numerically: greatest priority = lowest value)
-    if (want && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+    // SPFE_SIDE_CUS=N: the side stream (selection, descriptors, covariance) confined to the last N of the device's CUs
+    // (hipExtStreamCreateWithCUMask; mask bit i <-> CU i / 8 of XCD i % 8: tools/microbench/cumask_probe.hip), so that its
+    // long-lived small workgroups cannot sit on every CU while the convolutions of the next batch want whole CUs
+    const char *ce = getenv("SPFE_SIDE_CUS");
+    int side_cus = ce ? atoi(ce) : h->side_cus_default;
+    hipDeviceProp_t prop;
+    if (side_cus > 0 && hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount >= 64 &&
+        side_cus < prop.multiProcessorCount) {
+      const int ncu = prop.multiProcessorCount;
+      std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+      for (int b = ncu - side_cus; b < ncu; ++b) mask[b / 32] |= 1u << (b % 32);
+      if (hipExtStreamCreateWithCUMask(&h->side, (uint32_t)mask.size(), mask.data()) != hipSuccess) h->side = nullptr;
+    }
+    if (h->side) {
+    } else if (want && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
       HIP_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, want < 0 ? hi : lo));
     else
       HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
