@@ -6,14 +6,15 @@
 // makes a 1x1 layer acc = +0; for k = 0 .. 255: acc = fmaf(x[k], w[k], acc); out = acc + bias, and the MFMA is a
 // k-ordered fmaf chain, so 128 steps (k = 2 s, 2 s + 1) in ascending order are that chain.
 //
-// Same design as head_bf16.hip: the WEIGHTS LIVE IN REGISTERS — a wave owns 64 (convDb) or 32 (convPb) output
-// channels for the whole kernel, 128 K steps x 2 tiles = 256 VGPRs (one wave per SIMD, 512 registers) — persistent
-// workgroups, one per CU, walk 32-pixel tiles whose 32 KB come HBM -> LDS with LDS-direct loads into a double buffer,
+// Same design as head_bf16.hip: the WEIGHTS LIVE IN REGISTERS — a wave owns 32 output channels for the whole kernel,
+// 128 K steps = 128 VGPRs; eight waves per workgroup (two per SIMD: each other's MFMAs fill the issue gaps that the
+// operand selects leave — with one wave per SIMD and 256 weight registers, half of them parked in AccVGPRs, the
+// copies and selects between the 64-cycle MFMAs cost a third of the matrix time) — persistent workgroups, one per CU, walk 32-pixel tiles whose 32 KB come HBM -> LDS with LDS-direct loads into a double buffer,
 // XOR-swizzled by the pixel on the source side (conflict-free 16-byte reads: one read feeds two K steps), and a lane's
-// even / odd channel pair leaves as one 8-byte store (256-byte runs).  These layers are matrix-bound (7.4 GFLOP per
+// outputs leave as 4-byte stores in 128-byte runs.  These layers are matrix-bound (7.4 GFLOP per
 // eight 752x480 frames = 47 us at the f32 peak).
-// STATUS: opt-in (SPFE_F32_HEADS=1).  Measured (rocprofv3, 752x480 x 8): convDb 66 us, convPb 38 us — against 74 and 35 us for
-// the generic kernel: no gain worth a second code path by default; kept, tested for bit-identity, as the record of VERDICT
+// STATUS: opt-in (SPFE_F32_HEADS=1).  Measured (rocprofv3, 752x480 x 8): convDb 63 us, convPb 38.5 us — against 72 and 35.5 us
+// for the generic kernel (the first version, four waves with 256 weight registers each, half of them in AccVGPRs: 66 + 38): no gain worth a second code path by default; kept, tested for bit-identity, as the record of VERDICT
 // round 1 item 9 (whose "<= 0.05 ms" is the layers' roofline itself).
 #include <cstring>
 #include <utility>
@@ -35,12 +36,12 @@ constexpr int F_KSTEPS = 128;           // K = 256, two per MFMA
 }  // namespace
 
 // in: [npix][IN_STRIDE] f32, the head reads channels [in_choff, in_choff + 256); out: [npix][COUT] f32
-// wpack: [wave 4][tile NTW][K step 128][lane 64] f32 (head_f32_pack_weights)
+// wpack: [wave 8][K step 128 / 4][lane 64][4] f32 (head_f32_pack_weights)
 template <int COUT, int IN_STRIDE>
-__global__ __launch_bounds__(256, 1) void head1x1_f32_kernel(const float *__restrict__ in, int in_choff,
+__global__ __launch_bounds__(512, 1) void head1x1_f32_kernel(const float *__restrict__ in, int in_choff,
                                                              const float *__restrict__ wpack, const float *__restrict__ bias,
                                                              float *__restrict__ out, int npix) {
-  constexpr int NTW = COUT == 256 ? 2 : 1;
+  constexpr int NTW = 1;
   extern __shared__ __attribute__((aligned(16))) char sm_f[];
   lds_char *const lds = (lds_char *)sm_f;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -62,27 +63,28 @@ __global__ __launch_bounds__(256, 1) void head1x1_f32_kernel(const float *__rest
       const f32x4 v = reinterpret_cast<const f32x4 *>(wpack)[((wave * NTW + j) * (F_KSTEPS / 4) + s4) * 64 + lane];
       wreg[j][4 * s4] = v.x; wreg[j][4 * s4 + 1] = v.y; wreg[j][4 * s4 + 2] = v.z; wreg[j][4 * s4 + 3] = v.w;
     }
-  // output channel(s) of this lane: convDb 64 wave + 2 l31 + j; convPb 32 wave + l31
-  const int co = COUT == 256 ? wave * 64 + 2 * l31 : wave * 32 + l31;
+  // output channel of this lane
+  const int co = wave * 32 + l31;
   float bv[NTW];
 #pragma unroll
   for (int j = 0; j < NTW; ++j) bv[j] = co + j < COUT ? bias[co + j] : 0.0f;
   const bool lane_out = co < COUT;
+  const bool wave_active = wave * 32 < COUT;   // (convPb: waves 3..7 only help with the loads)
 
-  // a tile's 2048 16-byte pieces = 32 LDS-direct passes, 8 per wave: pass p, lane l -> LDS piece q = 64 p + l = (pixel
+  // a tile's 2048 16-byte pieces = 32 LDS-direct passes, 4 per wave: pass p, lane l -> LDS piece q = 64 p + l = (pixel
   // q >> 6, slot q & 63), which holds the pixel's piece slot ^ (pixel & 15)
-  unsigned dsrc[8];
+  unsigned dsrc[4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int q = (4 * i + wave) * 64 + lane, px = q >> 6, slot = q & 63;
+  for (int i = 0; i < 4; ++i) {
+    const int q = (8 * i + wave) * 64 + lane, px = q >> 6, slot = q & 63;
     dsrc[i] = (unsigned)px * (unsigned)(IN_STRIDE * 4) + (unsigned)((slot ^ (px & 15)) * 16);
   }
   auto dma = [&](int tile, int buf) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const unsigned base = (unsigned)tile * (unsigned)(FT * IN_STRIDE * 4);   // (past the last pixel: out of range -> zeros)
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void *)(lds + buf * FT_BYTES + (4 * i + wave) * 1024), 16, base + dsrc[i], 0, 0, 0);
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void *)(lds + buf * FT_BYTES + (8 * i + wave) * 1024), 16, base + dsrc[i], 0, 0, 0);
 #endif
   };
   const unsigned arow = (unsigned)(l31 * 1024);
@@ -112,8 +114,9 @@ __global__ __launch_bounds__(256, 1) void head1x1_f32_kernel(const float *__rest
     __syncthreads();                      // ... for every wave; and every wave is done reading the other buffer
     const int nxt = tile + (int)gridDim.x;
     if (nxt < ntiles) dma(nxt, buf ^ 1);
-    if (prev >= 0) store_tile(accPrev, prev);   // the previous tile's outputs leave while this one computes
+    if (prev >= 0 && wave_active) store_tile(accPrev, prev);   // the previous tile's outputs leave while this one computes
     lds_char *const a0 = lds + buf * FT_BYTES + arow;
+    if (wave_active) {
     // piece m = channels 4 m .. 4 m + 3 of this lane's pixel: K steps 2 m (dwords 0 | 1 by hi) and 2 m + 1 (dwords 2 | 3)
     f32x4 pc[3];
     auto rd = [&](int m) -> f32x4 {
@@ -146,6 +149,7 @@ __global__ __launch_bounds__(256, 1) void head1x1_f32_kernel(const float *__rest
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    }
     prev = tile;
     tile = nxt;
     buf ^= 1;
@@ -158,25 +162,22 @@ __global__ __launch_bounds__(256, 1) void head1x1_f32_kernel(const float *__rest
     run(accB, accA);
     lastA = false;
   }
-  if (prev >= 0) { if (lastA) store_tile(accA, prev); else store_tile(accB, prev); }
+  if (prev >= 0 && wave_active) { if (lastA) store_tile(accA, prev); else store_tile(accB, prev); }
 }
 
-size_t head_f32_weight_bytes(int cout) { return (size_t)4 * (cout == 256 ? 2 : 1) * F_KSTEPS * 64 * 4; }
+size_t head_f32_weight_bytes(int) { return (size_t)8 * F_KSTEPS * 64 * 4; }
 
 // W: [cout][256] f32 -> the fragment-order table the kernel's waves load once:
-// [wave][tile j][s / 4][lane][s % 4] = W[channel(wave, j, lane & 31)][2 s + (lane >> 5)]
+// [wave][s / 4][lane][s % 4] = W[32 wave + (lane & 31)][2 s + (lane >> 5)]
 void head_f32_pack_weights(const float *W, int cout, float *dst) {
-  const int ntw = cout == 256 ? 2 : 1;
   memset(dst, 0, head_f32_weight_bytes(cout));
-  for (int w = 0; w < 4; ++w)
-    for (int j = 0; j < ntw; ++j)
-      for (int s = 0; s < F_KSTEPS; ++s)
-        for (int ln = 0; ln < 64; ++ln) {
-          const int l31 = ln & 31, hi = ln >> 5;
-          const int co = cout == 256 ? w * 64 + 2 * l31 + j : w * 32 + l31;
-          if (co >= cout) continue;
-          dst[((((size_t)w * ntw + j) * (F_KSTEPS / 4) + s / 4) * 64 + ln) * 4 + s % 4] = W[(size_t)co * 256 + 2 * s + hi];
-        }
+  for (int w = 0; w < 8; ++w)
+    for (int s = 0; s < F_KSTEPS; ++s)
+      for (int ln = 0; ln < 64; ++ln) {
+        const int l31 = ln & 31, hi = ln >> 5, co = w * 32 + l31;
+        if (co >= cout) continue;
+        dst[(((size_t)w * (F_KSTEPS / 4) + s / 4) * 64 + ln) * 4 + s % 4] = W[(size_t)co * 256 + 2 * s + hi];
+      }
 }
 
 template <int COUT>
@@ -196,7 +197,7 @@ static hipError_t launch_head_f32(const float *in, int in_choff, const float *wp
   const int ntiles = (npix + FT - 1) / FT;
   int grid = num_cus > 0 ? num_cus : 256;
   if (grid > ntiles) grid = ntiles;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, in, in_choff, wpack, bias, out, npix);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, in, in_choff, wpack, bias, out, npix);
   return hipGetLastError();
 }
 

@@ -552,7 +552,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
     if ((rc = dev_alloc(h, &h->d_tile_ctr, 8 * 16))) return rc;
   }
   if (!h->bf16) {  // f32 heads with register-resident weights (head_f32.hip), bit-identical to the generic kernel — opt-in:
-    // measured 66 + 38 us per eight 752x480 frames against 74 + 35 for the generic kernel (matrix-bound: 47 us at the peak)
+    // measured 63 + 38.5 us per eight 752x480 frames against 72 + 35.5 for the generic kernel (matrix-bound: 47 us at the peak)
     const char *fe = getenv("SPFE_F32_HEADS");
     if (fe) h->f32_heads = atoi(fe) != 0;
     for (int which = 0; which < 2 && h->f32_heads; ++which) {

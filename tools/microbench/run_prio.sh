@@ -1,7 +1,9 @@
-for n in 0 16 32 64 0 32; do
-  SPFE_SIDE_CUS=$n python bench.py --precision bf16 --height 720 --width 1280 --no-cpu-baseline --no-bf16-leg --no-host-path --no-match --no-latency --no-stage-table --no-aten 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('720p side_cus=$n', d['value'], d['ms_per_step'], d['roofline']['frac'])"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+rm -rf gpurun_out/hf && mkdir -p gpurun_out/hf
+for fh in 1 0; do
+SPFE_F32_HEADS=$fh rocprofv3 --kernel-trace --stats -d gpurun_out/hf/kt -o trace -- python bench.py --no-cpu-baseline --no-bf16-leg --no-host-path --no-match --no-latency --no-stage-table --no-aten --steps 6 --sync-cov > gpurun_out/hf/log.txt 2>&1
+python tools/rocpd_summary.py gpurun_out/hf/kt/*.db > gpurun_out/hf/stats_$fh.txt 2>&1
+grep -i "head\|256,1,64" gpurun_out/hf/stats_$fh.txt | cut -c1-150
+rm -rf gpurun_out/hf/kt
 done
-for n in 0 32 64; do
-  SPFE_SIDE_CUS=$n python bench.py --precision bf16 --no-cpu-baseline --no-bf16-leg --no-host-path --no-match --no-latency --no-stage-table --no-aten 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('752 side_cus=$n', d['value'], d['ms_per_step'], d['roofline']['frac'])"
-  SPFE_SIDE_CUS=$n python bench.py --no-cpu-baseline --no-bf16-leg --no-host-path --no-match --no-latency --no-stage-table --no-aten 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('f32 side_cus=$n', d['value'], d['ms_per_step'], d['roofline']['frac'])"
-done
+SPFE_F32_HEADS=1 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | grep -E "passed|failed"
