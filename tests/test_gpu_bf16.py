@@ -174,3 +174,41 @@ def test_bf16_queue_order_equals_static_order(monkeypatch):
     for a, b in zip(out["1"][0], out["0"][0]):
         assert a.K == b.K and np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.descriptors, b.descriptors)
         assert np.array_equal(a.cov2, b.cov2)
+
+
+def test_bf16_tile_heights_of_the_streamed_weight_layers_are_bit_identical(monkeypatch):
+    """conv_bf16.hip runs the Cin = 128 layers with 8-, 12- (no pool) or 16-row tiles (SPFE_BF16_TILE_ROWS,
+    SPFE_BF16_TILE16_MIN_ITEMS): a tile's height decides who computes a pixel, not how."""
+    H, W, nf = 240, 376, 400
+    blob = weights.synthetic(7, "dense")
+    imgs = [synth.make_image(90 + i, H, W) for i in range(3)]
+    out = {}
+    for rows, mn in (("8", "0"), ("12", "1"), ("16", "1")):
+        monkeypatch.setenv("SPFE_BF16_TILE_ROWS", rows)
+        monkeypatch.setenv("SPFE_BF16_TILE16_MIN_ITEMS", mn)
+        ext = SPExtractor(nf, H, W, blob, max_batch=3, precision="bf16", with_heat=False)
+        frs = ext.extract_batch(imgs)
+        out[rows] = (frs, [ext.debug_read("semi", i) for i in range(3)], [ext.debug_read("coarse", i) for i in range(3)])
+        ext.close()
+    for other in ("12", "16"):
+        for a, b in zip(out["8"][1] + out["8"][2], out[other][1] + out[other][2]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        for a, b in zip(out["8"][0], out[other][0]):
+            assert np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.descriptors, b.descriptors)
+
+
+def test_side_stream_on_a_cu_mask(monkeypatch):
+    """SPFE_SIDE_CUS: the side stream (selection, descriptors, covariance) confined to 32 CUs gives the same records."""
+    H, W, nf = 240, 320, 300
+    blob = weights.synthetic(7, "dense")
+    img = synth.make_image(33, H, W)
+    res = []
+    for n in ("0", "32"):
+        monkeypatch.setenv("SPFE_SIDE_CUS", n)
+        ext = SPExtractor(nf, H, W, blob, precision="bf16", with_heat=False)
+        ext(img, None)
+        res.append(ext.last)
+        ext.close()
+    a, b = res
+    assert a.K == b.K and np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.descriptors, b.descriptors)
+    assert np.array_equal(a.cov2, b.cov2)
