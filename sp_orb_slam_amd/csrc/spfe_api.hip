@@ -149,7 +149,8 @@ struct spfe_handle_s {
   decltype(&ncclAllGather) p_ncclAllGather = nullptr;
   decltype(&ncclGetErrorString) p_ncclGetErrorString = nullptr;
   unsigned ws_mask = 15u;   // bf16 layers (bit i = conv layer i of enqueue(), Cin = 64 only) that may use the wave-specialised kernel
-  int ws_min_items = 11;    // ... when the launch has at least this many (tile, 64-channel block) items per workgroup
+  int ws_min_items = 11;    // ... when the launch has at least this many (tile, 64-channel block) items per workgroup (pipelined calls)
+  int ws_min_items_sync = 5;   // ... the same for synchronous calls
   unsigned char *d_wws[4] = {};  // their weights in conv_bf16_ws.hip's layout
   int side_cus_default = 0;      // SPFE_SIDE_CUS
   bool bf16_dyn = true;          // SPFE_BF16_DYN_QUEUE
@@ -408,9 +409,9 @@ int build(spfe_handle h, const spfe_config *cfg) {
     // 0.385 ms, conv1a fused).  Pipelined calls (SPFE_FLAG_ASYNC_COV): it holds all of a CU's LDS, the side-stream kernels of
     // the previous batch cannot start beside it, and at 752x480 x 8 (0.65 ms steps) their chain becomes the critical path
     // when the quarter-resolution layers take it too (12,450 -> 12,050 frames/s): those keep the higher bar.
-    h->ws_min_items = (cfg->flags & SPFE_FLAG_ASYNC_COV) ? 11 : 5;
+    // (the bar is picked per call: spfe_submit_batch pipelines on a handle created without the flag)
     const char *ienv = getenv("SPFE_BF16_WS_MIN_ITEMS");
-    if (ienv) h->ws_min_items = atoi(ienv);
+    if (ienv) h->ws_min_items = h->ws_min_items_sync = atoi(ienv);
     const char *t16env = getenv("SPFE_BF16_TILE16_MIN_ITEMS");
     if (t16env) h->tile16_min_items = atoi(t16env);
     const char *trenv = getenv("SPFE_BF16_TILE_ROWS");
@@ -596,18 +597,36 @@ int build(spfe_handle h, const spfe_config *cfg) {
 
 int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s);
 
+// D2H of the records by a kernel of our own that writes the pinned (device-mapped) host buffer: 8.9 MB in ~0.18 ms, no LDS,
+// fits beside the persistent convolution workgroups; the runtime's own D2H path cost 0.36 ms more per batch in the pipeline
+// (SPFE_PIPE_COPY_KERNEL=0 selects it)
+__global__ void copy16_kernel(uint4 *dst, const uint4 *src, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+  __threadfence_system();
+}
+
+__global__ void zero_ints_kernel(int *p, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
+}
+
 // Enqueue the whole path for n frames already in device memory.
 int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, hipStream_t s) {
   const int H = h->H, W = h->W;
   if (h->timing) h->ev = h->evpool.data() + (size_t)(h->calls % spfe_handle_s::EVSETS) * (NSTAGE + 1);
   h->calls++;
   STAGE_MARK(0);
-  if (h->d_tile_ctr) HIP_TRY(hipMemsetAsync(h->d_tile_ctr, 0, 8 * 16 * sizeof(int), s));
+  // (a kernel of our own, not hipMemsetAsync: the runtime's fill is a blit that queues behind its other blits — the
+  // pipelined host path's D2H copy of the PREVIOUS batch — and held the whole next batch back by 0.6 ms at 752x480 bf16)
+  if (h->d_tile_ctr) {
+    hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(128), 0, s, h->d_tile_ctr, 8 * 16);
+    HIP_TRY(hipGetLastError());
+  }
   const bool fused = !h->bf16 && h->fuse1a;  // f32: conv1b computes conv1a's outputs itself
   // bf16: when conv1b takes the wave-specialised kernel, its producer waves compute conv1a (no conv1a launch, no act0)
   const int grid_ws0 = std::max(16, (h->num_cus > 0 ? h->num_cus : 256) & ~15);
+  const int ws_min = ((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode) ? h->ws_min_items : h->ws_min_items_sync;
   const bool ws_layer0 = h->bf16 && h->d_wws[0] && W >= 32 &&
-                         (long)((W + 31) / 32) * ((H + 7) / 8) * n >= (long)h->ws_min_items * grid_ws0;
+                         (long)((W + 31) / 32) * ((H + 7) / 8) * n >= (long)ws_min * grid_ws0;
   const bool fused16 = ws_layer0 && h->fuse1a_bf16;
   h->act0_missing = fused || fused16;
   if (h->bf16 && !fused16) HIP_TRY(spfe::launch_conv1a_bf16(d_images, h->d_w1a_tab, h->d_b1a, h->act[0], n, H, W, s));
@@ -636,7 +655,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
       // barriers before the first MFMA): it takes the launches with enough work items per workgroup
       // (tools/microbench/conv_ws_probe: the crossover is at ~10 items)
       const int grid_ws = (h->num_cus > 0 ? h->num_cus : 256) & ~15;
-      if (i < 4 && h->d_wws[i] && L.W >= 32 && (long)p.tiles_x * p.tiles_y * n * p.nblk >= (long)h->ws_min_items * (grid_ws < 16 ? 16 : grid_ws)) {
+      if (i < 4 && h->d_wws[i] && L.W >= 32 && (long)p.tiles_x * p.tiles_y * n * p.nblk >= (long)ws_min * (grid_ws < 16 ? 16 : grid_ws)) {
         p.wpack = reinterpret_cast<const float *>(h->d_wws[i]);
         p.tile_ctr = h->d_tile_ctr + 16 * i;
         if (i == 0 && fused16) { p.img = d_images; p.w1a = reinterpret_cast<const float *>(h->d_w1a_tab); p.b1a = h->d_b1a; }
@@ -1200,13 +1219,31 @@ int spfe_submit_batch(spfe_handle h, const uint8_t *const *images, int stride, i
   h->pipe_mode = false;
   if (rc) return rc;
   const long t = h->ticket - 1;
-  HIP_TRY(hipStreamWaitEvent(h->s_d2h, h->ev_cov[t % spfe_handle_s::NTICKET], 0));
-  HIP_TRY(hipMemcpyAsync(ps.h_rec, ps.d_rec, (size_t)n * h->rl.bytes, hipMemcpyDeviceToHost, h->s_d2h));
-  if (want) {
-    HIP_TRY(hipMemcpyAsync(ps.h_heat_inv, h->d_heat_inv, (size_t)n * H * W * 4, hipMemcpyDeviceToHost, h->s_d2h));
-    HIP_TRY(hipMemcpyAsync(ps.h_heat, h->d_heat, (size_t)n * H * W * 4, hipMemcpyDeviceToHost, h->s_d2h));
+  // D2H on the SIDE stream, behind the covariance kernels it has to follow anyway.  (A copy stream of its own, waiting
+  // for the covariance event, looked cleaner and cost half the throughput in bf16 mode: HIP maps streams onto a few
+  // hardware queues, the waiting copy stream shared one with the compute stream, and its barrier packet held the NEXT
+  // batch's convolutions until the previous batch's covariance had finished — tools/microbench/run_hosttrace.sh.)
+  hipStream_t sc = h->side;
+  {
+    static const int copy_mode = getenv("SPFE_PIPE_COPY_KERNEL") ? atoi(getenv("SPFE_PIPE_COPY_KERNEL")) : 1;
+    if (copy_mode == 1) {          // a copy kernel of our own writing the pinned buffer
+      const size_t n16 = ((size_t)n * h->rl.bytes + 15) / 16;
+      hipLaunchKernelGGL(copy16_kernel, dim3(64), dim3(256), 0, sc, reinterpret_cast<uint4 *>(ps.h_rec),
+                         reinterpret_cast<const uint4 *>(ps.d_rec), n16);
+      HIP_TRY(hipGetLastError());
+    } else if (copy_mode != 2) {   // (2: no copy at all, timing probe)
+      HIP_TRY(hipMemcpyAsync(ps.h_rec, ps.d_rec, (size_t)n * h->rl.bytes, hipMemcpyDeviceToHost, sc));
+    }
   }
-  HIP_TRY(hipEventRecord(ps.ev_done, h->s_d2h));
+  if (want) {
+    const size_t m16 = (size_t)n * H * W * 4 / 16;   // (H, W multiples of 8)
+    hipLaunchKernelGGL(copy16_kernel, dim3(64), dim3(256), 0, sc, reinterpret_cast<uint4 *>(ps.h_heat_inv),
+                       reinterpret_cast<const uint4 *>(h->d_heat_inv), m16);
+    hipLaunchKernelGGL(copy16_kernel, dim3(64), dim3(256), 0, sc, reinterpret_cast<uint4 *>(ps.h_heat),
+                       reinterpret_cast<const uint4 *>(h->d_heat), m16);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(ps.ev_done, sc));
   ps.ticket = t;
   ps.n = n;
   h->pipe_submitted++;
