@@ -928,6 +928,8 @@ int finish_host(spfe_handle h, int n, spfe_result *outs) {
     h->cov_inflight = false;
   }
   const bool want = (h->cfg.flags & SPFE_FLAG_HEAT) != 0;
+  // (the synchronous path keeps the runtime's copy: a copy kernel as in spfe_submit_batch measured +4 % in f32 and -4 % in
+  // bf16 mode here, nothing for a single frame)
   HIP_TRY(hipMemcpyAsync(h->h_records, h->d_records, (size_t)n * h->rl.bytes, hipMemcpyDeviceToHost, s));
   if (want) {
     HIP_TRY(hipMemcpyAsync(h->h_heat_inv, h->d_heat_inv, (size_t)n * H * W * 4, hipMemcpyDeviceToHost, s));
