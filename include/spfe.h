@@ -181,10 +181,12 @@ SPFE_API int spfe_wait_records(spfe_handle h, long ticket, void *stream);
  *   per batch:  spfe_extract_batch_device(h, imgs, n, d_local, stream); t = spfe_last_ticket(h);
  *               spfe_allgather_records(h, t, d_local, d_all, n);   [d_all: world * n * spfe_record_bytes(h)]
  *               spfe_comm_wait(h, consumer_stream);                [or hipStreamSynchronize(spfe_comm_stream(h))]
- * The collective runs on a library-owned communication stream that waits only for the records of call
- * `ticket` (convolutions, selection and covariance of THAT batch), so the gather of batch i overlaps the
- * compute of batch i + 1.  d_local / d_all must stay untouched until the gather has completed (order the
- * next writer with spfe_comm_wait).  librccl is loaded on first use (dlopen), so single-GPU users of
+ * The collective is issued on the library's side stream, right behind the covariance kernels of the batch it
+ * gathers: call spfe_allgather_records for batch i BEFORE enqueueing batch i + 1 (with SPFE_FLAG_ASYNC_COV the gather
+ * of batch i then overlaps the convolutions of batch i + 1; called later it still is correct, it just queues behind
+ * batch i + 1's covariance).  No stream waits in a hardware queue for an event (a waiting stream of its own can land
+ * on the compute stream's hardware queue and stall it; SPFE_COMM_OWN_STREAM=1 restores that form).  d_local / d_all
+ * must stay untouched until the gather has completed (order the next writer with spfe_comm_wait).  librccl is loaded on first use (dlopen), so single-GPU users of
  * libspfe.so do not need it.  rank-major output: global frame g = rank * n + i. */
 #define SPFE_COMM_ID_BYTES 128
 SPFE_API int spfe_comm_unique_id(void *id, size_t cap);

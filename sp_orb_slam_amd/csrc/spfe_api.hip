@@ -141,7 +141,8 @@ struct spfe_handle_s {
   void *rccl_lib = nullptr;
   ncclComm_t comm = nullptr;
   int comm_rank = 0, comm_world = 0;
-  hipStream_t comm_stream = nullptr;   // library-owned: the collective never queues behind younger compute
+  hipStream_t comm_stream = nullptr;   // the stream of the collective: the side stream (default) or one of its own
+  bool comm_own_stream = false;        // SPFE_COMM_OWN_STREAM=1
   hipEvent_t ev_gather = nullptr;      // the last gather on comm_stream is done
   bool gather_recorded = false;
   decltype(&ncclCommInitRank) p_ncclCommInitRank = nullptr;
@@ -1325,7 +1326,16 @@ int spfe_comm_init(spfe_handle h, const void *id, int rank, int world) {
     return fail(SPFE_EHIP, "ncclCommInitRank(rank %d of %d, device %d): %s", rank, world, h->cfg.device,
                 h->p_ncclGetErrorString(r));
   }
-  if (!h->comm_stream) HIP_TRY(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+  // The collective runs on the SIDE stream, behind the covariance kernels of the batch it gathers (call
+  // spfe_allgather_records for batch i before enqueueing batch i + 1, as parallel.ShardedExtractor does): no stream sits in
+  // a hardware queue waiting for the covariance event.  HIP maps streams onto a few hardware queues; a waiting stream that
+  // lands on the compute stream's queue holds the NEXT batch's convolutions back (measured on the host path: half the
+  // throughput).  SPFE_COMM_OWN_STREAM=1: a communication stream of its own that waits for the batch's event.
+  h->comm_own_stream = getenv("SPFE_COMM_OWN_STREAM") && atoi(getenv("SPFE_COMM_OWN_STREAM")) != 0;
+  if (!h->comm_stream) {
+    if (h->comm_own_stream) HIP_TRY(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    else h->comm_stream = h->side;
+  }
   if (!h->ev_gather) HIP_TRY(hipEventCreateWithFlags(&h->ev_gather, hipEventDisableTiming));
   h->comm_rank = rank;
   h->comm_world = world;
@@ -1339,7 +1349,8 @@ int spfe_comm_destroy(spfe_handle h) {
   if (h->comm && h->p_ncclCommDestroy) (void)h->p_ncclCommDestroy(h->comm);
   h->comm = nullptr;
   if (h->ev_gather) { (void)hipEventDestroy(h->ev_gather); h->ev_gather = nullptr; }
-  if (h->comm_stream) { (void)hipStreamDestroy(h->comm_stream); h->comm_stream = nullptr; }
+  if (h->comm_stream && h->comm_own_stream) (void)hipStreamDestroy(h->comm_stream);
+  h->comm_stream = nullptr;
   h->comm_world = 0;
   h->gather_recorded = false;
   return SPFE_OK;
@@ -1354,9 +1365,10 @@ int spfe_allgather_records(spfe_handle h, long ticket, const void *d_local, void
   if (ticket < 0 || ticket >= h->ticket || ticket + spfe_handle_s::NTICKET <= h->ticket)
     return fail(SPFE_EINVAL, "ticket %ld is not one of the last %d calls", ticket, spfe_handle_s::NTICKET);
   HIP_TRY(hipSetDevice(h->cfg.device));
-  // the communication stream waits for exactly this batch's records (covariance included), never for
-  // younger compute: the gather of batch i runs beside the convolutions of batch i + 1
-  HIP_TRY(hipStreamWaitEvent(h->comm_stream, h->ev_cov[ticket % spfe_handle_s::NTICKET], 0));
+  // on the side stream the gather simply follows the batch's covariance kernels (and everything enqueued there since:
+  // gather batch i before enqueueing batch i + 1); a stream of its own waits for exactly this batch's records.  Either
+  // way the gather of batch i runs beside the convolutions of batch i + 1
+  if (h->comm_own_stream) HIP_TRY(hipStreamWaitEvent(h->comm_stream, h->ev_cov[ticket % spfe_handle_s::NTICKET], 0));
   const size_t count = (size_t)frames_per_rank * h->rl.bytes;   // bytes as ncclUint8; RCCL counts are size_t
   const ncclResult_t r = h->p_ncclAllGather(d_local, d_all, count, ncclUint8, h->comm, h->comm_stream);
   if (r != ncclSuccess) return fail(SPFE_EHIP, "ncclAllGather(%zu bytes per rank): %s", count, h->p_ncclGetErrorString(r));

@@ -265,9 +265,16 @@ class ShardedExtractor:
             stream.wait_event(self._local_free[k])
             self._local_free[k] = None
         buf = self.local[k]
+        if self.ext.async_cov and self._native and self._pending is not None:
+            # library gather: enqueued BEFORE this batch's work — it runs on the library's side stream right behind the
+            # previous batch's covariance kernels, so no stream sits in a hardware queue waiting for an event
+            self._complete(*self._pending, stream)
+            self._pending = None
         ticket = self.ext.extract_batch_device(d_images.data_ptr(), self.fpr, buf.data_ptr(), stream.cuda_stream)
         if self.ext.async_cov:
             if self._pending is not None:
+                # (no collective / torch collective: completing batch i orders `stream` or the torch communication stream
+                # after its records — that wait has to come behind batch i + 1's work in stream order)
                 self._complete(*self._pending, stream)
             self._pending = (ticket, k)
         else:
