@@ -177,7 +177,8 @@ def main():
         flop_frame = FLOP_PER_FRAME.get((H, W))
         # dominant kernel: conv1b (43.5 % of the FLOPs), one launch covers B frames
         bf16 = args.precision == "bf16"
-        traffic = (stamped_traffic("conv1b_bf16_traffic.json", ["conv_bf16_ws.hip", "conv1a_mfma.h"], H, W, B) if bf16 else
+        traffic = ((stamped_traffic("conv1b_bf16_traffic.json", ["conv_bf16_ws.hip", "conv1a_mfma.h"], H, W, B) or
+                    stamped_traffic("conv1b_bf16_720p_traffic.json", ["conv_bf16_ws.hip", "conv1a_mfma.h"], H, W, B)) if bf16 else
                    stamped_traffic("conv1b_traffic.json", ["conv_f32.hip"], H, W, B))
         out = {
             "metric": "frames/sec SuperPoint extract (%dx%d, %s kpts)" % (W, H, "1k" if nf == 1000 else str(nf)),
