@@ -1,5 +1,6 @@
-for m in 1 0; do
-for prec in f32 bf16; do
-SPFE_PIPE_COPY_KERNEL=$m python bench.py --precision $prec --no-cpu-baseline --no-bf16-leg --no-match --no-latency --no-stage-table --no-aten 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); h=d['host_path']; print('copy_kernel=$m $prec', 'pipelined', h['fps'], 'sync', h['fps_synchronous'], 'single frame ms', h['single_frame_operator_call_ms'], h['records_ok'])"
+for d in -1 3 2 1 0 -1 3; do
+  SPFE_DEFER_SIDE_LAYER=$d python bench.py --precision bf16 --height 720 --width 1280 --no-cpu-baseline --no-bf16-leg --no-host-path --no-match --no-latency --no-stage-table --no-aten 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('720p defer=$d', d['value'], d['ms_per_step'], d['roofline']['frac'], d.get('parity_frame0'))"
 done
+for d in -1 3 1 0; do
+  SPFE_DEFER_SIDE_LAYER=$d python bench.py --precision bf16 --no-cpu-baseline --no-bf16-leg --no-host-path --no-match --no-latency --no-stage-table --no-aten 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('752 defer=$d', d['value'], d['ms_per_step'], d['roofline']['frac'])"
 done
