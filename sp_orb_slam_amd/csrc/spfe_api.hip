@@ -80,12 +80,6 @@ struct spfe_handle_s {
   bool desc_recorded = false;
   long ticket = 0;          // calls so far; call t uses slot t % NTICKET
   bool cov_inflight = false;
-  // Deferred second half of the side chain (heat normalisation, descriptor sampling, covariance) of the LAST call: with
-  // SPFE_FLAG_ASYNC_COV and defer_layer >= 0 it is enqueued by the NEXT call, behind that call's layer `defer_layer` (an event on
-  // the caller's stream), or by whoever needs the records first (spfe_wait_records, host-facing calls, the gather).
-  struct DeferredPost { bool pending = false; spfe::FrameBufs f{}; int n = 0, slot = 0; long ticket = -1; } deferred;
-  int defer_layer = -1;           // SPFE_DEFER_SIDE_LAYER (0..7 = after conv1b..convPa|Da; -1 = off)
-  hipEvent_t ev_mid = nullptr;
   std::vector<void *> dev_allocs;
   std::vector<void *> host_allocs;
   uint8_t *d_img = nullptr;
@@ -403,8 +397,6 @@ int build(spfe_handle h, const spfe_config *cfg) {
     HIP_TRY(hipEventCreateWithFlags(&h->ev_cov[i], hipEventDisableTiming));
   }
   HIP_TRY(hipEventCreateWithFlags(&h->ev_desc, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming));
-  { const char *de = getenv("SPFE_DEFER_SIDE_LAYER"); if (de) h->defer_layer = atoi(de); if (h->defer_layer > 7) h->defer_layer = 7; }
   {
     const char *fenv = getenv("SPFE_FUSE_CONV1A");
     h->fuse1a = fenv && atoi(fenv) != 0;
@@ -614,8 +606,6 @@ __global__ void copy16_kernel(uint4 *dst, const uint4 *src, size_t n16) {
   __threadfence_system();
 }
 
-int run_deferred_post(spfe_handle h);
-
 __global__ void zero_ints_kernel(int *p, int n) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
 }
@@ -632,10 +622,6 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(128), 0, s, h->d_tile_ctr, 8 * 16);
     HIP_TRY(hipGetLastError());
   }
-  if (h->deferred.pending && !(h->defer_layer >= 0 && (h->cfg.flags & SPFE_FLAG_ASYNC_COV) && !h->pipe_mode && !h->comm)) {
-    int rc0 = run_deferred_post(h);
-    if (rc0) return rc0;
-  }
   const bool fused = !h->bf16 && h->fuse1a;  // f32: conv1b computes conv1a's outputs itself
   // bf16: when conv1b takes the wave-specialised kernel, its producer waves compute conv1a (no conv1a launch, no act0)
   const int grid_ws0 = std::max(16, (h->num_cus > 0 ? h->num_cus : 256) & ~15);
@@ -649,14 +635,6 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   STAGE_MARK(1);
   for (int i = 0; i < 10; ++i) {
     const ConvLayer &L = h->layers[i];
-    if (h->deferred.pending && i == h->defer_layer + 1) {
-      // the previous call's heat normalisation / descriptors / covariance start here, behind this call's layer
-      // `defer_layer`: the layers from here on leave LDS and registers for them, the ones before do not
-      HIP_TRY(hipEventRecord(h->ev_mid, s));
-      HIP_TRY(hipStreamWaitEvent(h->side, h->ev_mid, 0));
-      int rc2 = run_deferred_post(h);
-      if (rc2) return rc2;
-    }
     // convDb overwrites the coarse descriptor map the PREVIOUS call's descriptor sampling reads on
     // the side stream (pipelined callers): order it after that, by event, not by timing
     if (i == 9 && h->desc_recorded) HIP_TRY(hipStreamWaitEvent(s, h->ev_desc, 0));
@@ -742,23 +720,6 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   return enqueue_post(h, n, d_records, s);
 }
 
-// Second half of the side chain of the last call (see spfe_handle_s::deferred): heat normalisation (input of the
-// covariance), descriptor sampling, covariance, on the side stream; records ev_desc / ev_cov[slot].
-int run_deferred_post(spfe_handle h) {
-  if (!h->deferred.pending) return SPFE_OK;
-  h->deferred.pending = false;
-  const spfe::FrameBufs &f = h->deferred.f;
-  const int n = h->deferred.n, H = h->H, W = h->W;
-  HIP_TRY(spfe::launch_heat_norm(f, h->cov, h->rl.kmax, n, H, W, h->side));
-  HIP_TRY(spfe::launch_desc(f, h->rl, n, H, W, h->side));
-  HIP_TRY(hipEventRecord(h->ev_desc, h->side));  // d_coarse may be overwritten after this (next call's convDb)
-  h->desc_recorded = true;
-  HIP_TRY(spfe::launch_cov(f, h->rl, h->cov, n, H, W, h->side));
-  HIP_TRY(hipEventRecord(h->ev_cov[h->deferred.slot], h->side));
-  if (h->timing && h->timing_all && h->ev) HIP_TRY(hipEventRecord(h->ev[14], h->side));
-  return SPFE_OK;
-}
-
 // Detector tail, selection, descriptors, covariance for n frames whose semi /
 // coarse maps are in the handle's buffers.
 int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s) {
@@ -770,7 +731,6 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s) {
   f.cell_score = h->d_cell_score; f.cell_k = h->d_cell_k; f.kp_cell = h->d_kp_cell;
   f.records = d_records; f.heat_consts = h->d_heat_consts;
   if (h->timing && !h->ev) return fail(SPFE_EINVAL, "internal: no event set");
-  if (h->deferred.pending) { int rc0 = run_deferred_post(h); if (rc0) return rc0; }   // (spfe_postprocess after an async call)
   const int slot = (int)(h->ticket % spfe_handle_s::NTICKET);
   // the previous call's covariance still reads heat_inv / its record and owns the
   // covariance scratch: everything from here on must come after it
@@ -787,11 +747,13 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s) {
   HIP_TRY(hipStreamWaitEvent(h->side, h->ev_post[slot], 0));
   STAGE_MARK(13);   // ("select" reads 0 on the launch stream: it is part of post_side)
   HIP_TRY(spfe::launch_select(f, h->rl, n, H, W, h->cfg.num_features, h->side));
-  h->deferred.f = f; h->deferred.n = n; h->deferred.slot = slot; h->deferred.ticket = h->ticket;
-  h->deferred.pending = true;
-  // the wide and the long kernels of the chain: now, or behind a layer of the next call that leaves LDS for them
-  const bool defer = h->defer_layer >= 0 && (h->cfg.flags & SPFE_FLAG_ASYNC_COV) && !h->pipe_mode && !h->comm && !(h->timing && h->timing_all);
-  if (!defer) { int rc2 = run_deferred_post(h); if (rc2) return rc2; }
+  HIP_TRY(spfe::launch_heat_norm(f, h->cov, h->rl.kmax, n, H, W, h->side));
+  HIP_TRY(spfe::launch_desc(f, h->rl, n, H, W, h->side));
+  HIP_TRY(hipEventRecord(h->ev_desc, h->side));  // d_coarse may be overwritten after this (next call's convDb)
+  h->desc_recorded = true;
+  HIP_TRY(spfe::launch_cov(f, h->rl, h->cov, n, H, W, h->side));
+  HIP_TRY(hipEventRecord(h->ev_cov[slot], h->side));
+  if (h->timing && h->timing_all) HIP_TRY(hipEventRecord(h->ev[14], h->side));
   h->cov_inflight = true;
   h->ticket++;
   if (!(h->cfg.flags & SPFE_FLAG_ASYNC_COV) && !h->pipe_mode) {
@@ -875,7 +837,6 @@ void spfe_destroy(spfe_handle h) {
     if (h->ev_cov[i]) (void)hipEventDestroy(h->ev_cov[i]);
   }
   if (h->ev_desc) (void)hipEventDestroy(h->ev_desc);
-  if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
   (void)spfe_comm_destroy(h);
   for (auto &ps : h->pipe) {
     if (ps.ev_h2d) (void)hipEventDestroy(ps.ev_h2d);
@@ -962,7 +923,6 @@ int spfe_extract_batch(spfe_handle h, const uint8_t *const *images, int stride, 
 int finish_host(spfe_handle h, int n, spfe_result *outs) {
   const int H = h->H, W = h->W;
   hipStream_t s = h->stream;
-  if (h->deferred.pending) { int rc0 = run_deferred_post(h); if (rc0) return rc0; }
   if (h->cov_inflight) {
     const int prev = (int)((h->ticket + spfe_handle_s::NTICKET - 1) % spfe_handle_s::NTICKET);
     HIP_TRY(hipStreamWaitEvent(s, h->ev_cov[prev], 0));
@@ -1010,8 +970,6 @@ int spfe_wait_records(spfe_handle h, long ticket, void *stream) {
     return fail(SPFE_EINVAL, "ticket %ld is not one of the last %d calls", ticket, spfe_handle_s::NTICKET);
   HIP_TRY(hipSetDevice(h->cfg.device));
   hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
-  // the chain of THIS ticket still parked (no younger call has come to start it): start it now
-  if (h->deferred.pending && h->deferred.ticket <= ticket) { int rc = run_deferred_post(h); if (rc) return rc; }
   HIP_TRY(hipStreamWaitEvent(s, h->ev_cov[ticket % spfe_handle_s::NTICKET], 0));
   return SPFE_OK;
 }
@@ -1025,7 +983,6 @@ int spfe_view_record(spfe_handle h, const void *host_record, spfe_result *out) {
 long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size_t cap) {
   if (!h || !name || !dst) return fail(SPFE_EINVAL, "null argument");
   if (frame < 0 || frame >= h->B) return fail(SPFE_EINVAL, "frame %d out of range", frame);
-  if (h->deferred.pending) { int rc0 = run_deferred_post(h); if (rc0) return rc0; }
   const size_t C = h->C, HW = (size_t)h->H * h->W;
   const void *src = nullptr;
   size_t bytes = 0;
