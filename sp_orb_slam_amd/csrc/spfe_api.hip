@@ -93,7 +93,7 @@ struct spfe_handle_s {
   bool f32_heads = false;
   float *d_heat_log = nullptr, *d_heat = nullptr, *d_heat_inv = nullptr;
   float *d_minmax = nullptr, *d_cell_score = nullptr, *d_heat_consts = nullptr;
-  uint8_t *d_cell_k = nullptr;
+  uint8_t *d_cell_k = nullptr, *d_cell_mask = nullptr;
   int *d_kp_cell = nullptr;
   uint8_t *d_records = nullptr;
   spfe::CovScratch cov{};
@@ -476,6 +476,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
   if ((rc = dev_alloc(h, &h->d_cell_score, (size_t)B * C))) return rc;
   if ((rc = dev_alloc(h, &h->d_heat_consts, (size_t)B * 4))) return rc;
   if ((rc = dev_alloc(h, &h->d_cell_k, (size_t)B * C))) return rc;
+  if ((rc = dev_alloc(h, &h->d_cell_mask, (size_t)B * C))) return rc;
   if ((rc = dev_alloc(h, &h->d_kp_cell, (size_t)B * h->kmax))) return rc;
   {
     const char *qenv = getenv("SPFE_COV_QCAP");
@@ -728,7 +729,7 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s) {
   f.semi = h->d_semi; f.coarse = h->d_coarse;
   f.heat_log = h->d_heat_log; f.heat = h->d_heat; f.heat_inv = h->d_heat_inv;
   f.minmax = reinterpret_cast<uint32_t *>(h->d_minmax);
-  f.cell_score = h->d_cell_score; f.cell_k = h->d_cell_k; f.kp_cell = h->d_kp_cell;
+  f.cell_score = h->d_cell_score; f.cell_k = h->d_cell_k; f.cell_mask = h->d_cell_mask; f.kp_cell = h->d_kp_cell;
   f.records = d_records; f.heat_consts = h->d_heat_consts;
   if (h->timing && !h->ev) return fail(SPFE_EINVAL, "internal: no event set");
   const int slot = (int)(h->ticket % spfe_handle_s::NTICKET);

@@ -81,6 +81,7 @@ struct FrameBufs {
   uint32_t *minmax;     // [B][tail_parts][2] float partials of min/max of heat_log
   float *cell_score;    // [B][C]  0 = no candidate
   uint8_t *cell_k;      // [B][C]  arg-max channel
+  uint8_t *cell_mask;   // [B][C]  which of the 8 neighbouring cells' candidates can suppress this one (nms_mask_kernel)
   int *kp_cell;         // [B][kmax] cell index of emitted keypoint
   uint8_t *records;     // [B][record_bytes]
   float *heat_consts;   // [B][4] a_heat, b_heat, a_inv, b_inv

@@ -246,12 +246,50 @@ hipError_t launch_heat_norm(const FrameBufs &f, const CovScratch &cs, int kmax, 
 // (:211-213) keeps the num_features+1 best-ranked survivors; border reject
 // (:222-224) and raster numbering (:226-236) follow.
 // ---------------------------------------------------------------------------
+#ifdef SPFE_SELECT_PROBE   // phase timestamps of frame 0 (tools/microbench/run_selprof.sh builds a probe library with it)
+#define SEL_TP(i) do { __syncthreads(); if (threadIdx.x == 0) tp[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SEL_TP(i) do { } while (0)
+#endif
 enum : uint8_t { ST_NONE = 0, ST_UNDEC = 1, ST_ALIVE = 2, ST_DEAD = 3, ST_KEPT = 4 };
+
+// Which neighbours CAN suppress a candidate (inside the window and ranked before it) never changes during the rounds,
+// only their states do.  That 8-bit mask per candidate is local work — 8 neighbours x (score, k) from L2 — so it runs
+// over the whole chip in front of the one-workgroup-per-frame kernel (where it was 41 k of 186 k cycles at 1280x720:
+// one CU's VALU, 14 cells per thread).  Neighbour q: 0..2 row above (dx -1, 0, +1), 3 / 4 left / right, 5..7 row below.
+__global__ __launch_bounds__(256) void nms_mask_kernel(FrameBufs f, int hc, int wc) {
+  const int C = hc * wc, b = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float *gscore = f.cell_score + (size_t)b * C;
+  const uint8_t *gk = f.cell_k + (size_t)b * C;
+  const float sc = gscore[c];
+  unsigned m = 0;
+  if (sc > 0.0f) {
+    const int cy = c / wc, cx = c - cy * wc;
+    const int k = gk[c];
+    const int x = cx * 8 + (k & 7), y = cy * 8 + (k >> 3);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int dy = q < 3 ? -1 : (q < 5 ? 0 : 1);
+      const int dx = q < 3 ? q - 1 : (q == 3 ? -1 : (q == 4 ? 1 : q - 6));
+      const int ny = cy + dy, nx = cx + dx;
+      const bool valid = (unsigned)ny < (unsigned)hc && (unsigned)nx < (unsigned)wc;
+      const int n = valid ? ny * wc + nx : c;
+      const float sn = gscore[n];   // 0 where there is no candidate
+      const int kn = gk[n];
+      const int ddx = nx * 8 + (kn & 7) - x, ddy = ny * 8 + (kn >> 3) - y;
+      const bool close = ddx <= SPFE_NMS_DIST && ddx >= -SPFE_NMS_DIST && ddy <= SPFE_NMS_DIST && ddy >= -SPFE_NMS_DIST;
+      if (valid && sn > 0.0f && close && spfe_ranks_before(sn, n, sc, c)) m |= 1u << q;
+    }
+  }
+  f.cell_mask[(size_t)b * C + c] = (uint8_t)m;
+}
 
 size_t select_lds_bytes(int H, int W) {
   const size_t C = (size_t)(H / 8) * (W / 8);
   const size_t Cp = (C + 15) & ~(size_t)15;
-  return Cp * 4 + Cp * 2 + Cp + Cp + Cp + ((size_t)(H / 8) + 16) * 4 * 2 + 64 + 256 * 4 + 64;
+  return Cp * 4 + Cp * 2 + Cp + Cp + Cp + ((size_t)(H / 8) + 16) * 4 * 2 + 64 + 1024 * 4 + 64 + 64;
 }
 
 __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout rl, int H, int W,
@@ -277,58 +315,48 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
   int16_t *occ = reinterpret_cast<int16_t *>(rec + rl.off_occ);
   int *kp_cell = f.kp_cell + (size_t)b * rl.kmax;
 
+#ifdef SPFE_SELECT_PROBE
+  unsigned long long tp[12];
+#endif
+  SEL_TP(0);
   if (tid < 8) sCnt[tid] = 0;
   for (int i = tid; i < hc + 1; i += 1024) sRow[i] = 0;
   __syncthreads();
+  // a candidate nobody can suppress is alive from the start; `und` = this thread's undecided cells (bit j <-> cell
+  // tid + 1024 j; C <= 65535), so that the rounds only touch what is still open
+  const uint8_t *gmask = f.cell_mask + (size_t)b * C;
+  const int lane = tid & 63, wave = tid >> 6;
   int ncand = 0;
-  for (int c = tid; c < C; c += 1024) {
+  uint64_t und = 0;
+  for (int c = tid, j = 0; c < C; c += 1024, ++j) {
     const float s = gscore[c];
+    const uint8_t m = gmask[c];
     sScore[c] = s;
     sK[c] = gk[c];
-    sState[c] = s > 0.0f ? ST_UNDEC : ST_NONE;
+    sMask[c] = m;
+    sState[c] = s > 0.0f ? (m ? ST_UNDEC : ST_ALIVE) : ST_NONE;
+    und |= (uint64_t)(s > 0.0f && m) << j;
     ncand += s > 0.0f;
   }
   if (ncand) atomicAdd(&sCnt[2], ncand);
   __syncthreads();
-
+  SEL_TP(1);
   // ---- NMS fixed point ----
-  // Which neighbours CAN suppress a candidate (inside the window and ranked before it) never
-  // changes, only their states do: one pass builds that 8-bit mask per candidate from 24
-  // independent LDS reads (the serial version paid an LDS round trip per branch), the rounds
-  // then read 8 neighbour states each.  Neighbour q: 0..2 row above (dx -1, 0, +1), 3 / 4 left /
-  // right, 5..7 row below.
-  const int lane = tid & 63, wave = tid >> 6;
-  for (int c = tid; c < C; c += 1024) {
-    if (sState[c] == ST_NONE) continue;
-    const int cy = c / wc, cx = c - cy * wc;
-    const int k = sK[c];
-    const int x = cx * 8 + (k & 7), y = cy * 8 + (k >> 3);
-    const float sc = sScore[c];
-    unsigned m = 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int dy = q < 3 ? -1 : (q < 5 ? 0 : 1);
-      const int dx = q < 3 ? q - 1 : (q == 3 ? -1 : (q == 4 ? 1 : q - 6));
-      const int ny = cy + dy, nx = cx + dx;
-      const bool valid = (unsigned)ny < (unsigned)hc && (unsigned)nx < (unsigned)wc;
-      const int n = valid ? ny * wc + nx : c;
-      const float sn = sScore[n];   // 0 where there is no candidate
-      const int kn = sK[n];
-      const int ddx = nx * 8 + (kn & 7) - x, ddy = ny * 8 + (kn >> 3) - y;
-      const bool close = ddx <= SPFE_NMS_DIST && ddx >= -SPFE_NMS_DIST && ddy <= SPFE_NMS_DIST && ddy >= -SPFE_NMS_DIST;
-      if (valid && sn > 0.0f && close && spfe_ranks_before(sn, n, sc, c)) m |= 1u << q;
-    }
-    sMask[c] = (uint8_t)m;
-  }
-  __syncthreads();
+  SEL_TP(2);
   // every round decides at least the best-ranked undecided candidate, so C rounds always suffice (a strictly
   // rank-ordered staircase across the cells is the worst case); real frames need a handful
+  // ONE barrier per round: the "somebody is still undecided" flag rotates through four slots (slot r & 3 is written in
+  // round r, read behind its barrier, cleared in round r + 2 — after every thread has passed barrier r + 1 — and written
+  // again in round r + 4), and the states need none: they only move UNDEC -> ALIVE / DEAD, both decisions below rest on
+  // final states of the neighbours, so reading a state a thread has just written in this very round is as good as reading it
+  // in the next (the fixed point is unique).  The rounds were three barriers of a 1024-thread workgroup each.
+  int *sFlag = sCnt + 4;   // [4], zero on entry; sCnt[4..6] are re-used by the cut below
   for (int round = 0; round < C; ++round) {
-    if (tid == 0) sCnt[0] = 0;
-    __syncthreads();
-    int pending = 0;
-    for (int c = tid; c < C; c += 1024) {
-      if (sState[c] != ST_UNDEC) continue;
+    if (tid == 0) sFlag[(round + 2) & 3] = 0;
+    for (uint64_t rest = und; rest;) {
+      const int j = __ffsll((long long)rest) - 1;
+      rest &= rest - 1;
+      const int c = tid + j * 1024;
       const unsigned m = sMask[c];
       bool dead = false, blocked = false;
 #pragma unroll
@@ -341,76 +369,98 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
       }
       if (dead) sState[c] = ST_DEAD;
       else if (!blocked) sState[c] = ST_ALIVE;
-      else pending = 1;
+      if (dead || !blocked) und &= ~(1ull << j);
     }
-    if (pending) sCnt[0] = 1;
+    const int pending = und != 0;
+    if (pending) sFlag[round & 3] = 1;
     __syncthreads();
-    if (sCnt[0] == 0) break;
-    __syncthreads();
+    if (sFlag[round & 3] == 0) break;
   }
+  __syncthreads();
+  if (tid < 4) sFlag[tid] = 0;
+  __syncthreads();
 
+  SEL_TP(3);
   // ---- keep the num_features+1 best-ranked survivors (:211-213) ----
-  // Radix select on the score bits (positive floats order like their bit
-  // patterns): 4 passes of 8 bits, 256-bin LDS histograms.  Afterwards `prefix`
-  // is the key of the (num_features+1)-th best survivor, everything above it is
-  // kept, and among equal keys the lowest cell indices win (tie rule).
-  int *sHist = sRowBase + (hc + 16) + 16;  // [256]
+  // Radix select on the score bits (positive floats order like their bit patterns), 10 bits a pass over the RANGE the
+  // alive keys actually span (key - min: 2^26 for softmax scores between 1/65 and 1, so three passes): every thread holds
+  // its <= 16 cells' keys in registers, a pass is one plain LDS atomic per key still in the running into a 1024-bin
+  // histogram (range-normalised, so the first pass spreads over the bins), a suffix scan with one bin per thread, and
+  // the bucket holding the (num_features+1)-th best becomes the next pass's range.  Afterwards `prefix` is that
+  // survivor's key, everything above it is kept, and among equal keys the lowest cell indices win (tie rule).
+  // (First version: four 8-bit passes over the raw bits with wave-aggregated atomics, 9 ballots per cell and pass —
+  // 46 % of this kernel, 51 k of 110 k cycles at 752x480; a bisection on the key with register-held keys: 29 k.)
+  int *sHist = sRowBase + (hc + 16) + 16;  // [1024] + [16] wave totals
   int ns = 0;
   for (int c = tid; c < C; c += 1024) ns += sState[c] == ST_ALIVE;
   if (ns) atomicAdd(&sCnt[1], ns);
   __syncthreads();
   const int S = sCnt[1];
-  uint32_t prefix = 0, pmask = 0;
+  SEL_TP(4);
+  uint32_t prefix = 0;
   int need = num_features + 1;
   const bool cut = S > need;
   if (cut) {
-    int *sWaveTot = sHist + 256;  // [4] histogram totals of the four 64-bin groups
-    for (int shift = 24; shift >= 0; shift -= 8) {
-      if (tid < 256) sHist[tid] = 0;
-      __syncthreads();
-      for (int c0 = 0; c0 < C; c0 += 1024) {  // uniform trip count: ballots below need whole waves
-        const int c = c0 + tid;
-        bool has = false;
-        uint32_t bin = 0;
-        if (c < C && sState[c] == ST_ALIVE) {
-          const uint32_t key = __float_as_uint(sScore[c]);
-          has = (key & pmask) == prefix;
-          bin = (key >> shift) & 255u;
-        }
-        // lanes of this wave with the same bin: one atomic per distinct bin per wave (scores cluster,
-        // the top-byte pass has a handful of bins)
-        uint64_t same = __ballot(has);
+    constexpr int KREG = 16;                       // cells per thread kept in registers (C <= 16384)
+    const bool in_regs = C <= KREG * 1024;
+    uint32_t key[KREG];
+    uint32_t kmin = 0xffffffffu, kmax = 0u;
 #pragma unroll
-        for (int bit = 0; bit < 8; ++bit) {
-          const uint64_t bal = __ballot(has && ((bin >> bit) & 1u));
-          same &= ((bin >> bit) & 1u) ? bal : ~bal;
-        }
-        if (has && lane == (int)__ffsll((long long)same) - 1) atomicAdd(&sHist[bin], __popcll(same));
-      }
-      __syncthreads();
-      int mine = 0, suffix = 0;
-      if (tid < 256) {  // suffix sums: `above` = survivors in higher bins
-        mine = sHist[tid];
-        suffix = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          const int o = __shfl_down(suffix, off, 64);
-          if (lane + off < 64) suffix += o;
-        }
-        if (lane == 0) sWaveTot[wave] = suffix;
-      }
-      __syncthreads();
-      if (tid < 256) {
-        int above = suffix - mine;
-        for (int w2 = wave + 1; w2 < 4; ++w2) above += sWaveTot[w2];
-        if (above < need && above + mine >= need) { sCnt[4] = tid; sCnt[5] = need - above; }
-      }
-      __syncthreads();
-      prefix |= (uint32_t)sCnt[4] << shift;
-      pmask |= 255u << shift;
-      need = sCnt[5];
-      __syncthreads();
+    for (int j = 0; j < KREG; ++j) {
+      const int c = tid + j * 1024;
+      key[j] = (in_regs && c < C && sState[c] == ST_ALIVE) ? __float_as_uint(sScore[c]) : 0u;
+      if (key[j]) { kmin = key[j] < kmin ? key[j] : kmin; kmax = key[j] > kmax ? key[j] : kmax; }
     }
+    if (!in_regs)
+      for (int c = tid; c < C; c += 1024)
+        if (sState[c] == ST_ALIVE) { const uint32_t k = __float_as_uint(sScore[c]); kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; }
+    int *sAcc = sCnt + 4;
+    if (tid == 0) { sAcc[0] = 0x7fffffff; sAcc[1] = 0; }
+    __syncthreads();
+    if (kmax) { atomicMin(&sAcc[0], (int)kmin); atomicMax(&sAcc[1], (int)kmax); }   // (positive floats: int order = key order)
+    __syncthreads();
+    SEL_TP(5);
+    const uint32_t lo0 = (uint32_t)sAcc[0], range = (uint32_t)sAcc[1] - lo0;
+    int ub = 32 - __clz((int)(range | 1u));        // unresolved low bits of (key - lo0); the bucket is [base, base + 2^ub)
+    uint32_t base = 0;
+    int *sWaveTot = sHist + 1024;
+    while (ub > 0) {
+      const int sh = ub > 10 ? ub - 10 : 0;
+      sHist[tid] = 0;
+      __syncthreads();
+      if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < KREG; ++j) {
+          const uint32_t r = key[j] - lo0 - base;    // (wraps to something huge for keys below the bucket and for key 0)
+          if (key[j] && (r >> ub) == 0) atomicAdd(&sHist[r >> sh], 1);
+        }
+      } else {
+        for (int c = tid; c < C; c += 1024) {
+          const uint32_t r = __float_as_uint(sScore[c]) - lo0 - base;
+          if (sState[c] == ST_ALIVE && (r >> ub) == 0) atomicAdd(&sHist[r >> sh], 1);
+        }
+      }
+      __syncthreads();
+      const int mine = sHist[tid];                  // suffix sums: `above` = keys of the bucket in higher bins
+      int suffix = mine;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_down(suffix, off, 64);
+        if (lane + off < 64) suffix += o;
+      }
+      if (lane == 0) sWaveTot[wave] = suffix;
+      __syncthreads();
+      int above = suffix - mine;
+      for (int w2 = wave + 1; w2 < 16; ++w2) above += sWaveTot[w2];
+      if (above < need && above + mine >= need) { sCnt[4] = tid; sCnt[5] = need - above; }
+      __syncthreads();
+      base += (uint32_t)sCnt[4] << sh;
+      need = sCnt[5];
+      ub = sh;
+    }
+    prefix = lo0 + base;
+    SEL_TP(6);
+    __syncthreads();
     // ties on the threshold key: count them; if more than `need`, rank by index
     if (tid == 0) sCnt[6] = 0;
     __syncthreads();
@@ -419,6 +469,7 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
         sList[atomicAdd(&sCnt[6], 1)] = (uint16_t)c;
     __syncthreads();
   }
+  SEL_TP(7);
   const int nties = cut ? sCnt[6] : 0;
   for (int c = tid; c < C; c += 1024) {
     if (sState[c] != ST_ALIVE) continue;
@@ -443,6 +494,7 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
   }
   __syncthreads();
 
+  SEL_TP(8);
   // ---- raster order (y outer, x inner) (:220-238) and occ_grid (:227-228) ----
   // one wavefront per cell row: inside a row the order is (dy, cx), so the rank
   // of a keypoint is popcounts of ballots over the row's KEPT flags per dy.
@@ -457,6 +509,7 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
     if (lane == 0) sRow[cy] = cnt;
   }
   __syncthreads();
+  SEL_TP(9);
   if (wave == 0) {  // exclusive prefix over the cell rows: a wave scan per 64 rows
     int carry = 0;
     for (int r0 = 0; r0 < hc; r0 += 64) {
@@ -480,6 +533,7 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
     }
   }
   __syncthreads();
+  SEL_TP(10);
   for (int cy = wave; cy < hc; cy += 16) {
     // per-dy totals over the whole row
     int tot[8];
@@ -524,6 +578,13 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
       }
     }
   }
+#ifdef SPFE_SELECT_PROBE
+  SEL_TP(11);
+  if (tid == 0 && b == 0)
+    printf("SELECT C=%d S=%d | load %llu mask %llu nms %llu count %llu keys+range %llu passes %llu ties %llu keep %llu rowcnt %llu prefix %llu raster %llu | total %llu\n",
+           C, S, tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3], tp[5] - tp[4], tp[6] - tp[5], tp[7] - tp[6], tp[8] - tp[7],
+           tp[9] - tp[8], tp[10] - tp[9], tp[11] - tp[10], tp[11] - tp[0]);
+#endif
 }
 
 hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H, int W,
@@ -535,6 +596,7 @@ hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(((H / 8) * (W / 8) + 255) / 256, B), dim3(256), 0, s, f, H / 8, W / 8);
   hipLaunchKernelGGL(select_kernel, dim3(B), dim3(1024), lds, s, f, r, H, W, num_features);
   return hipGetLastError();
 }
