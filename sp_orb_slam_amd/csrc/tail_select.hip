@@ -327,7 +327,8 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
   const uint8_t *gmask = f.cell_mask + (size_t)b * C;
   const int lane = tid & 63, wave = tid >> 6;
   int ncand = 0;
-  uint64_t und = 0;
+  uint64_t und = 0, alive = 0;   // alive: this thread's cells in state ALIVE (the later passes walk bits, not LDS)
+#pragma unroll 4
   for (int c = tid, j = 0; c < C; c += 1024, ++j) {
     const float s = gscore[c];
     const uint8_t m = gmask[c];
@@ -336,6 +337,7 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
     sMask[c] = m;
     sState[c] = s > 0.0f ? (m ? ST_UNDEC : ST_ALIVE) : ST_NONE;
     und |= (uint64_t)(s > 0.0f && m) << j;
+    alive |= (uint64_t)(s > 0.0f && !m) << j;
     ncand += s > 0.0f;
   }
   if (ncand) atomicAdd(&sCnt[2], ncand);
@@ -370,6 +372,7 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
       if (dead) sState[c] = ST_DEAD;
       else if (!blocked) sState[c] = ST_ALIVE;
       if (dead || !blocked) und &= ~(1ull << j);
+      if (!dead && !blocked) alive |= 1ull << j;
     }
     const int pending = und != 0;
     if (pending) sFlag[round & 3] = 1;
@@ -391,8 +394,7 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
   // (First version: four 8-bit passes over the raw bits with wave-aggregated atomics, 9 ballots per cell and pass —
   // 46 % of this kernel, 51 k of 110 k cycles at 752x480; a bisection on the key with register-held keys: 29 k.)
   int *sHist = sRowBase + (hc + 16) + 16;  // [1024] + [16] wave totals
-  int ns = 0;
-  for (int c = tid; c < C; c += 1024) ns += sState[c] == ST_ALIVE;
+  const int ns = __popcll(alive);
   if (ns) atomicAdd(&sCnt[1], ns);
   __syncthreads();
   const int S = sCnt[1];
@@ -408,12 +410,14 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
 #pragma unroll
     for (int j = 0; j < KREG; ++j) {
       const int c = tid + j * 1024;
-      key[j] = (in_regs && c < C && sState[c] == ST_ALIVE) ? __float_as_uint(sScore[c]) : 0u;
+      key[j] = (in_regs && ((alive >> j) & 1)) ? __float_as_uint(sScore[c]) : 0u;
       if (key[j]) { kmin = key[j] < kmin ? key[j] : kmin; kmax = key[j] > kmax ? key[j] : kmax; }
     }
     if (!in_regs)
-      for (int c = tid; c < C; c += 1024)
-        if (sState[c] == ST_ALIVE) { const uint32_t k = __float_as_uint(sScore[c]); kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; }
+      for (uint64_t rest = alive; rest; rest &= rest - 1) {
+        const uint32_t k = __float_as_uint(sScore[tid + (__ffsll((long long)rest) - 1) * 1024]);
+        kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax;
+      }
     int *sAcc = sCnt + 4;
     if (tid == 0) { sAcc[0] = 0x7fffffff; sAcc[1] = 0; }
     __syncthreads();
@@ -435,9 +439,9 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
           if (key[j] && (r >> ub) == 0) atomicAdd(&sHist[r >> sh], 1);
         }
       } else {
-        for (int c = tid; c < C; c += 1024) {
-          const uint32_t r = __float_as_uint(sScore[c]) - lo0 - base;
-          if (sState[c] == ST_ALIVE && (r >> ub) == 0) atomicAdd(&sHist[r >> sh], 1);
+        for (uint64_t rest = alive; rest; rest &= rest - 1) {
+          const uint32_t r = __float_as_uint(sScore[tid + (__ffsll((long long)rest) - 1) * 1024]) - lo0 - base;
+          if ((r >> ub) == 0) atomicAdd(&sHist[r >> sh], 1);
         }
       }
       __syncthreads();
@@ -464,22 +468,27 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
     // ties on the threshold key: count them; if more than `need`, rank by index
     if (tid == 0) sCnt[6] = 0;
     __syncthreads();
-    for (int c = tid; c < C; c += 1024)
-      if (sState[c] == ST_ALIVE && __float_as_uint(sScore[c]) == prefix)
-        sList[atomicAdd(&sCnt[6], 1)] = (uint16_t)c;
+    for (uint64_t rest = alive; rest; rest &= rest - 1) {
+      const int c = tid + (__ffsll((long long)rest) - 1) * 1024;
+      if (__float_as_uint(sScore[c]) == prefix) sList[atomicAdd(&sCnt[6], 1)] = (uint16_t)c;
+    }
     __syncthreads();
   }
   SEL_TP(7);
   const int nties = cut ? sCnt[6] : 0;
-  for (int c = tid; c < C; c += 1024) {
-    if (sState[c] != ST_ALIVE) continue;
+  // keep / border reject, and the cell row's kept count on the way: a kept cell takes the next slot of its row (any
+  // order) and parks it where its score was (only the owner thread touches a cell in this phase)
+  uint64_t kept = 0;
+  for (uint64_t rest = alive; rest; rest &= rest - 1) {
+    const int j = __ffsll((long long)rest) - 1;
+    const int c = tid + j * 1024;
     bool keep = true;
     if (cut) {
       const uint32_t key = __float_as_uint(sScore[c]);
       if (key < prefix) keep = false;
       else if (key == prefix && nties > need) {
         int lower = 0;
-        for (int j = 0; j < nties; ++j) lower += sList[j] < c;
+        for (int t = 0; t < nties; ++t) lower += sList[t] < c;
         keep = lower < need;
       }
     }
@@ -489,28 +498,21 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
     const int x = cx * 8 + (k & 7), y = cy * 8 + (k >> 3);
     // border reject (:222-224)
     if (!(x < SPFE_NMS_BORDER || x >= W - SPFE_NMS_BORDER || y < SPFE_NMS_BORDER ||
-          y >= H - SPFE_NMS_BORDER))
+          y >= H - SPFE_NMS_BORDER)) {
       sState[c] = ST_KEPT;
+      reinterpret_cast<int *>(sScore)[c] = atomicAdd(&sRow[cy], 1);
+      kept |= 1ull << j;
+    }
   }
   __syncthreads();
 
   SEL_TP(8);
   // ---- raster order (y outer, x inner) (:220-238) and occ_grid (:227-228) ----
-  // one wavefront per cell row: inside a row the order is (dy, cx), so the rank
-  // of a keypoint is popcounts of ballots over the row's KEPT flags per dy.
-  const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  for (int cy = wave; cy < hc; cy += 16) {
-    int cnt = 0;
-    for (int cx0 = 0; cx0 < wc; cx0 += 64) {
-      const int cx = cx0 + lane;
-      const bool kept = cx < wc && sState[cy * wc + cx] == ST_KEPT;
-      cnt += __popcll(__ballot(kept));
-    }
-    if (lane == 0) sRow[cy] = cnt;
-  }
-  __syncthreads();
-  SEL_TP(9);
-  if (wave == 0) {  // exclusive prefix over the cell rows: a wave scan per 64 rows
+  // The order is (cell row, dy, cx).  Exclusive prefix over the cell rows' counts; the kept cells are laid out grouped by
+  // cell row (slot order inside a row); one thread per keypoint then ranks its (dy, cx) inside its row's group — a dozen
+  // entries on a 1000-keypoint frame, at most wc.  (Was: one wavefront per cell row, 2 x 8 ballots per 64 cells — a
+  // quarter of this kernel's cycles.)
+  if (wave == 0) {  // a wave scan per 64 rows
     int carry = 0;
     for (int r0 = 0; r0 < hc; r0 += 64) {
       const int r = r0 + lane;
@@ -533,55 +535,38 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
     }
   }
   __syncthreads();
-  SEL_TP(10);
-  for (int cy = wave; cy < hc; cy += 16) {
-    // per-dy totals over the whole row
-    int tot[8];
-#pragma unroll
-    for (int d = 0; d < 8; ++d) tot[d] = 0;
-    for (int cx0 = 0; cx0 < wc; cx0 += 64) {
-      const int cx = cx0 + lane;
-      const bool kept = cx < wc && sState[cy * wc + cx] == ST_KEPT;
-      const int dyc = kept ? (sK[cy * wc + cx] >> 3) : -1;
-#pragma unroll
-      for (int d = 0; d < 8; ++d) tot[d] += __popcll(__ballot(dyc == d));
-    }
-    int before[8];  // keypoints of this row in pixel rows above dy
-    int run = sRowBase[cy];
-#pragma unroll
-    for (int d = 0; d < 8; ++d) { before[d] = run; run += tot[d]; }
-    int seen[8];    // same dy, earlier 64-cell chunks
-#pragma unroll
-    for (int d = 0; d < 8; ++d) seen[d] = 0;
-    for (int cx0 = 0; cx0 < wc; cx0 += 64) {
-      const int cx = cx0 + lane;
-      const int c = cy * wc + cx;
-      const bool kept = cx < wc && sState[c] == ST_KEPT;
-      const int k = kept ? sK[c] : 0;
-      const int dyc = kept ? (k >> 3) : -1;
-      int idx = 0;
-#pragma unroll
-      for (int d = 0; d < 8; ++d) {
-        const uint64_t m = __ballot(dyc == d);
-        if (dyc == d) idx = before[d] + seen[d] + __popcll(m & lt_mask);
-        seen[d] += __popcll(m);
-      }
-      if (cx < wc) {
-        int16_t o = -1;
-        if (kept) {
-          o = (int16_t)idx;
-          kp_xy[2 * idx] = (float)(cx * 8 + (k & 7));
-          kp_xy[2 * idx + 1] = (float)(cy * 8 + dyc);
-          kp_cell[idx] = c;
-        }
-        occ[c] = o;
-      }
-    }
+  SEL_TP(9);
+  for (uint64_t rest = kept; rest; rest &= rest - 1) {   // (the tie list in sList is no longer needed)
+    const int c = tid + (__ffsll((long long)rest) - 1) * 1024;
+    sList[sRowBase[c / wc] + reinterpret_cast<int *>(sScore)[c]] = (uint16_t)c;
   }
+  __syncthreads();
+  SEL_TP(10);
+  const int K = sCnt[3];
+  for (int t = tid; t < K; t += 1024) {
+    const int c = sList[t];
+    const int cy = c / wc, cx = c - cy * wc;
+    const int k = sK[c];
+    const int mykey = ((k >> 3) << 16) | cx;
+    const int g0 = sRowBase[cy], g1 = g0 + sRow[cy];
+    int idx = g0;
+    for (int u = g0; u < g1; ++u) {
+      const int cu = sList[u];
+      idx += (((sK[cu] >> 3) << 16) | (cu - cy * wc)) < mykey;
+    }
+    kp_xy[2 * idx] = (float)(cx * 8 + (k & 7));
+    kp_xy[2 * idx + 1] = (float)(cy * 8 + (k >> 3));
+    kp_cell[idx] = c;
+    reinterpret_cast<int *>(sScore)[c] = idx;
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int c = tid; c < C; c += 1024)
+    occ[c] = sState[c] == ST_KEPT ? (int16_t)reinterpret_cast<int *>(sScore)[c] : (int16_t)-1;
 #ifdef SPFE_SELECT_PROBE
   SEL_TP(11);
   if (tid == 0 && b == 0)
-    printf("SELECT C=%d S=%d | load %llu mask %llu nms %llu count %llu keys+range %llu passes %llu ties %llu keep %llu rowcnt %llu prefix %llu raster %llu | total %llu\n",
+    printf("SELECT C=%d S=%d | load %llu mask %llu nms %llu count %llu keys+range %llu passes %llu ties %llu keep+rowcnt %llu rowprefix %llu place %llu rank+occ %llu | total %llu\n",
            C, S, tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3], tp[5] - tp[4], tp[6] - tp[5], tp[7] - tp[6], tp[8] - tp[7],
            tp[9] - tp[8], tp[10] - tp[9], tp[11] - tp[10], tp[11] - tp[0]);
 #endif
