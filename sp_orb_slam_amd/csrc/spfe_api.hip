@@ -91,9 +91,12 @@ struct spfe_handle_s {
   unsigned char *d_wdb = nullptr, *d_wpb = nullptr;   // bf16 mode: convDb / convPb weights, head_bf16.hip layout
   float *d_wdb32 = nullptr, *d_wpb32 = nullptr;       // f32 mode: the same for head_f32.hip (SPFE_F32_HEADS=1; default: generic kernel)
   bool f32_heads = false;
-  float *d_heat_log = nullptr, *d_heat = nullptr, *d_heat_inv = nullptr;
-  float *d_minmax = nullptr, *d_cell_score = nullptr, *d_heat_consts = nullptr;
-  uint8_t *d_cell_k = nullptr, *d_cell_mask = nullptr;
+  // what the detector tail (launch stream) hands to the side chain exists twice, by ticket parity: batch i + 1's tail then
+  // only has to wait for batch i - 1's side chain, not for batch i's (which runs beside batch i + 1's convolutions)
+  float *d_heat_log[2] = {}, *d_heat = nullptr, *d_heat_inv = nullptr;
+  float *d_minmax[2] = {}, *d_cell_score[2] = {}, *d_heat_consts = nullptr;
+  uint8_t *d_cell_k[2] = {}, *d_cell_mask = nullptr;
+  const uint8_t *rec_of[NTICKET] = {};   // record buffer of each ticket (same buffer twice in a row: the old ordering)
   int *d_kp_cell = nullptr;
   uint8_t *d_records = nullptr;
   spfe::CovScratch cov{};
@@ -468,14 +471,16 @@ int build(spfe_handle h, const spfe_config *cfg) {
   if ((rc = dev_alloc(h, &h->d_head, (size_t)B * C * 512))) return rc;
   if ((rc = dev_alloc(h, &h->d_semi, (size_t)B * C * SPFE_SEMI_CH))) return rc;
   if ((rc = dev_alloc(h, &h->d_coarse, (size_t)B * C * SPFE_DESC_DIM))) return rc;
-  if ((rc = dev_alloc(h, &h->d_heat_log, (size_t)B * H * W))) return rc;
+  for (int k = 0; k < 2; ++k) {
+    if ((rc = dev_alloc(h, &h->d_heat_log[k], (size_t)B * H * W))) return rc;
+    if ((rc = dev_alloc(h, &h->d_minmax[k], (size_t)B * spfe::tail_parts(h->H, h->W) * 2))) return rc;
+    if ((rc = dev_alloc(h, &h->d_cell_score[k], (size_t)B * C))) return rc;
+    if ((rc = dev_alloc(h, &h->d_cell_k[k], (size_t)B * C))) return rc;
+  }
   if ((rc = dev_alloc(h, &h->d_heat_inv, (size_t)B * H * W))) return rc;
   if (cfg->flags & SPFE_FLAG_HEAT)
     if ((rc = dev_alloc(h, &h->d_heat, (size_t)B * H * W))) return rc;
-  if ((rc = dev_alloc(h, &h->d_minmax, (size_t)B * spfe::tail_parts(h->H, h->W) * 2))) return rc;
-  if ((rc = dev_alloc(h, &h->d_cell_score, (size_t)B * C))) return rc;
   if ((rc = dev_alloc(h, &h->d_heat_consts, (size_t)B * 4))) return rc;
-  if ((rc = dev_alloc(h, &h->d_cell_k, (size_t)B * C))) return rc;
   if ((rc = dev_alloc(h, &h->d_cell_mask, (size_t)B * C))) return rc;
   if ((rc = dev_alloc(h, &h->d_kp_cell, (size_t)B * h->kmax))) return rc;
   {
@@ -727,18 +732,25 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s) {
   const int H = h->H, W = h->W;
   spfe::FrameBufs f{};
   f.semi = h->d_semi; f.coarse = h->d_coarse;
-  f.heat_log = h->d_heat_log; f.heat = h->d_heat; f.heat_inv = h->d_heat_inv;
-  f.minmax = reinterpret_cast<uint32_t *>(h->d_minmax);
-  f.cell_score = h->d_cell_score; f.cell_k = h->d_cell_k; f.cell_mask = h->d_cell_mask; f.kp_cell = h->d_kp_cell;
+  const int par = (int)(h->ticket & 1);
+  f.heat_log = h->d_heat_log[par]; f.heat = h->d_heat; f.heat_inv = h->d_heat_inv;
+  f.minmax = reinterpret_cast<uint32_t *>(h->d_minmax[par]);
+  f.cell_score = h->d_cell_score[par]; f.cell_k = h->d_cell_k[par]; f.cell_mask = h->d_cell_mask; f.kp_cell = h->d_kp_cell;
   f.records = d_records; f.heat_consts = h->d_heat_consts;
   if (h->timing && !h->ev) return fail(SPFE_EINVAL, "internal: no event set");
   const int slot = (int)(h->ticket % spfe_handle_s::NTICKET);
-  // the previous call's covariance still reads heat_inv / its record and owns the
-  // covariance scratch: everything from here on must come after it
+  // A side chain still in flight: heat_inv, the covariance scratch and everything else that only side-stream kernels
+  // touch is ordered by that stream.  This call's tail writes the buffers of its ticket parity — last read by the chain
+  // two tickets back — and the dust maps inside the record buffer, so it waits for the previous chain only when the
+  // caller passes the same record buffer twice in a row.
   if (h->cov_inflight) {
-    const int prev = (int)((h->ticket + spfe_handle_s::NTICKET - 1) % spfe_handle_s::NTICKET);
-    HIP_TRY(hipStreamWaitEvent(s, h->ev_cov[prev], 0));
+    const int NT = spfe_handle_s::NTICKET;
+    if (h->ticket >= 2) HIP_TRY(hipStreamWaitEvent(s, h->ev_cov[(h->ticket - 2) % NT], 0));
+    const int prev = (int)((h->ticket + NT - 1) % NT);
+    static const bool old_order = getenv("SPFE_TAIL_WAITS_PREV") && atoi(getenv("SPFE_TAIL_WAITS_PREV"));   // A/B knob
+    if (h->rec_of[prev] == d_records || old_order) HIP_TRY(hipStreamWaitEvent(s, h->ev_cov[prev], 0));
   }
+  h->rec_of[slot] = d_records;
   HIP_TRY(spfe::launch_tail(f, h->rl, n, H, W, s));
   STAGE_MARK(12);
   // Everything that only the finished record needs — selection (one latency-bound workgroup per frame), heat
@@ -995,11 +1007,11 @@ long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size
     if (h->bf16) return fail(SPFE_EINVAL, "'head' is f32 only: the bf16 mode keeps ReLU(convPa) | ReLU(convDa) as bf16");
     src = h->d_head + frame * C * 512; bytes = C * 512 * 4;
   }
-  else if (nm == "heat_log") { src = h->d_heat_log + frame * HW; bytes = HW * 4; }
+  else if (nm == "heat_log") { src = h->d_heat_log[(h->ticket + 1) & 1] + frame * HW; bytes = HW * 4; }
   else if (nm == "heat_inv") { src = h->d_heat_inv + frame * HW; bytes = HW * 4; }
   else if (nm == "heat" && h->d_heat) { src = h->d_heat + frame * HW; bytes = HW * 4; }
   else if (nm == "image") { src = h->d_img + frame * HW; bytes = HW; }
-  else if (nm == "cell_score") { src = h->d_cell_score + frame * C; bytes = C * 4; }
+  else if (nm == "cell_score") { src = h->d_cell_score[(h->ticket + 1) & 1] + frame * C; bytes = C * 4; }
   else if (nm == "cov_counters") { src = h->cov.counters + frame * 4; bytes = 16; }
   else if (nm == "cov_nxt") { src = h->cov.nxt + (size_t)frame * h->kmax; bytes = (size_t)h->kmax * 4; }
   else if (nm == "cov_workers") { src = h->cov.workers + (size_t)frame * h->kmax; bytes = (size_t)h->kmax * 4; }
