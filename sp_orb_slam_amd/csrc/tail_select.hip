@@ -297,6 +297,9 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
   const int wc = W >> 3, hc = H >> 3, C = hc * wc;
   const int Cp = (C + 15) & ~15;
   const int b = blockIdx.x, tid = threadIdx.x;
+  // c / wc for c < 2^16 as one multiply-high (exact: the error of ceil(2^32 / wc) stays below 2^-16 < 1 / wc)
+  const unsigned wc_magic = wc > 1 ? 0xffffffffu / (unsigned)wc + 1u : 0u;
+  auto row_of = [&](int c) -> int { return wc > 1 ? (int)__umulhi((unsigned)c, wc_magic) : c; };
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   float *sScore = reinterpret_cast<float *>(smem);
   uint16_t *sList = reinterpret_cast<uint16_t *>(sScore + Cp);
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
       }
     }
     if (!keep) continue;
-    const int cy = c / wc, cx = c - cy * wc;
+    const int cy = row_of(c), cx = c - cy * wc;
     const int k = sK[c];
     const int x = cx * 8 + (k & 7), y = cy * 8 + (k >> 3);
     // border reject (:222-224)
@@ -538,14 +541,14 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
   SEL_TP(9);
   for (uint64_t rest = kept; rest; rest &= rest - 1) {   // (the tie list in sList is no longer needed)
     const int c = tid + (__ffsll((long long)rest) - 1) * 1024;
-    sList[sRowBase[c / wc] + reinterpret_cast<int *>(sScore)[c]] = (uint16_t)c;
+    sList[sRowBase[row_of(c)] + reinterpret_cast<int *>(sScore)[c]] = (uint16_t)c;
   }
   __syncthreads();
   SEL_TP(10);
   const int K = sCnt[3];
   for (int t = tid; t < K; t += 1024) {
     const int c = sList[t];
-    const int cy = c / wc, cx = c - cy * wc;
+    const int cy = row_of(c), cx = c - cy * wc;
     const int k = sK[c];
     const int mykey = ((k >> 3) << 16) | cx;
     const int g0 = sRowBase[cy], g1 = g0 + sRow[cy];
