@@ -117,6 +117,35 @@ def test_random_logits_exact(H, W, nf, scale, seed):
     assert fr.K > 0
 
 
+@pytest.mark.parametrize("nf,levels", [(10, (4.0,)), (37, (4.0,)), (25, (5.0, 4.0)), (60, (5.0, 4.0, 4.0, 3.0))])
+def test_cut_through_a_group_of_equal_scores(nf, levels):
+    """The num_features+1 cut lands inside a run of identical scores (one score for the whole frame: the radix
+    select's range is zero): the lowest cell indices of the run survive (sp_extractor.cpp:489-498 with the
+    oracle's tie rule), on the GPU through the tie list of select_kernel."""
+    H, W = 128, 160
+    cands = []
+    i = 0
+    for y in range(12, H - 12, 10):          # >= 10 px apart: nobody suppresses anybody
+        for x in range(12, W - 12, 10):
+            cands.append((x, y, levels[i % len(levels)]))
+            i += 1
+    assert len(cands) > nf + 1
+    semi = _semi_from_candidates(H, W, cands)
+    fr, ref = _run(semi, _coarse(H, W, 5), H, W, nf)
+    _check_exact(fr, ref)
+    assert fr.K == nf + 1 or fr.K == nf    # (the nf+1-th survivor is kept, :211-213)
+
+
+def test_selection_with_more_cells_than_the_register_path_holds():
+    """1024 x 1088: 17,408 cells > 16 per thread — select_kernel's cut walks its keys in LDS instead of registers."""
+    H, W, nf = 1024, 1088, 1000
+    rng = np.random.default_rng(11)
+    semi = (rng.standard_normal((H // 8, W // 8, 65)) * 1.5).astype(f32)
+    fr, ref = _run(semi, _coarse(H, W, 11), H, W, nf)
+    _check_exact(fr, ref)
+    assert fr.K > nf // 2
+
+
 def _hills(H, W, seed, sigma, nh, rough=0.35):
     """Smooth per-pixel logit field (sum of Gaussian bumps): broad hills whose BFS regions overlap."""
     rng = np.random.default_rng(seed)
