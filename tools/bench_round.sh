@@ -6,10 +6,11 @@ cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/round_$tag
 mkdir -p $out
 run() { n=$1; shift; timeout 600 python bench.py "$@" > $out/bench_$n.json 2> $out/bench_$n.err || echo "bench $n failed"; tail -c 300 $out/bench_$n.json | head -c 300; echo; }
-run default
-run bf16_720p --precision bf16 --height 720 --width 1280 --no-bf16-leg
-run bf16_752 --precision bf16 --no-bf16-leg
-run f32_720p --height 720 --width 1280 --no-bf16-leg --no-match --no-host-path
-run f32_640 --height 480 --width 640 --no-bf16-leg --no-match --no-host-path
-run f32_sparse --detector sparse --no-bf16-leg --no-match --no-host-path --no-cpu-baseline
-run bf16_720p_sparse --detector sparse --precision bf16 --height 720 --width 1280 --no-bf16-leg --no-match --no-host-path --no-cpu-baseline
+run default --gpus 1 --steps 20 --warmup 5      # the driver's command line (BENCH_rNN.json)
+L="--steps 200 --warmup 20"                        # the others: steady state (a 20-step region reads up to 8 % low in bf16 mode)
+run bf16_720p $L --precision bf16 --height 720 --width 1280 --no-bf16-leg
+run bf16_752 $L --precision bf16 --no-bf16-leg
+run f32_720p $L --height 720 --width 1280 --no-bf16-leg --no-match --no-host-path
+run f32_640 $L --height 480 --width 640 --no-bf16-leg --no-match --no-host-path
+run f32_sparse $L --detector sparse --no-bf16-leg --no-match --no-host-path --no-cpu-baseline
+run bf16_720p_sparse $L --detector sparse --precision bf16 --height 720 --width 1280 --no-bf16-leg --no-match --no-host-path --no-cpu-baseline

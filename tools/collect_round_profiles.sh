@@ -8,7 +8,7 @@ R=gpurun_out/round_$tag
 declare -A ARGS=([f32_async]="" [f32_sync]="--sync-cov" [bf16_720p_async]="--precision bf16 --height 720 --width 1280" [bf16_720p_sync]="--precision bf16 --height 720 --width 1280 --sync-cov" [bf16_752_async]="--precision bf16")
 for f in f32_async f32_sync bf16_720p_async bf16_720p_sync bf16_752_async; do
   {
-    echo "# profiles/${pre}_kernel_stats_$f.txt — rocprofv3 --kernel-trace --stats of: python bench.py --no-cpu-baseline --no-bf16-leg --no-host-path --no-match --no-latency --no-stage-table --steps 10 ${ARGS[$f]}  (tools/profile_round.sh)"
+    echo "# profiles/${pre}_kernel_stats_$f.txt — rocprofv3 --kernel-trace --stats of: python bench.py --no-cpu-baseline --no-bf16-leg --no-host-path --no-match --no-latency --no-stage-table --steps 100 --warmup 10 ${ARGS[$f]}  (tools/profile_round.sh)"
     echo "# bench line of the same run: $(python -c 'import json,sys; d=json.load(open(sys.argv[1])); print("value", d["value"], "frames/s, ms_per_step", d["ms_per_step"], ", conv1b kernel_ms from the in-region HIP events", d["roofline"]["kernel_ms"], ", frac", d["roofline"]["frac"])' $R/bench_under_trace_$f.json)"
     sed -n 2,40p $R/kernel_stats_$f.txt | cut -c1-175
   } > profiles/${pre}_kernel_stats_$f.txt

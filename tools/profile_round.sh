@@ -9,7 +9,7 @@ mkdir -p $out
 common="--no-cpu-baseline --no-bf16-leg --no-host-path --no-match --no-latency --no-stage-table"
 trace() {   # name, bench args
   name=$1; shift
-  rocprofv3 --kernel-trace --stats -d $out/kt_$name -o trace -- python bench.py $common --steps 10 "$@" > $out/kt_$name.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $out/kt_$name -o trace -- python bench.py $common --steps 100 --warmup 10 "$@" > $out/kt_$name.log 2>&1
   python tools/rocpd_summary.py $out/kt_$name/*.db > $out/kernel_stats_$name.txt 2>&1
   grep '^{' $out/kt_$name.log | tail -1 > $out/bench_under_trace_$name.json
 }
