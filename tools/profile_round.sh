@@ -22,6 +22,7 @@ pmc() {   # name, counters, bench args
   name=$1; ctrs=$2; shift; shift
   timeout 600 rocprofv3 --kernel-trace --pmc $ctrs -d $out/pmc_$name -o pmc -- python bench.py $common --steps 2 --warmup 1 --sync-cov "$@" > $out/pmc_$name.log 2>&1 || echo "pmc $name failed"
 }
+if [ -n "$SKIP_PMC" ]; then rm -rf $out/kt_*/; ls $out | wc -l; exit 0; fi   # SKIP_PMC=1: the traces only
 for cfg in "f32:" "bf16_720p:--precision bf16 --height 720 --width 1280" "bf16_752:--precision bf16"; do
   n=${cfg%%:*}; a=${cfg#*:}
   pmc ${n}_fetch "FETCH_SIZE" $a
