@@ -63,7 +63,17 @@ struct Walk {
   int *gq;               // global pop list of this keypoint [qcap]
   float *gqv;
   int qcap, W, H, x0, y0, j;
+  unsigned wmagic;       // floor((2^32 - 1) / W): row_of()
 };
+
+// id / W for any id < 2^32 without the 40-instruction division (it sits on the walk's dependent chain): the
+// multiply-high with floor(2^32 / W) is the quotient or one less
+__device__ __forceinline__ unsigned w_magic(int W) { return 0xffffffffu / (unsigned)W; }
+__device__ __forceinline__ int row_of(int id, int W, unsigned magic) {
+  int q = (int)__umulhi((unsigned)id, magic);
+  if (id - q * W >= W) ++q;
+  return q;
+}
 
 // The slow paths (FIFO entries beyond the LDS part, pixels outside the window) are
 // real calls: written as `cond ? lds[i] : global[i]` the compiler speculates the
@@ -151,7 +161,7 @@ __device__ int walk(const Walk &w, int lane) {
     const int e = head + (act ? gi : 0);
     const int id = fifo_id(w, e);
     const float here = fifo_val(w, e);
-    const int y = id / W, x = id - y * W;
+    const int y = row_of(id, W, w.wmagic), x = id - y * W;
     const int cdx = x - x0 + COV_WIN, cdy = y - y0 + COV_WIN;
     const bool pin = (unsigned)cdx < 32u && (unsigned)cdy < 32u;   // the popped pixel is inside the window
     const int nx = x + ox, ny = y + oy;
@@ -207,37 +217,55 @@ __device__ int walk(const Walk &w, int lane) {
   return tail;
 }
 
-// second moments over the popped sequence, in pop order (:316-333).  Lanes hold
-// one entry each; lane order is pop order, and the running sums are accumulated
+// second moments over the popped sequence, in pop order (:316-333): the running sums are accumulated
 // one entry at a time exactly like the reference's loops.
-__device__ __forceinline__ float lane_bcast(float v, int src_lane) {  // src_lane is wave-uniform
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
-}
 __device__ void moments(const Walk &w, int n, int lane, float *cov2, float *cov2_inv) {
+  // The running sums are sequential float adds in pop order (:316-333): every lane runs them redundantly on values it
+  // reads from LDS with wave-uniform addresses (broadcast reads, four values a read, issued ahead of the dependent add
+  // chain).  The first version passed the terms from lane to lane with v_readlane — ~70 cycles per term, a third of a
+  // replayed member's time.
+  WaveMem *m = w.m;
   float sum = 0.0f;
-  for (int base = 0; base < n; base += 64) {
-    const int i = base + lane;
-    const float v = i < n ? fifo_val(w, i) : 0.0f;
-    const int cnt = n - base < 64 ? n - base : 64;
-    for (int u = 0; u < cnt; ++u) sum += lane_bcast(v, u);
+  {
+    const int nl = n < COV_LCAP ? n : COV_LCAP;
+    const float4 *v4 = reinterpret_cast<const float4 *>(m->lqv);
+    int i = 0;
+    for (; i + 4 <= nl; i += 4) {
+      const float4 v = v4[i >> 2];
+      sum += v.x; sum += v.y; sum += v.z; sum += v.w;
+    }
+    for (; i < nl; ++i) sum += m->lqv[i];
+    for (; i < n; ++i) sum += slow_ld_f(w.gqv, i);   // beyond the LDS part of the list (rare)
   }
+  // the weighted squares are independent per entry (all lanes), then staged in the window buffer — the walk is over,
+  // nothing reads hv any more — for the two ordered sums
   float cx = 0.0f, cy = 0.0f;
+  float *sx = m->hv, *sy = m->hv + 64;
   for (int base = 0; base < n; base += 64) {
     const int i = base + lane;
     float tx = 0.0f, ty = 0.0f;
     if (i < n) {
       const int id = fifo_id(w, i);
-      const int y = id / w.W, x = id - y * w.W;
+      const int y = row_of(id, w.W, w.wmagic), x = id - y * w.W;
       const float wgt = fifo_val(w, i) / sum;
       const float dx = (float)x - (float)w.x0, dy = (float)y - (float)w.y0;
       tx = wgt * (dx * dx);
       ty = wgt * (dy * dy);
     }
+    sx[lane] = tx;
+    sy[lane] = ty;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int cnt = n - base < 64 ? n - base : 64;
-    for (int u = 0; u < cnt; ++u) {
-      cx += lane_bcast(tx, u);
-      cy += lane_bcast(ty, u);
+    const float4 *x4 = reinterpret_cast<const float4 *>(sx), *y4 = reinterpret_cast<const float4 *>(sy);
+    int u = 0;
+    for (; u + 4 <= cnt; u += 4) {
+      const float4 a = x4[u >> 2], b = y4[u >> 2];
+      cx += a.x; cy += b.x; cx += a.y; cy += b.y; cx += a.z; cy += b.z; cx += a.w; cy += b.w;
     }
+    for (; u < cnt; ++u) { cx += sx[u]; cy += sy[u]; }
+    __builtin_amdgcn_wave_barrier();   // (the next chunk overwrites the staging area)
   }
   if (lane == 0) {
     cx = cx < 1.0f ? 1.0f : cx;
@@ -310,7 +338,7 @@ __global__ __launch_bounds__(64 * COV_WAVES) void cov_walk_kernel(FrameBufs f, R
   const CovFrame c = cov_frame(f, rl, cs, b, H, W);
   if (j >= c.K) return;
   Walk w{&s_mem[wv], c.hinv, nullptr, c.queues + (size_t)j * cs.qcap, c.qvals + (size_t)j * cs.qcap, cs.qcap, W, H,
-         (int)c.kp_xy[2 * j], (int)c.kp_xy[2 * j + 1], j};
+         (int)c.kp_xy[2 * j], (int)c.kp_xy[2 * j + 1], j, w_magic(W)};
   stage_window<false>(w, lane);
   int n = walk<false>(w, lane);
   if (n == -1) {
@@ -465,6 +493,7 @@ __global__ __launch_bounds__(64 * COV_WAVES) void cov_replay_kernel(FrameBufs f,
   WinRegs win;
   load_window<true>(c.hinv, c.done, W, H, (int)fx, (int)fy, lane, win);
   int n_prev = 0, j_prev = -1;
+  const unsigned wmagic = w_magic(W);
   while (j >= 0) {
     const int x0 = (int)fx, y0 = (int)fy;
     // this member's window goes to LDS; the pixels the previous member just stamped were loaded before its
@@ -473,13 +502,13 @@ __global__ __launch_bounds__(64 * COV_WAVES) void cov_replay_kernel(FrameBufs f,
     store_window<true>(m, lane, win);
     for (int i = lane; i < n_prev; i += 64) {
       const int id = i < COV_LCAP ? m->lq[i] : slow_ld_i(prev_q, i);
-      const int py = id / W, px = id - py * W;
+      const int py = row_of(id, W, wmagic), px = id - py * W;
       const int dx = px - x0 + COV_WIN, dy = py - y0 + COV_WIN;
       if ((unsigned)dx < 32u && (unsigned)dy < 32u) m->dn[dy * 32 + dx] = j_prev;
     }
     int *q; float *qv; int cap;
     pop_list(c, cs, j, q, qv, cap);
-    Walk w{m, c.hinv, c.done, q, qv, cap, W, H, x0, y0, j};
+    Walk w{m, c.hinv, c.done, q, qv, cap, W, H, x0, y0, j, wmagic};
     // the next member's window and the member after it (index + position): all addresses are known, so the
     // requests go out now and their round trips pass under this member's walk
     int jnn = -1;
