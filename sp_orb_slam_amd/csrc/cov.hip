@@ -230,6 +230,11 @@ __device__ void moments(const Walk &w, int n, int lane, float *cov2, float *cov2
     const int nl = n < COV_LCAP ? n : COV_LCAP;
     const float4 *v4 = reinterpret_cast<const float4 *>(m->lqv);
     int i = 0;
+    for (; i + 16 <= nl; i += 16) {   // four reads in flight ahead of sixteen dependent adds
+      const float4 a = v4[(i >> 2)], b = v4[(i >> 2) + 1], c = v4[(i >> 2) + 2], d = v4[(i >> 2) + 3];
+      sum += a.x; sum += a.y; sum += a.z; sum += a.w; sum += b.x; sum += b.y; sum += b.z; sum += b.w;
+      sum += c.x; sum += c.y; sum += c.z; sum += c.w; sum += d.x; sum += d.y; sum += d.z; sum += d.w;
+    }
     for (; i + 4 <= nl; i += 4) {
       const float4 v = v4[i >> 2];
       sum += v.x; sum += v.y; sum += v.z; sum += v.w;
@@ -260,6 +265,11 @@ __device__ void moments(const Walk &w, int n, int lane, float *cov2, float *cov2
     const int cnt = n - base < 64 ? n - base : 64;
     const float4 *x4 = reinterpret_cast<const float4 *>(sx), *y4 = reinterpret_cast<const float4 *>(sy);
     int u = 0;
+    for (; u + 8 <= cnt; u += 8) {    // four reads in flight ahead of the two add chains
+      const float4 a = x4[u >> 2], b = y4[u >> 2], c = x4[(u >> 2) + 1], d = y4[(u >> 2) + 1];
+      cx += a.x; cy += b.x; cx += a.y; cy += b.y; cx += a.z; cy += b.z; cx += a.w; cy += b.w;
+      cx += c.x; cy += d.x; cx += c.y; cy += d.y; cx += c.z; cy += d.z; cx += c.w; cy += d.w;
+    }
     for (; u + 4 <= cnt; u += 4) {
       const float4 a = x4[u >> 2], b = y4[u >> 2];
       cx += a.x; cy += b.x; cx += a.y; cy += b.y; cx += a.z; cy += b.z; cx += a.w; cy += b.w;
@@ -494,7 +504,17 @@ __global__ __launch_bounds__(64 * COV_WAVES) void cov_replay_kernel(FrameBufs f,
   load_window<true>(c.hinv, c.done, W, H, (int)fx, (int)fy, lane, win);
   int n_prev = 0, j_prev = -1;
   const unsigned wmagic = w_magic(W);
+#ifdef SPFE_REPLAY_PROBE   // phase cycles of the long chains (printf from chains of >= 8 members; tools/microbench/README.md)
+  unsigned long long tp0 = 0, tp_store = 0, tp_walk = 0, tp_mom = 0, tp_stamp = 0, tp_all = __builtin_readcyclecounter();
+  int members = 0, pops = 0;
+#define RP(acc) do { const unsigned long long t_ = __builtin_readcyclecounter(); acc += t_ - tp0; tp0 = t_; } while (0)
+#else
+#define RP(acc) do { } while (0)
+#endif
   while (j >= 0) {
+#ifdef SPFE_REPLAY_PROBE
+    tp0 = __builtin_readcyclecounter();
+#endif
     const int x0 = (int)fx, y0 = (int)fy;
     // this member's window goes to LDS; the pixels the previous member just stamped were loaded before its
     // stamps existed: patch them from its pop list, which still sits in the LDS FIFO (no other wavefront
@@ -519,18 +539,30 @@ __global__ __launch_bounds__(64 * COV_WAVES) void cov_replay_kernel(FrameBufs f,
       nnfx = c.nxy[2 * jn];
       nnfy = c.nxy[2 * jn + 1];
     }
+    RP(tp_store);
     // a replay's pop list is a subsequence of the lone walk's: it cannot overflow
     const int n = walk<true>(w, lane);
+    RP(tp_walk);
     if (n < 0) { if (lane == 0) atomicOr(&c.hdr[2], 1); return; }
     moments(w, n, lane, c.cov2 + 2 * j, c.cinv + 2 * j);
+    RP(tp_mom);
     // stamp before the next member starts: this wavefront is the only writer and
     // the only reader of these pixels during the kernel
     for (int i = lane; i < n; i += 64) c.done[fifo_id(w, i)] = j;  // popped => its stamp was >= j
     __threadfence_block();  // same wavefront, same CU: L1 is coherent for it
+    RP(tp_stamp);
+#ifdef SPFE_REPLAY_PROBE
+    ++members; pops += n;
+#endif
     n_prev = n; j_prev = j; prev_q = q;
     j = jn; fx = nfx; fy = nfy;
     jn = jnn; nfx = nnfx; nfy = nnfy;
   }
+#ifdef SPFE_REPLAY_PROBE
+  if (lane == 0 && members >= 8)
+    printf("REPLAY chain %d members %d pops | store+patch %llu walk %llu moments %llu stamp %llu | total %llu\n", members, pops,
+           tp_store, tp_walk, tp_mom, tp_stamp, __builtin_readcyclecounter() - tp_all);
+#endif
 }
 
 size_t cov_link_lds(int kmax) { return (size_t)kmax * 4 * sizeof(int); }   // parent, leader, 2 K sort keys
