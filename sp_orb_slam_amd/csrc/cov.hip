@@ -155,52 +155,64 @@ __device__ int walk(const Walk &w, int lane) {
   int head = 0, tail = 1, now = 0;
   const int t = lane & 3, gi = lane >> 2;
   const int ox = t == 0 ? -1 : (t == 2 ? 1 : 0), oy = t == 1 ? -1 : (t == 3 ? 1 : 0);
+  const unsigned long long below = (1ull << lane) - 1ull;
   while (head < tail) {
     const int G = tail - head < 16 ? tail - head : 16;
     const bool act = gi < G;
     const int e = head + (act ? gi : 0);
-    const int id = fifo_id(w, e);
-    const float here = fifo_val(w, e);
+    int id;
+    float here;
+    if (__builtin_expect(head + G <= COV_LCAP, 1)) {   // (uniform) the group's entries are in the LDS part of the list
+      id = m->lq[e];
+      here = m->lqv[e];
+    } else {
+      id = fifo_id(w, e);
+      here = fifo_val(w, e);
+    }
     const int y = row_of(id, W, w.wmagic), x = id - y * W;
     const int cdx = x - x0 + COV_WIN, cdy = y - y0 + COV_WIN;
-    const bool pin = (unsigned)cdx < 32u && (unsigned)cdy < 32u;   // the popped pixel is inside the window
+    const bool pin = ((unsigned)cdx < 32u) & ((unsigned)cdy < 32u);   // the popped pixel is inside the window
     const int nx = x + ox, ny = y + oy;
-    // bounds as in the reference: xx > 0, yy > 0, xx < w, yy < h
-    bool take = act && (t == 0 ? nx > 0 : t == 1 ? ny > 0 : t == 2 ? nx < W : ny < H);
+    // bounds as in the reference: xx > 0, yy > 0, xx < w, yy < h   (selects, not branches: `&` on purpose)
+    const int cc = (t & 1) ? ny : nx, lim = (t & 1) ? H : W;
+    const bool inb = act & ((t < 2) ? (cc > 0) : (cc < lim));
     const int nid = id + oy * W + ox;
     const int dx = cdx + ox, dy = cdy + oy;
-    const bool inwin = (unsigned)dx < 32u && (unsigned)dy < 32u;
-    float v = 0.0f;
-    if (__builtin_expect(!take || inwin, 1)) {
-      // common case: the three lookups are independent LDS reads issued together
-      const int wi = inwin ? dy * 32 + dx : 0;
-      const float hv = m->hv[wi];
-      const int dstamp = REPLAY ? m->dn[wi] : COV_INF;
-      const uint32_t row = m->bm[inwin ? dy : 0];
-      v = hv;
-      take = take && hv > 0.0f && hv < here && !(REPLAY && dstamp < w.j) && !((row >> dx) & 1u);
-    } else {  // a neighbour outside the staged window (rare): global lookups, search of the outside list
-      v = slow_ld_f(w.hinv, nid);
-      take = v > 0.0f && v < here;
-      if (take && REPLAY) take = !(slow_ld_i(w.done, nid) < w.j);
-      if (take) take = !ow_seen(m, now, nid);
+    const bool inwin = ((unsigned)dx < 32u) & ((unsigned)dy < 32u);
+    // common case: the three lookups are independent LDS reads issued together (index 0 for the lanes they do not concern)
+    const int wi = inwin ? dy * 32 + dx : 0;
+    const float hv = m->hv[wi];
+    const int dstamp = REPLAY ? m->dn[wi] : COV_INF;
+    const uint32_t row = m->bm[inwin ? dy : 0];
+    float v = hv;
+    bool take = inb & inwin & (hv > 0.0f) & (hv < here) & !(REPLAY & (dstamp < w.j)) & !((row >> dx) & 1u);
+    if (__builtin_expect(__ballot(inb & !inwin) != 0ull, 0)) {   // (uniform, rare) a neighbour outside the staged window:
+      if (inb && !inwin) {                                       // global lookups, search of the outside list
+        v = slow_ld_f(w.hinv, nid);
+        take = v > 0.0f && v < here;
+        if (take && REPLAY) take = !(slow_ld_i(w.done, nid) < w.j);
+        if (take) take = !ow_seen(m, now, nid);
+      }
     }
-    // popped earlier in this very group
-    for (int k = 0; k + 1 < G; ++k) {
-      const int idk = __builtin_amdgcn_readlane(id, 4 * k);
-      if (gi > k && nid == idk) take = false;
-    }
+    // popped earlier in this very group: entry k < gi with the same pixel.  Unrolled over constant lanes in three blocks
+    // (a lane past the group holds entry 0's id, and no active lane has gi > k there: harmless) — as a loop over k < G - 1
+    // with a variable lane index this was more instructions than the rest of the step
+#define COV_CHK(k) take &= !((gi > (k)) & (nid == __builtin_amdgcn_readlane(id, 4 * (k))))
+    if (G > 1) { COV_CHK(0); COV_CHK(1); COV_CHK(2); }
+    if (G > 4) { COV_CHK(3); COV_CHK(4); COV_CHK(5); COV_CHK(6); }
+    if (G > 8) { COV_CHK(7); COV_CHK(8); COV_CHK(9); COV_CHK(10); COV_CHK(11); COV_CHK(12); COV_CHK(13); COV_CHK(14); }
+#undef COV_CHK
     const unsigned long long mask = __ballot(take);
-    const int pos = tail + __popcll(mask & ((1ull << lane) - 1ull));
+    const int pos = tail + __popcll(mask & below);
     const int ntail = tail + __popcll(mask);
     if (ntail > w.qcap) return -1;
-    if (take) {
-      if (pos < COV_LCAP) { m->lq[pos] = nid; m->lqv[pos] = v; }
-      else { w.gq[pos] = nid; w.gqv[pos] = v; }
+    if (take & (pos < COV_LCAP)) { m->lq[pos] = nid; m->lqv[pos] = v; }
+    if (__builtin_expect(ntail > COV_LCAP, 0)) {                  // (uniform) the list has outgrown its LDS part
+      if (take && pos >= COV_LCAP) { w.gq[pos] = nid; w.gqv[pos] = v; }
     }
     // visited at POP (:285): a bitmap inside the window, a short list outside it
-    if (act && t == 0 && pin) atomicOr(&m->bm[cdy], 1u << cdx);
-    if (__ballot(act && !pin) != 0) {   // rare: some popped pixel lies outside the window
+    if (act & (t == 0) & pin) atomicOr(&m->bm[cdy], 1u << cdx);
+    if (__builtin_expect(__ballot(act & !pin) != 0ull, 0)) {   // rare: some popped pixel lies outside the window
       for (int k = 0; k < G; ++k) {
         const int idk = __builtin_amdgcn_readlane(id, 4 * k);
         const int pk = __builtin_amdgcn_readlane(pin ? 1 : 0, 4 * k);
