@@ -435,13 +435,17 @@ __global__ __launch_bounds__(LINK_THREADS) void cov_link_kernel(FrameBufs f, Rec
   __syncthreads();
   // every pixel links its claimants to its lowest claimant: union(claim[p], j).
   // (one wavefront per dirty keypoint, lanes over its pixels)
-  const int lane = tid & 63, wv = tid >> 6;
-  for (int d = wv; d < nd; d += LINK_THREADS / 64) {
+  // (a quarter-wavefront per dirty keypoint, its 16 lanes over the pixels: the phase is two dependent global round trips
+  // per keypoint — pop list, then the claims of its pixels — and 64 groups keep four times as many of them in flight
+  // as 16 wavefronts did)
+  constexpr int GL = 16;
+  const int gl = tid & (GL - 1), grp = tid / GL;
+  for (int d = grp; d < nd; d += LINK_THREADS / GL) {
     const int j = c.dirty[d];
     int *q; float *qv; int cap;
     pop_list(c, cs, j, q, qv, cap);
     const int n = c.npop[j];
-    for (int i = 1 + lane; i < n; i += 64) {
+    for (int i = 1 + gl; i < n; i += GL) {
       int a = c.claim[q[i]];
       int bb = j;
       if (a >= j) continue;
