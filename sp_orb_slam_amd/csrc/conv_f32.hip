@@ -639,11 +639,16 @@ static hipError_t launch_one(const ConvParams &p, hipStream_t s) {
 }
 
 int conv_kc(int ksize) { return ksize == 3 ? 16 : 64; }
-int conv_tile_rows(int tile_mode) { return tile_mode == 1 ? 4 : (tile_mode == 2 ? 16 : 8); }
+int conv_tile_rows(int tile_mode) { return tile_mode == 1 ? 4 : (tile_mode == 2 ? 16 : (tile_mode == 3 ? 2 : 8)); }
 
 hipError_t launch_conv_f32(const ConvParams &p, int cin, int ksize, bool pool, bool relu,
                            int tile_mode, int layer_tag, hipStream_t s) {
   const bool small_tile = tile_mode == 1;
+  if (tile_mode == 3 && ksize == 3 && relu && !pool) {  // 2-row tiles (2x2 waves, one row x 32 channels each): single frames
+    if (cin == 64) return launch_one<0, 64, 3, 16, 2, 2, 1, 1, false, true>(p, s);   // on the low-resolution layers, where
+    if (cin == 128) return launch_one<0, 128, 3, 16, 2, 2, 1, 1, false, true>(p, s);  // a 4-row item per CU leaves CUs idle
+    return hipErrorInvalidValue;
+  }
   if (tile_mode == 2 && ksize == 3 && relu) {  // 16-row tiles, 8 waves (two per SIMD)
     if (layer_tag == 1 && cin == 64 && pool) return launch_one<1, 64, 3, 16, 8, 1, 2, 2, true, true>(p, s);  // conv1b
     if (cin == 64 && pool) return launch_one<0, 64, 3, 16, 8, 1, 2, 2, true, true>(p, s);

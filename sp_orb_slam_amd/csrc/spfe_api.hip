@@ -122,6 +122,8 @@ struct spfe_handle_s {
   size_t p_stage_bytes = 0;
   int m_pairs = 0, m_cap = 0;      // capacity of m_best_* ([pairs][cap])
   int m_host_cap = 0;              // rows the host-API staging blocks / m_out hold
+  unsigned tile2_mask = 0;   // SPFE_TILE2_MASK: f32 layers forced onto 2-row tiles (probe knob)
+  bool tile2_auto = true;    // SPFE_TILE2_AUTO=0: never choose 2-row tiles
   unsigned tile16_mask = 0;  // f32 layers (bit i = conv layer i of enqueue()) on 16-row / 8-wave tiles
   bool fuse1a = false;  // f32: conv1a computed inside conv1b (opt-in: SPFE_FUSE_CONV1A=1; measured perf-neutral)
   bool fuse1a_bf16 = true;  // bf16: conv1a computed by the producer waves of the wave-specialised conv1b (SPFE_BF16_FUSE_CONV1A=0 to split)
@@ -405,6 +407,8 @@ int build(spfe_handle h, const spfe_config *cfg) {
     h->fuse1a = fenv && atoi(fenv) != 0;
     const char *menv = getenv("SPFE_TILE16_MASK");
     if (menv) h->tile16_mask = (unsigned)strtoul(menv, nullptr, 0);
+    if (const char *m2 = getenv("SPFE_TILE2_MASK")) h->tile2_mask = (unsigned)strtoul(m2, nullptr, 0);
+    if (const char *a2 = getenv("SPFE_TILE2_AUTO")) h->tile2_auto = atoi(a2) != 0;
     const char *wenv = getenv("SPFE_BF16_WS_MASK");
     if (wenv) h->ws_mask = (unsigned)strtoul(wenv, nullptr, 0) & 0xfu;
     const char *f16env = getenv("SPFE_BF16_FUSE_CONV1A");
@@ -705,7 +709,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
       STAGE_MARK(2 + i);
       continue;
     }
-    bool small_tile = L.small_tile;
+    bool small_tile = L.small_tile, tiny_tile = false;
     if (L.ks == 3 && h->small_maxh < 0) {
       const long tx = (L.W + 31) / 32;
       const long items_big = tx * ((L.H + 7) / 8) * L.nblk * n, items_small = tx * ((L.H + 3) / 4) * L.nblk * n;
@@ -713,10 +717,20 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
       const double cost_big = (double)((items_big + g - 1) / g) * 2.0 * 0.93;
       const double cost_small = (double)((items_small + g - 1) / g);
       small_tile = cost_small < cost_big;
+      // 2-row tiles (layers without a pool): a single frame's low-resolution layers are 90 ... 360 four-row items on 256
+      // CUs — one round of long items with CUs idle.  Half-height items cost 0.56 of a 4-row one (measured, batch 1:
+      // conv4a / 4b 45 -> 27 us, convPa|Da 80 -> 64, conv3a 46 -> 38); at 8 frames per call the model keeps the taller tiles
+      if (!L.pool && L.relu && !(i == 0 && fused) && h->tile2_auto) {
+        const long items_tiny = tx * ((L.H + 1) / 2) * L.nblk * n;
+        const double cost_tiny = (double)((items_tiny + g - 1) / g) * 0.56;
+        tiny_tile = cost_tiny < (cost_small < cost_big ? cost_small : cost_big);
+      }
     }
     if (i == 0 && fused) small_tile = false;  // the fused first layer exists for 8-row tiles only
     int tile_mode = small_tile ? 1 : 0;
     if (L.ks == 3 && !(i == 0 && fused) && ((h->tile16_mask >> i) & 1)) tile_mode = 2;
+    if (tiny_tile && tile_mode != 2) tile_mode = 3;
+    if (L.ks == 3 && !L.pool && L.relu && ((h->tile2_mask >> i) & 1)) tile_mode = 3;
     const int th = spfe::conv_tile_rows(tile_mode);
     p.tiles_x = (L.W + 31) / 32; p.tiles_y = (L.H + th - 1) / th; p.nblk = L.nblk;
     p.num_cus = h->num_cus;

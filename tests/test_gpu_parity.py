@@ -653,3 +653,27 @@ def test_f32_heads_with_register_resident_weights_are_bit_identical(monkeypatch)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     for a, b in zip(out["0"][0], out["1"][0]):
         assert np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.descriptors, b.descriptors)
+
+
+@pytest.mark.parametrize("H,W,B", [(240, 376, 1), (120, 168, 3), (480, 752, 1)])
+def test_f32_two_row_tiles_are_bit_identical(monkeypatch, H, W, B):
+    """2-row tiles of conv_f32_kernel (chosen by the cost model for single frames; forced here on every layer without a
+    pool) against the 4 / 8-row tiles (SPFE_TILE2_AUTO=0): the tile shape does not touch an output's K order, so semi,
+    coarse and the intermediate activations are the same bits — ragged heights (120 / 8 = 15 rows) included."""
+    nf = 300
+    blob = weights.synthetic(7, "dense")
+    imgs = [synth.make_image(70 + i, H, W) for i in range(B)]
+    out = {}
+    for name, auto, mask in (("tall", "0", "0"), ("two", "1", "0xEA"), ("auto", "1", "0")):
+        monkeypatch.setenv("SPFE_TILE2_AUTO", auto)
+        monkeypatch.setenv("SPFE_TILE2_MASK", mask)
+        ext = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=False)
+        frs = ext.extract_batch(imgs)
+        out[name] = (frs, [ext.debug_read(nm, i) for i in range(B) for nm in ("semi", "coarse", "feat")])
+        ext.close()
+    for name in ("two", "auto"):
+        for a, b in zip(out["tall"][1], out[name][1]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        for a, b in zip(out["tall"][0], out[name][0]):
+            assert np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.descriptors, b.descriptors)
+            assert np.array_equal(a.cov2, b.cov2)
