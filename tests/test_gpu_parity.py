@@ -677,3 +677,25 @@ def test_f32_two_row_tiles_are_bit_identical(monkeypatch, H, W, B):
         for a, b in zip(out["tall"][0], out[name][0]):
             assert np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.descriptors, b.descriptors)
             assert np.array_equal(a.cov2, b.cov2)
+
+
+def test_debug_read_follows_the_double_buffered_tail_outputs():
+    """heat_log / cell_score exist twice (by ticket parity, so that the next batch's detector tail does not wait for this
+    batch's side chain): debug_read must hand out the set the LAST call wrote, whichever parity that was."""
+    H, W = 120, 160
+    blob = weights.synthetic(7, "dense")
+    a, b = synth.make_image(81, H, W), synth.make_image(82, H, W)
+    one = SPExtractor(100, H, W, blob, with_heat=False)
+    one(b, None)                                    # ticket 0
+    ref = {nm: one.debug_read(nm) for nm in ("heat_log", "cell_score", "semi")}
+    one.close()
+    two = SPExtractor(100, H, W, blob, with_heat=False)
+    two(a, None)                                    # ticket 0
+    two(b, None)                                    # ticket 1: the other set
+    for nm, r in ref.items():
+        assert np.array_equal(two.debug_read(nm).view(np.uint32), r.view(np.uint32)), nm
+    two(a, None)                                    # ticket 2: back to the first set, now holding image a
+    assert not np.array_equal(two.debug_read("heat_log"), ref["heat_log"])
+    two(b, None)
+    assert np.array_equal(two.debug_read("heat_log").view(np.uint32), ref["heat_log"].view(np.uint32))
+    two.close()
