@@ -10,6 +10,7 @@
 #include <rccl/rccl.h>  // types and prototypes only: librccl is dlopen'ed by spfe_comm_init, not linked
 
 #include <algorithm>
+#include <functional>
 #include <cfloat>
 #include <cstdarg>
 #include <cstdio>
@@ -76,6 +77,8 @@ struct spfe_handle_s {
   hipStream_t side = nullptr;
   static constexpr int NTICKET = 4;
   hipEvent_t ev_post[NTICKET] = {}, ev_cov[NTICKET] = {};
+  hipEvent_t ev_db = nullptr;    // launch stream: this call's convDb is done (when it is launched behind the detector tail)
+  bool defer_db = true;          // SPFE_DEFER_DB=0: convDb in layer order
   hipEvent_t ev_desc = nullptr;  // side stream: the last call's descriptor sampling (reader of d_coarse) is done
   bool desc_recorded = false;
   long ticket = 0;          // calls so far; call t uses slot t % NTICKET
@@ -402,6 +405,8 @@ int build(spfe_handle h, const spfe_config *cfg) {
     HIP_TRY(hipEventCreateWithFlags(&h->ev_cov[i], hipEventDisableTiming));
   }
   HIP_TRY(hipEventCreateWithFlags(&h->ev_desc, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&h->ev_db, hipEventDisableTiming));
+  if (const char *de = getenv("SPFE_DEFER_DB")) h->defer_db = atoi(de) != 0;
   {
     const char *fenv = getenv("SPFE_FUSE_CONV1A");
     h->fuse1a = fenv && atoi(fenv) != 0;
@@ -606,7 +611,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
 #define STAGE_MARK(i) \
   do { if (h->timing && (h->timing_all || (i) == 1 || (i) == 2)) HIP_TRY(hipEventRecord(h->ev[i], s)); } while (0)
 
-int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s);
+int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const std::function<int()> *conv_db = nullptr);
 
 // D2H of the records by a kernel of our own that writes the pinned (device-mapped) host buffer: 8.9 MB in ~0.18 ms, no LDS,
 // fits beside the persistent convolution workgroups; the runtime's own D2H path cost 0.36 ms more per batch in the pipeline
@@ -643,7 +648,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   if (h->bf16 && !fused16) HIP_TRY(spfe::launch_conv1a_bf16(d_images, h->d_w1a_tab, h->d_b1a, h->act[0], n, H, W, s));
   else if (!h->bf16 && !fused) HIP_TRY(spfe::launch_conv1a(d_images, h->d_w1a, h->d_b1a, h->act[0], n, H, W, s));
   STAGE_MARK(1);
-  for (int i = 0; i < 10; ++i) {
+  auto run_layer = [&](int i) -> int {
     const ConvLayer &L = h->layers[i];
     // convDb overwrites the coarse descriptor map the PREVIOUS call's descriptor sampling reads on
     // the side stream (pipelined callers): order it after that, by event, not by timing
@@ -672,7 +677,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
         if (i == 0 && fused16) { p.img = d_images; p.w1a = reinterpret_cast<const float *>(h->d_w1a_tab); p.b1a = h->d_b1a; }
         HIP_TRY(spfe::launch_conv_bf16_ws(p, L.pool, i == 0 ? (fused16 ? 2 : 1) : 0, s));
         STAGE_MARK(2 + i);
-        continue;
+        return SPFE_OK;
       }
       // streamed-weight layers (Cin = 128): work items in queue order (conv_bf16.hip, CtlB::dyn); SPFE_BF16_DYN_QUEUE=0: static
       // (launches with a handful of items per workgroup stay static: the queue costs them more than it balances)
@@ -695,19 +700,19 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
       }
       HIP_TRY(spfe::launch_conv_bf16(p, L.cin, L.pool, false, s, tile_rows));
       STAGE_MARK(2 + i);
-      continue;
+      return SPFE_OK;
     }
     if (h->bf16 && i >= 8) {  // convPb (65 logits) and convDb (256 descriptor channels): bf16 GEMMs over all cells of the batch
       if (i == 8) HIP_TRY(spfe::launch_head1x1_bf16(h->d_hd, h->d_wpb, L.d_b, h->d_semi, n * h->C, 65, s));
       else HIP_TRY(spfe::launch_head1x1_bf16(h->d_hd, h->d_wdb, L.d_b, h->d_coarse, n * h->C, 256, s));
       STAGE_MARK(2 + i);
-      continue;
+      return SPFE_OK;
     }
     if (!h->bf16 && i >= 8 && h->f32_heads) {  // convPb / convDb in f32: head_f32.hip (weights in registers)
       if (i == 8) HIP_TRY(spfe::launch_head1x1_f32(h->d_head, h->d_wpb32, L.d_b, h->d_semi, n * h->C, 65, s));
       else HIP_TRY(spfe::launch_head1x1_f32(h->d_head, h->d_wdb32, L.d_b, h->d_coarse, n * h->C, 256, s));
       STAGE_MARK(2 + i);
-      continue;
+      return SPFE_OK;
     }
     bool small_tile = L.small_tile, tiny_tile = false;
     if (L.ks == 3 && h->small_maxh < 0) {
@@ -736,13 +741,27 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     p.num_cus = h->num_cus;
     HIP_TRY(spfe::launch_conv_f32(p, L.cin, L.ks, L.pool, L.relu, tile_mode, i == 0 ? (fused ? 2 : 1) : 0, s));
     STAGE_MARK(2 + i);
+    return SPFE_OK;
+  };
+  // The descriptor head (convDb) feeds only the descriptor sampling; the detector branch — tail, selection, heat
+  // normalisation, covariance — does not wait for it.  So it is launched BEHIND the detector tail and runs beside the side
+  // chain's first kernels (a synchronous single-frame call: p50 0.83 -> 0.80 ms at 752x480 f32, 0.38 -> 0.365 ms at 1280x720 bf16).  With
+  // per-stage events (SPFE_STAGE_TIMING=1) the launch order stays the table's order.
+  // Synchronous calls only: in the pipelined modes the side chain runs beside the NEXT batch anyway, and the deferred order
+  // measured 0.3 ... 0.7 % slower there.
+  const bool defer_db = !(h->timing && h->timing_all) && h->defer_db && !((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode);
+  for (int i = 0; i < (defer_db ? 9 : 10); ++i) {
+    const int rc = run_layer(i);
+    if (rc) return rc;
   }
-  return enqueue_post(h, n, d_records, s);
+  if (!defer_db) return enqueue_post(h, n, d_records, s);
+  const std::function<int()> conv_db = [&]() -> int { return run_layer(9); };
+  return enqueue_post(h, n, d_records, s, &conv_db);
 }
 
 // Detector tail, selection, descriptors, covariance for n frames whose semi /
 // coarse maps are in the handle's buffers.
-int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s) {
+int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const std::function<int()> *conv_db) {
   const int H = h->H, W = h->W;
   spfe::FrameBufs f{};
   f.semi = h->d_semi; f.coarse = h->d_coarse;
@@ -775,6 +794,12 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s) {
   STAGE_MARK(13);   // ("select" reads 0 on the launch stream: it is part of post_side)
   HIP_TRY(spfe::launch_select(f, h->rl, n, H, W, h->cfg.num_features, h->side));
   HIP_TRY(spfe::launch_heat_norm(f, h->cov, h->rl.kmax, n, H, W, h->side));
+  if (conv_db) {   // the descriptor head, launched behind the detector tail (enqueue()): the sampling waits for it
+    const int rc = (*conv_db)();
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(h->ev_db, s));
+    HIP_TRY(hipStreamWaitEvent(h->side, h->ev_db, 0));
+  }
   HIP_TRY(spfe::launch_desc(f, h->rl, n, H, W, h->side));
   HIP_TRY(hipEventRecord(h->ev_desc, h->side));  // d_coarse may be overwritten after this (next call's convDb)
   h->desc_recorded = true;
@@ -864,6 +889,7 @@ void spfe_destroy(spfe_handle h) {
     if (h->ev_cov[i]) (void)hipEventDestroy(h->ev_cov[i]);
   }
   if (h->ev_desc) (void)hipEventDestroy(h->ev_desc);
+  if (h->ev_db) (void)hipEventDestroy(h->ev_db);
   (void)spfe_comm_destroy(h);
   for (auto &ps : h->pipe) {
     if (ps.ev_h2d) (void)hipEventDestroy(ps.ev_h2d);
