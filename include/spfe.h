@@ -195,6 +195,7 @@ SPFE_API int spfe_comm_destroy(spfe_handle h);
 SPFE_API int spfe_allgather_records(spfe_handle h, long ticket, const void *d_local, void *d_all, int frames_per_rank);
 SPFE_API int spfe_comm_wait(spfe_handle h, void *stream);
 SPFE_API void *spfe_comm_stream(spfe_handle h); /* hipStream_t of the collective, NULL before spfe_comm_init */
+SPFE_API int spfe_comm_count(spfe_handle h, int *count); /* ncclCommCount: the rank count RCCL itself reports */
 
 /* Host view of ONE record that the caller copied to host memory. */
 SPFE_API int spfe_view_record(spfe_handle h, const void *host_record, spfe_result *out);
@@ -270,6 +271,10 @@ SPFE_API int spfe_match_patches_record_device(spfe_handle h, const void *d_mp_de
  * Outputs: Tcw_out (what pFrame->SetPose receives, :287), inlier[i] (is_visible[i] / in_view, :262-266: level 0
  * and chi2 <= inlier_chi2), proj_uv[i] = (dust_proj_u, dust_proj_v) of the inliers (:267-268), *n_inlier (the
  * return value), *iterations (optimize()'s).  n <= SPFE_DUST_MAX_POINTS (the tracker keeps 150-200).
+ * Degenerate calls, as g2o behaves: max_iterations == 0 evaluates nothing — every edge keeps level 0 / error 0, so all n
+ * points are reported as inliers with proj_uv = (0, 0) and the pose is echoed (use >= 1 for meaningful flags; the
+ * reference always passes 40); n == 0 has no active edge — the pose is echoed, *iterations = 0, *n_inlier = 0.
+ * The arithmetic is pinned by tests/golden/dust_*.npz (an independent f64 numpy / scipy statement).
  * g2o is not part of the reference snapshot: its algorithm is restated (include/spfe_dust_math.h) — results
  * equal the CPU oracle's up to the device's sin / cos in the exponential map. */
 #define SPFE_DUST_MAX_POINTS 512
@@ -292,6 +297,18 @@ SPFE_API int spfe_align_dust(spfe_handle h, const float *dense_dust, const float
 SPFE_API int spfe_align_dust_record_device(spfe_handle h, const void *d_record, const void *d_points_xyz, int n,
                                            const void *d_Tcw, const spfe_dust_params *prm, void *d_out,
                                            void *stream);
+
+/* The tracker's per-frame chain behind the extraction, on ONE record resident in HBM — Tracking::trackFrameDustKFLocal,
+ * orb_slam2/src/tracking/tracker_dust.cpp:92-172: PoseOptimizationDust(&mCurrentFrame, mps_for_track, is_visible) (:92-94),
+ * give up when n_inlier < min_inliers (tracking::dust::th_ninlier, :97-102), else the patch-wise association of the in_view
+ * map points at their dust_proj_u / v (:113-172; see spfe_match_patches).  Map point i = d_points_xyz[3 i..] with track
+ * descriptor d_mp_desc[256 i..] (MapPoint::getDescTrack()).  d_dust_out receives the SPFE_DUST_OUT_BYTES block above;
+ * d_kp_idx[i] (int32) = index of the keypoint map point i takes (mCurrentFrame.mvpMapPoints[idx] = mp), -1 for points that
+ * are not in view, find nothing below max_dist (0.75f, :121), or when the alignment had too few inliers.  Two kernels behind
+ * each other on `stream`: projections, flags and n_inlier never leave HBM; no host synchronisation.  n <= 512. */
+SPFE_API int spfe_track_dust_record_device(spfe_handle h, const void *d_record, const void *d_points_xyz,
+                                           const void *d_mp_desc, int n, const void *d_Tcw, const spfe_dust_params *prm,
+                                           int min_inliers, float max_dist, void *d_dust_out, void *d_kp_idx, void *stream);
 
 /* The batch path's form: n_frames independent solves in ONE launch, one workgroup each (a single solve is a chain of
  * dependent double-precision operations — latency, not throughput: 256 of them side by side take as long as one).

@@ -18,7 +18,7 @@
 
 #include <math.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define SPFE_DM __host__ __device__ static inline
 #else
 #define SPFE_DM static inline
@@ -238,8 +238,12 @@ SPFE_DM void spfe_huber(double e2, double delta, double rho[3]) {
   }
 }
 
-/* (H + lambda I) x = b for the 6x6 pose block (LinearSolverDense: Eigen LDLT; restated as Cholesky, which
- * fails on exactly the matrices LDLT reports as not positive).  H: full symmetric 6x6.  Returns 1 / 0. */
+/* (H + lambda I) x = b for the 6x6 pose block (LinearSolverDense: Eigen LDLT, solved when isPositive()).  Restated as
+ * Cholesky.  H is a sum of rho1 * J^T J (positive semi-definite) and lambda >= 0, so the two disagree on one input only:
+ * the ZERO matrix (no gradient anywhere and lambda = tau * 0), which LDLT calls positive and solves to x = 0 — one trial
+ * with rho = 0, Terminate — and Cholesky rejects — ten failed trials, Terminate.  Either way the pose is untouched, the
+ * edges are re-evaluated at it and optimize() reports one iteration (tests/golden/dust_flat.npz pins that).
+ * H: full symmetric 6x6.  Returns 1 / 0. */
 SPFE_DM int spfe_solve6(const double H[36], double lambda, const double b[6], double x[6]) {
   double L[36];
   for (int i = 0; i < 6; ++i)

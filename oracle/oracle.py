@@ -22,9 +22,9 @@ i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
 def build(force=False):
     """Compile oracle/libspfe_oracle.so with gcc (seconds)."""
     src = os.path.join(_HERE, "spfe_oracle.c")
-    hdr = os.path.join(_HERE, "..", "include", "spfe_exact_math.h")
+    hdrs = [os.path.join(_HERE, "..", "include", h) for h in ("spfe_exact_math.h", "spfe_dust_math.h")]
     if (not force and os.path.exists(_SO)
-            and os.path.getmtime(_SO) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+            and os.path.getmtime(_SO) >= max([os.path.getmtime(src)] + [os.path.getmtime(h) for h in hdrs])):
         return _SO
     subprocess.check_call(["make", "-C", _HERE, "-B", "libspfe_oracle.so"],
                           stdout=subprocess.DEVNULL)
@@ -279,24 +279,48 @@ def match_patches(mp_desc, mp_uv, occ_grid, kp_desc, max_dist=0.75):
 
 
 def align_dust(dust, pts, Tcw, fx, fy, cx, cy, max_iterations=40, delta=0.9, inlier_chi2=0.9):
-    """Optimizer::PoseOptimizationDust (optimizer_dust.cpp:170-294) -> dict(Tcw, inlier, uv, n_inlier, iterations)."""
+    """Optimizer::PoseOptimizationDust (optimizer_dust.cpp:170-294) -> dict(Tcw, inlier, uv, n_inlier, iterations,
+    pose64 = the pose in double precision before Converter::toCvMat's cast to float)."""
     dust = np.ascontiguousarray(dust, np.float32)
     pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 3)
     Tin = np.ascontiguousarray(Tcw, np.float32).reshape(16)
     n = len(pts)
     Tout = np.zeros(16, np.float32)
+    P64 = np.zeros(16, np.float64)
     inl = np.zeros(max(n, 1), np.uint8)
     uv = np.zeros((max(n, 1), 2), np.float32)
     it = C.c_int(0)
     L = lib()
-    L.oracle_align_dust.restype = C.c_int
-    L.oracle_align_dust.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float,
-                                    C.c_float, C.c_float, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
-                                    C.c_void_p, C.POINTER(C.c_int)]
-    k = L.oracle_align_dust(dust.ctypes.data, dust.shape[0], dust.shape[1], pts.ctypes.data, n, Tin.ctypes.data,
-                            float(fx), float(fy), float(cx), float(cy), int(max_iterations), float(delta),
-                            float(inlier_chi2), Tout.ctypes.data, inl.ctypes.data, uv.ctypes.data, C.byref(it))
-    return dict(Tcw=Tout.reshape(4, 4), inlier=inl[:n].astype(bool), uv=uv[:n], n_inlier=int(k), iterations=it.value)
+    L.oracle_align_dust_pose64.restype = C.c_int
+    L.oracle_align_dust_pose64.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float,
+                                           C.c_float, C.c_float, C.c_float, C.c_int, C.c_double, C.c_double, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
+    k = L.oracle_align_dust_pose64(dust.ctypes.data, dust.shape[0], dust.shape[1], pts.ctypes.data, n, Tin.ctypes.data,
+                                   float(fx), float(fy), float(cx), float(cy), int(max_iterations), float(delta),
+                                   float(inlier_chi2), Tout.ctypes.data, inl.ctypes.data, uv.ctypes.data, C.byref(it),
+                                   P64.ctypes.data)
+    return dict(Tcw=Tout.reshape(4, 4), inlier=inl[:n].astype(bool), uv=uv[:n], n_inlier=int(k), iterations=it.value,
+                pose64=P64.reshape(4, 4))
+
+
+def dust_edge(dust, Xw, Tcw, fx, fy, cx, cy, update=None):
+    """One EdgeSE3ProjectDustOnlyPose at the pose oplus(update) * Tcw: computeError + linearizeOplus
+    (types_dust_tracking.cpp:64-140) -> dict(err, level, J [6], uv [2], pose64 [4, 4])."""
+    dust = np.ascontiguousarray(dust, np.float32)
+    X = np.ascontiguousarray(Xw, np.float32).reshape(3)
+    Tin = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+    upd = None if update is None else np.ascontiguousarray(update, np.float64).reshape(6)
+    err, level = C.c_double(0), C.c_int(0)
+    J, uv, P64 = np.zeros(6, np.float64), np.zeros(2, np.float32), np.zeros(16, np.float64)
+    L = lib()
+    L.oracle_dust_edge.restype = None
+    L.oracle_dust_edge.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
+                                   C.c_float, C.c_float, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p, C.c_void_p,
+                                   C.c_void_p]
+    L.oracle_dust_edge(dust.ctypes.data, dust.shape[0], dust.shape[1], X.ctypes.data, Tin.ctypes.data,
+                       None if upd is None else upd.ctypes.data, float(fx), float(fy), float(cx), float(cy),
+                       C.byref(err), C.byref(level), J.ctypes.data, uv.ctypes.data, P64.ctypes.data)
+    return dict(err=err.value, level=level.value, J=J, uv=uv, pose64=P64.reshape(4, 4))
 
 
 def match_knn2(query, train):

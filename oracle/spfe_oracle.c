@@ -838,9 +838,10 @@ static double dust_errors(const spfe_se3 *T, const float *pts, int n, double fx,
   return chi;
 }
 
-EXPORT int oracle_align_dust(const float *dust, int hc, int wc, const float *pts, int n, const float *Tcw_in,
-                             float fxf, float fyf, float cxf, float cyf, int max_iterations, double delta,
-                             double inlier_chi2, float *Tcw_out, uint8_t *inlier, float *uv, int *iterations) {
+static int align_dust_core(const float *dust, int hc, int wc, const float *pts, int n, const float *Tcw_in,
+                           float fxf, float fyf, float cxf, float cyf, int max_iterations, double delta,
+                           double inlier_chi2, float *Tcw_out, uint8_t *inlier, float *uv, int *iterations,
+                           double *pose64) {
   const double fx = (double)(fxf / 8.0f), fy = (double)(fyf / 8.0f);           /* :223-224 */
   const double cx = ((double)cxf - 3.5) / 8.0f, cy = ((double)cyf - 3.5) / 8.0f; /* :225-226 */
   spfe_se3 T;
@@ -848,7 +849,7 @@ EXPORT int oracle_align_dust(const float *dust, int hc, int wc, const float *pts
   spfe_dust_edge *ed = (spfe_dust_edge *)calloc((size_t)(n > 0 ? n : 1), sizeof(spfe_dust_edge));
   spfe_lm lm = {0.0, 2.0};
   int it_done = 0, ok = 1;
-  for (int it = 0; it < max_iterations && ok; ++it) {
+  for (int it = 0; it < max_iterations && ok && n > 0; ++it) {   /* no edges: nothing active, the pose is echoed */
     double currentChi = dust_errors(&T, pts, n, fx, fy, cx, cy, dust, wc, hc, delta, ed);
     /* buildSystem: linearizeOplus + constructQuadraticForm of every edge */
     double H[36] = {0}, b[6] = {0};
@@ -893,9 +894,68 @@ EXPORT int oracle_align_dust(const float *dust, int hc, int wc, const float *pts
     if (out) n_inlier--;
   }
   spfe_se3_to_f32(&T, Tcw_out);
+  if (pose64) {   /* SE3Quat::to_homogeneous_matrix() before the cast to float */
+    double R[9];
+    spfe_quat_to_rot(T.q, R);
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) pose64[r * 4 + c] = R[r * 3 + c];
+      pose64[r * 4 + 3] = T.t[r];
+    }
+    pose64[12] = pose64[13] = pose64[14] = 0.0;
+    pose64[15] = 1.0;
+  }
   if (iterations) *iterations = it_done;
   free(ed);
   return n_inlier;
+}
+
+EXPORT int oracle_align_dust(const float *dust, int hc, int wc, const float *pts, int n, const float *Tcw_in,
+                             float fxf, float fyf, float cxf, float cyf, int max_iterations, double delta,
+                             double inlier_chi2, float *Tcw_out, uint8_t *inlier, float *uv, int *iterations) {
+  return align_dust_core(dust, hc, wc, pts, n, Tcw_in, fxf, fyf, cxf, cyf, max_iterations, delta, inlier_chi2, Tcw_out,
+                         inlier, uv, iterations, NULL);
+}
+
+/* The same, also returning the pose in double precision (4x4 row-major, what Converter::toCvMat rounds to float):
+ * lets tests/test_dust_golden.py hold the solve to the independent f64 fixtures at 1e-9 instead of float ulps. */
+EXPORT int oracle_align_dust_pose64(const float *dust, int hc, int wc, const float *pts, int n, const float *Tcw_in,
+                                    float fxf, float fyf, float cxf, float cyf, int max_iterations, double delta,
+                                    double inlier_chi2, float *Tcw_out, uint8_t *inlier, float *uv, int *iterations,
+                                    double *pose64) {
+  return align_dust_core(dust, hc, wc, pts, n, Tcw_in, fxf, fyf, cxf, cyf, max_iterations, delta, inlier_chi2, Tcw_out,
+                         inlier, uv, iterations, pose64);
+}
+
+/* One edge at the pose Tcw (float 4x4, converted as toSE3Quat does), optionally moved first by oplus(update):
+ * computeError then linearizeOplus (types_dust_tracking.cpp:64-140).  Outputs: err, level, J[6] (1x6, rotation
+ * columns first), uv[2] (u_, v_).  Test hook: tests/test_dust_golden.py checks spfe_dust_error / spfe_dust_jacobian /
+ * spfe_se3_oplus of include/spfe_dust_math.h against the independent fixtures and against numeric derivatives. */
+EXPORT void oracle_dust_edge(const float *dust, int hc, int wc, const float *Xw_f, const float *Tcw, const double *update,
+                             float fxf, float fyf, float cxf, float cyf, double *err, int *level, double *J, float *uv,
+                             double *pose64) {
+  const double fx = (double)(fxf / 8.0f), fy = (double)(fyf / 8.0f);
+  const double cx = ((double)cxf - 3.5) / 8.0f, cy = ((double)cyf - 3.5) / 8.0f;
+  spfe_se3 T;
+  spfe_se3_from_f32(Tcw, &T);
+  if (update) spfe_se3_oplus(&T, update);
+  const double Xw[3] = {(double)Xw_f[0], (double)Xw_f[1], (double)Xw_f[2]};
+  spfe_dust_edge e = {0.0, 0.0f, 0.0f, 0};
+  spfe_dust_error(&T, Xw, fx, fy, cx, cy, dust, wc, hc, &e);
+  spfe_dust_jacobian(&T, Xw, fx, fy, cx, cy, dust, wc, hc, e.level, J);
+  *err = e.err;
+  *level = e.level;
+  uv[0] = e.u;
+  uv[1] = e.v;
+  if (pose64) {
+    double R[9];
+    spfe_quat_to_rot(T.q, R);
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) pose64[r * 4 + c] = R[r * 3 + c];
+      pose64[r * 4 + 3] = T.t[r];
+    }
+    pose64[12] = pose64[13] = pose64[14] = 0.0;
+    pose64[15] = 1.0;
+  }
 }
 
 /* k = 2 nearest train rows per query — the EXACT search that the reference's

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(DUST_THREADS) void dust_align_kernel(DustArgs a) {
     spfe_se3_from_f32(Tin, &sh->T);
     sh->lm.lambda = 0.0; sh->lm.ni = 2.0;
     sh->it_done = 0;
-    sh->cont_iters = a.max_iterations > 0;
+    sh->cont_iters = a.max_iterations > 0 && n > 0;   // no edges: optimize() has nothing active, the pose is echoed
   }
   __syncthreads();
 

@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256, H_WG_PER_CU) void head1x1_bf16_kernel(const un
       const_cast<unsigned short *>(in) + in_choff, 0, (unsigned)((size_t)npix * IN_STRIDE * 2 - (size_t)in_choff * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rout =
       __builtin_amdgcn_make_buffer_rsrc(out, 0, (unsigned)((size_t)npix * COUT * 4), 0x00020000);
+  (void)rin;   // (the host pass of hipcc does not see the uses below)
 
   // this wave's weights, for the whole kernel
   bf16x8 wreg[NTW][H_KSTEPS];

@@ -53,6 +53,7 @@ __global__ __launch_bounds__(512, 1) void head1x1_f32_kernel(const float *__rest
       const_cast<float *>(in) + in_choff, 0, (unsigned)((size_t)npix * IN_STRIDE * 4 - (size_t)in_choff * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rout =
       __builtin_amdgcn_make_buffer_rsrc(out, 0, (unsigned)((size_t)npix * COUT * 4), 0x00020000);
+  (void)rin;   // (the host pass of hipcc does not see the uses below)
 
   // this wave's weights, for the whole kernel: B operand of step s = W[channel of lane & 31][k = 2 s + hi]
   float wreg[NTW][F_KSTEPS];

@@ -224,7 +224,9 @@ __global__ __launch_bounds__(256) void patch_dist_kernel(PatchArgs a, int *__res
   const float uf = a.mp_uv[2 * i], vf = a.mp_uv[2 * i + 1];
   const float fu = __builtin_floorf(uf), fv = __builtin_floorf(vf);
   // positions that do not floor into the grid have no candidates (the reference does not check)
-  const bool ok = fu >= 0.0f && fv >= 0.0f && fu < (float)a.wc && fv < (float)a.hc;
+  bool ok = fu >= 0.0f && fv >= 0.0f && fu < (float)a.wc && fv < (float)a.hc;
+  if (a.in_view && !a.in_view[i]) ok = false;                 // `if (!mp->in_view ...) continue;`
+  if (a.gate_ptr && *a.gate_ptr < a.gate_min) ok = false;     // `if (n_inlier < th_ninlier) return false;`
   const int u = ok ? (int)fu : 0, v = ok ? (int)fv : 0;
   const int K = a.k_ptr ? *a.k_ptr : a.k_imm;
   const float4 m4 = *reinterpret_cast<const float4 *>(a.mp_desc + (size_t)i * 256 + lane * 4);

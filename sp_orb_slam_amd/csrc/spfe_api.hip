@@ -7,7 +7,6 @@
 // operator() (:361-514) the extract calls replace.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
-#include <rccl/rccl.h>  // types and prototypes only: librccl is dlopen'ed by spfe_comm_init, not linked
 
 #include <algorithm>
 #include <functional>
@@ -22,6 +21,22 @@
 #include "../../include/spfe.h"
 #include "../../include/spfe_exact_math.h"
 #include "spfe_kernels.h"
+
+// The few RCCL types and signatures the gather needs, declared here so that building libspfe.so needs no RCCL development
+// headers: librccl is dlopen'ed by spfe_comm_init (a single-GPU host never loads it).  Values as in rccl.h (NCCL 2 ABI).
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1 } ncclDataType_t;
+typedef ncclResult_t (*pfn_ncclGetUniqueId)(ncclUniqueId *);
+typedef ncclResult_t (*pfn_ncclCommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+typedef ncclResult_t (*pfn_ncclCommDestroy)(ncclComm_t);
+typedef ncclResult_t (*pfn_ncclCommCount)(const ncclComm_t, int *);
+typedef ncclResult_t (*pfn_ncclAllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+typedef const char *(*pfn_ncclGetErrorString)(ncclResult_t);
+}
 
 namespace spfe {
 void covariance_host(const float *heat_inv, int H, int W, const float *kp_xy, int K, float *cov2,
@@ -153,10 +168,11 @@ struct spfe_handle_s {
   bool comm_own_stream = false;        // SPFE_COMM_OWN_STREAM=1
   hipEvent_t ev_gather = nullptr;      // the last gather on comm_stream is done
   bool gather_recorded = false;
-  decltype(&ncclCommInitRank) p_ncclCommInitRank = nullptr;
-  decltype(&ncclCommDestroy) p_ncclCommDestroy = nullptr;
-  decltype(&ncclAllGather) p_ncclAllGather = nullptr;
-  decltype(&ncclGetErrorString) p_ncclGetErrorString = nullptr;
+  pfn_ncclCommInitRank p_ncclCommInitRank = nullptr;
+  pfn_ncclCommDestroy p_ncclCommDestroy = nullptr;
+  pfn_ncclCommCount p_ncclCommCount = nullptr;
+  pfn_ncclAllGather p_ncclAllGather = nullptr;
+  pfn_ncclGetErrorString p_ncclGetErrorString = nullptr;
   unsigned ws_mask = 15u;   // bf16 layers (bit i = conv layer i of enqueue(), Cin = 64 only) that may use the wave-specialised kernel
   int ws_min_items = 11;    // ... when the launch has at least this many (tile, 64-channel block) items per workgroup (pipelined calls)
   int ws_min_items_sync = 5;   // ... the same for synchronous calls
@@ -1334,9 +1350,12 @@ int spfe_collect_batch(spfe_handle h, long ticket, spfe_result *outs) {
 // ---- multi-GPU: RCCL all-gather of the records -----------------------------------
 namespace {
 void *open_rccl() {
-  // an already loaded librccl (e.g. the one torch.distributed brought) is reused by soname
+  // an already loaded librccl (e.g. the one torch.distributed brought) is reused by soname; the handle is kept for the
+  // life of the process (one dlopen, never closed: communicators may outlive any one extractor handle)
+  static void *lib = nullptr;
+  if (lib) return lib;
   for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-    if (void *l = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) return l;
+    if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) return lib;
   }
   return nullptr;
 }
@@ -1346,8 +1365,8 @@ int spfe_comm_unique_id(void *id, size_t cap) {
   if (!id || cap < NCCL_UNIQUE_ID_BYTES) return fail(SPFE_EINVAL, "unique id buffer must hold %d bytes", NCCL_UNIQUE_ID_BYTES);
   void *lib = open_rccl();
   if (!lib) return fail(SPFE_EHIP, "librccl not found: %s", dlerror());
-  auto get = reinterpret_cast<decltype(&ncclGetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
-  auto err = reinterpret_cast<decltype(&ncclGetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+  auto get = reinterpret_cast<pfn_ncclGetUniqueId>(dlsym(lib, "ncclGetUniqueId"));
+  auto err = reinterpret_cast<pfn_ncclGetErrorString>(dlsym(lib, "ncclGetErrorString"));
   if (!get || !err) return fail(SPFE_EHIP, "librccl lacks ncclGetUniqueId");
   ncclUniqueId u;
   const ncclResult_t r = get(&u);
@@ -1364,11 +1383,12 @@ int spfe_comm_init(spfe_handle h, const void *id, int rank, int world) {
   if (!h->rccl_lib) {
     h->rccl_lib = open_rccl();
     if (!h->rccl_lib) return fail(SPFE_EHIP, "librccl not found: %s", dlerror());
-    h->p_ncclCommInitRank = reinterpret_cast<decltype(&ncclCommInitRank)>(dlsym(h->rccl_lib, "ncclCommInitRank"));
-    h->p_ncclCommDestroy = reinterpret_cast<decltype(&ncclCommDestroy)>(dlsym(h->rccl_lib, "ncclCommDestroy"));
-    h->p_ncclAllGather = reinterpret_cast<decltype(&ncclAllGather)>(dlsym(h->rccl_lib, "ncclAllGather"));
-    h->p_ncclGetErrorString = reinterpret_cast<decltype(&ncclGetErrorString)>(dlsym(h->rccl_lib, "ncclGetErrorString"));
-    if (!h->p_ncclCommInitRank || !h->p_ncclCommDestroy || !h->p_ncclAllGather || !h->p_ncclGetErrorString)
+    h->p_ncclCommInitRank = reinterpret_cast<pfn_ncclCommInitRank>(dlsym(h->rccl_lib, "ncclCommInitRank"));
+    h->p_ncclCommDestroy = reinterpret_cast<pfn_ncclCommDestroy>(dlsym(h->rccl_lib, "ncclCommDestroy"));
+    h->p_ncclCommCount = reinterpret_cast<pfn_ncclCommCount>(dlsym(h->rccl_lib, "ncclCommCount"));
+    h->p_ncclAllGather = reinterpret_cast<pfn_ncclAllGather>(dlsym(h->rccl_lib, "ncclAllGather"));
+    h->p_ncclGetErrorString = reinterpret_cast<pfn_ncclGetErrorString>(dlsym(h->rccl_lib, "ncclGetErrorString"));
+    if (!h->p_ncclCommInitRank || !h->p_ncclCommDestroy || !h->p_ncclCommCount || !h->p_ncclAllGather || !h->p_ncclGetErrorString)
       return fail(SPFE_EHIP, "librccl lacks a required entry point");
   }
   ncclUniqueId u;
@@ -1410,6 +1430,14 @@ int spfe_comm_destroy(spfe_handle h) {
 }
 
 void *spfe_comm_stream(spfe_handle h) { return h ? reinterpret_cast<void *>(h->comm_stream) : nullptr; }
+
+int spfe_comm_count(spfe_handle h, int *count) {
+  if (!h || !count) return fail(SPFE_EINVAL, "null argument");
+  if (!h->comm) return fail(SPFE_EINVAL, "spfe_comm_init has not been called");
+  const ncclResult_t r = h->p_ncclCommCount(h->comm, count);   // what RCCL itself says, not what the caller passed in
+  if (r != ncclSuccess) return fail(SPFE_EHIP, "ncclCommCount: %s", h->p_ncclGetErrorString(r));
+  return SPFE_OK;
+}
 
 int spfe_allgather_records(spfe_handle h, long ticket, const void *d_local, void *d_all, int frames_per_rank) {
   if (!h || !d_local || !d_all) return fail(SPFE_EINVAL, "null argument");
@@ -1562,6 +1590,40 @@ int spfe_match_patches_record_device(spfe_handle h, const void *d_mp_desc, const
   a.k_imm = 0;
   HIP_TRY(spfe::launch_match_patches(a, h->kmax, max_dist, h->p_cidx, h->p_cdist,
                                      reinterpret_cast<int32_t *>(d_kp_idx), s));
+  return SPFE_OK;
+}
+
+int spfe_track_dust_record_device(spfe_handle h, const void *d_record, const void *d_points_xyz, const void *d_mp_desc, int n,
+                                  const void *d_Tcw, const spfe_dust_params *prm, int min_inliers, float max_dist,
+                                  void *d_dust_out, void *d_kp_idx, void *stream) {
+  if (!h || !d_record || !d_Tcw || !prm || !d_dust_out || !d_kp_idx || (n > 0 && (!d_points_xyz || !d_mp_desc)))
+    return fail(SPFE_EINVAL, "null argument");
+  int rc = dust_check(h, n, prm);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  if ((rc = patch_scratch(h))) return rc;
+  hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
+  const uint8_t *rec = reinterpret_cast<const uint8_t *>(d_record);
+  uint8_t *dout = reinterpret_cast<uint8_t *>(d_dust_out);
+  // PoseOptimizationDust(&mCurrentFrame, mps_for_track, is_visible)   tracker_dust.cpp:92-94
+  rc = dust_launch(h, reinterpret_cast<const float *>(rec + h->rl.off_dd), reinterpret_cast<const float *>(d_points_xyz), n,
+                   reinterpret_cast<const float *>(d_Tcw), prm, dout, s);
+  if (rc || n == 0) return rc;
+  // the patch-wise association of the in_view points at their dust_proj_u / v   :113-172, on the same stream: the
+  // projections, the flags and n_inlier are read where the alignment left them
+  spfe::PatchArgs a{};
+  a.mp_desc = reinterpret_cast<const float *>(d_mp_desc);
+  a.mp_uv = reinterpret_cast<const float *>(dout + SPFE_DUST_OFF_UV);
+  a.n_points = n;
+  a.occ = reinterpret_cast<const int16_t *>(rec + h->rl.off_occ);
+  a.hc = h->hc; a.wc = h->wc;
+  a.kp_desc = reinterpret_cast<const float *>(rec + h->rl.off_desc);
+  a.k_ptr = reinterpret_cast<const int *>(rec + h->rl.off_hdr);
+  a.k_imm = 0;
+  a.in_view = dout + SPFE_DUST_OFF_INLIER;
+  a.gate_ptr = reinterpret_cast<const int *>(dout + 64);
+  a.gate_min = min_inliers;
+  HIP_TRY(spfe::launch_match_patches(a, h->kmax, max_dist, h->p_cidx, h->p_cdist, reinterpret_cast<int32_t *>(d_kp_idx), s));
   return SPFE_OK;
 }
 

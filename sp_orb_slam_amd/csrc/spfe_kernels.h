@@ -171,6 +171,11 @@ struct PatchArgs {
   const float *kp_desc;  // [K][256]
   const int *k_ptr;      // K on the device (a record header), or null -> k_imm
   int k_imm;
+  // chained form (spfe_track_dust_record_device): map points whose in_view flag is 0 are skipped
+  // (tracker_dust.cpp:114-116), and all of them when *gate_ptr < gate_min (the tracker gives up at :97-102)
+  const uint8_t *in_view;  // [n_points] or null
+  const int *gate_ptr;     // n_inlier of the alignment on the device, or null
+  int gate_min;
 };
 // cand_idx / cand_dist: [n_points][4] scratch; out: [n_points] keypoint index or -1; kcap >= K
 hipError_t launch_match_patches(const PatchArgs &a, int kcap, float max_dist, int *cand_idx, float *cand_dist,

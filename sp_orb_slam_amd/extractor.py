@@ -37,8 +37,9 @@ ABI_SYMBOLS = [
     "spfe_match_patches", "spfe_match_patches_record_device",
     "spfe_set_staging", "spfe_extract_staged", "spfe_extract_batch_staged", "spfe_stage_batch_device",
     "spfe_comm_unique_id", "spfe_comm_init", "spfe_comm_destroy", "spfe_allgather_records", "spfe_comm_wait",
-    "spfe_comm_stream", "spfe_submit_batch", "spfe_collect_batch",
+    "spfe_comm_stream", "spfe_comm_count", "spfe_submit_batch", "spfe_collect_batch",
     "spfe_align_dust", "spfe_align_dust_record_device", "spfe_align_dust_batch_device", "spfe_match_knn2",
+    "spfe_track_dust_record_device",
 ]
 
 
@@ -185,6 +186,9 @@ def load_library():
     L.spfe_align_dust_record_device.restype = C.c_int
     L.spfe_align_dust_record_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                 C.POINTER(_DustParams), C.c_void_p, C.c_void_p]
+    L.spfe_track_dust_record_device.restype = C.c_int
+    L.spfe_track_dust_record_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                C.POINTER(_DustParams), C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
     L.spfe_align_dust_batch_device.restype = C.c_int
     L.spfe_align_dust_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.POINTER(_DustParams), C.c_void_p, C.c_void_p]
@@ -204,6 +208,8 @@ def load_library():
     L.spfe_comm_wait.argtypes = [C.c_void_p, C.c_void_p]
     L.spfe_comm_stream.restype = C.c_void_p
     L.spfe_comm_stream.argtypes = [C.c_void_p]
+    L.spfe_comm_count.restype = C.c_int
+    L.spfe_comm_count.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.spfe_last_error.restype = C.c_char_p
     L.spfe_version.restype = C.c_char_p
     _lib = L
@@ -411,6 +417,17 @@ class SPExtractor:
                                                        C.c_void_p(d_Tcw), C.byref(prm), C.c_void_p(d_out),
                                                        C.c_void_p(stream or 0)))
 
+    def track_dust_record_device(self, d_record, d_points_xyz, d_mp_desc, n, d_Tcw, d_dust_out, d_kp_idx, fx, fy, cx, cy,
+                                 min_inliers=0, max_dist=0.75, max_iterations=40, huber_delta=0.9, inlier_chi2=0.9, stream=None):
+        """Tracking::trackFrameDustKFLocal's chain behind the extraction (tracker_dust.cpp:92-172) on a resident record:
+        PoseOptimizationDust, then the patch-wise association of the in_view points at their projections
+        (spfe_track_dust_record_device); nothing leaves HBM in between."""
+        prm = self._dust_params(fx, fy, cx, cy, max_iterations, huber_delta, inlier_chi2)
+        _check(self._lib.spfe_track_dust_record_device(self._h, C.c_void_p(d_record), C.c_void_p(d_points_xyz),
+                                                       C.c_void_p(d_mp_desc), int(n), C.c_void_p(d_Tcw), C.byref(prm),
+                                                       int(min_inliers), float(max_dist), C.c_void_p(d_dust_out),
+                                                       C.c_void_p(d_kp_idx), C.c_void_p(stream or 0)))
+
     def align_dust_batch_device(self, d_records, n_frames, d_points_xyz, d_n_points, d_Tcw, d_out, fx, fy, cx, cy,
                                 max_iterations=40, huber_delta=0.9, inlier_chi2=0.9, stream=None):
         """n_frames independent solves in one launch (spfe_align_dust_batch_device): frame f uses record f of `d_records`,
@@ -523,6 +540,12 @@ class SPExtractor:
     def comm_stream(self):
         """hipStream_t (int) of the library's communication stream, 0 before comm_init."""
         return int(self._lib.spfe_comm_stream(self._h) or 0)
+
+    def comm_count(self):
+        """Number of ranks in the communicator as RCCL reports it (ncclCommCount)."""
+        n = C.c_int(0)
+        _check(self._lib.spfe_comm_count(self._h, C.byref(n)))
+        return n.value
 
     def allgather_records(self, ticket, d_local, d_all, frames_per_rank):
         """ncclAllGather of this rank's `frames_per_rank` records (device pointers as ints) on the library's

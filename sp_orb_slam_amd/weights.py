@@ -94,6 +94,12 @@ def synthetic(seed=7, detector="dense"):
         position logits a larger gain, so only ~1/4 of the cells yield a
         candidate and many pixels fall under the 0.001 heat floor — closer to a
         trained detector's statistics.
+    detector="trackable": the dustbin logit is a CONSTANT (zero weights, bias 14)
+        and the position logits get a gain of 10, so dense_dust = 1 - sum of the
+        position probabilities is low exactly where some position logit is high —
+        what a trained SuperPoint's dustbin means, and what the tracker's direct
+        alignment (optimizer_dust.cpp:170-294) needs from the map: dust ~0.47 at
+        keypoint cells against ~0.79 on average.
     """
     rng = np.random.Generator(np.random.PCG64(seed))
     named = {}
@@ -104,6 +110,10 @@ def synthetic(seed=7, detector="dense"):
     if detector == "sparse":
         named["convPb.weight"] = named["convPb.weight"] * np.float32(3.5)
         named["convPb.bias"][64] += np.float32(7.75)
+    elif detector == "trackable":
+        named["convPb.weight"] = named["convPb.weight"] * np.float32(10.0)
+        named["convPb.weight"][64] = 0
+        named["convPb.bias"][64] = np.float32(14.0)
     elif detector != "dense":
-        raise ValueError("detector must be 'dense' or 'sparse'")
+        raise ValueError("detector must be 'dense', 'sparse' or 'trackable'")
     return from_named_tensors(named)

@@ -1,0 +1,146 @@
+"""GPU: the tracker's per-frame front end chained on records that never leave HBM — the stand-in for BASELINE configs[4]
+(EuRoC MH_05 through the tracker: dataset, trained weights and the SLAM back-end are absent), at the
+headline resolution, 100 frames:
+
+    raw BGR frame -> spfe_stage_batch_device       cv::remap + crop + cvtColor     data_loader.cc:519-521, mono_tracker.cpp:18-28
+                  -> spfe_extract_batch_device     SPExtractor::operator()         sp_extractor.cpp:361-514
+                  -> spfe_track_dust_record_device PoseOptimizationDust, then the patch-wise association of the in_view map
+                                                   points at their dust_proj_u / v  tracker_dust.cpp:92-172
+
+Only the pose block (pose, counts, flags, projections) and the keypoint indices leave the device.  Every frame is checked
+against the oracle chain (oracle.stage_input -> oracle.extract -> oracle.align_dust -> oracle.match_patches on the inliers,
+as the reference's loop filters them): the record bitwise, the pose within 1e-6, flags / iteration count / associations equal.
+The associations are also checked against the known camera motion."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from sp_orb_slam_amd import track_scene as ts
+from sp_orb_slam_amd import weights
+from sp_orb_slam_amd.extractor import DUST_OUT_BYTES, SPExtractor
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_track(ref, pts, mp_desc, T0, min_inliers=0):
+    r = oracle.align_dust(ref["dense_dust"], pts, T0, ts.FX, ts.FY, ts.CX, ts.CY)
+    kp = np.full(len(pts), -1, np.int32)
+    if r["n_inlier"] >= min_inliers:
+        inl = np.flatnonzero(r["inlier"])                 # `if (!mp->in_view || mp->isBad()) continue;`
+        kp[inl] = oracle.match_patches(mp_desc[inl], r["uv"][inl], ref["occ_grid"], ref["desc"])
+    return r, kp
+
+
+@pytest.mark.parametrize("nframes,H,W", [(100, 480, 752)])
+def test_frontend_chain_on_resident_records(nframes, H, W):
+    import torch
+    nf = 1000
+    blob = weights.synthetic(7, "trackable")
+    world = ts.texture(21, *ts.world_size(H, W))
+    ext = SPExtractor(nf, H, W, blob, max_batch=1, with_heat=False)
+    ext.set_staging(H, W, 3, False)
+    rb = ext.record_bytes()
+    stream = torch.cuda.Stream()
+    d_gray = torch.zeros((1, H, W), dtype=torch.uint8, device="cuda")
+    d_rec = torch.zeros(rb, dtype=torch.uint8, device="cuda")
+    d_out = torch.zeros(DUST_OUT_BYTES, dtype=torch.uint8, device="cuda")
+    d_kp = torch.zeros(512, dtype=torch.int32, device="cuda")
+    prev = None
+    n_assoc, n_correct, n_tracked = 0, 0, 0
+    for k in range(nframes):
+        gray = ts.frame(world, k, H, W)
+        raw = np.repeat(gray[:, :, None], 3, 2).copy()
+        d_raw = torch.from_numpy(raw[None]).cuda()
+        with torch.cuda.stream(stream):
+            ext.stage_batch_device(d_raw.data_ptr(), 1, d_gray.data_ptr(), stream.cuda_stream)
+            t = ext.extract_batch_device(d_gray.data_ptr(), 1, d_rec.data_ptr(), stream.cuda_stream)
+            ext.wait_records(t, stream.cuda_stream)
+            if prev is not None:
+                pts, mpd, _ = prev
+                n = len(pts)
+                d_pts, d_mpd = torch.from_numpy(pts).cuda(), torch.from_numpy(mpd).cuda()
+                d_T = torch.from_numpy(ts.start_pose(k).reshape(16)).cuda()
+                stream.wait_stream(torch.cuda.current_stream())
+                ext.track_dust_record_device(d_rec.data_ptr(), d_pts.data_ptr(), d_mpd.data_ptr(), n, d_T.data_ptr(),
+                                             d_out.data_ptr(), d_kp.data_ptr(), ts.FX, ts.FY, ts.CX, ts.CY, min_inliers=30,
+                                             stream=stream.cuda_stream)
+        stream.synchronize()
+        # ---- the checker: the oracle chain on the same raw frame
+        ref = oracle.extract(blob, oracle.stage_input(raw, H, W), nf)
+        rec = ext.view_record(d_rec.cpu().numpy())
+        assert rec.status == 0 and rec.K == ref["K"] and np.array_equal(rec.kp_xy, ref["kp_xy"])
+        assert np.array_equal(rec.descriptors.view(np.uint32), ref["desc"].view(np.uint32))
+        assert np.array_equal(rec.occ_grid, ref["occ_grid"])
+        assert np.array_equal(rec.dense_dust.view(np.uint32), ref["dense_dust"].view(np.uint32))
+        if prev is not None:
+            g = ext.decode_dust_out(d_out.cpu().numpy(), n)
+            gk = d_kp.cpu().numpy()[:n]
+            r, rk = oracle_track(ref, pts, mpd, ts.start_pose(k), min_inliers=30)
+            assert g["iterations"] == r["iterations"], k
+            assert np.abs(g["Tcw"] - r["Tcw"]).max() <= 1e-6, k
+            assert np.array_equal(g["inlier"], r["inlier"]) and g["n_inlier"] == r["n_inlier"], k
+            assert np.array_equal(gk, rk), k
+            # against the known motion: an associated keypoint is the map point's keypoint moved by the pan
+            m = gk >= 0
+            ox, oy = ts.offsets(k)
+            pox, poy = ts.offsets(k - 1)
+            d = rec.kp_xy[gk[m]] - prev[2][m]
+            n_assoc += int(m.sum())
+            n_correct += int(((d[:, 0] == -(ox - pox)) & (d[:, 1] == -(oy - poy))).sum())
+            n_tracked += int(m.sum() >= 100)
+        pts2, mpd2, sel = ts.map_points(rec.kp_xy, rec.descriptors, k)
+        prev = (pts2, mpd2, rec.kp_xy[sel].copy())
+    ext.close()
+    # the chain does the tracker's work on this sequence: most map points are re-found, at the right place
+    assert n_tracked >= 0.9 * (nframes - 1), n_tracked
+    assert n_correct >= 0.9 * n_assoc, (n_correct, n_assoc)
+
+
+def test_track_gate_and_empty_input():
+    """n_inlier < min_inliers -> no association at all (tracker_dust.cpp:97-102); n = 0 -> nothing to do."""
+    import torch
+    H, W, nf = 240, 320, 300
+    blob = weights.synthetic(7, "trackable")
+    world = ts.texture(5, *ts.world_size(H, W))
+    ext = SPExtractor(nf, H, W, blob, max_batch=1, with_heat=False)
+    stream = torch.cuda.Stream()
+    d_img = torch.from_numpy(ts.frame(world, 0, H, W)[None]).cuda()
+    d_rec = torch.zeros(ext.record_bytes(), dtype=torch.uint8, device="cuda")
+    t = ext.extract_batch_device(d_img.data_ptr(), 1, d_rec.data_ptr(), stream.cuda_stream)
+    ext.wait_records(t, stream.cuda_stream)
+    stream.synchronize()
+    rec = ext.view_record(d_rec.cpu().numpy())
+    # map points = this very frame's keypoints, pose exact: everything is in view and finds itself
+    T = ts.pose(*ts.offsets(0))
+    sel = np.arange(0, rec.K, max(1, rec.K // 120))[:120]
+    fx, fy, cx, cy = 200.0, 200.0, W / 2 - 3.0, H / 2 + 2.0
+    Xc = np.stack([(rec.kp_xy[sel, 0] - cx) / fx * 4.0, (rec.kp_xy[sel, 1] - cy) / fy * 4.0, np.full(len(sel), 4.0)], 1).astype(np.float32)
+    mpd = np.ascontiguousarray(rec.descriptors[sel])
+    d_pts, d_mpd, d_T = torch.from_numpy(Xc).cuda(), torch.from_numpy(mpd).cuda(), torch.from_numpy(np.eye(4, dtype=np.float32).reshape(16)).cuda()
+    d_out = torch.zeros(DUST_OUT_BYTES, dtype=torch.uint8, device="cuda")
+    d_kp = torch.full((512,), 7, dtype=torch.int32, device="cuda")
+    ref = dict(dense_dust=rec.dense_dust, occ_grid=rec.occ_grid, desc=rec.descriptors)
+    for gate in (0, 10 ** 6):
+        ext.track_dust_record_device(d_rec.data_ptr(), d_pts.data_ptr(), d_mpd.data_ptr(), len(sel), d_T.data_ptr(),
+                                     d_out.data_ptr(), d_kp.data_ptr(), fx, fy, cx, cy, min_inliers=gate,
+                                     max_iterations=1, stream=stream.cuda_stream)
+        stream.synchronize()
+        g = ext.decode_dust_out(d_out.cpu().numpy(), len(sel))
+        gk = d_kp.cpu().numpy()[:len(sel)]
+        r = oracle.align_dust(ref["dense_dust"], Xc, np.eye(4, dtype=np.float32), fx, fy, cx, cy, max_iterations=1)
+        assert np.array_equal(g["inlier"], r["inlier"])
+        rk = np.full(len(sel), -1, np.int32)
+        if r["n_inlier"] >= gate:
+            inl = np.flatnonzero(r["inlier"])
+            rk[inl] = oracle.match_patches(mpd[inl], r["uv"][inl], ref["occ_grid"], ref["desc"])
+        assert np.array_equal(gk, rk)
+        if gate:
+            assert (gk == -1).all()
+        else:
+            assert (gk >= 0).sum() >= 0.5 * r["n_inlier"] > 0
+    d_kp.fill_(7)
+    ext.track_dust_record_device(d_rec.data_ptr(), 0, 0, 0, d_T.data_ptr(), d_out.data_ptr(), d_kp.data_ptr(), fx, fy, cx, cy,
+                                 stream=stream.cuda_stream)
+    stream.synchronize()
+    assert ext.decode_dust_out(d_out.cpu().numpy(), 0)["n_inlier"] == 0 and (d_kp.cpu().numpy() == 7).all()
+    ext.close()
