@@ -11,6 +11,14 @@ Workload = BASELINE.json configs[1] scaled the way configs[2] shards it:
 752x480 frames, num_features = 1000, f32, 8 independent frames per GPU per step
 (64 frames on 8 GPUs); weak scaling.  The batch-1 latency of configs[1] is
 reported beside it as `latency_batch1_ms`.
+
+Order of the legs (N = 1): every GPU leg first, back to back — the headline, the per-stage table, the other
+resolutions / dtypes north_star lists (640x480 and 1280x720 in f32, 752x480 and 1280x720 = configs[3] in bf16), batch-1
+latency, the host boundary (f32 and bf16), matching, dust alignment, input staging, the tracker's front-end chain — then
+the CPU legs (oracle = cpu_baseline + the self-checks, ATen-CPU).  N > 1: the headline, then what makes the line prove
+itself: `parity_gathered` (a frame computed on ANOTHER rank, as it arrived through the all-gather, against the oracle),
+`allgather_ms`, `rccl_ranks`, `host_alt` (each rank copies its own shard to its host instead of gathering; SURVEY.md
+§8e), a barrier, and only then teardown on every rank.
 """
 import argparse
 import json
@@ -55,6 +63,14 @@ def stamped_traffic(profile_json, kernel_sources, H, W, B):
     return d.get("hbm_bytes_per_launch")
 
 
+def traffic_of(precision, H, W, B):
+    if precision == "bf16":
+        srcs = ["conv_bf16_ws.hip", "conv1a_mfma.h"]
+        return (stamped_traffic("conv1b_bf16_traffic.json", srcs, H, W, B) or
+                stamped_traffic("conv1b_bf16_720p_traffic.json", srcs, H, W, B))
+    return stamped_traffic("conv1b_traffic.json", ["conv_f32.hip"], H, W, B)
+
+
 def run_timed(ext, sharded, d_img, stream, steps, warmup, world, dist, torch):
     """W untimed + K timed steps bracketed by barrier + synchronize; returns seconds (max over ranks)."""
     for _ in range(warmup):
@@ -95,6 +111,270 @@ def roofline_of(precision, stages, H, W, B, traffic):
             "kernel_ms": round(t_conv1b * 1e3, 4)}
 
 
+def parity_of(rec, ref, bf16):
+    """A device record against the oracle's extraction of the same frame -> (ok, detail)."""
+    import numpy as np
+    kp_ok = rec.K == ref["K"] and np.array_equal(rec.kp_xy, ref["kp_xy"]) and np.array_equal(rec.occ_grid, ref["occ_grid"])
+    if bf16:
+        a = {(int(x), int(y)) for x, y in rec.kp_xy}
+        b = {(int(x), int(y)) for x, y in ref["kp_xy"]}
+        idx = {(int(x), int(y)): i for i, (x, y) in enumerate(ref["kp_xy"])}
+        cos = [float(np.dot(rec.descriptors[i], ref["desc"][idx[k]]))
+               for i, k in enumerate((int(x), int(y)) for x, y in rec.kp_xy) if k in idx]
+        jac = len(a & b) / max(1, len(a | b))
+        return bool(jac >= 0.8 and (not cos or min(cos) >= 0.999)), {
+            "rule": "bf16 mode vs the f32 oracle: keypoint-set Jaccard >= 0.8, descriptor cosine of common keypoints >= 0.999",
+            "jaccard": round(jac, 4), "desc_cos_min": round(min(cos), 6) if cos else None}
+    desc_bits = kp_ok and np.array_equal(rec.descriptors.view(np.uint32), ref["desc"].view(np.uint32))
+    cov_bits = kp_ok and np.array_equal(rec.cov2.view(np.uint32), ref["cov2"].view(np.uint32)) and \
+        np.array_equal(rec.cov2_inv.view(np.uint32), ref["cov2_inv"].view(np.uint32))
+    return bool(kp_ok and desc_bits and cov_bits), {
+        "rule": "f32 mode vs the oracle: keypoints / occ_grid exact, descriptors and cov2 / cov2_inv bitwise",
+        "keypoints_exact": bool(kp_ok), "desc_bitwise": bool(desc_bits), "cov2_bitwise": bool(cov_bits), "K": int(rec.K)}
+
+
+def device_leg(ctx, precision, H, W, B, seed0, steps, warmup, what):
+    """One more (precision, resolution) on its own handle: the same pipelined schedule, the same in-region event bracket
+    around conv1b and the same timing rules as the headline.  Compact sub-object."""
+    torch, parallel, synth, SPExtractor = ctx["torch"], ctx["parallel"], ctx["synth"], ctx["SPExtractor"]
+    os.environ["SPFE_STAGE_TIMING"] = "2"
+    ext = SPExtractor(ctx["nf"], H, W, ctx["blob"], max_batch=B, device=ctx["local"], with_heat=False,
+                      async_cov=not ctx["sync_cov"], precision=precision)
+    d = torch.from_numpy(synth.make_batch(seed0, B, H, W)).cuda()
+    sh = parallel.ShardedExtractor(ext, 1, 0, B)
+    dt = run_timed(ext, sh, d, ctx["stream"], steps, warmup, 1, ctx["dist"], torch)
+    st = ext.stage_times()
+    r = sh.decode(0)
+    ok = bool(0 < r.K <= ctx["nf"] + 1 and r.status == 0)
+    fps = B * steps / dt
+    out = {"what": "%s, %d timed steps after %d untimed" % (what, steps, warmup),
+           "value": round(fps, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 4), "dtype": precision,
+           "roofline": roofline_of(precision, st, H, W, B, traffic_of(precision, H, W, B)),
+           "whole_path_tflops": round(fps * FLOP_PER_FRAME[(H, W)] / 1e12, 2) if (H, W) in FLOP_PER_FRAME else None,
+           "records_ok": ok}
+    ext.close()
+    del d
+    os.environ["SPFE_STAGE_TIMING"] = "0"
+    return out
+
+
+def host_path_leg(ctx, precision, H, W, B, frames, fps_device, steps):
+    """The host boundary of operator() (sp_extractor.cpp:379-390 upload, :427-433 D2H): frames start in pageable host
+    memory, results end as host views of the records — PCIe inclusive, never `value`.  Pipelined (spfe_submit_batch /
+    spfe_collect_batch: pinned staging, H2D of batch i+1 and D2H of batch i-1 beside the compute of batch i) and
+    synchronous (spfe_extract_batch)."""
+    import numpy as np
+    torch, SPExtractor, nf = ctx["torch"], ctx["SPExtractor"], ctx["nf"]
+    exth = SPExtractor(nf, H, W, ctx["blob"], max_batch=B, device=ctx["local"], with_heat=False, precision=precision)
+    himgs = [np.array(f) for f in frames[:B]]
+    kh = max(100, steps)
+    for _ in range(3):
+        exth.extract_batch(himgs)
+    t1 = time.perf_counter()
+    for _ in range(kh):
+        exth.extract_batch(himgs)
+    dt_sync = time.perf_counter() - t1
+    tk = [exth.submit_batch(himgs) for _ in range(2)]
+    for _ in range(10):
+        tk.append(exth.submit_batch(himgs))
+        exth.collect_batch(tk.pop(0), copy=False)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(kh):
+        tk.append(exth.submit_batch(himgs))
+        res = exth.collect_batch(tk.pop(0), copy=False)
+    dt_pipe = time.perf_counter() - t1
+    k_ok = all(0 < res[i].K <= nf + 1 and res[i].status == 0 for i in range(B))
+    while tk:
+        exth.collect_batch(tk.pop(0), copy=False)
+    ext1h = SPExtractor(nf, H, W, ctx["blob"], max_batch=1, device=ctx["local"], with_heat=False, precision=precision)
+    for _ in range(10):
+        ext1h(himgs[0], None)
+    t1 = time.perf_counter()
+    for _ in range(200):
+        ext1h(himgs[0], None)
+    dt_one = (time.perf_counter() - t1) / 200
+    out = {"what": "pageable host frames in -> host views of the records out (C ABI boundary, no heat maps), %dx%d %s, "
+                   "%d frames per call, %d calls; pipelined = spfe_submit_batch/spfe_collect_batch, 3 in flight"
+                   % (W, H, precision, B, kh),
+           "fps": round(B * kh / dt_pipe, 2), "ms_per_call": round(dt_pipe / kh * 1e3, 4),
+           "fps_synchronous": round(B * kh / dt_sync, 2), "ms_per_call_synchronous": round(dt_sync / kh * 1e3, 4),
+           "frac_of_device_resident": round(B * kh / dt_pipe / fps_device, 4) if fps_device else None,
+           "bytes_h2d": int(B * H * W), "bytes_d2h": int(B * exth.record_bytes()),
+           "single_frame_operator_call_ms": round(dt_one * 1e3, 4), "records_ok": bool(k_ok)}
+    exth.close()
+    ext1h.close()
+    return out
+
+
+def frontend_chain_leg(ctx, H, W, nframes):
+    """The tracker's per-frame front end on records that never leave HBM (the C5 substitute): per frame
+    spfe_stage_batch_device (raw BGR -> gray) -> spfe_extract_batch_device -> spfe_track_dust_record_device
+    (PoseOptimizationDust + patch-wise association at the alignment's projections, tracker_dust.cpp:92-172); only the pose
+    block and the keypoint indices come back.  Returns (json object, what the CPU block needs for the parity check)."""
+    import numpy as np
+    from sp_orb_slam_amd import track_scene as ts
+    from sp_orb_slam_amd import weights
+    from sp_orb_slam_amd.extractor import DUST_OUT_BYTES
+    torch, SPExtractor, nf = ctx["torch"], ctx["SPExtractor"], ctx["nf"]
+    blob = weights.synthetic(7, "trackable")
+    world = ts.texture(21, *ts.world_size(H, W))
+    ext = SPExtractor(nf, H, W, blob, max_batch=1, device=ctx["local"], with_heat=False)
+    ext.set_staging(H, W, 3, False)
+    rb = ext.record_bytes()
+    stream = torch.cuda.Stream()
+    raws = np.stack([np.repeat(ts.frame(world, k, H, W)[:, :, None], 3, 2) for k in range(nframes)])
+    d_raw = torch.from_numpy(raws).cuda()                      # the camera's frames, resident (the staging boundary)
+    d_gray = torch.zeros((1, H, W), dtype=torch.uint8, device="cuda")
+    d_rec = torch.zeros(rb, dtype=torch.uint8, device="cuda")
+    # pass 1 (untimed): the map points of frame k come from frame k-1's keypoints (host side of the tracker: local map)
+    mp = [None]
+    for k in range(nframes - 1):
+        ext.stage_batch_device(d_raw[k].data_ptr(), 1, d_gray.data_ptr(), stream.cuda_stream)
+        t = ext.extract_batch_device(d_gray.data_ptr(), 1, d_rec.data_ptr(), stream.cuda_stream)
+        ext.wait_records(t, stream.cuda_stream)
+        stream.synchronize()
+        rec = ext.view_record(d_rec.cpu().numpy())
+        pts, mpd, sel = ts.map_points(rec.kp_xy, rec.descriptors, k)
+        mp.append((pts, mpd, rec.kp_xy[sel].copy()))
+    NP = 192
+    pts_all = np.zeros((nframes, NP, 3), np.float32)
+    mpd_all = np.zeros((nframes, NP, 256), np.float32)
+    T_all = np.zeros((nframes, 16), np.float32)
+    n_all = np.zeros(nframes, np.int32)
+    for k in range(1, nframes):
+        n = min(len(mp[k][0]), NP)
+        pts_all[k, :n], mpd_all[k, :n], n_all[k] = mp[k][0][:n], mp[k][1][:n], n
+        T_all[k] = ts.start_pose(k).reshape(16)
+    d_pts, d_mpd, d_T = torch.from_numpy(pts_all).cuda(), torch.from_numpy(mpd_all).cuda(), torch.from_numpy(T_all).cuda()
+    d_out = torch.zeros(DUST_OUT_BYTES, dtype=torch.uint8, device="cuda")
+    d_kp = torch.zeros(512, dtype=torch.int32, device="cuda")
+    h_out = torch.zeros(DUST_OUT_BYTES, dtype=torch.uint8).pin_memory()
+    h_kp = torch.zeros(512, dtype=torch.int32).pin_memory()
+    keep = {}
+    lat, assoc, correct, inl = [], 0, 0, []
+    torch.cuda.synchronize()
+    for rep in range(2):                                        # rep 0 warms up
+        lat = []
+        for k in range(1, nframes):
+            n = int(n_all[k])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ext.stage_batch_device(d_raw[k].data_ptr(), 1, d_gray.data_ptr(), stream.cuda_stream)
+            t = ext.extract_batch_device(d_gray.data_ptr(), 1, d_rec.data_ptr(), stream.cuda_stream)
+            ext.wait_records(t, stream.cuda_stream)
+            ext.track_dust_record_device(d_rec.data_ptr(), d_pts[k].data_ptr(), d_mpd[k].data_ptr(), n, d_T[k].data_ptr(),
+                                         d_out.data_ptr(), d_kp.data_ptr(), ts.FX, ts.FY, ts.CX, ts.CY, min_inliers=30,
+                                         stream=stream.cuda_stream)
+            with torch.cuda.stream(stream):
+                h_out.copy_(d_out, non_blocking=True)
+                h_kp.copy_(d_kp, non_blocking=True)
+            stream.synchronize()
+            lat.append((time.perf_counter() - t0) * 1e3)
+            if rep == 1:
+                g = ext.decode_dust_out(h_out.numpy(), n)
+                gk = h_kp.numpy()[:n].copy()
+                m = gk >= 0
+                inl.append(g["n_inlier"])
+                if k in (1, nframes // 2, nframes - 1):        # frames the CPU block re-does with the oracle chain
+                    keep[k] = dict(raw=raws[k], pts=pts_all[k, :n], mpd=mpd_all[k, :n], T0=T_all[k].reshape(4, 4), g=g, gk=gk,
+                                   rec=d_rec.cpu().numpy())
+                rec_xy = None
+                if m.any():
+                    rec_xy = ext.view_record(d_rec.cpu().numpy()).kp_xy
+                    ox, oy = ts.offsets(k)
+                    pox, poy = ts.offsets(k - 1)
+                    d = rec_xy[gk[m]] - mp[k][2][:n][m]
+                    assoc += int(m.sum())
+                    correct += int(((d[:, 0] == -(ox - pox)) & (d[:, 1] == -(oy - poy))).sum())
+    lat = sorted(lat)
+    out = {"what": "tracker front end per frame, device resident: spfe_stage_batch_device (BGR %dx%d -> gray) -> "
+                   "spfe_extract_batch_device -> spfe_track_dust_record_device (PoseOptimizationDust + patch association, "
+                   "tracker_dust.cpp:92-172); D2H = pose block + keypoint indices only; %d frames, <= %d map points, "
+                   "'trackable' synthetic weights (weights.py), f32" % (W, H, nframes - 1, NP),
+           "frontend_ms_per_frame": {"p50": round(lat[len(lat) // 2], 4), "p99": round(lat[int(len(lat) * 0.99) - 1], 4),
+                                     "frames": len(lat)},
+           "inliers_mean": round(float(np.mean(inl)), 1), "associations": assoc,
+           "associations_consistent_with_camera_motion": round(correct / max(1, assoc), 4)}
+    ext.close()
+    return out, dict(keep=keep, blob=blob, H=H, W=W)
+
+
+def frontend_chain_parity(fc, nf):
+    """CPU block: the oracle chain on the kept frames of the front-end leg."""
+    import numpy as np
+    from oracle import oracle
+    from sp_orb_slam_amd import track_scene as ts
+    from sp_orb_slam_amd import parallel
+    lay = parallel.RecordLayout(fc["H"], fc["W"], nf)
+    ok, detail = True, {}
+    for k, v in fc["keep"].items():
+        ref = oracle.extract(fc["blob"], oracle.stage_input(v["raw"], fc["H"], fc["W"]), nf)
+        rec = lay.unpack(v["rec"])
+        e_ok = rec["K"] == ref["K"] and np.array_equal(rec["kp_xy"], ref["kp_xy"]) and \
+            np.array_equal(rec["desc"].view(np.uint32), ref["desc"].view(np.uint32)) and \
+            np.array_equal(rec["dense_dust"].view(np.uint32), ref["dense_dust"].view(np.uint32))
+        r = oracle.align_dust(ref["dense_dust"], v["pts"], v["T0"], ts.FX, ts.FY, ts.CX, ts.CY)
+        rk = np.full(len(v["pts"]), -1, np.int32)
+        if r["n_inlier"] >= 30:
+            inl = np.flatnonzero(r["inlier"])
+            rk[inl] = oracle.match_patches(v["mpd"][inl], r["uv"][inl], ref["occ_grid"], ref["desc"])
+        a_ok = r["iterations"] == v["g"]["iterations"] and np.array_equal(r["inlier"], v["g"]["inlier"]) and \
+            float(np.abs(r["Tcw"] - v["g"]["Tcw"]).max()) <= 1e-6
+        m_ok = np.array_equal(rk, v["gk"])
+        detail[str(k)] = {"extract_bitwise": bool(e_ok), "alignment": bool(a_ok), "associations_equal": bool(m_ok)}
+        ok = ok and e_ok and a_ok and m_ok
+    return bool(ok), detail
+
+
+def multi_gpu_legs(ctx, args, ext, sharded, d_img, stream, frames_lo, B, H, W):
+    """N > 1: what makes the line prove itself.  Collective calls are made by EVERY rank, in the same order."""
+    import numpy as np
+    torch, dist, parallel = ctx["torch"], ctx["dist"], ctx["parallel"]
+    world, rank, nf = ctx["world"], ctx["rank"], ctx["nf"]
+    res = {}
+    # (1) a frame computed on ANOTHER rank, as it arrived through the gather of the timed region
+    if rank == 0 and not args.no_parity:
+        from oracle import oracle
+        from sp_orb_slam_amd import synth
+        bf16 = args.precision == "bf16"
+        oracle.set_num_threads(min(32, os.cpu_count() or 1))
+        det = {}
+        ok = True
+        for g in (B, 0, world * B - 1):                      # rank 1's first frame, our own, the last rank's last
+            ref = oracle.extract(ctx["blob"], synth.make_image(200 + g, H, W), nf)
+            p, d = parity_of(sharded.decode(g), ref, bf16)
+            det["frame_%d_from_rank_%d" % (g, g // B)] = d
+            ok = ok and p
+        res["parity_gathered"] = bool(ok)
+        res["parity_gathered_detail"] = det
+    # (2) the collective alone: events on the stream it runs on
+    res_g = sharded.time_gather(20)
+    # (3) the host-side alternative: no gather, every rank copies ITS shard to its own pinned host buffer
+    nbytes = B * ext.record_bytes()
+    pinned = [torch.zeros(nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
+    cnt = [0]
+
+    def d2h(out_unused, local):
+        pinned[cnt[0] % 2].copy_(local, non_blocking=True)
+        cnt[0] += 1
+    sh2 = parallel.ShardedExtractor(ext, world, rank, B, gather_fn=d2h)
+    k2 = max(args.steps, 50)
+    dt2 = run_timed(ext, sh2, d_img, stream, k2, max(args.warmup, 5), world, dist, torch)
+    own = ext.view_record(pinned[(cnt[0] - 1) % 2][:ext.record_bytes()].numpy())
+    if rank == 0:
+        res["allgather_ms"] = res_g["ms"]
+        res["allgather"] = res_g
+        res["rccl_ranks"] = sharded.comm_ranks()
+        res["host_alt"] = {"what": "no collective: each rank D2H-copies its own %d records (%d bytes) to pinned host memory on a "
+                                   "copy stream behind the batch's covariance (SURVEY.md 8e: the SLAM consumer is on the host), "
+                                   "%d timed steps" % (B, nbytes, k2),
+                           "value": round(world * B * k2 / dt2, 2), "unit": "frames/s",
+                           "ms_per_step": round(dt2 / k2 * 1e3, 4), "records_ok": bool(0 < own.K <= nf + 1 and own.status == 0)}
+        res["host_alt_ms"] = res["host_alt"]["ms_per_step"]
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,14 +391,16 @@ def main():
                     help="do not overlap the covariance stage of step i with the convolutions of step i+1")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-stage-table", action="store_true", help="skip the separate per-stage timing pass")
-    ap.add_argument("--no-match", action="store_true", help="skip the descriptor-matching and input-staging legs (SURVEY 8f-1, 8f-2)")
-    ap.add_argument("--no-bf16-leg", action="store_true", help="skip the configs[3] leg (bf16, 1280x720, batch 8)")
+    ap.add_argument("--no-match", action="store_true", help="skip the matching, dust-alignment, staging and front-end legs (SURVEY 8f)")
+    ap.add_argument("--no-bf16-leg", action="store_true", help="skip the other-resolution / other-dtype legs (incl. configs[3])")
     ap.add_argument("--no-aten", action="store_true", help="skip the ATen-CPU baseline")
-    ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host-path leg")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host-path legs")
+    ap.add_argument("--no-parity", action="store_true", help="N > 1: skip the oracle check of the gathered records")
     ap.add_argument("--latency-calls", type=int, default=1000)
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
-                    help="f32: BASELINE configs[1]/[2] (bit-exact path, the headline); bf16: configs[3] "
-                         "(bf16 convolutions conv1b..convPa/Da, f32 heads + post-processing)")
+                    help="f32: BASELINE configs[1]/[2] (bit-exact path, the headline); bf16: configs[3] (all twelve "
+                         "convolutions, the two 1x1 heads included, as bf16 MFMA GEMMs with f32 accumulation; softmax, "
+                         "NMS, descriptor sampling and covariance stay f32)")
     args = ap.parse_args()
 
     # timed region: HIP events around the dominant kernel only (two per step); the full per-stage table
@@ -162,6 +444,8 @@ def main():
     sharded = parallel.ShardedExtractor(ext, world, rank, B)
     stream = torch.cuda.Stream()   # compute stream (not the legacy default stream: no implicit barriers)
     torch.cuda.synchronize()
+    ctx = dict(torch=torch, dist=dist, parallel=parallel, synth=synth, SPExtractor=SPExtractor, nf=nf, blob=blob, local=local,
+               sync_cov=args.sync_cov, stream=stream, world=world, rank=rank)
 
     dt = run_timed(ext, sharded, d_img, stream, args.steps, args.warmup, world, dist, torch)
     stages = ext.stage_times()
@@ -171,15 +455,13 @@ def main():
     recl = sharded.decode(world * B - 1)
     assert 0 < rec0.K <= nf + 1 and 0 < recl.K <= nf + 1 and rec0.status == 0 and recl.status == 0
 
+    bf16 = args.precision == "bf16"
+    out = None
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         fps = world * B * args.steps / dt
         flop_frame = FLOP_PER_FRAME.get((H, W))
         # dominant kernel: conv1b (43.5 % of the FLOPs), one launch covers B frames
-        bf16 = args.precision == "bf16"
-        traffic = ((stamped_traffic("conv1b_bf16_traffic.json", ["conv_bf16_ws.hip", "conv1a_mfma.h"], H, W, B) or
-                    stamped_traffic("conv1b_bf16_720p_traffic.json", ["conv_bf16_ws.hip", "conv1a_mfma.h"], H, W, B)) if bf16 else
-                   stamped_traffic("conv1b_traffic.json", ["conv_f32.hip"], H, W, B))
         out = {
             "metric": "frames/sec SuperPoint extract (%dx%d, %s kpts)" % (W, H, "1k" if nf == 1000 else str(nf)),
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -188,7 +470,8 @@ def main():
             "config": {"workload": "%dx%d u8 frames, num_features=%d, %s, %d frames/GPU/step, "
                                    "%s synthetic detector weights; records all-gathered over RCCL when n_gpus>1; %s"
                                    % (W, H, nf,
-                                      "bf16 MFMA convolutions and heads (f32 accumulate), f32 post-processing"
+                                      "all twelve convolutions (1x1 heads included) as bf16 MFMA GEMMs with f32 accumulation, "
+                                      "f32 softmax / NMS / descriptor sampling / covariance"
                                       if bf16 else "f32 MFMA", B, args.detector,
                                       "covariance stage on the device, synchronous" if args.sync_cov else
                                       "covariance of step i overlapped with the convolutions of step i+1 (depth-2 pipeline)"),
@@ -197,345 +480,313 @@ def main():
                        "gather": ("none (1 GPU)" if world == 1 else
                                   "ncclAllGather inside libspfe (spfe_allgather_records)" if getattr(sharded, "_native", False)
                                   else "torch.distributed all_gather_into_tensor")},
-            "roofline": roofline_of(args.precision, stages, H, W, B, traffic),
+            "roofline": roofline_of(args.precision, stages, H, W, B, traffic_of(args.precision, H, W, B)),
             "whole_path_tflops": round(fps * flop_frame / 1e12, 2) if flop_frame else None,
         }
-        if not args.no_stage_table:
-            # per-stage table: separate pass, same workload and schedule, all stages bracketed by events
-            os.environ["SPFE_STAGE_TIMING"] = "1"
-            ext_t = SPExtractor(nf, H, W, blob, max_batch=B, device=local, with_heat=False,
-                                async_cov=not args.sync_cov, precision=args.precision)
-            sh_t = parallel.ShardedExtractor(ext_t, 1, 0, B)
-            for _ in range(2):
-                sh_t.step(d_img, stream)
-            sh_t.flush(stream)
-            torch.cuda.synchronize()
-            ext_t.stage_reset()
-            for _ in range(8):
-                sh_t.step(d_img, stream)
-            sh_t.flush(stream)
-            torch.cuda.synchronize()
-            out["stage_ms"] = {k: round(v, 4) for k, v in ext_t.stage_times().items()}
-            out["stage_ms_note"] = "separate 8-step pass with events around every stage (this rank only)"
-            ext_t.close()
-        os.environ["SPFE_STAGE_TIMING"] = "0"   # no events in the latency / matching / host-path legs
-        if world == 1 and not args.no_bf16_leg and not (bf16 and (H, W, B) == (720, 1280, 8)):
-            # BASELINE configs[3]: 1280x720, batch 8, bf16 convolutions + f32 NMS, 1 GPU — the same
-            # pipelined schedule and the same in-region event bracket around conv1b as the headline
-            os.environ["SPFE_STAGE_TIMING"] = "2"
-            H3, W3, B3 = 720, 1280, 8
-            ext3 = SPExtractor(nf, H3, W3, blob, max_batch=B3, device=local, with_heat=False,
-                               async_cov=not args.sync_cov, precision="bf16")
-            d3 = torch.from_numpy(synth.make_batch(300, B3, H3, W3)).cuda()
-            sh3 = parallel.ShardedExtractor(ext3, 1, 0, B3)
-            # >= 200 timed steps behind >= 20 untimed ones: a 20-step region (25 ms) of this leg reads 8 % low — clocks and
-            # caches still settling (tools/microbench/run_steps_ab.sh: 6616 / 7200 / 7245 frames/s at 20 / 100 / 300 steps)
-            k3, w3 = max(200, args.steps), max(20, args.warmup)
-            dt3 = run_timed(ext3, sh3, d3, stream, k3, w3, 1, dist, torch)
-            st3 = ext3.stage_times()
-            r3 = sh3.decode(0)
-            assert 0 < r3.K <= nf + 1 and r3.status == 0
-            fps3 = B3 * k3 / dt3
-            out["bf16_1280x720_b8"] = {
-                "what": "BASELINE configs[3]: 1280x720 frames, batch 8, bf16 MFMA convolutions (f32 accumulate), "
-                        "f32 detector head / NMS / descriptors / covariance, 1 GPU, %d timed steps after %d untimed" % (k3, w3),
-                "value": round(fps3, 2), "unit": "frames/s", "ms_per_step": round(dt3 / k3 * 1e3, 4), "dtype": "bf16",
-                "roofline": roofline_of("bf16", st3, H3, W3, B3,
-                                        stamped_traffic("conv1b_bf16_720p_traffic.json", ["conv_bf16_ws.hip", "conv1a_mfma.h"], H3, W3, B3)),
-                "whole_path_tflops": round(fps3 * FLOP_PER_FRAME[(H3, W3)] / 1e12, 2)}
-            ext3.close()
-            del d3
-            os.environ["SPFE_STAGE_TIMING"] = "0"
-        # batch-1 latency (configs[1] as written: one frame per call)
-        ext1 = None if args.no_latency else SPExtractor(nf, H, W, blob, max_batch=1, device=local, with_heat=False,
-                                                                precision=args.precision)
+
+    if world > 1:
+        # ---- N > 1: self-verification legs (every rank takes part), then ONE line, a barrier, and only then teardown
+        os.environ["SPFE_STAGE_TIMING"] = "0"
+        res = multi_gpu_legs(ctx, args, ext, sharded, d_img, stream, lo, B, H, W)
+        if rank == 0:
+            out.update(res)
+            print(json.dumps(out), flush=True)
+        torch.cuda.synchronize()
+        dist.barrier()            # no rank destroys its communicator while another is still in a leg (or printing)
+        ext.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
+    # ---------------------------------------------------------------- N = 1: GPU legs, back to back
+    fps = out["value"]
+    cpu_todo = {}
+    if not args.no_stage_table:
+        # per-stage table: separate pass, same workload and schedule, all stages bracketed by events
+        os.environ["SPFE_STAGE_TIMING"] = "1"
+        ext_t = SPExtractor(nf, H, W, blob, max_batch=B, device=local, with_heat=False,
+                            async_cov=not args.sync_cov, precision=args.precision)
+        sh_t = parallel.ShardedExtractor(ext_t, 1, 0, B)
+        for _ in range(2):
+            sh_t.step(d_img, stream)
+        sh_t.flush(stream)
+        torch.cuda.synchronize()
+        ext_t.stage_reset()
+        for _ in range(8):
+            sh_t.step(d_img, stream)
+        sh_t.flush(stream)
+        torch.cuda.synchronize()
+        out["stage_ms"] = {k: round(v, 4) for k, v in ext_t.stage_times().items()}
+        out["stage_ms_note"] = "separate 8-step pass with events around every stage (this rank only)"
+        ext_t.close()
+    os.environ["SPFE_STAGE_TIMING"] = "0"   # no events in the latency / matching / host-path legs
+    if not args.no_bf16_leg:
+        # What north_star lists beside the headline: "synthetic VGA / 752x480 / 1280x720 image batches", both dtypes.
+        # >= 100 (f32) / >= 200 (bf16) timed steps: a 20-step region of a 0.6 - 1.1 ms bf16 step is 12 - 25 ms and reads 8 % low
+        # — clocks and caches still settling (tools/microbench/run_steps_ab.sh: 6616 / 7200 / 7245 frames/s at 20 / 100 / 300
+        # steps) — so these legs do not take the driver's --steps 20 literally; the headline does.
+        legs = [("f32_640x480_b8", "f32", 480, 640, 400, 100, 10, "VGA 640x480, batch 8, f32 MFMA, 1 GPU"),
+                ("f32_1280x720_b8", "f32", 720, 1280, 300, 100, 10, "1280x720, batch 8, f32 MFMA, 1 GPU"),
+                ("bf16_752x480_b8", "bf16", 480, 752, 200, 200, 20, "752x480, batch 8, bf16 MFMA convolutions and heads (f32 accumulate), f32 softmax / NMS / descriptors / covariance, 1 GPU"),
+                ("bf16_1280x720_b8", "bf16", 720, 1280, 300, 200, 20, "BASELINE configs[3]: 1280x720, batch 8, bf16 MFMA convolutions and heads (f32 accumulate), f32 softmax / NMS / descriptors / covariance, 1 GPU")]
+        for name, prec, h2, w2, seed0, k2, wu2, what in legs:
+            if (prec, h2, w2, 8) == (args.precision, H, W, B):
+                continue
+            out[name] = device_leg(ctx, prec, h2, w2, 8, seed0, max(k2, args.steps), max(wu2, args.warmup), what)
+    # batch-1 latency (configs[1] as written: one frame per call)
+    if not args.no_latency:
+        ext1 = SPExtractor(nf, H, W, blob, max_batch=1, device=local, with_heat=False, precision=args.precision)
         d1 = d_img[:1].contiguous()
         r1 = torch.zeros(rec_bytes, dtype=torch.uint8, device="cuda")
         lat = []
-        for i in range(0 if ext1 is None else args.latency_calls + 50):
+        for i in range(args.latency_calls + 50):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             ext1.extract_batch_device(d1.data_ptr(), 1, r1.data_ptr(), stream.cuda_stream)
             torch.cuda.synchronize()
             lat.append((time.perf_counter() - t1) * 1e3)
-        if ext1 is not None:
-            lat = sorted(lat[50:])   # 1000 timed calls after 50 warm-up calls
-            out["latency_batch1_ms"] = {"p50": round(lat[len(lat) // 2], 4), "p99": round(lat[int(len(lat) * 0.99) - 1], 4),
-                                        "calls": len(lat)}
-            ext1.close()
+        lat = sorted(lat[50:])   # 1000 timed calls after 50 warm-up calls
+        out["latency_batch1_ms"] = {"p50": round(lat[len(lat) // 2], 4), "p99": round(lat[int(len(lat) * 0.99) - 1], 4),
+                                    "calls": len(lat)}
+        ext1.close()
 
-        if not args.no_host_path:
-            # The host boundary of operator() (sp_extractor.cpp:379-390 upload, :427-433 D2H): frames start in
-            # pageable host memory, results end as host views of the records — PCIe inclusive, never `value`.
-            # Pipelined (spfe_submit_batch / spfe_collect_batch: pinned staging, H2D of batch i+1 and D2H of
-            # batch i-1 on copy streams beside the compute of batch i) and synchronous (spfe_extract_batch).
-            exth = SPExtractor(nf, H, W, blob, max_batch=B, device=local, with_heat=False, precision=args.precision)
-            himgs = [np.array(f) for f in frames[:B]]
-            kh = max(100, args.steps)
-            for _ in range(3):
-                exth.extract_batch(himgs)
+    if not args.no_host_path:
+        out["host_path"] = host_path_leg(ctx, args.precision, H, W, B, frames, fps, args.steps)
+        if not args.no_bf16_leg and not (bf16 and (H, W) == (720, 1280)):
+            fr3 = synth.make_batch(300, 8, 720, 1280)
+            dev3 = (out.get("bf16_1280x720_b8") or {}).get("value")
+            out["host_path_bf16"] = host_path_leg(ctx, "bf16", 720, 1280, 8, fr3, dev3, args.steps)
+
+    if not args.no_match:
+        # SURVEY.md §8(f) rank 1 (outside the timed region): match this step's B frames against
+        # the same frames shifted by one cell, records resident in HBM, cross-check on.
+        extm = SPExtractor(nf, H, W, blob, max_batch=B, device=local, with_heat=False,
+                           precision=args.precision)
+        d_img2 = torch.roll(d_img, (8, 16), (1, 2)).contiguous()
+        ra = torch.zeros(B * rec_bytes, dtype=torch.uint8, device="cuda")
+        rb2 = torch.zeros(B * rec_bytes, dtype=torch.uint8, device="cuda")
+        mo = torch.zeros(B * extm.match_out_bytes(), dtype=torch.uint8, device="cuda")
+        mstream = torch.cuda.Stream()   # an explicit stream: a NULL stream argument means "the handle's own"
+        torch.cuda.synchronize()
+        extm.extract_batch_device(d_img.data_ptr(), B, ra.data_ptr(), mstream.cuda_stream)
+        extm.extract_batch_device(d_img2.data_ptr(), B, rb2.data_ptr(), mstream.cuda_stream)
+        for _ in range(3):
+            extm.match_records_device(rb2.data_ptr(), ra.data_ptr(), B, mo.data_ptr(), True, mstream.cuda_stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        nit = 30
+        e0.record(mstream)
+        for _ in range(nit):
+            extm.match_records_device(rb2.data_ptr(), ra.data_ptr(), B, mo.data_ptr(), True, mstream.cuda_stream)
+        e1.record(mstream)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / nit
+        ka = [extm.view_record(ra[i * rec_bytes:(i + 1) * rec_bytes].cpu().numpy()) for i in range(B)]
+        kb = [extm.view_record(rb2[i * rec_bytes:(i + 1) * rec_bytes].cpu().numpy()) for i in range(B)]
+        pair_elems = sum(a.K * b.K for a, b in zip(ka, kb)) * 256
+        mb = extm.match_out_bytes()
+        idx0, _ = extm.decode_match_out(mo[:mb].cpu().numpy(), kb[0].K)
+        out["match_bruteforce"] = {
+            "what": "cv::BFMatcher(NORM_L2, crossCheck=true) rule, %d frame pairs per launch, K~%d x %d, "
+                    "records in HBM" % (B, kb[0].K, ka[0].K),
+            "ms_per_batch": round(ms, 4), "pairs_per_s": round(B / ms * 1e3, 1),
+            # 1 subtract + 1 fma per descriptor element pair, on the f32 VALU
+            "valu_tflops": round(pair_elems * 3 / (ms * 1e-3) / 1e12, 2),
+            "matched_frac_pair0": round(float((idx0 >= 0).mean()), 3)}
+        cpu_todo["match"] = (kb[0].descriptors.copy(), ka[0].descriptors.copy())
+        # patch-wise association of 200 projected map points against frame 0's resident record
+        # (tracker_dust.cpp:113-172; mps_for_track holds 150-200 points)
+        f0 = ka[0]
+        rngp = np.random.default_rng(3)
+        kk = rngp.integers(0, f0.K, 200)
+        mpd = f0.descriptors[kk] + np.float32(0.3) * (rngp.standard_normal((200, 256)).astype(np.float32) / 16)
+        mpuv = np.stack([f0.kp_xy[kk, 0] // 8 + 0.5 - rngp.integers(0, 2, 200), f0.kp_xy[kk, 1] // 8 + 0.5 - rngp.integers(0, 2, 200)], 1)
+        d_mpd, d_mpuv = torch.from_numpy(mpd.astype(np.float32)).cuda(), torch.from_numpy(mpuv.astype(np.float32)).cuda()
+        d_pidx = torch.zeros(200, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for _ in range(3):
+            extm.match_patches_record_device(d_mpd.data_ptr(), d_mpuv.data_ptr(), 200, ra.data_ptr(), d_pidx.data_ptr(),
+                                             0.75, mstream.cuda_stream)
+        e0.record(mstream)
+        for _ in range(nit):
+            extm.match_patches_record_device(d_mpd.data_ptr(), d_mpuv.data_ptr(), 200, ra.data_ptr(), d_pidx.data_ptr(),
+                                             0.75, mstream.cuda_stream)
+        e1.record(mstream)
+        torch.cuda.synchronize()
+        out["match_patches"] = {"what": "tracker_dust.cpp:113-172 association, 200 map points vs one resident record",
+                                "us_per_call": round(e0.elapsed_time(e1) / nit * 1e3, 2),
+                                "matched": int((d_pidx.cpu().numpy() >= 0).sum())}
+        extm.close()
+
+        # SURVEY.md §8(f) rank 3 (outside the timed region): direct dust alignment, 160 map points against the
+        # dense_dust of frame 0's resident record (optimizer_dust.cpp:170-294: 40 LM iterations)
+        from sp_orb_slam_amd import dust_scene
+        from sp_orb_slam_amd.extractor import DUST_MAX_POINTS, DUST_OUT_BYTES
+        extd = SPExtractor(nf, H, W, blob, max_batch=1, device=local, with_heat=False)
+        dsc = dust_scene.make_scene(0, H=H, W=W, n_points=160, cx=W / 2 - 8.8, cy=H / 2 + 8.4)
+        gz = None
+        if (H, W) == (480, 752):
+            # the scene of tests/golden/dust_std0.npz: its expected pose / flags come from an INDEPENDENT f64 numpy / scipy
+            # statement of the optimisation (tests/golden/make_golden_dust.py; no code shared with the kernel or the oracle)
+            try:
+                gz = np.load(os.path.join(ROOT, "tests", "golden", "dust_std0.npz"))
+                fxg, fyg, cxg, cyg = (np.float32(v) for v in gz["intr"])
+                dsc = dict(dust=gz["dust"], pts=gz["pts"], Tcw_init=gz["Tcw_init"], fx=fxg, fy=fyg, cx=cxg, cy=cyg)
+            except Exception:
+                gz = None
+        d_rec = torch.zeros(rec_bytes, dtype=torch.uint8, device="cuda")
+        dstream = torch.cuda.Stream()
+        extd.extract_batch_device(d_img.data_ptr(), 1, d_rec.data_ptr(), dstream.cuda_stream)
+        # a scene-shaped dust map in the record, so that the solve does real work (synthetic weights give a flat one)
+        lay = parallel.RecordLayout(H, W, nf)
+        d_rec[lay.off_dd:lay.off_dd + dsc["dust"].size * 4] = torch.from_numpy(dsc["dust"].reshape(-1).view(np.uint8)).cuda()
+        d_pts, d_T = torch.from_numpy(dsc["pts"]).cuda(), torch.from_numpy(dsc["Tcw_init"].reshape(16)).cuda()
+        d_do = torch.zeros(DUST_OUT_BYTES, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+
+        def dust_once():
+            extd.align_dust_record_device(d_rec.data_ptr(), d_pts.data_ptr(), 160, d_T.data_ptr(), d_do.data_ptr(),
+                                          dsc["fx"], dsc["fy"], dsc["cx"], dsc["cy"], stream=dstream.cuda_stream)
+        for _ in range(3):
+            dust_once()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(dstream)
+        for _ in range(20):
+            dust_once()
+        e1.record(dstream)
+        torch.cuda.synchronize()
+        gd = extd.decode_dust_out(d_do.cpu().numpy(), 160)
+        out["dust_alignment"] = {"what": "Optimizer::PoseOptimizationDust: 160 map points vs the dense_dust of a resident "
+                                         "record, Huber 0.9, <= 40 LM iterations, one workgroup, f64",
+                                 "us_per_solve": round(e0.elapsed_time(e1) / 20 * 1e3, 1), "iterations": gd["iterations"],
+                                 "n_inlier": gd["n_inlier"]}
+        if gz is not None:
+            out["dust_alignment"]["vs_independent_fixture"] = {
+                "fixture": "tests/golden/dust_std0.npz",
+                "pose_max_abs_diff": float(np.abs(gd["Tcw"].astype(np.float64) - gz["pose64"]).max()),
+                "iterations_equal": bool(gd["iterations"] == int(gz["iterations"])),
+                "inlier_flags_equal": bool(np.array_equal(gd["inlier"], gz["inlier"]))}
+        # the batch path's form: one workgroup per frame, 64 independent solves (each its own record, points and start
+        # pose) in one launch — a solve is a latency chain, so they take about as long as one
+        NB = 64
+        d_recs = d_rec.repeat(NB, 1).contiguous()
+        pts_b = np.zeros((NB, DUST_MAX_POINTS, 3), np.float32)
+        T_b = np.zeros((NB, 16), np.float32)
+        for f in range(NB):
+            scf = dust_scene.make_scene(f, H=H, W=W, n_points=160, cx=W / 2 - 8.8, cy=H / 2 + 8.4)
+            pts_b[f, :160] = scf["pts"]
+            T_b[f] = scf["Tcw_init"].reshape(16)
+            d_recs[f, lay.off_dd:lay.off_dd + scf["dust"].size * 4] = torch.from_numpy(scf["dust"].reshape(-1).view(np.uint8)).cuda()
+        d_pb, d_Tb = torch.from_numpy(pts_b).cuda(), torch.from_numpy(T_b).cuda()
+        d_nb = torch.full((NB,), 160, dtype=torch.int32, device="cuda")
+        d_ob = torch.zeros((NB, DUST_OUT_BYTES), dtype=torch.uint8, device="cuda")
+
+        def dust_batch():
+            extd.align_dust_batch_device(d_recs.data_ptr(), NB, d_pb.data_ptr(), d_nb.data_ptr(), d_Tb.data_ptr(), d_ob.data_ptr(),
+                                         dsc["fx"], dsc["fy"], dsc["cx"], dsc["cy"], stream=dstream.cuda_stream)
+        for _ in range(2):
+            dust_batch()
+        e0.record(dstream)
+        for _ in range(10):
+            dust_batch()
+        e1.record(dstream)
+        torch.cuda.synchronize()
+        ob = d_ob.cpu().numpy()
+        out["dust_alignment"]["batch64_us_per_launch"] = round(e0.elapsed_time(e1) / 10 * 1e3, 1)
+        out["dust_alignment"]["batch64_us_per_solve"] = round(e0.elapsed_time(e1) / 10 / NB * 1e3, 2)
+        out["dust_alignment"]["batch64_frame0_equals_single"] = bool(np.array_equal(ob[0][:64], d_do.cpu().numpy()[:64]))
+        cpu_todo["dust"] = (dsc, gd)
+        extd.close()
+
+        # SURVEY.md §8(f) rank 2 (outside the timed region): staging kernel on B raw BGR frames
+        exts = SPExtractor(nf, H, W, blob, max_batch=B, device=local, with_heat=False)
+        vv, uu = np.mgrid[0:H, 0:W].astype(np.float64)
+        r2 = ((uu - W / 2) / W) ** 2 + ((vv - H / 2) / W) ** 2
+        mx = (uu + (uu - W / 2) * (-0.28 * r2)).astype(np.float32)
+        my = (vv + (vv - H / 2) * (-0.28 * r2)).astype(np.float32)
+        exts.set_staging(H, W, 3, False, mx, my)
+        d_raw = d_img[:, :, :, None].expand(B, H, W, 3).contiguous()
+        d_gray = torch.zeros((B, H, W), dtype=torch.uint8, device="cuda")
+        sstream = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            exts.stage_batch_device(d_raw.data_ptr(), B, d_gray.data_ptr(), sstream.cuda_stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(sstream)
+        for _ in range(30):
+            exts.stage_batch_device(d_raw.data_ptr(), B, d_gray.data_ptr(), sstream.cuda_stream)
+        e1.record(sstream)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 30
+        # algorithmic bytes: 4 taps x 3 ch gathered (hits L2: ~1 raw frame) + 2 maps + 1 gray out
+        alg = B * H * W * (3 + 8 + 1)
+        out["input_staging"] = {"what": "cv::remap(INTER_LINEAR) + crop + BGR2GRAY, %d frames %dx%dx3 per launch"
+                                        % (B, W, H), "ms_per_batch": round(ms, 4),
+                                "hbm_GBps_algorithmic": round(alg / (ms * 1e-3) / 1e9, 1)}
+        exts.close()
+        del d_raw
+
+        # the tracker's front end chained on resident records (the C5 substitute)
+        out["frontend_chain"], cpu_todo["frontend"] = frontend_chain_leg(ctx, H, W, 101)
+
+    # ---------------------------------------------------------------- CPU legs (the oracle is the checker / the baseline)
+    if not args.no_cpu_baseline:
+        # CPU baseline: the C oracle (a port of the path; the reference has no CPU
+        # path and cannot be built here) on this host's cores, bounded sample.
+        from oracle import oracle
+        # the port's loops scale to a few dozen threads (tools/cpu_baseline.py sweeps 1..all: the
+        # best team on the 256-thread GPU-box host is 32), so that is the team it gets
+        nthr = oracle.set_num_threads(min(32, os.cpu_count() or 1))
+        ref0 = oracle.extract(blob, frames[0], nf)   # warm-up (thread team, caches) + the parity check below
+        done, t1 = 0, time.perf_counter()
+        while True:
+            oracle.extract(blob, frames[done % B], nf)
+            done += 1
+            el = time.perf_counter() - t1
+            if el >= args.cpu_seconds or done >= 512:
+                break
+        out["cpu_baseline"] = {"value": round(done / el, 3), "unit": "frames/s", "cores": nthr,
+                               "kind": "port",
+                               "sample": "%d frames of the same %dx%d workload through oracle/spfe_oracle.c "
+                                         "(OpenMP, %d threads), %.1f s" % (done, W, H, nthr, el)}
+        # self-check of the timed workload: frame 0 of the LAST timed batch (pipelined, device
+        # resident) against the oracle's extraction of the same frame
+        out["parity_frame0"], out["parity_frame0_detail"] = parity_of(rec0, ref0, bf16)
+        if "match" in cpu_todo:
             t1 = time.perf_counter()
-            for _ in range(kh):
-                exth.extract_batch(himgs)
-            dt_sync = time.perf_counter() - t1
-            tk = [exth.submit_batch(himgs) for _ in range(2)]
-            for _ in range(10):
-                tk.append(exth.submit_batch(himgs))
-                exth.collect_batch(tk.pop(0), copy=False)
-            torch.cuda.synchronize()
+            oracle.match_bruteforce(cpu_todo["match"][0], cpu_todo["match"][1], True)
+            out["match_bruteforce"]["cpu_oracle_ms_per_pair"] = round((time.perf_counter() - t1) * 1e3, 2)
+        if "dust" in cpu_todo:
+            dsc, gd = cpu_todo["dust"]
             t1 = time.perf_counter()
-            for _ in range(kh):
-                tk.append(exth.submit_batch(himgs))
-                res = exth.collect_batch(tk.pop(0), copy=False)
-            dt_pipe = time.perf_counter() - t1
-            k_ok = all(0 < res[i].K <= nf + 1 and res[i].status == 0 for i in range(B))
-            while tk:
-                exth.collect_batch(tk.pop(0), copy=False)
-            ext1h = SPExtractor(nf, H, W, blob, max_batch=1, device=local, with_heat=False, precision=args.precision)
-            for _ in range(10):
-                ext1h(himgs[0], None)
-            t1 = time.perf_counter()
-            for _ in range(200):
-                ext1h(himgs[0], None)
-            dt_one = (time.perf_counter() - t1) / 200
-            out["host_path"] = {
-                "what": "pageable host frames in -> host views of the records out (C ABI boundary, no heat maps), "
-                        "%d frames per call, %d calls; pipelined = spfe_submit_batch/spfe_collect_batch, 3 in flight" % (B, kh),
-                "fps": round(B * kh / dt_pipe, 2), "ms_per_call": round(dt_pipe / kh * 1e3, 4),
-                "fps_synchronous": round(B * kh / dt_sync, 2), "ms_per_call_synchronous": round(dt_sync / kh * 1e3, 4),
-                "frac_of_device_resident": round(B * kh / dt_pipe / fps * world, 4),
-                "bytes_h2d": int(B * H * W), "bytes_d2h": int(B * rec_bytes),
-                "single_frame_operator_call_ms": round(dt_one * 1e3, 4), "records_ok": bool(k_ok)}
-            exth.close()
-            ext1h.close()
-
-        if not args.no_match:
-            # SURVEY.md §8(f) rank 1 (outside the timed region): match this step's B frames against
-            # the same frames shifted by one cell, records resident in HBM, cross-check on.
-            extm = SPExtractor(nf, H, W, blob, max_batch=B, device=local, with_heat=False,
-                               precision=args.precision)
-            d_img2 = torch.roll(d_img, (8, 16), (1, 2)).contiguous()
-            ra = torch.zeros(B * rec_bytes, dtype=torch.uint8, device="cuda")
-            rb2 = torch.zeros(B * rec_bytes, dtype=torch.uint8, device="cuda")
-            mo = torch.zeros(B * extm.match_out_bytes(), dtype=torch.uint8, device="cuda")
-            mstream = torch.cuda.Stream()   # an explicit stream: a NULL stream argument means "the handle's own"
-            torch.cuda.synchronize()
-            extm.extract_batch_device(d_img.data_ptr(), B, ra.data_ptr(), mstream.cuda_stream)
-            extm.extract_batch_device(d_img2.data_ptr(), B, rb2.data_ptr(), mstream.cuda_stream)
-            for _ in range(3):
-                extm.match_records_device(rb2.data_ptr(), ra.data_ptr(), B, mo.data_ptr(), True, mstream.cuda_stream)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            nit = 30
-            e0.record(mstream)
-            for _ in range(nit):
-                extm.match_records_device(rb2.data_ptr(), ra.data_ptr(), B, mo.data_ptr(), True, mstream.cuda_stream)
-            e1.record(mstream)
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / nit
-            ka = [extm.view_record(ra[i * rec_bytes:(i + 1) * rec_bytes].cpu().numpy()) for i in range(B)]
-            kb = [extm.view_record(rb2[i * rec_bytes:(i + 1) * rec_bytes].cpu().numpy()) for i in range(B)]
-            pair_elems = sum(a.K * b.K for a, b in zip(ka, kb)) * 256
-            mb = extm.match_out_bytes()
-            idx0, _ = extm.decode_match_out(mo[:mb].cpu().numpy(), kb[0].K)
-            out["match_bruteforce"] = {
-                "what": "cv::BFMatcher(NORM_L2, crossCheck=true) rule, %d frame pairs per launch, K~%d x %d, "
-                        "records in HBM" % (B, kb[0].K, ka[0].K),
-                "ms_per_batch": round(ms, 4), "pairs_per_s": round(B / ms * 1e3, 1),
-                # 1 subtract + 1 fma per descriptor element pair, on the f32 VALU
-                "valu_tflops": round(pair_elems * 3 / (ms * 1e-3) / 1e12, 2),
-                "matched_frac_pair0": round(float((idx0 >= 0).mean()), 3)}
-            # patch-wise association of 200 projected map points against frame 0's resident record
-            # (tracker_dust.cpp:113-172; mps_for_track holds 150-200 points)
-            f0 = ka[0]
-            rngp = np.random.default_rng(3)
-            kk = rngp.integers(0, f0.K, 200)
-            mpd = f0.descriptors[kk] + np.float32(0.3) * (rngp.standard_normal((200, 256)).astype(np.float32) / 16)
-            mpuv = np.stack([f0.kp_xy[kk, 0] // 8 + 0.5 - rngp.integers(0, 2, 200), f0.kp_xy[kk, 1] // 8 + 0.5 - rngp.integers(0, 2, 200)], 1)
-            d_mpd, d_mpuv = torch.from_numpy(mpd.astype(np.float32)).cuda(), torch.from_numpy(mpuv.astype(np.float32)).cuda()
-            d_pidx = torch.zeros(200, dtype=torch.int32, device="cuda")
-            torch.cuda.synchronize()
-            for _ in range(3):
-                extm.match_patches_record_device(d_mpd.data_ptr(), d_mpuv.data_ptr(), 200, ra.data_ptr(), d_pidx.data_ptr(),
-                                                 0.75, mstream.cuda_stream)
-            e0.record(mstream)
-            for _ in range(nit):
-                extm.match_patches_record_device(d_mpd.data_ptr(), d_mpuv.data_ptr(), 200, ra.data_ptr(), d_pidx.data_ptr(),
-                                                 0.75, mstream.cuda_stream)
-            e1.record(mstream)
-            torch.cuda.synchronize()
-            out["match_patches"] = {"what": "tracker_dust.cpp:113-172 association, 200 map points vs one resident record",
-                                    "us_per_call": round(e0.elapsed_time(e1) / nit * 1e3, 2),
-                                    "matched": int((d_pidx.cpu().numpy() >= 0).sum())}
-            if world == 1 and not args.no_cpu_baseline:
-                from oracle import oracle as _orc
-                t1 = time.perf_counter()
-                _orc.match_bruteforce(kb[0].descriptors, ka[0].descriptors, True)
-                out["match_bruteforce"]["cpu_oracle_ms_per_pair"] = round((time.perf_counter() - t1) * 1e3, 2)
-            extm.close()
-
-        if not args.no_match:
-            # SURVEY.md §8(f) rank 3 (outside the timed region): direct dust alignment, 160 map points against the
-            # dense_dust of frame 0's resident record (optimizer_dust.cpp:170-294: 40 LM iterations)
-            from sp_orb_slam_amd import dust_scene
-            from sp_orb_slam_amd.extractor import DUST_OUT_BYTES
-            extd = SPExtractor(nf, H, W, blob, max_batch=1, device=local, with_heat=False)
-            dsc = dust_scene.make_scene(0, H=H, W=W, n_points=160, cx=W / 2 - 8.8, cy=H / 2 + 8.4)
-            d_rec = torch.zeros(rec_bytes, dtype=torch.uint8, device="cuda")
-            dstream = torch.cuda.Stream()
-            extd.extract_batch_device(d_img.data_ptr(), 1, d_rec.data_ptr(), dstream.cuda_stream)
-            # a scene-shaped dust map in the record, so that the solve does real work (synthetic weights give a flat one)
-            lay = parallel.RecordLayout(H, W, nf)
-            d_rec[lay.off_dd:lay.off_dd + dsc["dust"].size * 4] = torch.from_numpy(dsc["dust"].reshape(-1).view(np.uint8)).cuda()
-            d_pts, d_T = torch.from_numpy(dsc["pts"]).cuda(), torch.from_numpy(dsc["Tcw_init"].reshape(16)).cuda()
-            d_do = torch.zeros(DUST_OUT_BYTES, dtype=torch.uint8, device="cuda")
-            torch.cuda.synchronize()
-            def dust_once():
-                extd.align_dust_record_device(d_rec.data_ptr(), d_pts.data_ptr(), 160, d_T.data_ptr(), d_do.data_ptr(),
-                                              dsc["fx"], dsc["fy"], dsc["cx"], dsc["cy"], stream=dstream.cuda_stream)
-            for _ in range(3):
-                dust_once()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(dstream)
-            for _ in range(20):
-                dust_once()
-            e1.record(dstream)
-            torch.cuda.synchronize()
-            gd = extd.decode_dust_out(d_do.cpu().numpy(), 160)
-            out["dust_alignment"] = {"what": "Optimizer::PoseOptimizationDust: 160 map points vs the dense_dust of a resident "
-                                             "record, Huber 0.9, <= 40 LM iterations, one workgroup, f64",
-                                     "us_per_solve": round(e0.elapsed_time(e1) / 20 * 1e3, 1), "iterations": gd["iterations"],
-                                     "n_inlier": gd["n_inlier"]}
-            # the batch path's form: one workgroup per frame, 64 independent solves (each its own record, points and start
-            # pose) in one launch — a solve is a latency chain, so they take about as long as one
-            from sp_orb_slam_amd.extractor import DUST_MAX_POINTS
-            NB = 64
-            d_recs = d_rec.repeat(NB, 1).contiguous()
-            pts_b = np.zeros((NB, DUST_MAX_POINTS, 3), np.float32)
-            T_b = np.zeros((NB, 16), np.float32)
-            for f in range(NB):
-                scf = dust_scene.make_scene(f, H=H, W=W, n_points=160, cx=W / 2 - 8.8, cy=H / 2 + 8.4)
-                pts_b[f, :160] = scf["pts"]; T_b[f] = scf["Tcw_init"].reshape(16)
-                d_recs[f, lay.off_dd:lay.off_dd + scf["dust"].size * 4] = torch.from_numpy(scf["dust"].reshape(-1).view(np.uint8)).cuda()
-            d_pb, d_Tb = torch.from_numpy(pts_b).cuda(), torch.from_numpy(T_b).cuda()
-            d_nb = torch.full((NB,), 160, dtype=torch.int32, device="cuda")
-            d_ob = torch.zeros((NB, DUST_OUT_BYTES), dtype=torch.uint8, device="cuda")
-            def dust_batch():
-                extd.align_dust_batch_device(d_recs.data_ptr(), NB, d_pb.data_ptr(), d_nb.data_ptr(), d_Tb.data_ptr(), d_ob.data_ptr(),
-                                             dsc["fx"], dsc["fy"], dsc["cx"], dsc["cy"], stream=dstream.cuda_stream)
-            for _ in range(2):
-                dust_batch()
-            e0.record(dstream)
-            for _ in range(10):
-                dust_batch()
-            e1.record(dstream)
-            torch.cuda.synchronize()
-            ob = d_ob.cpu().numpy()
-            out["dust_alignment"]["batch64_us_per_launch"] = round(e0.elapsed_time(e1) / 10 * 1e3, 1)
-            out["dust_alignment"]["batch64_us_per_solve"] = round(e0.elapsed_time(e1) / 10 / NB * 1e3, 2)
-            out["dust_alignment"]["batch64_frame0_equals_single"] = bool(np.array_equal(ob[0][:64], d_do.cpu().numpy()[:64]))
-            if world == 1 and not args.no_cpu_baseline:
-                from oracle import oracle as _orc2
-                t1 = time.perf_counter()
-                rd = _orc2.align_dust(dsc["dust"], dsc["pts"], dsc["Tcw_init"], dsc["fx"], dsc["fy"], dsc["cx"], dsc["cy"])
-                out["dust_alignment"]["cpu_oracle_us_per_solve"] = round((time.perf_counter() - t1) * 1e6, 1)
-                out["dust_alignment"]["pose_max_abs_diff_vs_oracle"] = float(np.abs(rd["Tcw"] - gd["Tcw"]).max())
-            extd.close()
-
-        if not args.no_match:
-            # SURVEY.md §8(f) rank 2 (outside the timed region): staging kernel on B raw BGR frames
-            exts = SPExtractor(nf, H, W, blob, max_batch=B, device=local, with_heat=False)
-            vv, uu = np.mgrid[0:H, 0:W].astype(np.float64)
-            r2 = ((uu - W / 2) / W) ** 2 + ((vv - H / 2) / W) ** 2
-            mx = (uu + (uu - W / 2) * (-0.28 * r2)).astype(np.float32)
-            my = (vv + (vv - H / 2) * (-0.28 * r2)).astype(np.float32)
-            exts.set_staging(H, W, 3, False, mx, my)
-            d_raw = d_img[:, :, :, None].expand(B, H, W, 3).contiguous()
-            d_gray = torch.zeros((B, H, W), dtype=torch.uint8, device="cuda")
-            sstream = torch.cuda.Stream()
-            torch.cuda.synchronize()
-            for _ in range(3):
-                exts.stage_batch_device(d_raw.data_ptr(), B, d_gray.data_ptr(), sstream.cuda_stream)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(sstream)
-            for _ in range(30):
-                exts.stage_batch_device(d_raw.data_ptr(), B, d_gray.data_ptr(), sstream.cuda_stream)
-            e1.record(sstream)
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 30
-            # algorithmic bytes: 4 taps x 3 ch gathered (hits L2: ~1 raw frame) + 2 maps + 1 gray out
-            alg = B * H * W * (3 + 8 + 1)
-            out["input_staging"] = {"what": "cv::remap(INTER_LINEAR) + crop + BGR2GRAY, %d frames %dx%dx3 per launch"
-                                            % (B, W, H), "ms_per_batch": round(ms, 4),
-                                    "hbm_GBps_algorithmic": round(alg / (ms * 1e-3) / 1e9, 1)}
-            exts.close()
-
-        if world == 1 and not args.no_cpu_baseline:
-            # CPU baseline: the C oracle (a port of the path; the reference has no CPU
-            # path and cannot be built here) on this host's cores, bounded sample.
-            from oracle import oracle
-            # the port's loops scale to a few dozen threads (tools/cpu_baseline.py sweeps 1..all: the
-            # best team on the 256-thread GPU-box host is 32), so that is the team it gets
-            nthr = oracle.set_num_threads(min(32, os.cpu_count() or 1))
-            ref0 = oracle.extract(blob, frames[0], nf)   # warm-up (thread team, caches) + the parity check below
-            done, t1 = 0, time.perf_counter()
-            while True:
-                oracle.extract(blob, frames[done % B], nf)
-                done += 1
-                el = time.perf_counter() - t1
-                if el >= args.cpu_seconds or done >= 512:
-                    break
-            out["cpu_baseline"] = {"value": round(done / el, 3), "unit": "frames/s", "cores": nthr,
-                                   "kind": "port",
-                                   "sample": "%d frames of the same %dx%d workload through oracle/spfe_oracle.c "
-                                             "(OpenMP, %d threads), %.1f s" % (done, W, H, nthr, el)}
-            # self-check of the timed workload: frame 0 of the LAST timed batch (pipelined, device
-            # resident) against the oracle's extraction of the same frame
-            kp_ok = rec0.K == ref0["K"] and np.array_equal(rec0.kp_xy, ref0["kp_xy"]) and \
-                np.array_equal(rec0.occ_grid, ref0["occ_grid"])
-            if bf16:
-                a = {(int(x), int(y)) for x, y in rec0.kp_xy}
-                b = {(int(x), int(y)) for x, y in ref0["kp_xy"]}
-                idx = {(int(x), int(y)): i for i, (x, y) in enumerate(ref0["kp_xy"])}
-                cos = [float(np.dot(rec0.descriptors[i], ref0["desc"][idx[k]]))
-                       for i, k in enumerate((int(x), int(y)) for x, y in rec0.kp_xy) if k in idx]
-                jac = len(a & b) / max(1, len(a | b))
-                out["parity_frame0"] = bool(jac >= 0.8 and (not cos or min(cos) >= 0.999))
-                out["parity_frame0_detail"] = {"rule": "bf16 mode vs the f32 oracle: keypoint-set Jaccard >= 0.8, "
-                                                       "descriptor cosine of common keypoints >= 0.999",
-                                               "jaccard": round(jac, 4), "desc_cos_min": round(min(cos), 6) if cos else None}
-            else:
-                desc_bits = kp_ok and np.array_equal(rec0.descriptors.view(np.uint32), ref0["desc"].view(np.uint32))
-                cov_bits = kp_ok and np.array_equal(rec0.cov2.view(np.uint32), ref0["cov2"].view(np.uint32)) and \
-                    np.array_equal(rec0.cov2_inv.view(np.uint32), ref0["cov2_inv"].view(np.uint32))
-                out["parity_frame0"] = bool(kp_ok and desc_bits and cov_bits)
-                out["parity_frame0_detail"] = {"rule": "f32 mode vs the oracle: keypoints / occ_grid exact, descriptors "
-                                                       "and cov2 / cov2_inv bitwise",
-                                               "keypoints_exact": bool(kp_ok), "desc_bitwise": bool(desc_bits),
-                                               "cov2_bitwise": bool(cov_bits), "K": int(rec0.K)}
-            if not args.no_aten:
-                # north_star: "the reference's CPU libtorch path timed on the same box's host cores".  The
-                # reference has no CPU path (CUDA hard-wired); libtorch-CPU == ATen-CPU, and torch is here
-                # for device plumbing, so the builder's statement of SPFrontend::forward's op sequence
-                # (tools/aten_path.py) is timed on the best of a thread sweep.  Network + detector tail +
-                # descriptor sampling only (the host glue nms / computeCovariance is not ATen code).
-                from tools import aten_path
-                named = weights.to_named_tensors(blob)
-                ncpu = os.cpu_count() or 1
-                sweep, best = {}, None
-                for thr in [t for t in (8, 16, 32, 64, 128) if t <= ncpu] or [ncpu]:
-                    fps_a, n_a, el_a = aten_path.time_forward(named, list(frames), thr, seconds=2.5, max_frames=48)
-                    sweep[str(thr)] = round(fps_a, 2)
-                    if best is None or fps_a > best[0]:
-                        best = (fps_a, thr, n_a, el_a)
-                out["cpu_baseline_aten"] = {
-                    "value": round(best[0], 3), "unit": "frames/s", "cores": best[1],
-                    "kind": "aten-cpu op sequence (torch %s, MKL-DNN), network + tail + descriptor sampling" % torch.__version__,
-                    "sample": "%d frames of the same %dx%d workload, %.1f s, best of the thread sweep" % (best[2], W, H, best[3]),
-                    "thread_sweep_fps": sweep, "host_cpus": ncpu}
-        print(json.dumps(out), flush=True)
+            rd = oracle.align_dust(dsc["dust"], dsc["pts"], dsc["Tcw_init"], dsc["fx"], dsc["fy"], dsc["cx"], dsc["cy"])
+            out["dust_alignment"]["cpu_oracle_us_per_solve"] = round((time.perf_counter() - t1) * 1e6, 1)
+            out["dust_alignment"]["pose_max_abs_diff_vs_oracle"] = float(np.abs(rd["Tcw"] - gd["Tcw"]).max())
+        if "frontend" in cpu_todo:
+            ok, det = frontend_chain_parity(cpu_todo["frontend"], nf)
+            out["frontend_chain"]["parity_vs_oracle_chain"] = ok
+            out["frontend_chain"]["parity_detail"] = det
+        if not args.no_aten:
+            # north_star: "the reference's CPU libtorch path timed on the same box's host cores".  The
+            # reference has no CPU path (CUDA hard-wired); libtorch-CPU == ATen-CPU, and torch is here
+            # for device plumbing, so the builder's statement of SPFrontend::forward's op sequence
+            # (tools/aten_path.py) is timed on the best of a thread sweep.  Network + detector tail +
+            # descriptor sampling only (the host glue nms / computeCovariance is not ATen code).
+            from tools import aten_path
+            named = weights.to_named_tensors(blob)
+            ncpu = os.cpu_count() or 1
+            sweep, best = {}, None
+            for thr in [t for t in (8, 16, 32, 64, 128) if t <= ncpu] or [ncpu]:
+                fps_a, n_a, el_a = aten_path.time_forward(named, list(frames), thr, seconds=2.5, max_frames=48)
+                sweep[str(thr)] = round(fps_a, 2)
+                if best is None or fps_a > best[0]:
+                    best = (fps_a, thr, n_a, el_a)
+            out["cpu_baseline_aten"] = {
+                "value": round(best[0], 3), "unit": "frames/s", "cores": best[1],
+                "kind": "aten-cpu op sequence (torch %s, MKL-DNN), network + tail + descriptor sampling" % torch.__version__,
+                "sample": "%d frames of the same %dx%d workload, %.1f s, best of the thread sweep" % (best[2], W, H, best[3]),
+                "thread_sweep_fps": sweep, "host_cpus": ncpu}
+    print(json.dumps(out), flush=True)
     ext.close()
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -517,6 +517,10 @@ class SPExtractor:
                                                    C.c_void_p(stream or 0)))
         return int(self._lib.spfe_last_ticket(self._h))
 
+    def last_ticket(self):
+        """Ticket of the most recent extract_batch_device call on this handle (spfe_last_ticket)."""
+        return int(self._lib.spfe_last_ticket(self._h))
+
     def wait_records(self, ticket, stream=None):
         """Order `stream` after the covariance stage of call `ticket` (async_cov mode)."""
         _check(self._lib.spfe_wait_records(self._h, int(ticket), C.c_void_p(stream or 0)))

@@ -294,6 +294,64 @@ class ShardedExtractor:
         if self._gathered_event is not None:
             stream.wait_event(self._gathered_event)
 
+    def comm_ranks(self):
+        """{"library": ranks RCCL reports for the library's communicator (ncclCommCount) or None when torch's collective is the
+        one in use, "process_group": torch.distributed's world size} — what actually took part in the gather."""
+        import torch.distributed as dist
+
+        lib = None
+        if self._native:
+            lib = self.ext.comm_count()
+        return {"library": lib, "process_group": dist.get_world_size() if dist.is_initialized() else 1,
+                "backend": dist.get_backend() if dist.is_initialized() else None}
+
+    def time_gather(self, iters=20):
+        """The collective alone: `iters` all-gathers of the last completed batch's local records, bracketed by events on the
+        stream the collective runs on.  Called by EVERY rank.  -> dict(ms per gather, bytes per rank, bus GB/s)."""
+        import time as _time
+
+        import torch
+        import torch.distributed as dist
+
+        if not self._collective:
+            return {"ms": 0.0, "bytes_per_rank": 0, "iters": 0}
+        k = (self._calls - 1) % len(self.local)
+        local, out = self.local[k], self.all[self._gathers % 2]
+        ticket = self.ext.last_ticket()
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def once():
+            if self._native:
+                self.ext.allgather_records(ticket, local.data_ptr(), out.data_ptr(), self.fpr)
+            else:
+                with torch.cuda.stream(self.comm):
+                    if self._gather_fn is not None:
+                        self._gather_fn(out, local)
+                    else:
+                        dist.all_gather_into_tensor(out, local)
+        once()
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        t0 = _time.perf_counter()
+        e0.record(self.comm)
+        for _ in range(iters):
+            once()
+        e1.record(self.comm)
+        e1.synchronize()
+        torch.cuda.synchronize()
+        wall = (_time.perf_counter() - t0) / iters * 1e3
+        ms = e0.elapsed_time(e1) / iters
+        self._gathers += 1                       # `out` now holds the re-gathered batch: it is the current result
+        self.gathered, self._gathered_event = out, e1
+        nb = local.numel()
+        return {"ms": round(ms, 4), "wall_ms": round(wall, 4), "bytes_per_rank": int(nb), "iters": iters,
+                "recv_GBps_per_rank": round((self.world - 1) * nb / (max(ms, 1e-6) * 1e-3) / 1e9, 2),
+                "stream": "libspfe side stream (ncclAllGather)" if self._native else "torch communication stream"}
+
     def decode(self, frame):
         """Host copy + decode of global frame `frame` of the last completed batch."""
         if self._gathered_event is not None:

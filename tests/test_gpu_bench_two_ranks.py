@@ -1,11 +1,14 @@
 """GPU: the N > 1 flow of bench.py as the driver launches it (torch.distributed.run, one process per
 rank), dry-run on ONE GPU: both ranks share the device and the record all-gather goes through gloo
 (SPFE_BENCH_BACKEND=gloo) instead of RCCL.  Covers the rendezvous, barriers, the communication-stream
-all-gather of the record buffers, decoding the last rank's frames and the single JSON line."""
+all-gather of the record buffers, decoding the last rank's frames, the self-verification fields of the N > 1 line
+(parity_gathered: a frame computed by the OTHER rank, as it arrived, against the oracle; allgather_ms; rccl_ranks;
+host_alt), the barrier before teardown and the single JSON line."""
 import json
 import os
 import subprocess
 import sys
+import time
 
 import pytest
 
@@ -20,6 +23,7 @@ def test_bench_two_ranks_one_gpu():
            "--gpus", "2", "--steps", "3", "--warmup", "1", "--height", "240", "--width", "320",
            "--frames-per-gpu", "3", "--num-features", "200",
            "--no-cpu-baseline", "--no-match", "--no-latency", "--no-stage-table"]
+    t0 = time.time()
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -27,3 +31,12 @@ def test_bench_two_ranks_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["config"]["frames_per_gpu"] == 3 and d["config"]["parallelism"] == "dp2"
+    # the line proves itself: rank 1's first frame (global frame 3), rank 0's own and the last one, through the gather
+    assert d["parity_gathered"] is True
+    assert set(d["parity_gathered_detail"]) == {"frame_3_from_rank_1", "frame_0_from_rank_0", "frame_5_from_rank_1"}
+    assert all(v["keypoints_exact"] and v["desc_bitwise"] and v["cov2_bitwise"] for v in d["parity_gathered_detail"].values())
+    assert d["allgather_ms"] > 0 and d["allgather"]["bytes_per_rank"] > 0
+    assert d["rccl_ranks"]["process_group"] == 2          # (gloo dry run: the library communicator is not in use)
+    assert d["host_alt"]["value"] > 0 and d["host_alt"]["records_ok"] and d["host_alt_ms"] > 0
+    # teardown: both ranks left through the final barriers (no rank exits while rank 0 is still printing)
+    assert "Traceback" not in out.stderr

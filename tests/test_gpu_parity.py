@@ -578,6 +578,13 @@ def test_rccl_native_allgather_single_rank():
                 assert g.status == 0 and g.K == e.K and np.array_equal(g.kp_xy, e.kp_xy)
                 assert np.array_equal(g.descriptors, e.descriptors) and np.array_equal(g.cov2_inv, e.cov2_inv)
                 assert np.array_equal(g.occ_grid, e.occ_grid)
+        # what RCCL itself says about the communicator, and the collective timed alone (bench.py's N > 1 fields)
+        assert ext.comm_count() == 1 and sh.comm_ranks()["library"] == 1
+        tg = sh.time_gather(5)
+        assert tg["ms"] > 0 and tg["bytes_per_rank"] == B * ext.record_bytes() and tg["iters"] == 5
+        again = [sh.decode(i) for i in range(B)]           # the timed gathers re-gathered the last batch: same records
+        for g, e in zip(again, expect[6 % 3]):
+            assert g.K == e.K and np.array_equal(g.descriptors, e.descriptors)
         # errors: double init, bad ticket
         with pytest.raises(SpfeError):
             ext.comm_init(ext.comm_unique_id(), 0, 1)
