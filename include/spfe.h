@@ -38,11 +38,14 @@ extern "C" {
 
 /* spfe_config.precision */
 #define SPFE_PRECISION_F32 0  /* exact f32 on v_mfma_f32_32x32x2_f32; bit-identical to the CPU oracle */
-#define SPFE_PRECISION_BF16 1 /* conv1b..convPa/Da and the descriptor head convDb on v_mfma_f32_32x32x16_bf16:
-                                 bf16 activations and weights, f32 accumulate / bias / ReLU / pool; the detector
-                                 head convPb, softmax, NMS, descriptor sampling and covariance stay f32
-                                 (BASELINE configs[3]: "bf16 conv path with fp32 NMS").  Keypoints /
-                                 descriptors match the f32 path within tolerance, not bitwise. */
+#define SPFE_PRECISION_BF16 1 /* ALL twelve convolutions — conv1a..conv4b, convPa / convDa and both 1x1 heads convPb /
+                                 convDb — on v_mfma_f32_32x32x16_bf16: bf16 activations and weights, f32 accumulate /
+                                 bias / ReLU / pool.  The heads read the bf16 ReLU(convPa) / ReLU(convDa) buffer and
+                                 write f32 logits / coarse descriptors, so the detector logits carry bf16 rounding.
+                                 Softmax, NMS, descriptor sampling, heat and covariance stay f32 (BASELINE configs[3]:
+                                 "bf16 conv path with fp32 NMS"): everything behind the logits is bit-exact GIVEN the
+                                 logits.  Keypoints / descriptors match the f32 path within tolerance, not bitwise
+                                 (keypoint-set Jaccard ~0.93, descriptor cosine >= 0.9999 at 1280x720). */
 
 /* spfe_config.flags */
 #define SPFE_FLAG_HEAT 1u /* also produce heat / heat_inv (H*W floats each), sp_extractor.cpp:461-474 */
@@ -73,7 +76,9 @@ typedef struct spfe_handle_s *spfe_handle;
 typedef struct {
   int height;               /* camera::height, multiple of 8 (:70) */
   int width;                /* camera::width, multiple of 8 */
-  int num_features;         /* tracking::num_features; up to num_features+1 keypoints (:211-213) */
+  int num_features;         /* tracking::num_features; up to num_features+1 keypoints (:211-213); 1 .. 10000 (the
+                               covariance link stage keeps 16 bytes per keypoint in one workgroup's LDS; the
+                               shipped configurations use 800 - 1000) */
   int max_batch;            /* frames per spfe_extract_batch* call (>=1) */
   int device;               /* HIP device ordinal */
   int precision;            /* SPFE_PRECISION_* */

@@ -473,7 +473,7 @@ __global__ __launch_bounds__(LINK_THREADS) void cov_link_kernel(FrameBufs f, Rec
   for (int d = tid; d < P; d += LINK_THREADS) {
     if (d < nd) {
       const int j = c.dirty[d];
-      key[d] = (parent[j] << 15) | j;   // K <= 16385 < 2^15 + 1: bounded by spfe_create
+      key[d] = (parent[j] << 15) | j;   // K <= 10001 < 2^15: spfe_create bounds num_features to 10000
     } else {
       key[d] = COV_INF;
     }

@@ -183,7 +183,7 @@ struct spfe_handle_s {
   int tile_rows_big = 12;        // SPFE_BF16_TILE_ROWS (12 | 16)
   int *d_tile_ctr = nullptr;     // [8 layers][16] tile-queue counters, zeroed once per enqueue()
   bool act0_missing = false;  // the last call computed conv1a inside conv1b
-  bool bf16 = false;  // SPFE_PRECISION_BF16: bf16 conv stack (conv1a .. convPa/Da), f32 heads and tail
+  bool bf16 = false;  // SPFE_PRECISION_BF16: all twelve convolutions (1x1 heads included) as bf16 GEMMs with f32 accumulation; f32 tail
   // per-stage timing: a ring of event sets, one set per enqueue() call
   bool timing = false;
   bool timing_all = true;  // false (SPFE_STAGE_TIMING=2): events around the dominant kernel (conv1b) only
