@@ -177,6 +177,9 @@ struct spfe_handle_s {
   int ws_min_items = 11;    // ... when the launch has at least this many (tile, 64-channel block) items per workgroup (pipelined calls)
   int ws_min_items_sync = 5;   // ... the same for synchronous calls
   unsigned char *d_wws[4] = {};  // their weights in conv_bf16_ws.hip's layout
+  unsigned char *d_wrw[4] = {};  // bf16 Cin = 128 layers (conv3b, 4a, 4b, Pa|Da): weights in conv_bf16_rw.hip's fragment order
+  bool bf16_rw = true;           // SPFE_BF16_RW: register-resident-weights kernel for those layers
+  int rw_min4 = 3, rw_min2 = 2;  // ... 4-row tiles from this many tiles per workgroup, 2-row tiles from this many, else conv_bf16.hip
   int side_cus_default = 0;      // SPFE_SIDE_CUS
   bool bf16_dyn = true;          // SPFE_BF16_DYN_QUEUE
   int tile16_min_items = 3;      // SPFE_BF16_TILE16_MIN_ITEMS (0 = 8-row tiles only)
@@ -352,6 +355,30 @@ int pack_layer_bf16_ws(spfe_handle h, const float *blob, int lid, unsigned char 
   return SPFE_OK;
 }
 
+// conv_bf16_rw.hip layout for a Cin = 128 layer (or two concatenated ones: convPa | convDa)
+int pack_layer_bf16_rw(spfe_handle h, const float *blob, const int *lids, int nl, unsigned char **out) {
+  int cout = 0;
+  for (int i = 0; i < nl; ++i) {
+    const spfe_layer_t &L = SPFE_LAYERS[lids[i]];
+    if (L.cin != 128 || L.ksize != 3) return fail(SPFE_EINVAL, "internal: layer %d is not a Cin = 128 3x3 layer", lids[i]);
+    cout += L.cout;
+  }
+  if (cout % 128) return fail(SPFE_EINVAL, "internal: %d output channels are not whole 128-channel groups", cout);
+  std::vector<unsigned short> wb((size_t)cout * 128 * 9);
+  size_t o = 0;
+  for (int i = 0; i < nl; ++i) {
+    const spfe_layer_t &L = SPFE_LAYERS[lids[i]];
+    const float *W = blob + blob_weight_offset(lids[i]);
+    for (size_t k = 0; k < (size_t)L.cout * 128 * 9; ++k) wb[o++] = host_bf16_rne(W[k]);
+  }
+  std::vector<unsigned char> w((size_t)(cout / 128) * spfe::conv_bf16_rw_weight_bytes());
+  spfe::conv_bf16_rw_pack_weights(wb.data(), cout, w.data());
+  int rc;
+  if ((rc = dev_alloc(h, out, w.size()))) return rc;
+  HIP_TRY(hipMemcpy(*out, w.data(), w.size(), hipMemcpyHostToDevice));
+  return SPFE_OK;
+}
+
 int load_blob(const spfe_config *cfg, std::vector<float> *blob) {
   blob->resize(SPFE_NUM_PARAMS);
   if (cfg->weights) {
@@ -447,6 +474,9 @@ int build(spfe_handle h, const spfe_config *cfg) {
     if (trenv) h->tile_rows_big = atoi(trenv);
     const char *denv = getenv("SPFE_BF16_DYN_QUEUE");
     if (denv) h->bf16_dyn = atoi(denv) != 0;
+    if (const char *e = getenv("SPFE_BF16_RW")) h->bf16_rw = atoi(e) != 0;
+    if (const char *e = getenv("SPFE_BF16_RW_MIN4")) h->rw_min4 = atoi(e);
+    if (const char *e = getenv("SPFE_BF16_RW_MIN2")) h->rw_min2 = atoi(e);
   }
   const char *tenv = getenv("SPFE_STAGE_TIMING");
   h->timing = tenv && atoi(tenv) != 0;
@@ -582,7 +612,12 @@ int build(spfe_handle h, const spfe_config *cfg) {
     for (int i = 0; i < 4; ++i)
       if ((h->ws_mask >> i) & 1)
         if ((rc = pack_layer_bf16_ws(h, blob.data(), specs[i].l0, &h->d_wws[i]))) return rc;
-    if ((rc = dev_alloc(h, &h->d_tile_ctr, 8 * 16))) return rc;
+    if (h->bf16_rw)
+      for (int i = 4; i < 8; ++i) {
+        const int lids2[2] = {specs[i].l0, specs[i].l1};   // (convPa | convDa for the last one)
+        if ((rc = pack_layer_bf16_rw(h, blob.data(), lids2, specs[i].nl, &h->d_wrw[i - 4]))) return rc;
+      }
+    if ((rc = dev_alloc(h, &h->d_tile_ctr, 8 * 32))) return rc;
   }
   if (!h->bf16) {  // f32 heads with register-resident weights (head_f32.hip), bit-identical to the generic kernel — opt-in:
     // measured 63 + 38.5 us per eight 752x480 frames against 72 + 35.5 for the generic kernel (matrix-bound: 47 us at the peak)
@@ -650,7 +685,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   // (a kernel of our own, not hipMemsetAsync: the runtime's fill is a blit that queues behind its other blits — the
   // pipelined host path's D2H copy of the PREVIOUS batch — and held the whole next batch back by 0.6 ms at 752x480 bf16)
   if (h->d_tile_ctr) {
-    hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(128), 0, s, h->d_tile_ctr, 8 * 16);
+    hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(256), 0, s, h->d_tile_ctr, 8 * 32);
     HIP_TRY(hipGetLastError());
   }
   const bool fused = !h->bf16 && h->fuse1a;  // f32: conv1b computes conv1a's outputs itself
@@ -689,7 +724,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
       const int grid_ws = (h->num_cus > 0 ? h->num_cus : 256) & ~15;
       if (i < 4 && h->d_wws[i] && L.W >= 32 && (long)p.tiles_x * p.tiles_y * n * p.nblk >= (long)ws_min * (grid_ws < 16 ? 16 : grid_ws)) {
         p.wpack = reinterpret_cast<const float *>(h->d_wws[i]);
-        p.tile_ctr = h->d_tile_ctr + 16 * i;
+        p.tile_ctr = h->d_tile_ctr + 32 * i;
         if (i == 0 && fused16) { p.img = d_images; p.w1a = reinterpret_cast<const float *>(h->d_w1a_tab); p.b1a = h->d_b1a; }
         HIP_TRY(spfe::launch_conv_bf16_ws(p, L.pool, i == 0 ? (fused16 ? 2 : 1) : 0, s));
         STAGE_MARK(2 + i);
@@ -700,6 +735,26 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
       // taller tiles for the streamed-weight layers when that still leaves every workgroup >= tile16_min_items items
       // (conv_bf16.hip, MT = 3 / 4: a stage's weight chunk feeds 1.5x / 2x the MFMAs).  Measured: 12-row tiles (layers
       // without a pool) -3...5 % on convPa|Da; 16-row tiles need 512 VGPRs + spills and lose 35 %: not the default.
+      if (i == 7) {   // convPa | convDa: one launch, 512 output channels, bf16 (both 1x1 heads are bf16 GEMMs)
+        p.out = reinterpret_cast<float *>(h->d_hd); p.out_stride = 512; p.out_choff = 0;
+      }
+      // Cin = 128: weights resident in registers (conv_bf16_rw.hip) when every workgroup of a 128-channel group gets enough
+      // tiles; 4-row tiles, or 2-row tiles for the small launches (twice the tiles)
+      if (L.cin == 128 && h->bf16_rw && h->d_wrw[i - 4] && L.W >= 32 && !(L.W & 1) && !(L.pool && (L.H & 1))) {
+        const int ncg = L.nblk / 2;
+        const long wgs = std::max(8L * ncg, (long)((h->num_cus > 0 ? h->num_cus : 256) / (8 * ncg)) * 8 * ncg) / ncg;
+        const long t4 = (long)p.tiles_x * ((L.H + 3) / 4) * n, t2 = (long)p.tiles_x * ((L.H + 1) / 2) * n;
+        const int tr = t4 >= (long)h->rw_min4 * wgs ? 4 : t2 >= (long)h->rw_min2 * wgs ? 2 : 0;
+        if (tr) {
+          p.wpack = reinterpret_cast<const float *>(h->d_wrw[i - 4]);
+          p.nblk = ncg;
+          p.tiles_y = (L.H + tr - 1) / tr;
+          p.tile_ctr = h->d_tile_ctr + 32 * i;
+          HIP_TRY(spfe::launch_conv_bf16_rw(p, L.pool, tr, s));
+          STAGE_MARK(2 + i);
+          return SPFE_OK;
+        }
+      }
       int tile_rows = 8;
       if (L.cin == 128 && h->tile16_min_items > 0) {
         const int tr = h->tile_rows_big > 0 ? h->tile_rows_big : 16;
@@ -710,10 +765,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
         }
       }
       if (L.cin == 128 && h->bf16_dyn && (long)p.tiles_x * p.tiles_y * n * p.nblk >= 5L * (grid_ws < 8 ? 8 : grid_ws))
-        p.tile_ctr = h->d_tile_ctr + 16 * i;
-      if (i == 7) {   // convPa | convDa: one launch, 512 output channels, bf16 (both 1x1 heads are bf16 GEMMs)
-        p.out = reinterpret_cast<float *>(h->d_hd); p.out_stride = 512; p.out_choff = 0;
-      }
+        p.tile_ctr = h->d_tile_ctr + 32 * i;
       HIP_TRY(spfe::launch_conv_bf16(p, L.cin, L.pool, false, s, tile_rows));
       STAGE_MARK(2 + i);
       return SPFE_OK;

@@ -44,6 +44,12 @@ size_t conv_bf16_slab_bytes();
 // 64-channel block, [nblk][tap][cout 64][8 x 16-byte pieces, piece g in slot g ^ ((cout >> 1) & 7)]
 hipError_t launch_conv_bf16_ws(const ConvParams &p, bool pool, int layer_tag /* 1 = conv1b, 2 = conv1b with conv1a fused in (p.img / p.w1a / p.b1a) */, hipStream_t s);
 size_t conv_bf16_ws_weight_bytes();
+// register-resident-weights variant for the Cin = 128 layers (conv_bf16_rw.hip): p.nblk = 128-channel output groups,
+// wpack = conv_bf16_rw_weight_bytes() per group in fragment order (conv_bf16_rw_pack_weights from [cout][128][9] bf16),
+// bias f32 in channel order; tile_rows 4 | 2; p.tile_ctr: nblk * 8 zeroed counters.  Bit-identical to launch_conv_bf16.
+hipError_t launch_conv_bf16_rw(const ConvParams &p, bool pool, int tile_rows, hipStream_t s);
+size_t conv_bf16_rw_weight_bytes();
+void conv_bf16_rw_pack_weights(const unsigned short *Wb, int cout, unsigned char *dst);
 // conv1a of the bf16 mode (conv1a_mfma.h): wtab = the bf16 operand table [2][64][8] (conv1a_bf16_table_bytes()), b64 = bias
 hipError_t launch_conv1a_bf16(const uint8_t *img, const void *wtab, const float *b64, void *out, int B, int H,
                               int W, hipStream_t s);

@@ -197,6 +197,31 @@ def test_bf16_tile_heights_of_the_streamed_weight_layers_are_bit_identical(monke
             assert np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.descriptors, b.descriptors)
 
 
+@pytest.mark.parametrize("H,W,B", [(480, 752, 2), (256, 384, 3), (720, 1280, 2), (264, 400, 1)])
+def test_bf16_rw_kernel_equals_streamed_weight_kernel(monkeypatch, H, W, B):
+    """conv_bf16_rw.hip (Cin = 128 layers, weights resident in registers, 4- or 2-row tiles, SPFE_BF16_RW / _MIN4 / _MIN2)
+    against conv_bf16.hip (weights streamed through LDS): same K order, same epilogue arithmetic -> the same bits in every
+    activation, logit and record, whichever kernel a launch size selects.  Ragged widths (188 / 94 columns at 752x480, 100 /
+    50 at 264x400), ragged heights (90 rows in 4-row tiles at 1280x720, 33 at 264x400), pooled and unpooled layers."""
+    nf = 500
+    blob = weights.synthetic(7, "sparse")
+    imgs = [synth.make_image(40 + i, H, W) for i in range(B)]
+    out = {}
+    for key, rw, m4, m2 in (("ref", "0", "0", "0"), ("rows4", "1", "0", "0"), ("rows2", "1", "1000000", "0")):
+        monkeypatch.setenv("SPFE_BF16_RW", rw)
+        monkeypatch.setenv("SPFE_BF16_RW_MIN4", m4)
+        monkeypatch.setenv("SPFE_BF16_RW_MIN2", m2)
+        ext = SPExtractor(nf, H, W, blob, max_batch=B, precision="bf16", with_heat=False)
+        frs = ext.extract_batch(imgs)
+        out[key] = (frs, [ext.debug_read(nm, B - 1) for nm in ("act5", "act6", "act7", "semi", "coarse")])
+        ext.close()
+    for other in ("rows4", "rows2"):
+        for nm, a, b in zip(("act5", "act6", "act7", "semi", "coarse"), out["ref"][1], out[other][1]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (other, nm, float(np.abs(a - b).max()))
+        for a, b in zip(out["ref"][0], out[other][0]):
+            assert a.K == b.K and np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.descriptors, b.descriptors)
+
+
 def test_side_stream_on_a_cu_mask(monkeypatch):
     """SPFE_SIDE_CUS: the side stream (selection, descriptors, covariance) confined to 32 CUs gives the same records."""
     H, W, nf = 240, 320, 300
