@@ -56,12 +56,14 @@ extern "C" {
                                   convolutions of batch i+1.  Pass a different record buffer to consecutive calls. */
 
 /* spfe_result.status / record header word 2 */
-#define SPFE_STATUS_COV_OVERFLOW 1 /* a covariance region outgrew even the device-side overflow lists (a walk longer
-                                      than SPFE_COV_QCAP = 1024 pops reruns in one of SPFE_COV_OVF_SLOTS = 16
-                                      lists of SPFE_COV_OVF_CAP = 16384 pops per frame, on the device, exactly,
-                                      status stays 0; this bit means those ran out too).  Device records:
-                                      cov2/cov2_inv of that frame are not valid.  Host calls: the frame's
-                                      covariance was recomputed by the host routine, values are valid. */
+#define SPFE_STATUS_COV_OVERFLOW 1 /* Set only when ONE covariance region has more pops than the device's last-resort list
+                                      holds (SPFE_COV_FALLBACK_CAP, 4 M by default — the reference's own loop would spend
+                                      ~0.1 s in that one BFS): cov2 / cov2_inv of that frame are then not valid.  Everything
+                                      short of that is handled on the device, exactly, with status 0, for host calls, device
+                                      records and all-gathered records alike: a walk longer than SPFE_COV_QCAP = 1024 pops
+                                      reruns in one of SPFE_COV_OVF_SLOTS = 16 lists of SPFE_COV_OVF_CAP = 16384 pops per
+                                      frame; a frame that exhausts those (or whose hills leave the staged window) is redone
+                                      sequentially by cov_fallback_kernel.  The library has no host compute routine. */
 
 #define SPFE_DESC_DIM 256
 #define SPFE_NUM_PARAMS 1300865 /* sp_extractor.cpp:16-43; order = register_module order :46-62 */

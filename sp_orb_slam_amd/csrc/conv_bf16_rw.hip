@@ -286,6 +286,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16_rw_kernel(ConvParams p) {
   };
   u32x2 dgeo[2] = {{OOB, 0xffff00u}, {OOB, 0xffff00u}};
   unsigned dvoff = OOB;
+  (void)dvoff;   // (the host pass of hipcc does not see the uses below)
   // phase 0: the table entry of the NEXT pass (a pass reads its own three gaps ahead: no wait on the LDS queue);
   // 1: where this lane's 16 bytes come from; 2: the pass itself.  dma_first: the entry of pass 0.
   auto dma_first = [&]() { dgeo[0] = *reinterpret_cast<const __attribute__((address_space(3))) u32x2 *>(geo_base); };

@@ -581,6 +581,92 @@ __global__ __launch_bounds__(64 * COV_WAVES) void cov_replay_kernel(FrameBufs f,
 #endif
 }
 
+// ---- D: the last resort, on the device.  A frame whose record carries SPFE_STATUS_COV_OVERFLOW — more walks outgrew their
+// lists than there are overflow slots, a region has more pops than a slot holds, a hill left the staged window by more than
+// COV_OW pixels — is redone here from scratch, literally as the reference's loop (:252-340): keypoints in emitted order, ONE
+// visited mask for the whole frame (the claim map, reused), every lookup from global memory, the pop list in one large
+// list shared by the batch (fb_cap entries; one workgroup walks the flagged frames one after the other).  Same group-parallel
+// FIFO step as walk(), so pop order, duplicates and the float sums are the sequential loop's.  Slow (a chain of global round
+// trips per FIFO group) and never taken by benchmark, golden or sequence inputs; what it buys is that records are complete
+// on the device — the all-gathered ones too — and that the library has no host compute routine.  Only a region with more
+// than fb_cap pops (4 M by default: the reference itself would spend ~0.1 s in that one BFS) leaves the status bit set.
+__device__ int walk_fallback(const Walk &w, int *visited, int lane) {
+  WaveMem *m = w.m;
+  const int W = w.W, H = w.H;
+  if (lane == 0) {
+    const int id0 = w.y0 * W + w.x0;
+    const float v0 = w.hinv[id0];
+    m->lq[0] = id0; m->lqv[0] = v0;
+    w.gq[0] = id0; w.gqv[0] = v0;
+  }
+  __threadfence_block();
+  int head = 0, tail = 1;
+  const int t = lane & 3, gi = lane >> 2;
+  const int ox = t == 0 ? -1 : (t == 2 ? 1 : 0), oy = t == 1 ? -1 : (t == 3 ? 1 : 0);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  while (head < tail) {
+    const int G = tail - head < 16 ? tail - head : 16;
+    const bool act = gi < G;
+    const int e = head + (act ? gi : 0);
+    const int id = w.gq[e];
+    const float here = w.gqv[e];
+    const int y = row_of(id, W, w.wmagic), x = id - y * W;
+    const int nx = x + ox, ny = y + oy;
+    const int cc = (t & 1) ? ny : nx, lim = (t & 1) ? H : W;
+    const bool inb = act & ((t < 2) ? (cc > 0) : (cc < lim));          // xx > 0, yy > 0, xx < w, yy < h
+    const int nid = id + oy * W + ox;
+    float v = 0.0f;
+    bool take = false;
+    if (inb) {
+      v = w.hinv[nid];
+      take = v > 0.0f && v < here && visited[nid] == 0;
+    }
+#define COV_CHK(k) take &= !((gi > (k)) & (nid == __builtin_amdgcn_readlane(id, 4 * (k))))
+    if (G > 1) { COV_CHK(0); COV_CHK(1); COV_CHK(2); }
+    if (G > 4) { COV_CHK(3); COV_CHK(4); COV_CHK(5); COV_CHK(6); }
+    if (G > 8) { COV_CHK(7); COV_CHK(8); COV_CHK(9); COV_CHK(10); COV_CHK(11); COV_CHK(12); COV_CHK(13); COV_CHK(14); }
+#undef COV_CHK
+    const unsigned long long mask = __ballot(take);
+    const int pos = tail + __popcll(mask & below);
+    const int ntail = tail + __popcll(mask);
+    if (ntail > w.qcap) return -1;
+    if (take) {
+      w.gq[pos] = nid; w.gqv[pos] = v;
+      if (pos < COV_LCAP) { m->lq[pos] = nid; m->lqv[pos] = v; }
+    }
+    if (act & (t == 0)) visited[id] = 1;      // visited at POP (:285)
+    __threadfence_block();                    // the next group reads the list and the mask this one wrote (same wavefront)
+    head += G;
+    tail = ntail;
+  }
+  return tail;
+}
+
+__global__ __launch_bounds__(256) void cov_fallback_kernel(FrameBufs f, RecordLayout rl, CovScratch cs, int B, int H, int W) {
+  __shared__ WaveMem s_mem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int b = 0; b < B; ++b) {
+    const CovFrame c = cov_frame(f, rl, cs, b, H, W);
+    if (!(c.hdr[2] & 1)) continue;            // (uniform: written by earlier kernels of this stream)
+    for (int i = tid; i < H * W; i += 256) c.claim[i] = 0;
+    __threadfence();
+    __syncthreads();
+    if (tid < 64) {
+      bool ok = true;
+      for (int j = 0; j < c.K && ok; ++j) {
+        Walk w{&s_mem, c.hinv, nullptr, cs.fb_q, cs.fb_v, cs.fb_cap, W, H, (int)c.kp_xy[2 * j], (int)c.kp_xy[2 * j + 1], j,
+               w_magic(W)};
+        const int n = walk_fallback(w, c.claim, lane);
+        if (n < 0) { ok = false; break; }
+        moments(w, n, lane, c.cov2 + 2 * j, c.cinv + 2 * j);
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (ok && lane == 0) atomicAnd(&c.hdr[2], ~1);
+    }
+    __syncthreads();
+  }
+}
+
 size_t cov_link_lds(int kmax) { return (size_t)kmax * 4 * sizeof(int); }   // parent, leader, 2 K sort keys
 
 hipError_t launch_cov(const FrameBufs &f, const RecordLayout &r, const CovScratch &cs, int B, int H, int W,
@@ -599,6 +685,8 @@ hipError_t launch_cov(const FrameBufs &f, const RecordLayout &r, const CovScratc
   }
   hipLaunchKernelGGL(cov_link_kernel, dim3(B), dim3(LINK_THREADS), lds, s, f, r, cs, H, W);
   hipLaunchKernelGGL(cov_replay_kernel, grid, block, 0, s, f, r, cs, H, W);
+  // (one workgroup that returns at once unless a record carries the overflow bit: ~2 us at the end of the chain)
+  if (cs.fb_q) hipLaunchKernelGGL(cov_fallback_kernel, dim3(1), dim3(256), 0, s, f, r, cs, B, H, W);
   return hipGetLastError();
 }
 

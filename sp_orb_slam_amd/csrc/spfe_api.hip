@@ -38,10 +38,6 @@ typedef ncclResult_t (*pfn_ncclAllGather)(const void *, void *, size_t, ncclData
 typedef const char *(*pfn_ncclGetErrorString)(ncclResult_t);
 }
 
-namespace spfe {
-void covariance_host(const float *heat_inv, int H, int W, const float *kp_xy, int K, float *cov2,
-                     float *cov2_inv);
-}
 
 namespace {
 
@@ -560,6 +556,12 @@ int build(spfe_handle h, const spfe_config *cfg) {
     if ((rc = dev_alloc(h, &h->cov.ovf_slot, (size_t)B * h->kmax))) return rc;
     if ((rc = dev_alloc(h, &h->cov.ovf_q, (size_t)B * h->cov.ovf_slots * h->cov.ovf_cap + 1))) return rc;
     if ((rc = dev_alloc(h, &h->cov.ovf_v, (size_t)B * h->cov.ovf_slots * h->cov.ovf_cap + 1))) return rc;
+    // the device-side last resort (cov.hip, cov_fallback_kernel): one list for the batch, 4 M pops by default (48 MB)
+    const char *fenv = getenv("SPFE_COV_FALLBACK_CAP");
+    h->cov.fb_cap = fenv ? atoi(fenv) : (1 << 22);
+    if (h->cov.fb_cap < 1024) h->cov.fb_cap = 1024;
+    if ((rc = dev_alloc(h, &h->cov.fb_q, (size_t)h->cov.fb_cap))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.fb_v, (size_t)h->cov.fb_cap))) return rc;
   }
   make_layout(h->kmax, C, &h->rl);
   if ((rc = dev_alloc(h, &h->d_records, (size_t)B * h->rl.bytes))) return rc;
@@ -1061,17 +1063,6 @@ int finish_host(spfe_handle h, int n, spfe_result *outs) {
   for (int i = 0; i < n; ++i) {
     uint8_t *rec = h->h_records + (size_t)i * h->rl.bytes;
     float *hinv = h->h_heat_inv + (size_t)i * H * W;
-    const int *hdr = reinterpret_cast<const int *>(rec + h->rl.off_hdr);
-    if (hdr[2] & 1) {
-      if (!want)
-        HIP_TRY(hipMemcpy(hinv, h->d_heat_inv + (size_t)i * H * W, (size_t)H * W * 4, hipMemcpyDeviceToHost));
-      // A covariance region outgrew the device FIFO (SPFE_COV_QCAP pixels per
-      // keypoint): redo this frame's computeCovariance (sp_extractor.cpp:252-340)
-      // where the reference runs it, on the host.  status bit 0 stays set.
-      spfe::covariance_host(hinv, H, W, reinterpret_cast<const float *>(rec + h->rl.off_xy), hdr[0],
-                            reinterpret_cast<float *>(rec + h->rl.off_cov),
-                            reinterpret_cast<float *>(rec + h->rl.off_cinv));
-    }
     view_record(h, rec, want ? h->h_heat + (size_t)i * H * W : nullptr, want ? hinv : nullptr, &outs[i]);
   }
   return SPFE_OK;
@@ -1387,11 +1378,6 @@ int spfe_collect_batch(spfe_handle h, long ticket, spfe_result *outs) {
   const bool want = (h->cfg.flags & SPFE_FLAG_HEAT) != 0;
   for (int i = 0; i < ps->n; ++i) {
     uint8_t *rec = ps->h_rec + (size_t)i * h->rl.bytes;
-    const int *hdr = reinterpret_cast<const int *>(rec + h->rl.off_hdr);
-    if ((hdr[2] & SPFE_STATUS_COV_OVERFLOW) && want)
-      spfe::covariance_host(ps->h_heat_inv + (size_t)i * H * W, H, W, reinterpret_cast<const float *>(rec + h->rl.off_xy),
-                            hdr[0], reinterpret_cast<float *>(rec + h->rl.off_cov),
-                            reinterpret_cast<float *>(rec + h->rl.off_cinv));
     view_record(h, rec, want ? ps->h_heat + (size_t)i * H * W : nullptr, want ? ps->h_heat_inv + (size_t)i * H * W : nullptr,
                 &outs[i]);
   }

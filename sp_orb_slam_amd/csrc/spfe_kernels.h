@@ -117,6 +117,11 @@ struct CovScratch {
   int *ovf_q;     // [B][ovf_slots][ovf_cap]
   float *ovf_v;
   int ovf_slots, ovf_cap;
+  // last resort (cov_fallback_kernel): ONE pop list of fb_cap entries for the whole batch; a flagged frame is redone
+  // sequentially, literally, on the device
+  int *fb_q;
+  float *fb_v;
+  int fb_cap;
 };
 size_t cov_link_lds(int kmax);
 hipError_t launch_cov(const FrameBufs &f, const RecordLayout &r, const CovScratch &cs, int B, int H, int W,

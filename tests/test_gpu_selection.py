@@ -195,26 +195,81 @@ def test_covariance_queue_overflow_is_handled_on_the_device(monkeypatch):
     assert np.array_equal(fr.kp_xy, ref["kp_xy"])
 
 
-def test_covariance_overflow_beyond_capacity_is_reported_and_repaired(monkeypatch):
-    """No overflow slots left (forced: none configured): the frame's status carries SPFE_STATUS_COV_OVERFLOW and
-    the host-facing call repairs cov2 with the host routine, exactly."""
+def test_covariance_overflow_beyond_the_slots_is_redone_on_the_device(monkeypatch):
+    """No overflow slots (forced: none configured) / walks that outgrow them: the frame is redone by the device-side last
+    resort (cov_fallback_kernel: the reference's sequential loop, literally, on global memory) — exact, status 0, for the
+    host call AND for the device-resident record (what an all-gather would ship).  No host routine exists any more."""
+    import torch
+    H, W = 128, 160
+    semi = _hills(H, W, 1, 10.0, 12)
+    coarse = _coarse(H, W, 1)
+    ref = oracle.postprocess(semi, coarse, H, W, 1000)
+    for slots, cap in (("0", "16384"), ("2", "40")):
+        monkeypatch.setenv("SPFE_COV_QCAP", "24")
+        monkeypatch.setenv("SPFE_COV_OVF_SLOTS", slots)
+        monkeypatch.setenv("SPFE_COV_OVF_CAP", cap)
+        ext = SPExtractor(1000, H, W, _blob())
+        fr = ext.postprocess(semi, coarse)[0]
+        assert fr.status == 0
+        assert np.array_equal(_bits(fr.cov2), _bits(ref["cov2"])) and np.array_equal(_bits(fr.cov2_inv), _bits(ref["cov2_inv"]))
+        assert np.array_equal(fr.kp_xy, ref["kp_xy"])
+        ext.close()
+
+
+def test_covariance_last_resort_capacity_is_the_only_reported_failure(monkeypatch):
+    """SPFE_COV_FALLBACK_CAP forced tiny: a region with more pops than the last-resort list holds is the one case that
+    leaves SPFE_STATUS_COV_OVERFLOW in the record (reported, not guessed); keypoints and descriptors are unaffected."""
     H, W = 128, 160
     semi = _hills(H, W, 1, 10.0, 12)
     coarse = _coarse(H, W, 1)
     monkeypatch.setenv("SPFE_COV_QCAP", "24")
     monkeypatch.setenv("SPFE_COV_OVF_SLOTS", "0")
+    monkeypatch.setenv("SPFE_COV_FALLBACK_CAP", "1024")
     ext = SPExtractor(1000, H, W, _blob())
     fr = ext.postprocess(semi, coarse)[0]
     ext.close()
     ref = oracle.postprocess(semi, coarse, H, W, 1000)
-    assert fr.status & 1                                    # SPFE_STATUS_COV_OVERFLOW
-    assert np.array_equal(_bits(fr.cov2), _bits(ref["cov2"]))   # host call repaired the frame
-    assert np.array_equal(fr.kp_xy, ref["kp_xy"])
+    assert np.array_equal(fr.kp_xy, ref["kp_xy"]) and np.array_equal(_bits(fr.descriptors), _bits(ref["desc"]))
+    if fr.status == 0:     # every region fits in 1024 pops on this input: then the values must be exact
+        assert np.array_equal(_bits(fr.cov2), _bits(ref["cov2"]))
+    else:
+        assert fr.status == 1
+
+
+def test_covariance_overflow_on_the_pipelined_host_path_without_heat_maps(monkeypatch):
+    """spfe_submit_batch / spfe_collect_batch on a handle WITHOUT SPFE_FLAG_HEAT used to hand out invalid
+    covariances when a frame overflowed (the host repair needed heat_inv, which that path never copied).  With the
+    device-side last resort there is nothing to repair: tiny lists, no slots -> exact values, status 0, three batches in
+    flight."""
+    from sp_orb_slam_amd import synth, weights
+    H, W, nf, B = 120, 160, 150, 2
+    blob = weights.synthetic(7, "dense")
+    monkeypatch.setenv("SPFE_COV_QCAP", "16")
+    monkeypatch.setenv("SPFE_COV_OVF_SLOTS", "1")
+    monkeypatch.setenv("SPFE_COV_OVF_CAP", "32")
+    batches = [[synth.make_image(900 + 10 * s + i, H, W) for i in range(B)] for s in range(4)]
+    ext = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=False)
+    tk = [ext.submit_batch(b) for b in batches[:3]]
+    got = []
+    for k in range(4):
+        got.append(ext.collect_batch(tk.pop(0)))
+        if k == 0:
+            tk.append(ext.submit_batch(batches[3]))
+    ext.close()
+    npop_max = 0
+    for b, res in zip(batches, got):
+        for img, fr in zip(b, res):
+            ref = oracle.extract(blob, img, nf)
+            assert fr.status == 0 and fr.K == ref["K"] and np.array_equal(fr.kp_xy, ref["kp_xy"])
+            assert np.array_equal(_bits(fr.cov2), _bits(ref["cov2"])) and np.array_equal(_bits(fr.cov2_inv), _bits(ref["cov2_inv"]))
+            npop_max = max(npop_max, int(np.max(ref["cov2"])))
+    assert npop_max > 1       # regions are wider than a pixel: the 16-entry lists did overflow
 
 
 def test_covariance_wide_hills_leave_the_staged_window(monkeypatch):
     """Regions wider than the 32x32 window staged in LDS: the walk continues on global lookups and remembers the
-    pixels it popped out there; exact against the sequential oracle."""
+    pixels it popped out there; a hill with more than 256 distinct pixels outside the window sends the frame to the
+    device-side last resort.  Exact against the sequential oracle either way, status 0."""
     H, W = 128, 160
     for sigma, nh, rough in ((30.0, 4, 0.01), (24.0, 5, 0.03), (30.0, 4, 0.05)):
         semi = _hills(H, W, 1, sigma, nh, rough=rough)
@@ -224,10 +279,8 @@ def test_covariance_wide_hills_leave_the_staged_window(monkeypatch):
         ext.close()
         ref = oracle.postprocess(semi, coarse, H, W, 1000)
         assert np.array_equal(fr.kp_xy, ref["kp_xy"])
-        if fr.status == 0:
-            assert np.array_equal(_bits(fr.cov2), _bits(ref["cov2"]))
-        else:   # a hill with more than 256 distinct pixels outside the window: reported and repaired by the host call
-            assert np.array_equal(_bits(fr.cov2), _bits(ref["cov2"]))
+        assert fr.status == 0
+        assert np.array_equal(_bits(fr.cov2), _bits(ref["cov2"])) and np.array_equal(_bits(fr.cov2_inv), _bits(ref["cov2_inv"]))
 
 
 def test_postprocess_batch():
