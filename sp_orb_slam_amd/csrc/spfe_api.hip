@@ -112,6 +112,8 @@ struct spfe_handle_s {
   uint8_t *d_cell_k[2] = {}, *d_cell_mask = nullptr;
   const uint8_t *rec_of[NTICKET] = {};   // record buffer of each ticket (same buffer twice in a row: the old ordering)
   int *d_kp_cell = nullptr;
+  int *d_sel_slot = nullptr;          // frames of more than 16,384 cells: select_kernel's global scratch (tail_select.hip)
+  uint16_t *d_sel_list = nullptr;
   uint8_t *d_records = nullptr;
   spfe::CovScratch cov{};
   ConvLayer layers[10];
@@ -534,6 +536,10 @@ int build(spfe_handle h, const spfe_config *cfg) {
   if ((rc = dev_alloc(h, &h->d_heat_consts, (size_t)B * 4))) return rc;
   if ((rc = dev_alloc(h, &h->d_cell_mask, (size_t)B * C))) return rc;
   if ((rc = dev_alloc(h, &h->d_kp_cell, (size_t)B * h->kmax))) return rc;
+  if (spfe::select_big(H, W)) {
+    if ((rc = dev_alloc(h, &h->d_sel_slot, (size_t)B * C))) return rc;
+    if ((rc = dev_alloc(h, &h->d_sel_list, (size_t)B * C))) return rc;
+  }
   {
     const char *qenv = getenv("SPFE_COV_QCAP");
     h->cov.qcap = qenv ? atoi(qenv) : 1024;
@@ -839,6 +845,7 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
   f.heat_log = h->d_heat_log[par]; f.heat = h->d_heat; f.heat_inv = h->d_heat_inv;
   f.minmax = reinterpret_cast<uint32_t *>(h->d_minmax[par]);
   f.cell_score = h->d_cell_score[par]; f.cell_k = h->d_cell_k[par]; f.cell_mask = h->d_cell_mask; f.kp_cell = h->d_kp_cell;
+  f.sel_slot = h->d_sel_slot; f.sel_list = h->d_sel_list;
   f.records = d_records; f.heat_consts = h->d_heat_consts;
   if (h->timing && !h->ev) return fail(SPFE_EINVAL, "internal: no event set");
   const int slot = (int)(h->ticket % spfe_handle_s::NTICKET);
@@ -928,10 +935,10 @@ int spfe_create(const spfe_config *cfg, spfe_handle *out) {
   if (cfg->max_batch < 1) return fail(SPFE_EINVAL, "max_batch must be >= 1");
   if (cfg->precision != SPFE_PRECISION_F32 && cfg->precision != SPFE_PRECISION_BF16)
     return fail(SPFE_EINVAL, "unsupported precision %d", cfg->precision);
-  if ((size_t)(cfg->height / 8) * (cfg->width / 8) > 65535 ||
+  if ((size_t)(cfg->height / 8) * (cfg->width / 8) > spfe::select_max_cells() ||
       spfe::select_lds_bytes(cfg->height, cfg->width) > 160 * 1024)
-    return fail(SPFE_EINVAL, "image %dx%d too large for the single-workgroup selection stage", cfg->width,
-                cfg->height);
+    return fail(SPFE_EINVAL, "image %dx%d has more than 65,535 cells (e.g. 2560x1632): too large for the selection stage "
+                             "(16-bit cell indices; 1920x1080 and 2560x1440 fit)", cfg->width, cfg->height);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(SPFE_EHIP, "no HIP device available (libspfe has no CPU path)");

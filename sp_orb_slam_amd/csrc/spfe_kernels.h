@@ -89,6 +89,8 @@ struct FrameBufs {
   uint8_t *cell_k;      // [B][C]  arg-max channel
   uint8_t *cell_mask;   // [B][C]  which of the 8 neighbouring cells' candidates can suppress this one (nms_mask_kernel)
   int *kp_cell;         // [B][kmax] cell index of emitted keypoint
+  int *sel_slot;        // [B][C] frames of more than 16,384 cells: select_kernel's per-cell slot / index hand-off (else null)
+  uint16_t *sel_list;   // [B][C] ... and its tie / layout list
   uint8_t *records;     // [B][record_bytes]
   float *heat_consts;   // [B][4] a_heat, b_heat, a_inv, b_inv
 };
@@ -135,6 +137,8 @@ hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H
 hipError_t launch_heat_norm(const FrameBufs &f, const CovScratch &cs, int kmax, int B, int H, int W, hipStream_t s);
 hipError_t launch_desc(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s);
 size_t select_lds_bytes(int H, int W);
+bool select_big(int H, int W);     // more than 16,384 cells: per-cell private data in global scratch (FrameBufs::sel_slot / sel_list)
+size_t select_max_cells();         // 65,535
 
 // ---------------------------------------------------------------------------
 // brute-force descriptor matching (match.hip)

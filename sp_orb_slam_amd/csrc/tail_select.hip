@@ -286,12 +286,23 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(FrameBufs f, int hc, int 
   f.cell_mask[(size_t)b * C + c] = (uint8_t)m;
 }
 
+// LDS of select_kernel.  Up to SELECT_SMALL_CELLS cells everything the kernel touches per cell sits in LDS (9 bytes a
+// cell).  Larger frames (1920x1080 = 32,400 cells ... 65,535 cells) keep only what OTHER threads read during the rounds —
+// the cell states and the neighbour masks, 2 bytes a cell — and the thread-private per-cell data (score, arg-max, the
+// slot / index hand-off, the tie / layout list) in global scratch (FrameBufs::sel_slot / sel_list), which a single
+// workgroup reads back coherently through its CU's L1 behind __syncthreads().
+constexpr int SELECT_SMALL_CELLS = 16384;   // (also the register-resident key path of the cut: 16 cells per thread)
+static size_t select_fixed_lds(int H) { return ((size_t)(H / 8) + 16) * 4 * 2 + 64 + 1024 * 4 + 64 + 64; }
+bool select_big(int H, int W) { return (size_t)(H / 8) * (W / 8) > (size_t)SELECT_SMALL_CELLS; }
 size_t select_lds_bytes(int H, int W) {
   const size_t C = (size_t)(H / 8) * (W / 8);
   const size_t Cp = (C + 15) & ~(size_t)15;
-  return Cp * 4 + Cp * 2 + Cp + Cp + Cp + ((size_t)(H / 8) + 16) * 4 * 2 + 64 + 1024 * 4 + 64 + 64;
+  if (select_big(H, W)) return Cp + Cp + select_fixed_lds(H);
+  return Cp * 4 + Cp * 2 + Cp + Cp + Cp + select_fixed_lds(H);
 }
+size_t select_max_cells() { return 65535; }   // 16-bit cell indices (sList, row_of), 64 cells per thread
 
+template <bool BIG>
 __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout rl, int H, int W,
                                                       int num_features) {
   const int wc = W >> 3, hc = H >> 3, C = hc * wc;
@@ -301,10 +312,11 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
   const unsigned wc_magic = wc > 1 ? 0xffffffffu / (unsigned)wc + 1u : 0u;
   auto row_of = [&](int c) -> int { return wc > 1 ? (int)__umulhi((unsigned)c, wc_magic) : c; };
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  float *sScore = reinterpret_cast<float *>(smem);
-  uint16_t *sList = reinterpret_cast<uint16_t *>(sScore + Cp);
-  uint8_t *sK = reinterpret_cast<uint8_t *>(sList + Cp);
-  uint8_t *sState = sK + Cp;
+  // small frames: [score f32 | list u16 | k u8 | state u8 | mask u8 | rows ...]; big frames: [state u8 | mask u8 | rows ...]
+  float *sScoreL = reinterpret_cast<float *>(smem);
+  uint16_t *sListL = reinterpret_cast<uint16_t *>(sScoreL + Cp);
+  uint8_t *sKL = reinterpret_cast<uint8_t *>(sListL + Cp);
+  uint8_t *sState = BIG ? smem : sKL + Cp;
   uint8_t *sMask = sState + Cp;                      // per candidate: which of its 8 neighbours can suppress it
   int *sRow = reinterpret_cast<int *>(sMask + Cp);   // [hc+1] counts, then [hc+1] bases
   int *sRowBase = sRow + (hc + 16);
@@ -317,6 +329,11 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
   float *kp_xy = reinterpret_cast<float *>(rec + rl.off_xy);
   int16_t *occ = reinterpret_cast<int16_t *>(rec + rl.off_occ);
   int *kp_cell = f.kp_cell + (size_t)b * rl.kmax;
+  // per-cell data only the owner thread touches (plus one hand-off behind a barrier): LDS, or global scratch when BIG
+  int *const slotp = BIG ? f.sel_slot + (size_t)b * C : reinterpret_cast<int *>(sScoreL);
+  uint16_t *const sList = BIG ? f.sel_list + (size_t)b * C : sListL;
+  auto score_of = [&](int c) -> float { return BIG ? gscore[c] : sScoreL[c]; };
+  auto k_of = [&](int c) -> int { return BIG ? (int)gk[c] : (int)sKL[c]; };
 
 #ifdef SPFE_SELECT_PROBE
   unsigned long long tp[12];
@@ -335,8 +352,7 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
   for (int c = tid, j = 0; c < C; c += 1024, ++j) {
     const float s = gscore[c];
     const uint8_t m = gmask[c];
-    sScore[c] = s;
-    sK[c] = gk[c];
+    if constexpr (!BIG) { sScoreL[c] = s; sKL[c] = gk[c]; }
     sMask[c] = m;
     sState[c] = s > 0.0f ? (m ? ST_UNDEC : ST_ALIVE) : ST_NONE;
     und |= (uint64_t)(s > 0.0f && m) << j;
@@ -407,18 +423,18 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
   const bool cut = S > need;
   if (cut) {
     constexpr int KREG = 16;                       // cells per thread kept in registers (C <= 16384)
-    const bool in_regs = C <= KREG * 1024;
+    const bool in_regs = !BIG && C <= KREG * 1024;
     uint32_t key[KREG];
     uint32_t kmin = 0xffffffffu, kmax = 0u;
 #pragma unroll
     for (int j = 0; j < KREG; ++j) {
       const int c = tid + j * 1024;
-      key[j] = (in_regs && ((alive >> j) & 1)) ? __float_as_uint(sScore[c]) : 0u;
+      key[j] = (in_regs && ((alive >> j) & 1)) ? __float_as_uint(score_of(c)) : 0u;
       if (key[j]) { kmin = key[j] < kmin ? key[j] : kmin; kmax = key[j] > kmax ? key[j] : kmax; }
     }
     if (!in_regs)
       for (uint64_t rest = alive; rest; rest &= rest - 1) {
-        const uint32_t k = __float_as_uint(sScore[tid + (__ffsll((long long)rest) - 1) * 1024]);
+        const uint32_t k = __float_as_uint(score_of(tid + (__ffsll((long long)rest) - 1) * 1024));
         kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax;
       }
     int *sAcc = sCnt + 4;
@@ -443,7 +459,7 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
         }
       } else {
         for (uint64_t rest = alive; rest; rest &= rest - 1) {
-          const uint32_t r = __float_as_uint(sScore[tid + (__ffsll((long long)rest) - 1) * 1024]) - lo0 - base;
+          const uint32_t r = __float_as_uint(score_of(tid + (__ffsll((long long)rest) - 1) * 1024)) - lo0 - base;
           if ((r >> ub) == 0) atomicAdd(&sHist[r >> sh], 1);
         }
       }
@@ -473,7 +489,7 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
     __syncthreads();
     for (uint64_t rest = alive; rest; rest &= rest - 1) {
       const int c = tid + (__ffsll((long long)rest) - 1) * 1024;
-      if (__float_as_uint(sScore[c]) == prefix) sList[atomicAdd(&sCnt[6], 1)] = (uint16_t)c;
+      if (__float_as_uint(score_of(c)) == prefix) sList[atomicAdd(&sCnt[6], 1)] = (uint16_t)c;
     }
     __syncthreads();
   }
@@ -487,7 +503,7 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
     const int c = tid + j * 1024;
     bool keep = true;
     if (cut) {
-      const uint32_t key = __float_as_uint(sScore[c]);
+      const uint32_t key = __float_as_uint(score_of(c));
       if (key < prefix) keep = false;
       else if (key == prefix && nties > need) {
         int lower = 0;
@@ -497,13 +513,13 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
     }
     if (!keep) continue;
     const int cy = row_of(c), cx = c - cy * wc;
-    const int k = sK[c];
+    const int k = k_of(c);
     const int x = cx * 8 + (k & 7), y = cy * 8 + (k >> 3);
     // border reject (:222-224)
     if (!(x < SPFE_NMS_BORDER || x >= W - SPFE_NMS_BORDER || y < SPFE_NMS_BORDER ||
           y >= H - SPFE_NMS_BORDER)) {
       sState[c] = ST_KEPT;
-      reinterpret_cast<int *>(sScore)[c] = atomicAdd(&sRow[cy], 1);
+      slotp[c] = atomicAdd(&sRow[cy], 1);
       kept |= 1ull << j;
     }
   }
@@ -541,7 +557,7 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
   SEL_TP(9);
   for (uint64_t rest = kept; rest; rest &= rest - 1) {   // (the tie list in sList is no longer needed)
     const int c = tid + (__ffsll((long long)rest) - 1) * 1024;
-    sList[sRowBase[row_of(c)] + reinterpret_cast<int *>(sScore)[c]] = (uint16_t)c;
+    sList[sRowBase[row_of(c)] + slotp[c]] = (uint16_t)c;
   }
   __syncthreads();
   SEL_TP(10);
@@ -549,23 +565,23 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
   for (int t = tid; t < K; t += 1024) {
     const int c = sList[t];
     const int cy = row_of(c), cx = c - cy * wc;
-    const int k = sK[c];
+    const int k = k_of(c);
     const int mykey = ((k >> 3) << 16) | cx;
     const int g0 = sRowBase[cy], g1 = g0 + sRow[cy];
     int idx = g0;
     for (int u = g0; u < g1; ++u) {
       const int cu = sList[u];
-      idx += (((sK[cu] >> 3) << 16) | (cu - cy * wc)) < mykey;
+      idx += (((k_of(cu) >> 3) << 16) | (cu - cy * wc)) < mykey;
     }
     kp_xy[2 * idx] = (float)(cx * 8 + (k & 7));
     kp_xy[2 * idx + 1] = (float)(cy * 8 + (k >> 3));
     kp_cell[idx] = c;
-    reinterpret_cast<int *>(sScore)[c] = idx;
+    slotp[c] = idx;
   }
   __syncthreads();
 #pragma unroll 4
   for (int c = tid; c < C; c += 1024)
-    occ[c] = sState[c] == ST_KEPT ? (int16_t)reinterpret_cast<int *>(sScore)[c] : (int16_t)-1;
+    occ[c] = sState[c] == ST_KEPT ? (int16_t)slotp[c] : (int16_t)-1;
 #ifdef SPFE_SELECT_PROBE
   SEL_TP(11);
   if (tid == 0 && b == 0)
@@ -578,14 +594,18 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
 hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H, int W,
                          int num_features, hipStream_t s) {
   const size_t lds = select_lds_bytes(H, W);
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  const bool big = select_big(H, W);
+  if (lds > 160 * 1024 || (size_t)(H / 8) * (W / 8) > select_max_cells()) return hipErrorInvalidValue;
+  if (big && (!f.sel_slot || !f.sel_list)) return hipErrorInvalidValue;
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(select_kernel),
+    hipError_t e = hipFuncSetAttribute(big ? reinterpret_cast<const void *>(select_kernel<true>)
+                                           : reinterpret_cast<const void *>(select_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(nms_mask_kernel, dim3(((H / 8) * (W / 8) + 255) / 256, B), dim3(256), 0, s, f, H / 8, W / 8);
-  hipLaunchKernelGGL(select_kernel, dim3(B), dim3(1024), lds, s, f, r, H, W, num_features);
+  if (big) hipLaunchKernelGGL(select_kernel<true>, dim3(B), dim3(1024), lds, s, f, r, H, W, num_features);
+  else hipLaunchKernelGGL(select_kernel<false>, dim3(B), dim3(1024), lds, s, f, r, H, W, num_features);
   return hipGetLastError();
 }
 

@@ -293,3 +293,41 @@ def test_postprocess_batch():
     ext.close()
     for i in range(n):
         _check_exact(frs[i], oracle.postprocess(semi[i], coarse[i], H, W, 40))
+
+
+@pytest.mark.parametrize("H,W,nf,scale,seed", [(1080, 1920, 1000, 1.5, 0), (1080, 1920, 10000, 0.2, 1), (1440, 2560, 2000, 1.0, 2),
+                                               (1088, 1920, 1000, 0.0, 3)])
+def test_selection_beyond_16k_cells(H, W, nf, scale, seed):
+    """Frames of more than 16,384 cells (1920x1080 = 32,400; 2560x1440 = 57,600): select_kernel keeps only the cell states
+    and neighbour masks in LDS and its thread-private per-cell data in global scratch (tail_select.hip, BIG) — the reference
+    takes any multiple of 8 (sp_extractor.cpp:70).  Exact against the literal oracle: candidates, the cut (scale 0.2: the
+    softmax scores crowd together -> many keys in the threshold bucket; scale 0: ALL scores equal -> the cut is decided by
+    the index tie rule alone), border, raster order, occ_grid, and everything behind the selection."""
+    rng = np.random.default_rng(seed)
+    semi = (rng.standard_normal((H // 8, W // 8, 65)) * scale).astype(f32)
+    coarse = rng.standard_normal((H // 8, W // 8, 256)).astype(f32)
+    fr, ref = _run(semi, coarse, H, W, nf)
+    _check_exact(fr, ref)
+    assert fr.K > 0.5 * min(nf, ref["n_candidates"] // 9)
+
+
+def test_full_extraction_1080p_matches_oracle():
+    """1920x1080 through the whole f32 path (network, tail, BIG selection, descriptors, covariance): bitwise vs the oracle."""
+    from sp_orb_slam_amd import synth
+    H, W, nf = 1080, 1920, 1000
+    blob = weights.synthetic(7, "sparse")
+    img = synth.make_image(77, H, W)
+    ext = SPExtractor(nf, H, W, blob, with_heat=False)
+    kps, desc = ext(img, None)
+    fr = ext.last
+    ext.close()
+    ref = oracle.extract(blob, img, nf)
+    assert fr.status == 0 and fr.K == ref["K"] and np.array_equal(fr.kp_xy, ref["kp_xy"])
+    assert np.array_equal(fr.occ_grid, ref["occ_grid"])
+    assert np.array_equal(_bits(fr.descriptors), _bits(ref["desc"]))
+    assert np.array_equal(_bits(fr.cov2_inv), _bits(ref["cov2_inv"]))
+
+
+def test_frames_beyond_65535_cells_are_refused():
+    with pytest.raises(Exception):
+        SPExtractor(1000, 2160, 3840, _blob())
