@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <functional>
 #include <cfloat>
 #include <cstdarg>
@@ -91,6 +92,18 @@ struct spfe_handle_s {
   hipEvent_t ev_db = nullptr;    // launch stream: this call's convDb is done (when it is launched behind the detector tail)
   bool defer_db = true;          // SPFE_DEFER_DB=0: convDb in layer order
   hipEvent_t ev_desc = nullptr;  // side stream: the last call's descriptor sampling (reader of d_coarse) is done
+  // f32, batches of >= 2 frames: the layers behind conv1b run as TWO half batches on two streams (SPFE_F32_SPLIT), so that the
+  // workgroups of one half's kernel fill the CUs the other half's kernel leaves idle in its last, partial round of work items.
+  // (Tried on top and removed: conv1a of call i + 1 on the handle's idle stream beside the later layers of call i — it fits
+  // on every CU beside a convolution workgroup, but what it saves as a stage the matrix-bound kernels lose beside it: +-0.)
+  // No other stream is created for the convolutions: HIP maps streams onto a few hardware queues, and ONE more stream in the
+  // process moved this one onto the launch stream's queue — -4 % instead of +2 %.
+  hipStream_t conv2 = nullptr;
+  std::vector<hipStream_t> conv2_pool;   // candidates tried so far (kept: destroying one would reshuffle the queue mapping)
+  hipStream_t conv2_probed_for = nullptr;  // the launch stream conv2 was checked against; conv2_ok = it shares no hardware queue
+  bool conv2_ok = false;                   // with that stream or with the side stream
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int f32_split = 2;   // parts (0 = off)
   bool desc_recorded = false;
   long ticket = 0;          // calls so far; call t uses slot t % NTICKET
   bool cov_inflight = false;
@@ -446,6 +459,9 @@ int build(spfe_handle h, const spfe_config *cfg) {
     HIP_TRY(hipEventCreateWithFlags(&h->ev_cov[i], hipEventDisableTiming));
   }
   HIP_TRY(hipEventCreateWithFlags(&h->ev_desc, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  if (const char *e = getenv("SPFE_F32_SPLIT")) h->f32_split = atoi(e);
   HIP_TRY(hipEventCreateWithFlags(&h->ev_db, hipEventDisableTiming));
   if (const char *de = getenv("SPFE_DEFER_DB")) h->defer_db = atoi(de) != 0;
   {
@@ -680,6 +696,58 @@ __global__ void copy16_kernel(uint4 *dst, const uint4 *src, size_t n16) {
   __threadfence_system();
 }
 
+// ---- which stream for the second half batch?  HIP maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default;
+// the assignment depends on what else the process has created), and two streams on ONE queue run their kernels one after the
+// other: a second-half stream that shares the launch stream's queue (or the side stream's, whose kernels wait for events)
+// turns the +2 % of the split into -3 %.  The runtime offers no query, so the library measures: two 150 us spin kernels, one
+// on each stream, take 150 us together on different queues and 300 us on the same one.  Once per launch stream (the first
+// call that brings it synchronises that stream), up to four candidates; without a free queue the split stays off.
+__global__ void spin_kernel(long long ticks) {   // wall_clock64: 100 MHz
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+namespace {
+bool streams_share_a_queue(hipStream_t a, hipStream_t b) {
+  constexpr long long kTicks = 15000;   // 150 us
+  if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return true;
+  double best = 1e9;
+  for (int rep = 0; rep < 2; ++rep) {   // (first launch of the kernel includes its code load)
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, kTicks);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, kTicks);
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return true;
+    best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+  }
+  return best > 240.0;
+}
+int pick_conv2(spfe_handle h, hipStream_t s) {
+  if (h->conv2_probed_for == s) return SPFE_OK;
+  h->conv2_probed_for = s;
+  h->conv2_ok = false;
+  if (const char *e = getenv("SPFE_F32_SPLIT_PROBE"))   // 0: trust the first candidate (no measurement, no synchronisation)
+    if (atoi(e) == 0) {
+      if (h->conv2_pool.empty()) { hipStream_t c; HIP_TRY(hipStreamCreateWithFlags(&c, hipStreamNonBlocking)); h->conv2_pool.push_back(c); }
+      h->conv2 = h->conv2_pool[0];
+      h->conv2_ok = true;
+      return SPFE_OK;
+    }
+  for (int k = 0; k < 4; ++k) {
+    if ((int)h->conv2_pool.size() <= k) {
+      hipStream_t c = nullptr;
+      HIP_TRY(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+      h->conv2_pool.push_back(c);
+    }
+    hipStream_t c = h->conv2_pool[k];
+    if (!streams_share_a_queue(c, s) && !streams_share_a_queue(c, h->side)) {
+      h->conv2 = c;
+      h->conv2_ok = true;
+      break;
+    }
+  }
+  return SPFE_OK;
+}
+}  // namespace
+
 __global__ void zero_ints_kernel(int *p, int n) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
 }
@@ -707,8 +775,13 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   if (h->bf16 && !fused16) HIP_TRY(spfe::launch_conv1a_bf16(d_images, h->d_w1a_tab, h->d_b1a, h->act[0], n, H, W, s));
   else if (!h->bf16 && !fused) HIP_TRY(spfe::launch_conv1a(d_images, h->d_w1a, h->d_b1a, h->act[0], n, H, W, s));
   STAGE_MARK(1);
-  auto run_layer = [&](int i) -> int {
+  // frames [f0, f0 + nfr) of the batch on stream `s` (the whole batch on the caller's stream by default)
+  const int n_all = n;
+  hipStream_t const s_all = s;
+  auto run_layer = [&](int i, int f0 = 0, int nfr = -1, hipStream_t s_use = nullptr) -> int {
     const ConvLayer &L = h->layers[i];
+    hipStream_t s = s_use ? s_use : s_all;
+    const int n = nfr < 0 ? n_all : nfr;
     // convDb overwrites the coarse descriptor map the PREVIOUS call's descriptor sampling reads on
     // the side stream (pipelined callers): order it after that, by event, not by timing
     if (i == 9 && h->desc_recorded) HIP_TRY(hipStreamWaitEvent(s, h->ev_desc, 0));
@@ -717,6 +790,10 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     p.wpack = L.d_w; p.bias = L.d_b;
     p.out = L.out; p.out_stride = L.out_stride; p.out_choff = L.out_choff; p.cout_real = L.cout_real;
     p.B = n; p.H = L.H; p.W = L.W;
+    if (f0 > 0) {   // (f32 layers only: element offsets of the first frame of this part)
+      p.in = L.in + (size_t)f0 * L.H * L.W * L.in_stride;
+      p.out = L.out + (size_t)f0 * (L.pool ? (L.H / 2) * (L.W / 2) : L.H * L.W) * L.out_stride;
+    }
     p.img = nullptr; p.w1a = nullptr; p.b1a = nullptr; p.tile_ctr = nullptr;
     if (i == 0 && fused) { p.img = d_images; p.w1a = h->d_w1a; p.b1a = h->d_b1a; }
     // tile height per layer and batch: 8-row tiles do 4 MFMAs per K step and wave
@@ -826,6 +903,32 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   // Synchronous calls only: in the pipelined modes the side chain runs beside the NEXT batch anyway, and the deferred order
   // measured 0.3 ... 0.7 % slower there.
   const bool defer_db = !(h->timing && h->timing_all) && h->defer_db && !((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode);
+  // f32, >= 2 frames: conv1b for the whole batch (its work list divides evenly over the CUs), then everything behind it as
+  // two half batches on two streams: a layer's work list is 5.6 / 11.25 / 2.8 items per workgroup at 8 frames of 752x480, its
+  // last round leaves most CUs idle, and the other half's kernel — independent frames — starts on exactly those CUs
+  bool split = !h->bf16 && h->f32_split >= 1 && n >= 2 && !(h->timing && h->timing_all) && !defer_db;
+  if (split) {
+    const int rcp = pick_conv2(h, s);
+    if (rcp) return rcp;
+    split = h->conv2_ok;
+  }
+  if (split) {
+    int rc = run_layer(0);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(h->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(h->conv2, h->ev_fork, 0));
+    // (SPFE_F32_SPLIT = number of parts, alternating between the two streams; 2 = halves)
+    const int parts = std::min(h->f32_split < 2 ? 2 : h->f32_split, n);
+    for (int q = 0; q < parts; q += 2)
+      for (int i = 1; i < 10; ++i)
+        for (int r = q; r < std::min(q + 2, parts); ++r) {
+          const int f0 = (int)((long)n * r / parts), f1 = (int)((long)n * (r + 1) / parts);
+          if ((rc = run_layer(i, f0, f1 - f0, (r & 1) ? h->conv2 : s))) return rc;
+        }
+    HIP_TRY(hipEventRecord(h->ev_join, h->conv2));
+    HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
+    return enqueue_post(h, n, d_records, s);
+  }
   for (int i = 0; i < (defer_db ? 9 : 10); ++i) {
     const int rc = run_layer(i);
     if (rc) return rc;
@@ -966,6 +1069,9 @@ void spfe_destroy(spfe_handle h) {
     if (h->ev_cov[i]) (void)hipEventDestroy(h->ev_cov[i]);
   }
   if (h->ev_desc) (void)hipEventDestroy(h->ev_desc);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  for (hipStream_t c : h->conv2_pool) (void)hipStreamDestroy(c);
   if (h->ev_db) (void)hipEventDestroy(h->ev_db);
   (void)spfe_comm_destroy(h);
   for (auto &ps : h->pipe) {
