@@ -645,6 +645,11 @@ __device__ int walk_fallback(const Walk &w, int *visited, int lane) {
 __global__ __launch_bounds__(256) void cov_fallback_kernel(FrameBufs f, RecordLayout rl, CovScratch cs, int B, int H, int W) {
   __shared__ WaveMem s_mem;
   const int tid = threadIdx.x, lane = tid & 63;
+  {  // the common case — no record carries the bit — is one parallel look at the headers and out
+    int any = 0;
+    for (int b = tid; b < B; b += 256) any |= reinterpret_cast<const int *>(f.records + (size_t)b * rl.bytes + rl.off_hdr)[2] & 1;
+    if (!__syncthreads_or(any)) return;
+  }
   for (int b = 0; b < B; ++b) {
     const CovFrame c = cov_frame(f, rl, cs, b, H, W);
     if (!(c.hdr[2] & 1)) continue;            // (uniform: written by earlier kernels of this stream)
