@@ -13,13 +13,14 @@ for f in f32_async f32_sync bf16_720p_async bf16_720p_sync bf16_752_async; do
     sed -n 2,40p $R/kernel_stats_$f.txt | cut -c1-175
   } > profiles/${pre}_kernel_stats_$f.txt
 done
-for n in f32 bf16_720p bf16_752; do
+for n in f32 bf16_720p bf16_752 bf16_720p_rw0; do
   {
     echo "# profiles/${pre}_pmc_$n.txt — rocprofv3 PMC passes (tools/profile_round.sh: separate runs, --kernel-trace --pmc <ctrs> only; bench.py --steps 2 --warmup 1 --sync-cov)"
     echo "# rows: kernel, counter, sum over dispatches, dispatches x instances, min, max per dispatch-instance (SQ_*: one per shader engine, x32 for the chip; GRBM: one per XCD)"
-    grep -E "conv_f32_kernel<1,64|conv_bf16_ws_kernel<true,2>|conv1a|cov_replay" $R/pmc_summary_$n.txt | grep -v "^#" | grep -E "FETCH|WRITE|SQ_|GRBM|TCC|LDS" | cut -c1-175
+    grep -E "conv_f32_kernel<1,64|conv_bf16_ws_kernel<true,2>|conv1a|cov_replay|conv_bf16_rw_kernel|conv_bf16_kernel<128" $R/pmc_summary_$n.txt | grep -v "^#" | grep -E "FETCH|WRITE|SQ_|GRBM|TCC|LDS" | cut -c1-175
   } > profiles/${pre}_pmc_$n.txt
 done
+[ -f $R/probes.txt ] && { echo "# profiles/${pre}_probes.txt — tools/microbench probes run on the GPU box by tools/profile_round.sh (clock_probe: MFMAs only, operands in registers: the clock ceiling; conv_rw_plain: conv_bf16_rw.hip stand-alone on random data)"; cat $R/probes.txt; } > profiles/${pre}_probes.txt
 for f in $R/bench_*.json; do b=$(basename $f); case $b in bench_under_trace*) ;; *) cp $f profiles/${pre}_$b;; esac; done
 python tools/make_traffic_json.py profiles/${pre}_pmc_f32.txt "conv_f32_kernel<1,64,3,16,4,1,2,2,true,true>" 480 752 8 conv_f32.hip > profiles/conv1b_traffic.json
 python tools/make_traffic_json.py profiles/${pre}_pmc_bf16_752.txt "conv_bf16_ws_kernel<true,2>" 480 752 8 conv_bf16_ws.hip conv1a_mfma.h > profiles/conv1b_bf16_traffic.json

@@ -1,0 +1,9 @@
+#!/bin/bash
+# Build container: the stand-alone probes tools/profile_round.sh runs on the GPU box (tools/microbench/bin/ travels with gpurun).
+set -e
+cd "$(dirname "$0")/../.."
+mkdir -p tools/microbench/bin
+F="--offload-arch=gfx950 -O3 -std=c++20 -ffp-contract=off -mllvm -amdgpu-atomic-optimizer-strategy=None -Iinclude -Isp_orb_slam_amd/csrc"
+/opt/rocm/bin/hipcc $F tools/microbench/clock_probe.hip -o tools/microbench/bin/clock_probe
+/opt/rocm/bin/hipcc $F -mllvm -amdgpu-mfma-vgpr-form tools/microbench/conv_rw_probe.hip -o tools/microbench/bin/conv_rw_plain
+/opt/rocm/bin/hipcc $F -mllvm -amdgpu-mfma-vgpr-form -DRW_PROBE tools/microbench/conv_rw_probe.hip -o tools/microbench/bin/conv_rw_probe_a0

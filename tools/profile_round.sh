@@ -31,5 +31,18 @@ for cfg in "f32:" "bf16_720p:--precision bf16 --height 720 --width 1280" "bf16_7
   pmc ${n}_grbm "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE TCC_HIT_sum TCC_MISS_sum" $a
   python tools/rocpd_summary.py $out/pmc_${n}_*/*.db > $out/pmc_summary_$n.txt 2>&1
 done
+# the Cin = 128 layers on the streamed-weight kernel (conv_bf16.hip), for the comparison with conv_bf16_rw.hip above
+export SPFE_BF16_RW=0
+a="--precision bf16 --height 720 --width 1280"
+pmc bf16_720p_rw0_fetch "FETCH_SIZE" $a
+pmc bf16_720p_rw0_write "WRITE_SIZE" $a
+pmc bf16_720p_rw0_sq "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VALU" $a
+pmc bf16_720p_rw0_grbm "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE TCC_HIT_sum TCC_MISS_sum" $a
+python tools/rocpd_summary.py $out/pmc_bf16_720p_rw0_*/*.db > $out/pmc_summary_bf16_720p_rw0.txt 2>&1
+unset SPFE_BF16_RW
+# probes DESIGN.md leans on (built by tools/microbench/build_probes.sh in the build container)
+for pb in clock_probe conv_rw_plain; do
+  [ -x tools/microbench/bin/$pb ] && { echo "== $pb"; if [ $pb = conv_rw_plain ]; then for a in "180 320 8 128 1 4 50" "90 160 8 512 0 4 50" "90 160 8 128 0 4 50" "90 160 8 128 0 2 50"; do tools/microbench/bin/$pb $a; done; else tools/microbench/bin/$pb; fi; } >> $out/probes.txt 2>&1
+done
 rm -rf $out/kt_*/ $out/pmc_*/   # the databases are large; the summaries are what is kept
 ls -la $out
