@@ -104,6 +104,7 @@ struct spfe_handle_s {
   bool conv2_ok = false;                   // with that stream or with the side stream
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int f32_split = 2;   // parts (0 = off)
+  int bf16_split = -1;  // SPFE_BF16_SPLIT: the same for the bf16 stack; -1 = frames of fewer than 10,000 cells (752x480: +2 %; 1280x720: +-0)
   bool desc_recorded = false;
   long ticket = 0;          // calls so far; call t uses slot t % NTICKET
   bool cov_inflight = false;
@@ -462,6 +463,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
   HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
   if (const char *e = getenv("SPFE_F32_SPLIT")) h->f32_split = atoi(e);
+  if (const char *e = getenv("SPFE_BF16_SPLIT")) h->bf16_split = atoi(e);
   HIP_TRY(hipEventCreateWithFlags(&h->ev_db, hipEventDisableTiming));
   if (const char *de = getenv("SPFE_DEFER_DB")) h->defer_db = atoi(de) != 0;
   {
@@ -641,7 +643,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
         const int lids2[2] = {specs[i].l0, specs[i].l1};   // (convPa | convDa for the last one)
         if ((rc = pack_layer_bf16_rw(h, blob.data(), lids2, specs[i].nl, &h->d_wrw[i - 4]))) return rc;
       }
-    if ((rc = dev_alloc(h, &h->d_tile_ctr, 8 * 32))) return rc;
+    if ((rc = dev_alloc(h, &h->d_tile_ctr, 8 * 64))) return rc;   // [layer][part of the batch][32]
   }
   if (!h->bf16) {  // f32 heads with register-resident weights (head_f32.hip), bit-identical to the generic kernel — opt-in:
     // measured 63 + 38.5 us per eight 752x480 frames against 72 + 35.5 for the generic kernel (matrix-bound: 47 us at the peak)
@@ -761,7 +763,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   // (a kernel of our own, not hipMemsetAsync: the runtime's fill is a blit that queues behind its other blits — the
   // pipelined host path's D2H copy of the PREVIOUS batch — and held the whole next batch back by 0.6 ms at 752x480 bf16)
   if (h->d_tile_ctr) {
-    hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(256), 0, s, h->d_tile_ctr, 8 * 32);
+    hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(256), 0, s, h->d_tile_ctr, 8 * 64);
     HIP_TRY(hipGetLastError());
   }
   const bool fused = !h->bf16 && h->fuse1a;  // f32: conv1b computes conv1a's outputs itself
@@ -790,9 +792,14 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     p.wpack = L.d_w; p.bias = L.d_b;
     p.out = L.out; p.out_stride = L.out_stride; p.out_choff = L.out_choff; p.cout_real = L.cout_real;
     p.B = n; p.H = L.H; p.W = L.W;
-    if (f0 > 0) {   // (f32 layers only: element offsets of the first frame of this part)
-      p.in = L.in + (size_t)f0 * L.H * L.W * L.in_stride;
-      p.out = L.out + (size_t)f0 * (L.pool ? (L.H / 2) * (L.W / 2) : L.H * L.W) * L.out_stride;
+    const int part = f0 > 0 ? 1 : 0;
+    // first frame of this part: byte offsets (bf16 activations are 2-byte elements behind the float pointers)
+    auto shift = [&](const float *base, size_t elems) -> const float * {
+      return reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + elems * (h->bf16 ? 2 : 4));
+    };
+    if (f0 > 0) {
+      p.in = shift(L.in, (size_t)f0 * L.H * L.W * L.in_stride);
+      p.out = const_cast<float *>(shift(L.out, (size_t)f0 * (L.pool ? (L.H / 2) * (L.W / 2) : L.H * L.W) * L.out_stride));
     }
     p.img = nullptr; p.w1a = nullptr; p.b1a = nullptr; p.tile_ctr = nullptr;
     if (i == 0 && fused) { p.img = d_images; p.w1a = h->d_w1a; p.b1a = h->d_b1a; }
@@ -809,7 +816,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
       const int grid_ws = (h->num_cus > 0 ? h->num_cus : 256) & ~15;
       if (i < 4 && h->d_wws[i] && L.W >= 32 && (long)p.tiles_x * p.tiles_y * n * p.nblk >= (long)ws_min * (grid_ws < 16 ? 16 : grid_ws)) {
         p.wpack = reinterpret_cast<const float *>(h->d_wws[i]);
-        p.tile_ctr = h->d_tile_ctr + 32 * i;
+        p.tile_ctr = h->d_tile_ctr + 64 * i + 32 * part;
         if (i == 0 && fused16) { p.img = d_images; p.w1a = reinterpret_cast<const float *>(h->d_w1a_tab); p.b1a = h->d_b1a; }
         HIP_TRY(spfe::launch_conv_bf16_ws(p, L.pool, i == 0 ? (fused16 ? 2 : 1) : 0, s));
         STAGE_MARK(2 + i);
@@ -821,7 +828,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
       // (conv_bf16.hip, MT = 3 / 4: a stage's weight chunk feeds 1.5x / 2x the MFMAs).  Measured: 12-row tiles (layers
       // without a pool) -3...5 % on convPa|Da; 16-row tiles need 512 VGPRs + spills and lose 35 %: not the default.
       if (i == 7) {   // convPa | convDa: one launch, 512 output channels, bf16 (both 1x1 heads are bf16 GEMMs)
-        p.out = reinterpret_cast<float *>(h->d_hd); p.out_stride = 512; p.out_choff = 0;
+        p.out = reinterpret_cast<float *>(h->d_hd + (size_t)f0 * h->C * 512); p.out_stride = 512; p.out_choff = 0;
       }
       // Cin = 128: weights resident in registers (conv_bf16_rw.hip) when every workgroup of a 128-channel group gets enough
       // tiles; 4-row tiles, or 2-row tiles for the small launches (twice the tiles)
@@ -834,7 +841,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
           p.wpack = reinterpret_cast<const float *>(h->d_wrw[i - 4]);
           p.nblk = ncg;
           p.tiles_y = (L.H + tr - 1) / tr;
-          p.tile_ctr = h->d_tile_ctr + 32 * i;
+          p.tile_ctr = h->d_tile_ctr + 64 * i + 32 * part;
           HIP_TRY(spfe::launch_conv_bf16_rw(p, L.pool, tr, s));
           STAGE_MARK(2 + i);
           return SPFE_OK;
@@ -850,14 +857,15 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
         }
       }
       if (L.cin == 128 && h->bf16_dyn && (long)p.tiles_x * p.tiles_y * n * p.nblk >= 5L * (grid_ws < 8 ? 8 : grid_ws))
-        p.tile_ctr = h->d_tile_ctr + 32 * i;
+        p.tile_ctr = h->d_tile_ctr + 64 * i + 32 * part;
       HIP_TRY(spfe::launch_conv_bf16(p, L.cin, L.pool, false, s, tile_rows));
       STAGE_MARK(2 + i);
       return SPFE_OK;
     }
     if (h->bf16 && i >= 8) {  // convPb (65 logits) and convDb (256 descriptor channels): bf16 GEMMs over all cells of the batch
-      if (i == 8) HIP_TRY(spfe::launch_head1x1_bf16(h->d_hd, h->d_wpb, L.d_b, h->d_semi, n * h->C, 65, s));
-      else HIP_TRY(spfe::launch_head1x1_bf16(h->d_hd, h->d_wdb, L.d_b, h->d_coarse, n * h->C, 256, s));
+      const unsigned short *hd = h->d_hd + (size_t)f0 * h->C * 512;
+      if (i == 8) HIP_TRY(spfe::launch_head1x1_bf16(hd, h->d_wpb, L.d_b, h->d_semi + (size_t)f0 * h->C * SPFE_SEMI_CH, n * h->C, 65, s));
+      else HIP_TRY(spfe::launch_head1x1_bf16(hd, h->d_wdb, L.d_b, h->d_coarse + (size_t)f0 * h->C * SPFE_DESC_DIM, n * h->C, 256, s));
       STAGE_MARK(2 + i);
       return SPFE_OK;
     }
@@ -906,7 +914,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   // f32, >= 2 frames: conv1b for the whole batch (its work list divides evenly over the CUs), then everything behind it as
   // two half batches on two streams: a layer's work list is 5.6 / 11.25 / 2.8 items per workgroup at 8 frames of 752x480, its
   // last round leaves most CUs idle, and the other half's kernel — independent frames — starts on exactly those CUs
-  bool split = !h->bf16 && h->f32_split >= 1 && n >= 2 && !(h->timing && h->timing_all) && !defer_db;
+  bool split = (h->bf16 ? (h->bf16_split >= 1 || (h->bf16_split < 0 && h->C < 10000)) : (h->f32_split >= 1 && !h->f32_heads)) && n >= 2 && !(h->timing && h->timing_all) && !defer_db;
   if (split) {
     const int rcp = pick_conv2(h, s);
     if (rcp) return rcp;
@@ -918,7 +926,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     HIP_TRY(hipEventRecord(h->ev_fork, s));
     HIP_TRY(hipStreamWaitEvent(h->conv2, h->ev_fork, 0));
     // (SPFE_F32_SPLIT = number of parts, alternating between the two streams; 2 = halves)
-    const int parts = std::min(h->f32_split < 2 ? 2 : h->f32_split, n);
+    const int parts = 2;
     for (int q = 0; q < parts; q += 2)
       for (int i = 1; i < 10; ++i)
         for (int r = q; r < std::min(q + 2, parts); ++r) {

@@ -237,3 +237,31 @@ def test_side_stream_on_a_cu_mask(monkeypatch):
     a, b = res
     assert a.K == b.K and np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.descriptors, b.descriptors)
     assert np.array_equal(a.cov2, b.cov2)
+
+
+def test_two_stream_half_batches_are_bit_identical(monkeypatch):
+    """SPFE_F32_SPLIT / SPFE_BF16_SPLIT: the layers behind conv1b issued as two half batches on two streams (one half's
+    workgroups fill the CUs the other half's kernel leaves idle in its last partial round) — same kernels on other frame
+    ranges, so every record is bit-identical to the single-launch order, in both precisions, pipelined driver, odd batch."""
+    import torch
+    from sp_orb_slam_amd import parallel
+    H, W, nf, B = 240, 376, 400, 5
+    blob = weights.synthetic(7, "dense")
+    imgs = np.stack([synth.make_image(60 + i, H, W) for i in range(B)])
+    d_img = torch.from_numpy(imgs).cuda()
+    for prec, var in (("f32", "SPFE_F32_SPLIT"), ("bf16", "SPFE_BF16_SPLIT")):
+        out = {}
+        for val in ("0", "2"):
+            monkeypatch.setenv(var, val)
+            ext = SPExtractor(nf, H, W, blob, max_batch=B, precision=prec, with_heat=False, async_cov=True)
+            sh = parallel.ShardedExtractor(ext, 1, 0, B)
+            stream = torch.cuda.Stream()
+            for _ in range(3):
+                sh.step(d_img, stream)
+            sh.flush(stream)
+            out[val] = [sh.decode(i) for i in range(B)]
+            ext.close()
+        for a, b in zip(out["0"], out["2"]):
+            assert a.status == 0 and b.status == 0 and a.K == b.K and np.array_equal(a.kp_xy, b.kp_xy)
+            assert np.array_equal(a.descriptors.view(np.uint32), b.descriptors.view(np.uint32))
+            assert np.array_equal(a.cov2.view(np.uint32), b.cov2.view(np.uint32)) and np.array_equal(a.occ_grid, b.occ_grid)
