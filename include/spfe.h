@@ -172,6 +172,10 @@ SPFE_API int spfe_get_record_layout(spfe_handle h, spfe_record_layout *out);
 SPFE_API size_t spfe_record_bytes(spfe_handle h);
 SPFE_API int spfe_extract_batch_device(spfe_handle h, const void *d_images, int n, void *d_records,
                               void *stream);
+/* (Batches of >= 2 frames issue the layers behind conv1b as two half batches, the second on a library-owned stream that must
+ * not share a hardware queue with `stream`: the first call that brings a new `stream` measures that with two 150 us spin
+ * kernels and synchronises `stream` once while doing so.  SPFE_F32_SPLIT=0 / SPFE_F32_SPLIT_PROBE=0 switch the split / the
+ * measurement off.) */
 /* Ticket of the most recent spfe_extract_batch_device call on this handle (0, 1, 2, ...), and the
  * ordering point for SPFE_FLAG_ASYNC_COV: makes `stream` (NULL = the handle's stream) wait until the
  * records of call `ticket` (one of the last 4 calls) are complete.  Without the flag the call itself

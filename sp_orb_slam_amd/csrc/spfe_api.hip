@@ -100,8 +100,9 @@ struct spfe_handle_s {
   // process moved this one onto the launch stream's queue — -4 % instead of +2 %.
   hipStream_t conv2 = nullptr;
   std::vector<hipStream_t> conv2_pool;   // candidates tried so far (kept: destroying one would reshuffle the queue mapping)
-  hipStream_t conv2_probed_for = nullptr;  // the launch stream conv2 was checked against; conv2_ok = it shares no hardware queue
-  bool conv2_ok = false;                   // with that stream or with the side stream
+  struct Conv2Choice { hipStream_t for_stream, conv2; bool ok; };
+  std::vector<Conv2Choice> conv2_known;    // per launch stream seen so far: the candidate that shares no hardware queue with it
+  bool conv2_ok = false;                   // or with the side stream (ok = false: none found, no split on that stream)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int f32_split = 2;   // parts (0 = off)
   int bf16_split = -1;  // SPFE_BF16_SPLIT: the same for the bf16 stack; -1 = frames of fewer than 10,000 cells (752x480: +2 %; 1280x720: +-0)
@@ -723,9 +724,14 @@ bool streams_share_a_queue(hipStream_t a, hipStream_t b) {
   return best > 240.0;
 }
 int pick_conv2(spfe_handle h, hipStream_t s) {
-  if (h->conv2_probed_for == s) return SPFE_OK;
-  h->conv2_probed_for = s;
+  for (const auto &k : h->conv2_known)
+    if (k.for_stream == s) { h->conv2 = k.conv2; h->conv2_ok = k.ok; return SPFE_OK; }
+  if (h->conv2_known.size() >= 16) { h->conv2_ok = false; return SPFE_OK; }   // (a caller that keeps making streams: no split)
   h->conv2_ok = false;
+  struct Remember {   // whatever the outcome below, it is this stream's answer from now on
+    spfe_handle h; hipStream_t s;
+    ~Remember() { h->conv2_known.push_back({s, h->conv2, h->conv2_ok}); }
+  } remember{h, s};
   if (const char *e = getenv("SPFE_F32_SPLIT_PROBE"))   // 0: trust the first candidate (no measurement, no synchronisation)
     if (atoi(e) == 0) {
       if (h->conv2_pool.empty()) { hipStream_t c; HIP_TRY(hipStreamCreateWithFlags(&c, hipStreamNonBlocking)); h->conv2_pool.push_back(c); }
