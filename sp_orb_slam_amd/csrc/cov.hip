@@ -38,6 +38,7 @@
 // global loads.  Claims, stamps, the list flush and the products of the moment
 // sums are done by all lanes in parallel after the walk.
 #include "spfe_kernels.h"
+#include "desc_body.h"
 
 namespace spfe {
 
@@ -502,11 +503,18 @@ __global__ __launch_bounds__(LINK_THREADS) void cov_link_kernel(FrameBufs f, Rec
 }
 
 // ---- C2: replay.  One wavefront per component, members in ascending order. ----
+// desc_first >= 0: blocks from that index on are not replay workers but the descriptor sampling of the frame's keypoints, one
+// wavefront each (desc_body.h) — synchronous calls: the sampling is needed by the finished record only, so it runs beside the
+// longest kernel of the chain instead of in front of the chain.
 __global__ __launch_bounds__(64 * COV_WAVES) void cov_replay_kernel(FrameBufs f, RecordLayout rl, CovScratch cs,
-                                                                    int H, int W) {
+                                                                    int H, int W, int desc_first) {
   __shared__ WaveMem s_mem[COV_WAVES];
   const int b = blockIdx.y, lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (desc_first >= 0 && (int)blockIdx.x >= desc_first) {
+    desc_keypoint(f, rl, H, W, b, ((int)blockIdx.x - desc_first) * COV_WAVES + wv, lane);
+    return;
+  }
   const int widx = blockIdx.x * COV_WAVES + wv;
   const CovFrame c = cov_frame(f, rl, cs, b, H, W);
   if ((c.hdr[2] & 1) || widx >= *c.nworkers) return;
@@ -675,7 +683,7 @@ __global__ __launch_bounds__(256) void cov_fallback_kernel(FrameBufs f, RecordLa
 size_t cov_link_lds(int kmax) { return (size_t)kmax * 4 * sizeof(int); }   // parent, leader, 2 K sort keys
 
 hipError_t launch_cov(const FrameBufs &f, const RecordLayout &r, const CovScratch &cs, int B, int H, int W,
-                      hipStream_t s) {
+                      hipStream_t s, bool with_desc, hipEvent_t before_replay) {
   // claim / done / counters / ovf_slot were reset by heat_norm_kernel (the kernel in front of this stage)
   hipError_t e = hipSuccess;
   const dim3 grid((r.kmax + COV_WAVES - 1) / COV_WAVES, B), block(64 * COV_WAVES);
@@ -689,7 +697,12 @@ hipError_t launch_cov(const FrameBufs &f, const RecordLayout &r, const CovScratc
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(cov_link_kernel, dim3(B), dim3(LINK_THREADS), lds, s, f, r, cs, H, W);
-  hipLaunchKernelGGL(cov_replay_kernel, grid, block, 0, s, f, r, cs, H, W);
+  if (before_replay) {   // (the descriptor head, when it was launched behind the detector tail: the sampling reads its output)
+    e = hipStreamWaitEvent(s, before_replay, 0);
+    if (e != hipSuccess) return e;
+  }
+  const int nb = (r.kmax + COV_WAVES - 1) / COV_WAVES;
+  hipLaunchKernelGGL(cov_replay_kernel, dim3(with_desc ? 2 * nb : nb, B), block, 0, s, f, r, cs, H, W, with_desc ? nb : -1);
   // (one workgroup that returns at once unless a record carries the overflow bit: ~2 us at the end of the chain)
   if (cs.fb_q) hipLaunchKernelGGL(cov_fallback_kernel, dim3(1), dim3(256), 0, s, f, r, cs, B, H, W);
   return hipGetLastError();

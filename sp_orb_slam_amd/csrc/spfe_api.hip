@@ -104,6 +104,7 @@ struct spfe_handle_s {
   std::vector<Conv2Choice> conv2_known;    // per launch stream seen so far: the candidate that shares no hardware queue with it
   bool conv2_ok = false;                   // or with the side stream (ok = false: none found, no split on that stream)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int desc_in_replay = 1;   // SPFE_DESC_IN_REPLAY
   int f32_split = 2;   // parts (0 = off)
   int bf16_split = -1;  // SPFE_BF16_SPLIT: the same for the bf16 stack; -1 = frames of fewer than 10,000 cells (752x480: +2 %; 1280x720: +-0)
   bool desc_recorded = false;
@@ -464,6 +465,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
   HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
   if (const char *e = getenv("SPFE_F32_SPLIT")) h->f32_split = atoi(e);
+  if (const char *e = getenv("SPFE_DESC_IN_REPLAY")) h->desc_in_replay = atoi(e);
   if (const char *e = getenv("SPFE_BF16_SPLIT")) h->bf16_split = atoi(e);
   HIP_TRY(hipEventCreateWithFlags(&h->ev_db, hipEventDisableTiming));
   if (const char *de = getenv("SPFE_DEFER_DB")) h->defer_db = atoi(de) != 0;
@@ -986,18 +988,30 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
   HIP_TRY(hipEventRecord(h->ev_post[slot], s));
   HIP_TRY(hipStreamWaitEvent(h->side, h->ev_post[slot], 0));
   STAGE_MARK(13);   // ("select" reads 0 on the launch stream: it is part of post_side)
-  HIP_TRY(spfe::launch_select(f, h->rl, n, H, W, h->cfg.num_features, h->side));
-  HIP_TRY(spfe::launch_heat_norm(f, h->cov, h->rl.kmax, n, H, W, h->side));
+  // (the heat normalisation rides in the selection's first launch: both depend on the detector tail only)
+  HIP_TRY(spfe::launch_select(f, h->rl, n, H, W, h->cfg.num_features, h->side, &h->cov, h->rl.kmax));
+  // Synchronous calls: the descriptor sampling rides in the covariance replay launch (the chain's longest kernel) instead of
+  // standing in front of the chain; pipelined calls keep it early — the NEXT call's convDb waits for it, and behind a replay
+  // that shares the chip with that call's convolutions it would wait too long (0.5 ms steps in bf16 mode).
+  const bool desc_in_replay = h->desc_in_replay && !((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode) && !(h->timing && h->timing_all);
+  hipEvent_t before_replay = nullptr;
   if (conv_db) {   // the descriptor head, launched behind the detector tail (enqueue()): the sampling waits for it
     const int rc = (*conv_db)();
     if (rc) return rc;
     HIP_TRY(hipEventRecord(h->ev_db, s));
-    HIP_TRY(hipStreamWaitEvent(h->side, h->ev_db, 0));
+    if (desc_in_replay) before_replay = h->ev_db;
+    else HIP_TRY(hipStreamWaitEvent(h->side, h->ev_db, 0));
   }
-  HIP_TRY(spfe::launch_desc(f, h->rl, n, H, W, h->side));
-  HIP_TRY(hipEventRecord(h->ev_desc, h->side));  // d_coarse may be overwritten after this (next call's convDb)
-  h->desc_recorded = true;
-  HIP_TRY(spfe::launch_cov(f, h->rl, h->cov, n, H, W, h->side));
+  if (!desc_in_replay) {
+    HIP_TRY(spfe::launch_desc(f, h->rl, n, H, W, h->side));
+    HIP_TRY(hipEventRecord(h->ev_desc, h->side));  // d_coarse may be overwritten after this (next call's convDb)
+    h->desc_recorded = true;
+  }
+  HIP_TRY(spfe::launch_cov(f, h->rl, h->cov, n, H, W, h->side, desc_in_replay, before_replay));
+  if (desc_in_replay) {
+    HIP_TRY(hipEventRecord(h->ev_desc, h->side));
+    h->desc_recorded = true;
+  }
   HIP_TRY(hipEventRecord(h->ev_cov[slot], h->side));
   if (h->timing && h->timing_all) HIP_TRY(hipEventRecord(h->ev[14], h->side));
   h->cov_inflight = true;

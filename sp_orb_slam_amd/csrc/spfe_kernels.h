@@ -126,13 +126,15 @@ struct CovScratch {
   int fb_cap;
 };
 size_t cov_link_lds(int kmax);
+// with_desc: the descriptor sampling (launch_desc) as extra wavefronts of the replay launch, behind `before_replay` if given
 hipError_t launch_cov(const FrameBufs &f, const RecordLayout &r, const CovScratch &cs, int B, int H, int W,
-                      hipStream_t s);
+                      hipStream_t s, bool with_desc = false, hipEvent_t before_replay = nullptr);
 
 int tail_parts(int H, int W);  // min/max partials per frame written by the tail kernel
 hipError_t launch_tail(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s);
+// with_heat_norm: the heat normalisation (launch_heat_norm) rides in the neighbour-mask launch in front of the selection
 hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H, int W,
-                         int num_features, hipStream_t s);
+                         int num_features, hipStream_t s, const CovScratch *with_heat_norm = nullptr, int kmax_hn = 0);
 // (also resets the covariance scratch: launch_cov must follow it)
 hipError_t launch_heat_norm(const FrameBufs &f, const CovScratch &cs, int kmax, int B, int H, int W, hipStream_t s);
 hipError_t launch_desc(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s);

@@ -177,9 +177,9 @@ hipError_t launch_tail(const FrameBufs &f, const RecordLayout &r, int B, int H, 
 // The same pass also resets the covariance stage's scratch (claim / done maps to "nobody", counters to 0,
 // overflow slots to "none"): it touches every pixel anyway, and four memset launches leave the latency-bound
 // side chain.
-__global__ __launch_bounds__(256) void heat_norm_kernel(FrameBufs f, int H, int W, int nparts, CovScratch cs, int kmax) {
-  const int b = blockIdx.y;
-  if (blockIdx.x == 0) {
+__device__ __forceinline__ void heat_norm_body(const FrameBufs &f, int H, int W, int nparts, const CovScratch &cs, int kmax, int b,
+                                               int blk, int nblk) {
+  if (blk == 0) {
     if (threadIdx.x < 4) cs.counters[b * 4 + threadIdx.x] = 0;
     for (int k = threadIdx.x; k < kmax; k += 256) cs.ovf_slot[(size_t)b * kmax + k] = -1;
   }
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void heat_norm_kernel(FrameBufs f, int H, int 
       sc[1] = (float)(-dmin * inv);
       sc[2] = (float)(inv);
       sc[3] = (float)(dmax * inv);
-      if (blockIdx.x == 0) {
+      if (blk == 0) {
         float *hc4 = f.heat_consts + (size_t)b * 4;
         hc4[0] = sc[0]; hc4[1] = sc[1]; hc4[2] = sc[2]; hc4[3] = sc[3];
       }
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void heat_norm_kernel(FrameBufs f, int H, int 
   float4 *h4 = f.heat ? reinterpret_cast<float4 *>(f.heat + (size_t)b * H * W) : nullptr;
   int4 *cl4 = reinterpret_cast<int4 *>(cs.claim + (size_t)b * H * W), *dn4 = reinterpret_cast<int4 *>(cs.done + (size_t)b * H * W);
   const int4 none = {0x7f7f7f7f, 0x7f7f7f7f, 0x7f7f7f7f, 0x7f7f7f7f};
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+  for (size_t i = (size_t)blk * 256 + threadIdx.x; i < n4; i += (size_t)nblk * 256) {
     const float4 L = L4[i];
     float4 o;
     o.x = L.x * a_i + b_i; o.y = L.y * a_i + b_i; o.z = L.z * a_i + b_i; o.w = L.w * a_i + b_i;
@@ -227,6 +227,10 @@ __global__ __launch_bounds__(256) void heat_norm_kernel(FrameBufs f, int H, int 
       h4[i] = o;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void heat_norm_kernel(FrameBufs f, int H, int W, int nparts, CovScratch cs, int kmax) {
+  heat_norm_body(f, H, W, nparts, cs, kmax, blockIdx.y, blockIdx.x, gridDim.x);
 }
 
 hipError_t launch_heat_norm(const FrameBufs &f, const CovScratch &cs, int kmax, int B, int H, int W, hipStream_t s) {
@@ -257,9 +261,9 @@ enum : uint8_t { ST_NONE = 0, ST_UNDEC = 1, ST_ALIVE = 2, ST_DEAD = 3, ST_KEPT =
 // only their states do.  That 8-bit mask per candidate is local work — 8 neighbours x (score, k) from L2 — so it runs
 // over the whole chip in front of the one-workgroup-per-frame kernel (where it was 41 k of 186 k cycles at 1280x720:
 // one CU's VALU, 14 cells per thread).  Neighbour q: 0..2 row above (dx -1, 0, +1), 3 / 4 left / right, 5..7 row below.
-__global__ __launch_bounds__(256) void nms_mask_kernel(FrameBufs f, int hc, int wc) {
-  const int C = hc * wc, b = blockIdx.y;
-  const int c = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void nms_mask_body(const FrameBufs &f, int hc, int wc, int b, int blk) {
+  const int C = hc * wc;
+  const int c = blk * 256 + threadIdx.x;
   if (c >= C) return;
   const float *gscore = f.cell_score + (size_t)b * C;
   const uint8_t *gk = f.cell_k + (size_t)b * C;
@@ -284,6 +288,15 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(FrameBufs f, int hc, int 
     }
   }
   f.cell_mask[(size_t)b * C + c] = (uint8_t)m;
+}
+
+__global__ __launch_bounds__(256) void nms_mask_kernel(FrameBufs f, int hc, int wc) { nms_mask_body(f, hc, wc, blockIdx.y, blockIdx.x); }
+// The neighbour masks (input of the selection) and the heat normalisation (input of the covariance stage) both depend on the
+// detector tail only: ONE launch, the first `nmask` blocks of a frame do the masks, the rest the normalisation — a kernel
+// boundary less on the latency-bound side chain.
+__global__ __launch_bounds__(256) void mask_and_heat_norm_kernel(FrameBufs f, int H, int W, int nparts, CovScratch cs, int kmax, int nmask) {
+  if ((int)blockIdx.x < nmask) nms_mask_body(f, H >> 3, W >> 3, blockIdx.y, blockIdx.x);
+  else heat_norm_body(f, H, W, nparts, cs, kmax, blockIdx.y, (int)blockIdx.x - nmask, (int)gridDim.x - nmask);
 }
 
 // LDS of select_kernel.  Up to SELECT_SMALL_CELLS cells everything the kernel touches per cell sits in LDS (9 bytes a
@@ -592,7 +605,7 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
 }
 
 hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H, int W,
-                         int num_features, hipStream_t s) {
+                         int num_features, hipStream_t s, const CovScratch *with_heat_norm, int kmax_hn) {
   const size_t lds = select_lds_bytes(H, W);
   const bool big = select_big(H, W);
   if (lds > 160 * 1024 || (size_t)(H / 8) * (W / 8) > select_max_cells()) return hipErrorInvalidValue;
@@ -603,73 +616,24 @@ hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(((H / 8) * (W / 8) + 255) / 256, B), dim3(256), 0, s, f, H / 8, W / 8);
+  if (with_heat_norm) {
+    const int nmask = ((H / 8) * (W / 8) + 255) / 256, hb = (int)(((size_t)H * W / 4 + 255) / 256);
+    hipLaunchKernelGGL(mask_and_heat_norm_kernel, dim3(nmask + (hb < 128 ? hb : 128), B), dim3(256), 0, s, f, H, W, tail_parts(H, W),
+                       *with_heat_norm, kmax_hn, nmask);
+  } else {
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(((H / 8) * (W / 8) + 255) / 256, B), dim3(256), 0, s, f, H / 8, W / 8);
+  }
   if (big) hipLaunchKernelGGL(select_kernel<true>, dim3(B), dim3(1024), lds, s, f, r, H, W, num_features);
   else hipLaunchKernelGGL(select_kernel<false>, dim3(B), dim3(1024), lds, s, f, r, H, W, num_features);
   return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------
-// Descriptors for the emitted keypoints: one wavefront per keypoint, lane l owns
-// channels 4l..4l+3 (one float4 of the NHWC coarse map per tap: 1 KiB coalesced).
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ float sum256_wave(float4 sq) {
-  float s = sq.x;
-  s = s + sq.y;
-  s = s + sq.z;
-  s = s + sq.w;
-  return wave_sum64(s);
-}
+}  // namespace spfe
+#include "desc_body.h"
+namespace spfe {
 
 __global__ __launch_bounds__(256) void desc_kernel(FrameBufs f, RecordLayout rl, int H, int W) {
-  const int wc = W >> 3, hc = H >> 3, C = hc * wc;
-  const int b = blockIdx.y;
-  const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  uint8_t *rec = f.records + (size_t)b * rl.bytes;
-  const int K = reinterpret_cast<const int *>(rec + rl.off_hdr)[0];
-  if (i >= K) return;
-  const float *kp_xy = reinterpret_cast<const float *>(rec + rl.off_xy);
-  const float x = kp_xy[2 * i], y = kp_xy[2 * i + 1];
-  // :137-138 with ATen-CUDA scalar division (x * float(1/(w/2))), then the
-  // align_corners un-normalisation of grid_sampler
-  const float inv_hw = (float)(1.0 / (double)(float)(W / 2.0));
-  const float inv_hh = (float)(1.0 / (double)(float)(H / 2.0));
-  const float gx = x * inv_hw - 1.0f;
-  const float gy = y * inv_hh - 1.0f;
-  const float ix = ((gx + 1.0f) / 2.0f) * (float)(wc - 1);
-  const float iy = ((gy + 1.0f) / 2.0f) * (float)(hc - 1);
-  const float fx0 = floorf(ix), fy0 = floorf(iy);
-  const int x0 = (int)fx0, y0 = (int)fy0;
-  const float wx1 = ix - fx0, wy1 = iy - fy0;
-  const float wx0 = (fx0 + 1.0f) - ix, wy0 = (fy0 + 1.0f) - iy;
-  const float tw[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
-  const float *coarse = f.coarse + (size_t)b * C * SPFE_DESC_DIM;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int txx = x0 + (t & 1), tyy = y0 + (t >> 1);
-    if (txx < 0 || txx >= wc || tyy < 0 || tyy >= hc) continue;  // zeros padding
-    const float4 v = *reinterpret_cast<const float4 *>(coarse + ((size_t)tyy * wc + txx) * SPFE_DESC_DIM + lane * 4);
-    float4 sq;
-    sq.x = v.x * v.x; sq.y = v.y * v.y; sq.z = v.z * v.z; sq.w = v.w * v.w;
-    const float nrm = sqrtf(sum256_wave(sq));
-    acc.x = acc.x + (v.x / nrm) * tw[t];
-    acc.y = acc.y + (v.y / nrm) * tw[t];
-    acc.z = acc.z + (v.z / nrm) * tw[t];
-    acc.w = acc.w + (v.w / nrm) * tw[t];
-  }
-  float4 sq;
-  sq.x = acc.x * acc.x; sq.y = acc.y * acc.y; sq.z = acc.z * acc.z; sq.w = acc.w * acc.w;
-  const float nrm = sqrtf(sum256_wave(sq));
-  float4 o;
-  o.x = acc.x / nrm; o.y = acc.y / nrm; o.z = acc.z / nrm; o.w = acc.w / nrm;
-  float *desc = reinterpret_cast<float *>(rec + rl.off_desc);
-  *reinterpret_cast<float4 *>(desc + (size_t)i * SPFE_DESC_DIM + lane * 4) = o;
-  if (lane == 0) {
-    float *resp = reinterpret_cast<float *>(rec + rl.off_resp);
-    resp[i] = f.heat_inv[(size_t)b * H * W + (size_t)(int)y * W + (int)x];  // :271
-  }
+  desc_keypoint(f, rl, H, W, blockIdx.y, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
 }
 
 hipError_t launch_desc(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s) {
