@@ -53,10 +53,16 @@ __global__ __launch_bounds__(DUST_THREADS) void dust_align_kernel(DustArgs a) {
   double *s_rho0 = s_err + DUST_MAX_POINTS;
   double *s_w = s_rho0 + DUST_MAX_POINTS;
   double *s_J = s_w + DUST_MAX_POINTS;                       // [n][6]
-  float *s_dust = reinterpret_cast<float *>(s_J + 6 * DUST_MAX_POINTS);
   const int tid = threadIdx.x, n = a.n, hc = a.hc, wc = a.wc;
   const float *gdust = a.dust;
-  for (int i = tid; i < hc * wc; i += DUST_THREADS) s_dust[i] = gdust[i];
+  // the dust map in LDS when it fits beside the per-point arrays (up to ~31 k cells); larger frames (1920x1080: 32,400) read it
+  // where it is, through the L2
+  const float *s_dust = gdust;
+  if (a.map_in_lds) {
+    float *sd = reinterpret_cast<float *>(s_J + 6 * DUST_MAX_POINTS);
+    for (int i = tid; i < hc * wc; i += DUST_THREADS) sd[i] = gdust[i];
+    s_dust = sd;
+  }
 
   const double fx = (double)(a.fx / 8.0f), fy = (double)(a.fy / 8.0f);            // optimizer_dust.cpp:223-224
   const double cx = ((double)a.cx - 3.5) / 8.0f, cy = ((double)a.cy - 3.5) / 8.0f;  // :225-226
@@ -196,14 +202,16 @@ __global__ __launch_bounds__(DUST_THREADS) void dust_align_kernel(DustArgs a) {
 }
 
 size_t dust_lds_bytes(int hc, int wc) {
-  return 1024 + (size_t)DUST_MAX_POINTS * 9 * sizeof(double) + (size_t)hc * wc * sizeof(float);
+  const size_t fixed = 1024 + (size_t)DUST_MAX_POINTS * 9 * sizeof(double), with_map = fixed + (size_t)hc * wc * sizeof(float);
+  return with_map <= 160 * 1024 ? with_map : fixed;
 }
 
-hipError_t launch_dust_align(const DustArgs &a, hipStream_t s) {
+hipError_t launch_dust_align(const DustArgs &a0, hipStream_t s) {
+  DustArgs a = a0;
   if (a.n < 0 || a.n > DUST_MAX_POINTS) return hipErrorInvalidValue;
   static_assert(sizeof(Shared) <= 1024, "control block");
   const size_t lds = dust_lds_bytes(a.hc, a.wc);
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  a.map_in_lds = lds > 1024 + (size_t)DUST_MAX_POINTS * 9 * sizeof(double) ? 1 : 0;
   static bool attr_done[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);

@@ -218,6 +218,7 @@ struct DustArgs {
   int nframes;
   size_t dust_stride, pts_stride, pose_stride, out_stride;
   const int *n_dev;
+  int map_in_lds;   // set by launch_dust_align: the dust map fits in LDS beside the per-point arrays
 };
 hipError_t launch_dust_align(const DustArgs &a, hipStream_t s);
 size_t dust_lds_bytes(int hc, int wc);

@@ -36,7 +36,8 @@ def _compare(g, r, dust):
 
 
 @pytest.mark.parametrize("H,W,n,seed", [(480, 752, 160, 0), (480, 752, 200, 1), (480, 640, 97, 2), (720, 1280, 300, 3),
-                                        (480, 752, 512, 4), (480, 752, 1, 5), (120, 160, 40, 6)])
+                                        (480, 752, 512, 4), (480, 752, 1, 5), (120, 160, 40, 6),
+                                        (1080, 1920, 160, 8)])   # (32,400 cells: the map no longer fits in LDS, read through L2)
 def test_align_dust_matches_oracle(H, W, n, seed):
     sc = dust_scene.make_scene(seed, H=H, W=W, n_points=n, cx=W / 2 - 8.8, cy=H / 2 + 8.4)
     ext = SPExtractor(100, H, W, weights.synthetic(7, "dense"), with_heat=False)
