@@ -1531,12 +1531,12 @@ namespace {
 void *open_rccl() {
   // an already loaded librccl (e.g. the one torch.distributed brought) is reused by soname; the handle is kept for the
   // life of the process (one dlopen, never closed: communicators may outlive any one extractor handle)
-  static void *lib = nullptr;
-  if (lib) return lib;
-  for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-    if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) return lib;
-  }
-  return nullptr;
+  static void *const lib = []() -> void * {   // (function-local static: initialised once, also under concurrent first calls)
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+      if (void *l = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) return l;
+    return nullptr;
+  }();
+  return lib;
 }
 }  // namespace
 
