@@ -508,11 +508,12 @@ static hipError_t launch(const ConvParams &p, hipStream_t s) {
 
 size_t conv_bf16_rw_weight_bytes() { return 4 * (size_t)rw::W_WAVE_BYTES; }   // per 128-channel group
 
-// cin = 128; p.nblk = 128-channel output groups (1 .. 4); p.tiles_y = ceil(H / tile_rows); tile_rows 4 or 2 (no pool: 2)
+// cin = 128; p.nblk = 128-channel output groups (1 .. 4); p.tiles_y = ceil(H / tile_rows); tile_rows 4, 2, or 3 (layers without a pool)
 hipError_t launch_conv_bf16_rw(const ConvParams &p, bool pool, int tile_rows, hipStream_t s) {
   if (!p.tile_ctr || p.nblk < 1 || p.nblk > 4 || p.W < 32 || (p.W & 1) || (pool && (p.H & 1))) return hipErrorInvalidValue;
   if ((long)p.tiles_x * p.tiles_y * p.B >= (1 << 20)) return hipErrorInvalidValue;
   if (tile_rows == 4) return pool ? rw::launch<4, true>(p, s) : rw::launch<4, false>(p, s);
+  if (tile_rows == 3 && !pool) return rw::launch<3, false>(p, s);
   if (tile_rows == 2) return pool ? rw::launch<2, true>(p, s) : rw::launch<2, false>(p, s);
   return hipErrorInvalidValue;
 }

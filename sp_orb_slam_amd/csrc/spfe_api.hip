@@ -193,6 +193,7 @@ struct spfe_handle_s {
   unsigned char *d_wws[4] = {};  // their weights in conv_bf16_ws.hip's layout
   unsigned char *d_wrw[4] = {};  // bf16 Cin = 128 layers (conv3b, 4a, 4b, Pa|Da): weights in conv_bf16_rw.hip's fragment order
   bool bf16_rw = true;           // SPFE_BF16_RW: register-resident-weights kernel for those layers
+  int rw_rows3 = 1;              // SPFE_BF16_RW_ROWS3
   int rw_min4 = 3, rw_min2 = 2;  // ... 4-row tiles from this many tiles per workgroup, 2-row tiles from this many, else conv_bf16.hip
   int side_cus_default = 0;      // SPFE_SIDE_CUS
   bool bf16_dyn = true;          // SPFE_BF16_DYN_QUEUE
@@ -495,6 +496,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
     if (denv) h->bf16_dyn = atoi(denv) != 0;
     if (const char *e = getenv("SPFE_BF16_RW")) h->bf16_rw = atoi(e) != 0;
     if (const char *e = getenv("SPFE_BF16_RW_MIN4")) h->rw_min4 = atoi(e);
+    if (const char *e = getenv("SPFE_BF16_RW_ROWS3")) h->rw_rows3 = atoi(e);
     if (const char *e = getenv("SPFE_BF16_RW_MIN2")) h->rw_min2 = atoi(e);
   }
   const char *tenv = getenv("SPFE_STAGE_TIMING");
@@ -844,7 +846,13 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
         const int ncg = L.nblk / 2;
         const long wgs = std::max(8L * ncg, (long)((h->num_cus > 0 ? h->num_cus : 256) / (8 * ncg)) * 8 * ncg) / ncg;
         const long t4 = (long)p.tiles_x * ((L.H + 3) / 4) * n, t2 = (long)p.tiles_x * ((L.H + 1) / 2) * n;
-        const int tr = t4 >= (long)h->rw_min4 * wgs ? 4 : t2 >= (long)h->rw_min2 * wgs ? 2 : 0;
+        int tr = t4 >= (long)h->rw_min4 * wgs ? 4 : t2 >= (long)h->rw_min2 * wgs ? 2 : 0;
+        // layers without a pool may take 3-row tiles: whichever of 4 / 3 rows needs fewer row-rounds on the slowest workgroup
+        // (convPa|Da at 1280x720 x 8: 920 four-row tiles over 64 workgroups = 15 rounds of 4 rows, 1200 three-row tiles = 19 of 3)
+        if (tr == 4 && !L.pool && h->rw_rows3) {
+          const long t3 = (long)p.tiles_x * ((L.H + 2) / 3) * n;
+          if (((t3 + wgs - 1) / wgs) * 3 < ((t4 + wgs - 1) / wgs) * 4) tr = 3;
+        }
         if (tr) {
           p.wpack = reinterpret_cast<const float *>(h->d_wrw[i - 4]);
           p.nblk = ncg;

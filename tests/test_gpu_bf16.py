@@ -207,15 +207,17 @@ def test_bf16_rw_kernel_equals_streamed_weight_kernel(monkeypatch, H, W, B):
     blob = weights.synthetic(7, "sparse")
     imgs = [synth.make_image(40 + i, H, W) for i in range(B)]
     out = {}
-    for key, rw, m4, m2 in (("ref", "0", "0", "0"), ("rows4", "1", "0", "0"), ("rows2", "1", "1000000", "0")):
+    for key, rw, m4, m2, r3 in (("ref", "0", "0", "0", "0"), ("rows4", "1", "0", "0", "0"), ("rows2", "1", "1000000", "0", "0"),
+                               ("rows3", "1", "0", "0", "1")):
         monkeypatch.setenv("SPFE_BF16_RW", rw)
         monkeypatch.setenv("SPFE_BF16_RW_MIN4", m4)
         monkeypatch.setenv("SPFE_BF16_RW_MIN2", m2)
+        monkeypatch.setenv("SPFE_BF16_RW_ROWS3", r3)
         ext = SPExtractor(nf, H, W, blob, max_batch=B, precision="bf16", with_heat=False)
         frs = ext.extract_batch(imgs)
         out[key] = (frs, [ext.debug_read(nm, B - 1) for nm in ("act5", "act6", "act7", "semi", "coarse")])
         ext.close()
-    for other in ("rows4", "rows2"):
+    for other in ("rows4", "rows2", "rows3"):
         for nm, a, b in zip(("act5", "act6", "act7", "semi", "coarse"), out["ref"][1], out[other][1]):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (other, nm, float(np.abs(a - b).max()))
         for a, b in zip(out["ref"][0], out[other][0]):
