@@ -672,7 +672,7 @@ def main():
         pts_b = np.zeros((NB, DUST_MAX_POINTS, 3), np.float32)
         T_b = np.zeros((NB, 16), np.float32)
         for f in range(NB):
-            scf = dust_scene.make_scene(f, H=H, W=W, n_points=160, cx=W / 2 - 8.8, cy=H / 2 + 8.4)
+            scf = dsc if f == 0 else dust_scene.make_scene(f, H=H, W=W, n_points=160, cx=W / 2 - 8.8, cy=H / 2 + 8.4)  # frame 0 = the single solve's scene
             pts_b[f, :160] = scf["pts"]
             T_b[f] = scf["Tcw_init"].reshape(16)
             d_recs[f, lay.off_dd:lay.off_dd + scf["dust"].size * 4] = torch.from_numpy(scf["dust"].reshape(-1).view(np.uint8)).cuda()
