@@ -38,6 +38,26 @@ def conv1b_flop(H, W):
     return 2 * H * W * 64 * 64 * 9
 
 
+def path_tflops(ext, fps, H, W, B):
+    """Whole-path TFLOP/s = EXECUTED flops per frame x frames/s.  The descriptor head (convDb, 2 x 256 x 256 flops per coarse
+    cell) runs on the cells the emitted keypoints' bilinear taps read only (libspfe's gathered head, on by default in f32
+    mode and for bf16 frames of >= 10,000 cells): the rows it skips are not counted.  `dense_graph` is the reference's dense
+    graph over the same time, for comparison with earlier rounds."""
+    if (H, W) not in FLOP_PER_FRAME:
+        return {"whole_path_tflops": None}
+    nominal = FLOP_PER_FRAME[(H, W)]
+    C = (H // 8) * (W // 8)
+    try:
+        frac = float(ext.debug_read("db_total")[0]) / float(B * C)   # the last call's list
+        gathered = True
+    except Exception:
+        frac, gathered = 1.0, False
+    executed = nominal - (1.0 - frac) * C * 2 * 256 * 256
+    return {"whole_path_tflops": round(fps * executed / 1e12, 2),
+            "whole_path_tflops_dense_graph": round(fps * nominal / 1e12, 2),
+            "descriptor_head": {"gathered": gathered, "cells_computed_frac": round(frac, 4)}}
+
+
 def file_sha16(path):
     import hashlib
     try:
@@ -150,8 +170,8 @@ def device_leg(ctx, precision, H, W, B, seed0, steps, warmup, what):
     out = {"what": "%s, %d timed steps after %d untimed" % (what, steps, warmup),
            "value": round(fps, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 4), "dtype": precision,
            "roofline": roofline_of(precision, st, H, W, B, traffic_of(precision, H, W, B)),
-           "whole_path_tflops": round(fps * FLOP_PER_FRAME[(H, W)] / 1e12, 2) if (H, W) in FLOP_PER_FRAME else None,
            "records_ok": ok}
+    out.update(path_tflops(ext, fps, H, W, B))
     ext.close()
     del d
     os.environ["SPFE_STAGE_TIMING"] = "0"
@@ -460,7 +480,6 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         fps = world * B * args.steps / dt
-        flop_frame = FLOP_PER_FRAME.get((H, W))
         # dominant kernel: conv1b (43.5 % of the FLOPs), one launch covers B frames
         out = {
             "metric": "frames/sec SuperPoint extract (%dx%d, %s kpts)" % (W, H, "1k" if nf == 1000 else str(nf)),
@@ -481,8 +500,8 @@ def main():
                                   "ncclAllGather inside libspfe (spfe_allgather_records)" if getattr(sharded, "_native", False)
                                   else "torch.distributed all_gather_into_tensor")},
             "roofline": roofline_of(args.precision, stages, H, W, B, traffic_of(args.precision, H, W, B)),
-            "whole_path_tflops": round(fps * flop_frame / 1e12, 2) if flop_frame else None,
         }
+        out.update(path_tflops(ext, fps, H, W, B))
 
     if world > 1:
         # ---- N > 1: self-verification legs (every rank takes part), then ONE line, a barrier, and only then teardown

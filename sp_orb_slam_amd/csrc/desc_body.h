@@ -25,13 +25,15 @@ __device__ __forceinline__ float sum256_wave(float4 sq) {
   return desc_wave_sum64(s);
 }
 
-__device__ __forceinline__ void desc_keypoint(const FrameBufs &f, const RecordLayout &rl, int H, int W, int b, int i, int lane) {
-  const int wc = W >> 3, hc = H >> 3, C = hc * wc;
-  uint8_t *rec = f.records + (size_t)b * rl.bytes;
-  const int K = reinterpret_cast<const int *>(rec + rl.off_hdr)[0];
-  if (i >= K) return;
-  const float *kp_xy = reinterpret_cast<const float *>(rec + rl.off_xy);
-  const float x = kp_xy[2 * i], y = kp_xy[2 * i + 1];
+// The bilinear taps of a keypoint at (x, y) on the coarse map: the top-left cell (x0, y0) — may be -1 / past the last
+// row or column: those taps are the zero padding — and the weights.  ONE definition for the sampling below and for the
+// selection kernel's list of the cells the descriptor head has to compute (tail_select.hip, "sparse convDb").
+struct DescTaps {
+  int x0, y0;
+  float tw[4];
+};
+__device__ __forceinline__ DescTaps desc_taps(float x, float y, int H, int W) {
+  const int wc = W >> 3, hc = H >> 3;
   // :137-138 with ATen-CUDA scalar division (x * float(1/(w/2))), then the
   // align_corners un-normalisation of grid_sampler
   const float inv_hw = (float)(1.0 / (double)(float)(W / 2.0));
@@ -41,10 +43,24 @@ __device__ __forceinline__ void desc_keypoint(const FrameBufs &f, const RecordLa
   const float ix = ((gx + 1.0f) / 2.0f) * (float)(wc - 1);
   const float iy = ((gy + 1.0f) / 2.0f) * (float)(hc - 1);
   const float fx0 = floorf(ix), fy0 = floorf(iy);
-  const int x0 = (int)fx0, y0 = (int)fy0;
+  DescTaps t;
+  t.x0 = (int)fx0; t.y0 = (int)fy0;
   const float wx1 = ix - fx0, wy1 = iy - fy0;
   const float wx0 = (fx0 + 1.0f) - ix, wy0 = (fy0 + 1.0f) - iy;
-  const float tw[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+  t.tw[0] = wx0 * wy0; t.tw[1] = wx1 * wy0; t.tw[2] = wx0 * wy1; t.tw[3] = wx1 * wy1;
+  return t;
+}
+
+__device__ __forceinline__ void desc_keypoint(const FrameBufs &f, const RecordLayout &rl, int H, int W, int b, int i, int lane) {
+  const int wc = W >> 3, hc = H >> 3, C = hc * wc;
+  uint8_t *rec = f.records + (size_t)b * rl.bytes;
+  const int K = reinterpret_cast<const int *>(rec + rl.off_hdr)[0];
+  if (i >= K) return;
+  const float *kp_xy = reinterpret_cast<const float *>(rec + rl.off_xy);
+  const float x = kp_xy[2 * i], y = kp_xy[2 * i + 1];
+  const DescTaps taps = desc_taps(x, y, H, W);
+  const int x0 = taps.x0, y0 = taps.y0;
+  const float (&tw)[4] = taps.tw;
   const float *coarse = f.coarse + (size_t)b * C * SPFE_DESC_DIM;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll

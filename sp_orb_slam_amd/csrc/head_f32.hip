@@ -16,6 +16,7 @@
 // STATUS: opt-in (SPFE_F32_HEADS=1).  Measured (rocprofv3, 752x480 x 8): convDb 63 us, convPb 38.5 us — against 72 and 35.5 us
 // for the generic kernel (the first version, four waves with 256 weight registers each, half of them in AccVGPRs: 66 + 38): no gain worth a second code path by default; kept, tested for bit-identity, as the record of VERDICT
 // round 1 item 9 (whose "<= 0.05 ms" is the layers' roofline itself).
+#include <algorithm>
 #include <cstring>
 #include <utility>
 
@@ -37,17 +38,22 @@ constexpr int F_KSTEPS = 128;           // K = 256, two per MFMA
 
 // in: [npix][IN_STRIDE] f32, the head reads channels [in_choff, in_choff + 256); out: [npix][COUT] f32
 // wpack: [wave 8][K step 128 / 4][lane 64][4] f32 (head_f32_pack_weights)
-template <int COUT, int IN_STRIDE>
+// GATHER: as in head_bf16.hip — the pixels are the `*total` cells of `list` (select_kernel's list of the cells the descriptor
+// sampling reads), row list[p] of `in` -> row list[p] of `out`, the dense kernel's bits in the rows anybody reads.
+template <int COUT, int IN_STRIDE, bool GATHER>
 __global__ __launch_bounds__(512, 1) void head1x1_f32_kernel(const float *__restrict__ in, int in_choff,
                                                              const float *__restrict__ wpack, const float *__restrict__ bias,
-                                                             float *__restrict__ out, int npix) {
+                                                             float *__restrict__ out, int npix,
+                                                             const int *__restrict__ list, const int *__restrict__ total) {
   constexpr int NTW = 1;
   extern __shared__ __attribute__((aligned(16))) char sm_f[];
   lds_char *const lds = (lds_char *)sm_f;
+  int *const sIdx = reinterpret_cast<int *>(sm_f + 2 * FT_BYTES);   // GATHER: [4][32] cell indices of the tiles in flight
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
-  const int ntiles = (npix + FT - 1) / FT;
+  const int nwalk = GATHER ? __builtin_amdgcn_readfirstlane(*total) : npix;   // pixels this launch walks
+  const int ntiles = (nwalk + FT - 1) / FT;
 
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(in) + in_choff, 0, (unsigned)((size_t)npix * IN_STRIDE * 4 - (size_t)in_choff * 4), 0x00020000);
@@ -80,23 +86,43 @@ __global__ __launch_bounds__(512, 1) void head1x1_f32_kernel(const float *__rest
     const int q = (8 * i + wave) * 64 + lane, px = q >> 6, slot = q & 63;
     dsrc[i] = (unsigned)px * (unsigned)(IN_STRIDE * 4) + (unsigned)((slot ^ (px & 15)) * 16);
   }
-  auto dma = [&](int tile, int buf) {
+  // GATHER: pass i of this wave carries the tile's pixel 8 i + wave; the cell indices are fetched one tile ahead
+  int gidx[4] = {-1, -1, -1, -1};
+  auto load_idx = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = tile * FT + 8 * i + wave;
+      gidx[i] = p < nwalk ? list[p] : -1;
+    }
+  };
+  auto dma = [&](int tile, int buf, int ring) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const unsigned base = (unsigned)tile * (unsigned)(FT * IN_STRIDE * 4);   // (past the last pixel: out of range -> zeros)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void *)(lds + buf * FT_BYTES + (8 * i + wave) * 1024), 16, base + dsrc[i], 0, 0, 0);
+    for (int i = 0; i < 4; ++i) {
+      unsigned src = base + dsrc[i];
+      if constexpr (GATHER) {
+        const unsigned inrow = (unsigned)(lane ^ ((8 * i + wave) & 15)) * 16u;
+        src = gidx[i] < 0 ? 0x80000000u : (unsigned)gidx[i] * (unsigned)(IN_STRIDE * 4) + inrow;
+        if (lane == 0) sIdx[ring * FT + 8 * i + wave] = gidx[i];
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void *)(lds + buf * FT_BYTES + (8 * i + wave) * 1024), 16, src, 0, 0, 0);
+    }
 #endif
   };
   const unsigned arow = (unsigned)(l31 * 1024);
   const unsigned akey = (unsigned)(l31 & 15);
 
   // D[pixel][channel]: register r = pixel (r & 3) + 8 (r >> 2) + 4 hi of the tile
-  auto store_tile = [&](const f32x16 (&acc)[NTW], int tile) {
+  auto store_tile = [&](const f32x16 (&acc)[NTW], int tile, int ring) {
     const unsigned base = (unsigned)tile * (unsigned)(FT * COUT * 4) + (unsigned)co * 4u;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const unsigned off = lane_out ? base + (unsigned)(((r & 3) + 8 * (r >> 2) + 4 * hi) * COUT * 4) : 0x80000000u;
+      unsigned off = lane_out ? base + (unsigned)(((r & 3) + 8 * (r >> 2) + 4 * hi) * COUT * 4) : 0x80000000u;
+      if constexpr (GATHER) {
+        const int cell = sIdx[ring * FT + (r & 3) + 8 * (r >> 2) + 4 * hi];
+        off = lane_out && cell >= 0 ? (unsigned)cell * (unsigned)(COUT * 4) + (unsigned)co * 4u : 0x80000000u;
+      }
       if constexpr (NTW == 2) {
         const f32x2 v = {acc[0][r] + bv[0], acc[1][r] + bv[1]};
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, v), rout, off, 0, 0);
@@ -108,14 +134,22 @@ __global__ __launch_bounds__(512, 1) void head1x1_f32_kernel(const float *__rest
 
   f32x16 accA[NTW], accB[NTW];
   int tile = blockIdx.x, prev = -1;
-  if (tile < ntiles) dma(tile, 0);
+  int it = 0;   // tiles this workgroup has started; tile number `it` keeps its cell indices in ring slot it & 3
+  if (tile < ntiles) {
+    if constexpr (GATHER) load_idx(tile);
+    dma(tile, 0, 0);
+    if constexpr (GATHER) load_idx(tile + (int)gridDim.x);
+  }
   int buf = 0;
   auto run = [&](f32x16 (&acc)[NTW], const f32x16 (&accPrev)[NTW]) {
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this tile has landed
     __syncthreads();                      // ... for every wave; and every wave is done reading the other buffer
     const int nxt = tile + (int)gridDim.x;
-    if (nxt < ntiles) dma(nxt, buf ^ 1);
-    if (prev >= 0 && wave_active) store_tile(accPrev, prev);   // the previous tile's outputs leave while this one computes
+    if (nxt < ntiles) {
+      dma(nxt, buf ^ 1, (it + 1) & 3);
+      if constexpr (GATHER) load_idx(nxt + (int)gridDim.x);
+    }
+    if (prev >= 0 && wave_active) store_tile(accPrev, prev, (it - 1) & 3);   // the previous tile's outputs leave while this one computes
     lds_char *const a0 = lds + buf * FT_BYTES + arow;
     if (wave_active) {
     // piece m = channels 4 m .. 4 m + 3 of this lane's pixel: K steps 2 m (dwords 0 | 1 by hi) and 2 m + 1 (dwords 2 | 3)
@@ -154,6 +188,7 @@ __global__ __launch_bounds__(512, 1) void head1x1_f32_kernel(const float *__rest
     prev = tile;
     tile = nxt;
     buf ^= 1;
+    ++it;
   };
   bool lastA = true;
   while (tile < ntiles) {
@@ -163,7 +198,7 @@ __global__ __launch_bounds__(512, 1) void head1x1_f32_kernel(const float *__rest
     run(accB, accA);
     lastA = false;
   }
-  if (prev >= 0 && wave_active) { if (lastA) store_tile(accA, prev); else store_tile(accB, prev); }
+  if (prev >= 0 && wave_active) { if (lastA) store_tile(accA, prev, (it - 1) & 3); else store_tile(accB, prev, (it - 1) & 3); }
 }
 
 size_t head_f32_weight_bytes(int) { return (size_t)8 * F_KSTEPS * 64 * 4; }
@@ -181,12 +216,12 @@ void head_f32_pack_weights(const float *W, int cout, float *dst) {
       }
 }
 
-template <int COUT>
+template <int COUT, bool GATHER>
 static hipError_t launch_head_f32(const float *in, int in_choff, const float *wpack, const float *bias, float *out, int npix,
-                                  int num_cus, hipStream_t s) {
-  constexpr size_t lds = 2 * (size_t)FT_BYTES;
-  auto k = head1x1_f32_kernel<COUT, 512>;
-  if (npix <= 0) return hipSuccess;
+                                  const int *list, const int *total, int max_walk, int num_cus, int tiles_per_wg, hipStream_t s) {
+  constexpr size_t lds = 2 * (size_t)FT_BYTES + (GATHER ? 4 * FT * sizeof(int) : 0);
+  auto k = head1x1_f32_kernel<COUT, 512, GATHER>;
+  if (npix <= 0 || max_walk <= 0) return hipSuccess;
   static bool attr_done[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -195,10 +230,11 @@ static hipError_t launch_head_f32(const float *in, int in_choff, const float *wp
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64) attr_done[dev] = true;
   }
-  const int ntiles = (npix + FT - 1) / FT;
+  const int ntiles = (max_walk + FT - 1) / FT;
   int grid = num_cus > 0 ? num_cus : 256;
   if (grid > ntiles) grid = ntiles;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, in, in_choff, wpack, bias, out, npix);
+  if (GATHER && tiles_per_wg > 1) grid = std::max(1, std::min(grid, (ntiles + tiles_per_wg - 1) / tiles_per_wg));
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, in, in_choff, wpack, bias, out, npix, list, total);
   return hipGetLastError();
 }
 
@@ -206,9 +242,16 @@ static hipError_t launch_head_f32(const float *in, int in_choff, const float *wp
 // cout 65: the detector head on channels 0..255
 hipError_t launch_head1x1_f32(const float *in, const float *wpack, const float *bias, float *out, int npix, int cout,
                               hipStream_t s) {
-  if (cout == 256) return launch_head_f32<256>(in, 256, wpack, bias, out, npix, 0, s);
-  if (cout == 65) return launch_head_f32<65>(in, 0, wpack, bias, out, npix, 0, s);
+  if (cout == 256) return launch_head_f32<256, false>(in, 256, wpack, bias, out, npix, nullptr, nullptr, npix, 0, 0, s);
+  if (cout == 65) return launch_head_f32<65, false>(in, 0, wpack, bias, out, npix, nullptr, nullptr, npix, 0, 0, s);
   return hipErrorInvalidValue;
+}
+
+// The descriptor head on the `*total` (<= max_total) rows that `list` names, of the npix rows of in / out.
+hipError_t launch_head1x1_f32_gather(const float *in, const float *wpack, const float *bias, float *out, int npix,
+                                     const int *list, const int *total, int max_total, int tiles_per_wg, hipStream_t s) {
+  if (!list || !total) return hipErrorInvalidValue;
+  return launch_head_f32<256, true>(in, 256, wpack, bias, out, npix, list, total, max_total, 0, tiles_per_wg, s);
 }
 
 }  // namespace spfe

@@ -121,6 +121,17 @@ struct spfe_handle_s {
   unsigned char *d_wdb = nullptr, *d_wpb = nullptr;   // bf16 mode: convDb / convPb weights, head_bf16.hip layout
   float *d_wdb32 = nullptr, *d_wpb32 = nullptr;       // f32 mode: the same for head_f32.hip (SPFE_F32_HEADS=1; default: generic kernel)
   bool f32_heads = false;
+  // "sparse convDb": the descriptor head runs BEHIND the selection, on the cells some emitted keypoint's bilinear taps read
+  // (<= 4 per keypoint: 28 % of a 1280x720 frame at 1000 keypoints), gathered through select_kernel's list; d_coarse keeps
+  // the dense layout, only the rows anybody reads are written.  SPFE_SPARSE_DB=0: the dense head in the launch stream.
+  bool sparse_db = true;
+  bool sparse_last = false;      // the last call left d_coarse sparse (spfe_debug_read("coarse") completes it on demand)
+  int *d_db_list = nullptr, *d_db_total = nullptr;
+  int db_cap = 0;                // list entries per frame: min(4 kmax, C)
+  int db_tiles_per_wg = 4;       // SPFE_DB_TILES_PER_WG: the gathered head's grid = listed tiles / this (a workgroup's weights: 128 KB)
+  hipEvent_t ev_sel = nullptr;   // side stream: this call's selection (and its cell list) is done
+  hipEvent_t ev_dbs = nullptr;   // the last call's gathered head (reader of the head activations) is done
+  bool dbs_recorded = false;
   // what the detector tail (launch stream) hands to the side chain exists twice, by ticket parity: batch i + 1's tail then
   // only has to wait for batch i - 1's side chain, not for batch i's (which runs beside batch i + 1's convolutions)
   float *d_heat_log[2] = {}, *d_heat = nullptr, *d_heat_inv = nullptr;
@@ -469,6 +480,16 @@ int build(spfe_handle h, const spfe_config *cfg) {
   if (const char *e = getenv("SPFE_DESC_IN_REPLAY")) h->desc_in_replay = atoi(e);
   if (const char *e = getenv("SPFE_BF16_SPLIT")) h->bf16_split = atoi(e);
   HIP_TRY(hipEventCreateWithFlags(&h->ev_db, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&h->ev_sel, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&h->ev_dbs, hipEventDisableTiming));
+  // Measured, pipelined, 8 frames per call (same-box A/B): bf16 1280x720 +2.5 ... 3.8 % (7590 -> 7780, 7322 -> 7604 frames/s),
+  // f32 752x480 +0.4 ... 0.7 %, bf16 752x480 -2 ... 3 %: there the launch stream runs as two half batches on two streams, the
+  // dense head (HBM-bound) hid completely beside the other half's convolutions (removing it altogether gains nothing), and
+  // the gathered launch is pure extra work for the chip.  So: f32, and bf16 frames of >= 10,000 cells (= no two-stream split).
+  h->sparse_db = !h->bf16 || h->C >= 10000;
+  h->db_tiles_per_wg = h->bf16 ? 4 : 1;
+  if (const char *e = getenv("SPFE_SPARSE_DB")) h->sparse_db = atoi(e) != 0;
+  if (const char *e = getenv("SPFE_DB_TILES_PER_WG")) h->db_tiles_per_wg = atoi(e);
   if (const char *de = getenv("SPFE_DEFER_DB")) h->defer_db = atoi(de) != 0;
   {
     const char *fenv = getenv("SPFE_FUSE_CONV1A");
@@ -559,6 +580,12 @@ int build(spfe_handle h, const spfe_config *cfg) {
   if ((rc = dev_alloc(h, &h->d_heat_consts, (size_t)B * 4))) return rc;
   if ((rc = dev_alloc(h, &h->d_cell_mask, (size_t)B * C))) return rc;
   if ((rc = dev_alloc(h, &h->d_kp_cell, (size_t)B * h->kmax))) return rc;
+  if (h->sparse_db) {
+    h->db_cap = (int)std::min<size_t>((size_t)4 * h->kmax, (size_t)C);
+    if ((rc = dev_alloc(h, &h->d_db_list, (size_t)B * h->db_cap))) return rc;
+    if ((rc = dev_alloc(h, &h->d_db_total, 16))) return rc;
+    HIP_TRY(hipMemset(h->d_db_total, 0, 16 * sizeof(int)));
+  }
   if (spfe::select_big(H, W)) {
     if ((rc = dev_alloc(h, &h->d_sel_slot, (size_t)B * C))) return rc;
     if ((rc = dev_alloc(h, &h->d_sel_list, (size_t)B * C))) return rc;
@@ -654,7 +681,8 @@ int build(spfe_handle h, const spfe_config *cfg) {
     // measured 63 + 38.5 us per eight 752x480 frames against 72 + 35.5 for the generic kernel (matrix-bound: 47 us at the peak)
     const char *fe = getenv("SPFE_F32_HEADS");
     if (fe) h->f32_heads = atoi(fe) != 0;
-    for (int which = 0; which < 2 && h->f32_heads; ++which) {
+    for (int which = 0; which < 2; ++which) {
+      if (!h->f32_heads && !(which == 0 && h->sparse_db)) continue;   // (the gathered descriptor head is head_f32.hip's kernel)
       const int lid = which ? 9 : 11;
       const spfe_layer_t &Ld = SPFE_LAYERS[lid];
       std::vector<float> w(spfe::head_f32_weight_bytes(Ld.cout) / 4, 0.0f);
@@ -693,7 +721,8 @@ int build(spfe_handle h, const spfe_config *cfg) {
 #define STAGE_MARK(i) \
   do { if (h->timing && (h->timing_all || (i) == 1 || (i) == 2)) HIP_TRY(hipEventRecord(h->ev[i], s)); } while (0)
 
-int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const std::function<int()> *conv_db = nullptr);
+int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const std::function<int()> *conv_db = nullptr, bool sparse = false);
+int launch_db_gathered(spfe_handle h, int n, hipStream_t s);
 
 // D2H of the records by a kernel of our own that writes the pinned (device-mapped) host buffer: 8.9 MB in ~0.18 ms, no LDS,
 // fits beside the persistent convolution workgroups; the runtime's own D2H path cost 0.36 ms more per batch in the pipeline
@@ -797,6 +826,8 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     // convDb overwrites the coarse descriptor map the PREVIOUS call's descriptor sampling reads on
     // the side stream (pipelined callers): order it after that, by event, not by timing
     if (i == 9 && h->desc_recorded) HIP_TRY(hipStreamWaitEvent(s, h->ev_desc, 0));
+    // convPa | convDa overwrite the head activations the PREVIOUS call's gathered descriptor head reads (side stream)
+    if (i == 7 && h->dbs_recorded) HIP_TRY(hipStreamWaitEvent(s, h->ev_dbs, 0));
     spfe::ConvParams p;
     p.in = L.in; p.in_stride = L.in_stride; p.in_choff = L.in_choff;
     p.wpack = L.d_w; p.bias = L.d_b;
@@ -926,7 +957,9 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   // per-stage events (SPFE_STAGE_TIMING=1) the launch order stays the table's order.
   // Synchronous calls only: in the pipelined modes the side chain runs beside the NEXT batch anyway, and the deferred order
   // measured 0.3 ... 0.7 % slower there.
-  const bool defer_db = !(h->timing && h->timing_all) && h->defer_db && !((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode);
+  const bool sparse = h->sparse_db && h->d_db_list;
+  const bool defer_db = !sparse && !(h->timing && h->timing_all) && h->defer_db && !((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode);
+  const int nlayers = sparse ? 9 : 10;   // sparse: convDb is enqueue_post's gathered launch behind the selection
   // f32, >= 2 frames: conv1b for the whole batch (its work list divides evenly over the CUs), then everything behind it as
   // two half batches on two streams: a layer's work list is 5.6 / 11.25 / 2.8 items per workgroup at 8 frames of 752x480, its
   // last round leaves most CUs idle, and the other half's kernel — independent frames — starts on exactly those CUs
@@ -944,30 +977,50 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     // (SPFE_F32_SPLIT = number of parts, alternating between the two streams; 2 = halves)
     const int parts = 2;
     for (int q = 0; q < parts; q += 2)
-      for (int i = 1; i < 10; ++i)
+      for (int i = 1; i < nlayers; ++i)
         for (int r = q; r < std::min(q + 2, parts); ++r) {
           const int f0 = (int)((long)n * r / parts), f1 = (int)((long)n * (r + 1) / parts);
           if ((rc = run_layer(i, f0, f1 - f0, (r & 1) ? h->conv2 : s))) return rc;
         }
     HIP_TRY(hipEventRecord(h->ev_join, h->conv2));
     HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
-    return enqueue_post(h, n, d_records, s);
+    return enqueue_post(h, n, d_records, s, nullptr, sparse);
   }
-  for (int i = 0; i < (defer_db ? 9 : 10); ++i) {
+  for (int i = 0; i < (defer_db ? 9 : nlayers); ++i) {
     const int rc = run_layer(i);
     if (rc) return rc;
   }
-  if (!defer_db) return enqueue_post(h, n, d_records, s);
+  if (sparse) STAGE_MARK(2 + 9);   // ("convDb" reads 0 on the launch stream: the gathered head is part of post_side)
+  if (!defer_db) return enqueue_post(h, n, d_records, s, nullptr, sparse);
   const std::function<int()> conv_db = [&]() -> int { return run_layer(9); };
   return enqueue_post(h, n, d_records, s, &conv_db);
 }
 
+// The descriptor head on select_kernel's cell list (stream `s`, behind the selection of the same call).
+int launch_db_gathered(spfe_handle h, int n, hipStream_t s) {
+  const ConvLayer &L = h->layers[9];
+  const int max_total = n * h->db_cap;
+  if (h->bf16) HIP_TRY(spfe::launch_head1x1_bf16_gather(h->d_hd, h->d_wdb, L.d_b, h->d_coarse, n * h->C, h->d_db_list, h->d_db_total, max_total, h->db_tiles_per_wg, s));
+  else HIP_TRY(spfe::launch_head1x1_f32_gather(h->d_head, h->d_wdb32, L.d_b, h->d_coarse, n * h->C, h->d_db_list, h->d_db_total, max_total, h->db_tiles_per_wg, s));
+  return SPFE_OK;
+}
+
+// The dense descriptor head over the last call's head activations (spfe_debug_read("coarse") after a sparse call).
+int launch_db_dense(spfe_handle h, int n, hipStream_t s) {
+  const ConvLayer &L = h->layers[9];
+  if (h->bf16) HIP_TRY(spfe::launch_head1x1_bf16(h->d_hd, h->d_wdb, L.d_b, h->d_coarse, n * h->C, 256, s));
+  else HIP_TRY(spfe::launch_head1x1_f32(h->d_head, h->d_wdb32, L.d_b, h->d_coarse, n * h->C, 256, s));
+  return SPFE_OK;
+}
+
 // Detector tail, selection, descriptors, covariance for n frames whose semi /
 // coarse maps are in the handle's buffers.
-int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const std::function<int()> *conv_db) {
+int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const std::function<int()> *conv_db, bool sparse) {
   const int H = h->H, W = h->W;
   spfe::FrameBufs f{};
   f.semi = h->d_semi; f.coarse = h->d_coarse;
+  if (sparse) { f.db_list = h->d_db_list; f.db_total = h->d_db_total; }
+  h->sparse_last = sparse;
   const int par = (int)(h->ticket & 1);
   f.heat_log = h->d_heat_log[par]; f.heat = h->d_heat; f.heat_inv = h->d_heat_inv;
   f.minmax = reinterpret_cast<uint32_t *>(h->d_minmax[par]);
@@ -1001,7 +1054,12 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
   // Synchronous calls: the descriptor sampling rides in the covariance replay launch (the chain's longest kernel) instead of
   // standing in front of the chain; pipelined calls keep it early — the NEXT call's convDb waits for it, and behind a replay
   // that shares the chip with that call's convolutions it would wait too long (0.5 ms steps in bf16 mode).
-  const bool desc_in_replay = h->desc_in_replay && !((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode) && !(h->timing && h->timing_all);
+  const bool sync_call = !((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode);
+  // pipelined calls, sparse: nothing on the launch stream waits for the sampling any more (the dense convDb of the NEXT call
+  // did), so it may ride in the replay launch there too: bf16 1280x720 +0.2 %, f32 752x480 -0.7 % (kept early in f32 mode)
+  static const int sparse_dir_env = getenv("SPFE_SPARSE_DESC_IN_REPLAY") ? atoi(getenv("SPFE_SPARSE_DESC_IN_REPLAY")) : -1;
+  const bool sparse_dir = sparse_dir_env < 0 ? h->bf16 : sparse_dir_env != 0;
+  const bool desc_in_replay = h->desc_in_replay && (sync_call || (sparse && sparse_dir)) && !(h->timing && h->timing_all);
   hipEvent_t before_replay = nullptr;
   if (conv_db) {   // the descriptor head, launched behind the detector tail (enqueue()): the sampling waits for it
     const int rc = (*conv_db)();
@@ -1009,6 +1067,23 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
     HIP_TRY(hipEventRecord(h->ev_db, s));
     if (desc_in_replay) before_replay = h->ev_db;
     else HIP_TRY(hipStreamWaitEvent(h->side, h->ev_db, 0));
+  }
+  if (sparse) {
+    // The gathered descriptor head.  Synchronous calls: on the launch stream, behind the selection, beside the covariance
+    // chain's first kernels; the replay launch (which carries the sampling) waits for it.  Pipelined calls: in the side chain.
+    if (desc_in_replay && sync_call) {
+      HIP_TRY(hipEventRecord(h->ev_sel, h->side));
+      HIP_TRY(hipStreamWaitEvent(s, h->ev_sel, 0));
+      const int rc = launch_db_gathered(h, n, s);
+      if (rc) return rc;
+      HIP_TRY(hipEventRecord(h->ev_dbs, s));
+      before_replay = h->ev_dbs;
+    } else {
+      const int rc = launch_db_gathered(h, n, h->side);
+      if (rc) return rc;
+      HIP_TRY(hipEventRecord(h->ev_dbs, h->side));
+    }
+    h->dbs_recorded = true;
   }
   if (!desc_in_replay) {
     HIP_TRY(spfe::launch_desc(f, h->rl, n, H, W, h->side));
@@ -1109,6 +1184,8 @@ void spfe_destroy(spfe_handle h) {
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   for (hipStream_t c : h->conv2_pool) (void)hipStreamDestroy(c);
   if (h->ev_db) (void)hipEventDestroy(h->ev_db);
+  if (h->ev_sel) (void)hipEventDestroy(h->ev_sel);
+  if (h->ev_dbs) (void)hipEventDestroy(h->ev_dbs);
   (void)spfe_comm_destroy(h);
   for (auto &ps : h->pipe) {
     if (ps.ev_h2d) (void)hipEventDestroy(ps.ev_h2d);
@@ -1250,7 +1327,17 @@ long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size
   bool bf16_src = false;
   std::string nm(name);
   if (nm == "semi") { src = h->d_semi + frame * C * SPFE_SEMI_CH; bytes = C * SPFE_SEMI_CH * 4; }
-  else if (nm == "coarse") { src = h->d_coarse + frame * C * SPFE_DESC_DIM; bytes = C * SPFE_DESC_DIM * 4; }
+  else if (nm == "coarse" || nm == "coarse_sparse") {
+    src = h->d_coarse + frame * C * SPFE_DESC_DIM; bytes = C * SPFE_DESC_DIM * 4;
+    if (nm == "coarse" && h->sparse_last) {   // the last call wrote only the rows its keypoints read: complete the map
+      if (hipSetDevice(h->cfg.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(SPFE_EHIP, "debug read of 'coarse' failed");
+      const int rc = launch_db_dense(h, h->last_n, h->stream);
+      if (rc) return rc;
+      h->sparse_last = false;
+    }
+  }
+  else if (nm == "db_total" && h->d_db_total) { src = h->d_db_total; bytes = 4; }
+  else if (nm == "db_list" && h->d_db_list) { src = h->d_db_list; bytes = (size_t)h->B * h->db_cap * 4; }
   else if (nm == "head") {
     if (h->bf16) return fail(SPFE_EINVAL, "'head' is f32 only: the bf16 mode keeps ReLU(convPa) | ReLU(convDa) as bf16");
     src = h->d_head + frame * C * 512; bytes = C * 512 * 4;

@@ -60,12 +60,18 @@ inline size_t conv1a_bf16_table_bytes() { return 2 * 64 * 8 * 2; }
 // wpack: head_bf16_weight_bytes(cout) bytes in MFMA fragment order, made by head_bf16_pack_weights from Wb = [cout][256] bf16
 hipError_t launch_head1x1_bf16(const void *in_bf16, const void *wpack, const float *bias, float *out, int npix, int cout,
                                hipStream_t s);
+// the descriptor head (cout = 256) on the *total (<= max_total) rows of in_bf16 / out that `list` names (device memory,
+// select_kernel's FrameBufs::db_list / db_total): "sparse convDb"
+hipError_t launch_head1x1_bf16_gather(const void *in_bf16, const void *wpack, const float *bias, float *out, int npix,
+                                      const int *list, const int *total, int max_total, int tiles_per_wg, hipStream_t s);
 size_t head_bf16_weight_bytes(int cout);
 void head_bf16_pack_weights(const unsigned short *Wb, int cout, unsigned char *dst);
 
 // f32 mode, the 1x1 heads (head_f32.hip): same shapes, in / out f32, bit-identical to conv_f32.hip's 1x1 path
 hipError_t launch_head1x1_f32(const float *in, const float *wpack, const float *bias, float *out, int npix, int cout,
                               hipStream_t s);
+hipError_t launch_head1x1_f32_gather(const float *in, const float *wpack, const float *bias, float *out, int npix,
+                                     const int *list, const int *total, int max_total, int tiles_per_wg, hipStream_t s);
 size_t head_f32_weight_bytes(int cout);
 void head_f32_pack_weights(const float *W, int cout, float *dst);
 
@@ -91,6 +97,8 @@ struct FrameBufs {
   int *kp_cell;         // [B][kmax] cell index of emitted keypoint
   int *sel_slot;        // [B][C] frames of more than 16,384 cells: select_kernel's per-cell slot / index hand-off (else null)
   uint16_t *sel_list;   // [B][C] ... and its tie / layout list
+  int *db_list;         // [B * min(4 kmax, C)] global cell indices (b * C + cell) some emitted keypoint's descriptor taps read,
+  int *db_total;        // [1] ... and how many: written by select_kernel for the gathered descriptor head (or both null)
   uint8_t *records;     // [B][record_bytes]
   float *heat_consts;   // [B][4] a_heat, b_heat, a_inv, b_inv
 };

@@ -14,6 +14,8 @@
 #include "spfe_kernels.h"
 #include "../../include/spfe_exact_math.h"
 
+#include "desc_body.h"
+
 namespace spfe {
 
 #define TAIL_THREADS 256  // tail_kernel: 4 waves x 16 cells per workgroup (a DPP quad per cell)
@@ -290,11 +292,15 @@ __device__ __forceinline__ void nms_mask_body(const FrameBufs &f, int hc, int wc
   f.cell_mask[(size_t)b * C + c] = (uint8_t)m;
 }
 
-__global__ __launch_bounds__(256) void nms_mask_kernel(FrameBufs f, int hc, int wc) { nms_mask_body(f, hc, wc, blockIdx.y, blockIdx.x); }
+__global__ __launch_bounds__(256) void nms_mask_kernel(FrameBufs f, int hc, int wc) {
+  if (f.db_total && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *f.db_total = 0;   // select_kernel (next launch) appends
+  nms_mask_body(f, hc, wc, blockIdx.y, blockIdx.x);
+}
 // The neighbour masks (input of the selection) and the heat normalisation (input of the covariance stage) both depend on the
 // detector tail only: ONE launch, the first `nmask` blocks of a frame do the masks, the rest the normalisation — a kernel
 // boundary less on the latency-bound side chain.
 __global__ __launch_bounds__(256) void mask_and_heat_norm_kernel(FrameBufs f, int H, int W, int nparts, CovScratch cs, int kmax, int nmask) {
+  if (f.db_total && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *f.db_total = 0;   // select_kernel (next launch) appends
   if ((int)blockIdx.x < nmask) nms_mask_body(f, H >> 3, W >> 3, blockIdx.y, blockIdx.x);
   else heat_norm_body(f, H, W, nparts, cs, kmax, blockIdx.y, (int)blockIdx.x - nmask, (int)gridDim.x - nmask);
 }
@@ -305,7 +311,8 @@ __global__ __launch_bounds__(256) void mask_and_heat_norm_kernel(FrameBufs f, in
 // slot / index hand-off, the tie / layout list) in global scratch (FrameBufs::sel_slot / sel_list), which a single
 // workgroup reads back coherently through its CU's L1 behind __syncthreads().
 constexpr int SELECT_SMALL_CELLS = 16384;   // (also the register-resident key path of the cut: 16 cells per thread)
-static size_t select_fixed_lds(int H) { return ((size_t)(H / 8) + 16) * 4 * 2 + 64 + 1024 * 4 + 64 + 64; }
+constexpr int SELECT_DB_WORDS = 2048 + 32;   // bitmap of the cells the descriptor head must compute (<= 65,535 cells) + scan scratch
+static size_t select_fixed_lds(int H) { return ((size_t)(H / 8) + 16) * 4 * 2 + 64 + 1024 * 4 + 64 + 64 + SELECT_DB_WORDS * 4; }
 bool select_big(int H, int W) { return (size_t)(H / 8) * (W / 8) > (size_t)SELECT_SMALL_CELLS; }
 size_t select_lds_bytes(int H, int W) {
   const size_t C = (size_t)(H / 8) * (W / 8);
@@ -354,6 +361,9 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
   SEL_TP(0);
   if (tid < 8) sCnt[tid] = 0;
   for (int i = tid; i < hc + 1; i += 1024) sRow[i] = 0;
+  unsigned *const sBits = reinterpret_cast<unsigned *>(sRowBase + (hc + 16) + 16 + 1024 + 16);   // behind sHist: [2048] bits, [16] wave totals, [1] base
+  if (f.db_list)
+    for (int i = tid; i < 2048; i += 1024) sBits[i] = 0;
   __syncthreads();
   // a candidate nobody can suppress is alive from the start; `und` = this thread's undecided cells (bit j <-> cell
   // tid + 1024 j; C <= 65535), so that the rounds only touch what is still open
@@ -590,8 +600,46 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
     kp_xy[2 * idx + 1] = (float)(cy * 8 + (k >> 3));
     kp_cell[idx] = c;
     slotp[c] = idx;
+    if (f.db_list) {   // the coarse cells this keypoint's descriptor reads (desc_keypoint's taps, same arithmetic)
+      const DescTaps tp = desc_taps((float)(cx * 8 + (k & 7)), (float)(cy * 8 + (k >> 3)), H, W);
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) {
+        const int txx = tp.x0 + (t4 & 1), tyy = tp.y0 + (t4 >> 1);
+        if (txx < 0 || txx >= wc || tyy < 0 || tyy >= hc) continue;
+        const int cell = tyy * wc + txx;
+        atomicOr(&sBits[cell >> 5], 1u << (cell & 31));
+      }
+    }
   }
   __syncthreads();
+  if (f.db_list) {
+    // the marked cells, in cell order, appended to the batch's list: two bitmap words per thread, a workgroup scan of their
+    // counts, one global atomic per frame for the base (the frames' order in the list does not matter: a cell's output row
+    // depends on its own input row only)
+    const unsigned b0 = sBits[2 * tid], b1 = sBits[2 * tid + 1];
+    const int cnt = __popc(b0) + __popc(b1);
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    int *sTot = reinterpret_cast<int *>(sBits + 2048);
+    if (lane == 63) sTot[wave] = incl;
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < 16; ++w2) {
+      const int v = sTot[w2];
+      wbase += w2 < wave ? v : 0;
+      total += v;
+    }
+    if (tid == 0) sTot[16] = atomicAdd(f.db_total, total);
+    __syncthreads();
+    int pos = sTot[16] + wbase + incl - cnt;
+    for (unsigned rest = b0; rest; rest &= rest - 1) f.db_list[pos++] = b * C + 64 * tid + (__ffs((int)rest) - 1);
+    for (unsigned rest = b1; rest; rest &= rest - 1) f.db_list[pos++] = b * C + 64 * tid + 32 + (__ffs((int)rest) - 1);
+  }
 #pragma unroll 4
   for (int c = tid; c < C; c += 1024)
     occ[c] = sState[c] == ST_KEPT ? (int16_t)slotp[c] : (int16_t)-1;
@@ -628,9 +676,6 @@ hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H
   return hipGetLastError();
 }
 
-}  // namespace spfe
-#include "desc_body.h"
-namespace spfe {
 
 __global__ __launch_bounds__(256) void desc_kernel(FrameBufs f, RecordLayout rl, int H, int W) {
   desc_keypoint(f, rl, H, W, blockIdx.y, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);

@@ -691,8 +691,14 @@ class SPExtractor:
         ch = [64, 64, 64, 64, 128, 128, 128, 128]
         for i in range(8):
             shapes["act%d" % i] = (self.height // div[i], self.width // div[i], ch[i])
+        shapes["coarse_sparse"] = shapes["coarse"]   # the descriptor map as the last call left it (only the rows it read)
         if name.startswith("cov_"):   # covariance scratch (int32): counters [4], nxt / workers / npop [kmax]
             out = np.empty(4 if name == "cov_counters" else self.nfeatures + 1, np.int32)
+        elif name == "db_total":      # gathered descriptor head: number of listed cells of the last call
+            out = np.empty(1, np.int32)
+        elif name == "db_list":       # ... and the list (global cell indices b * C + cell), max_batch * min(4 kmax, C) entries
+            C_ = (self.height // 8) * (self.width // 8)
+            out = np.empty(self.max_batch * min(4 * (self.nfeatures + 1), C_), np.int32)
         else:
             out = (np.empty((self.height, self.width), np.uint8) if name == "image"   # the staged gray frame
                    else np.empty(shapes[name], np.float32))

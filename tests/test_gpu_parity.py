@@ -650,6 +650,7 @@ def test_f32_heads_with_register_resident_weights_are_bit_identical(monkeypatch)
     blob = weights.synthetic(7, "dense")
     imgs = [synth.make_image(60 + i, H, W) for i in range(3)]
     out = {}
+    monkeypatch.setenv("SPFE_SPARSE_DB", "0")   # (the gathered descriptor head IS head_f32.hip's kernel: compare the dense launches)
     for flag in ("0", "1"):
         monkeypatch.setenv("SPFE_F32_HEADS", flag)
         ext = SPExtractor(nf, H, W, blob, max_batch=3, with_heat=False)
