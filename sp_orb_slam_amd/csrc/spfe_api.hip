@@ -126,12 +126,21 @@ struct spfe_handle_s {
   // the dense layout, only the rows anybody reads are written.  SPFE_SPARSE_DB=0: the dense head in the launch stream.
   bool sparse_db = true;
   bool sparse_last = false;      // the last call left d_coarse sparse (spfe_debug_read("coarse") completes it on demand)
+  // ... and convDa with it (bf16 mode, da_gather_bf16.hip): the dense launch computes convPa only, the descriptor branch
+  // runs on the listed cells from conv4b's output on.  SPFE_SPARSE_DA=0: convPa|Da dense, only convDb gathered.
+  bool sparse_da = false;
+  int sparse_da_mode = 1;        // SPFE_SPARSE_DA: 0 never, 1 synchronous calls only (default), 2 pipelined calls too
+  bool sparse_da_call = false;   // ... this / the last call
   int *d_db_list = nullptr, *d_db_total = nullptr;
   int db_cap = 0;                // list entries per frame: min(4 kmax, C)
   int db_tiles_per_wg = 4;       // SPFE_DB_TILES_PER_WG: the gathered head's grid = listed tiles / this (a workgroup's weights: 128 KB)
   hipEvent_t ev_sel = nullptr;   // side stream: this call's selection (and its cell list) is done
-  hipEvent_t ev_dbs = nullptr;   // the last call's gathered head (reader of the head activations) is done
-  bool dbs_recorded = false;
+  hipEvent_t ev_dbs[2] = {};     // by ticket parity: that call's gathered head (reader of the head activations / of conv4b's output) is done
+  bool dbs_recorded[2] = {};
+  // sparse_da: conv4b's output exists twice (by ticket parity), so that the NEXT call's conv4b does not wait for this
+  // call's gathered convDa, which runs behind the selection on the side stream
+  float *act7_alt = nullptr;
+  const float *feat_cur = nullptr;   // conv4b's output of the call being enqueued / of the last call
   // what the detector tail (launch stream) hands to the side chain exists twice, by ticket parity: batch i + 1's tail then
   // only has to wait for batch i - 1's side chain, not for batch i's (which runs beside batch i + 1's convolutions)
   float *d_heat_log[2] = {}, *d_heat = nullptr, *d_heat_inv = nullptr;
@@ -481,7 +490,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
   if (const char *e = getenv("SPFE_BF16_SPLIT")) h->bf16_split = atoi(e);
   HIP_TRY(hipEventCreateWithFlags(&h->ev_db, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&h->ev_sel, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&h->ev_dbs, hipEventDisableTiming));
+  for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&h->ev_dbs[i], hipEventDisableTiming));
   // Measured, pipelined, 8 frames per call (same-box A/B): bf16 1280x720 +2.5 ... 3.8 % (7590 -> 7780, 7322 -> 7604 frames/s),
   // f32 752x480 +0.4 ... 0.7 %, bf16 752x480 -2 ... 3 %: there the launch stream runs as two half batches on two streams, the
   // dense head (HBM-bound) hid completely beside the other half's convolutions (removing it altogether gains nothing), and
@@ -676,6 +685,14 @@ int build(spfe_handle h, const spfe_config *cfg) {
         if ((rc = pack_layer_bf16_rw(h, blob.data(), lids2, specs[i].nl, &h->d_wrw[i - 4]))) return rc;
       }
     if ((rc = dev_alloc(h, &h->d_tile_ctr, 8 * 64))) return rc;   // [layer][part of the batch][32]
+    h->sparse_da = h->sparse_db && h->d_wrw[3] && (size_t)B * C * 1024 < ((size_t)1 << 31);
+    // Measured at 1280x720 x 8 (da_gather_bf16.hip): 25 us alone against the 43 us the dense launch loses without convDa, a
+    // single-frame call's p50 0.357 -> 0.352 ms; but pipelined 7640 -> 7500 frames/s — a workgroup needs a whole CU (148 KB
+    // of LDS, 380 registers), so beside the next batch's convolutions it only starts where one of theirs has ended, and
+    // then holds that CU for its ~6 tiles.  So: synchronous calls only.
+    if (const char *e = getenv("SPFE_SPARSE_DA")) h->sparse_da_mode = atoi(e);
+    h->sparse_da = h->sparse_da && h->sparse_da_mode != 0;
+    if (h->sparse_da && (rc = dev_alloc(h, &h->act7_alt, (size_t)B * C * 128))) return rc;
   }
   if (!h->bf16) {  // f32 heads with register-resident weights (head_f32.hip), bit-identical to the generic kernel — opt-in:
     // measured 63 + 38.5 us per eight 752x480 frames against 72 + 35.5 for the generic kernel (matrix-bound: 47 us at the peak)
@@ -819,6 +836,11 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   // frames [f0, f0 + nfr) of the batch on stream `s` (the whole batch on the caller's stream by default)
   const int n_all = n;
   hipStream_t const s_all = s;
+  const bool sparse = h->sparse_db && h->d_db_list;   // the descriptor head (bf16: convDa too) runs gathered, in enqueue_post
+  const bool sparse_da = sparse && h->bf16 && h->sparse_da && (h->sparse_da_mode >= 2 || !((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode));
+  h->sparse_da_call = sparse_da;
+  const int par_db = (int)(h->ticket & 1);
+  h->feat_cur = sparse_da && par_db ? h->act7_alt : h->act[7];
   auto run_layer = [&](int i, int f0 = 0, int nfr = -1, hipStream_t s_use = nullptr) -> int {
     const ConvLayer &L = h->layers[i];
     hipStream_t s = s_use ? s_use : s_all;
@@ -826,12 +848,17 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     // convDb overwrites the coarse descriptor map the PREVIOUS call's descriptor sampling reads on
     // the side stream (pipelined callers): order it after that, by event, not by timing
     if (i == 9 && h->desc_recorded) HIP_TRY(hipStreamWaitEvent(s, h->ev_desc, 0));
-    // convPa | convDa overwrite the head activations the PREVIOUS call's gathered descriptor head reads (side stream)
-    if (i == 7 && h->dbs_recorded) HIP_TRY(hipStreamWaitEvent(s, h->ev_dbs, 0));
+    // convPa | convDa overwrite the head activations the PREVIOUS call's gathered descriptor head reads (side stream).
+    // sparse_da: the dense launch writes convPa's channels only, the gathered convDa / convDb touch the others; what the
+    // gathered convDa reads is conv4b's output — kept twice, so conv4b waits for the call TWO tickets back
+    if (!sparse_da && i == 7 && h->dbs_recorded[par_db ^ 1]) HIP_TRY(hipStreamWaitEvent(s, h->ev_dbs[par_db ^ 1], 0));
+    if (sparse_da && i == 6 && h->dbs_recorded[par_db]) HIP_TRY(hipStreamWaitEvent(s, h->ev_dbs[par_db], 0));
     spfe::ConvParams p;
     p.in = L.in; p.in_stride = L.in_stride; p.in_choff = L.in_choff;
     p.wpack = L.d_w; p.bias = L.d_b;
     p.out = L.out; p.out_stride = L.out_stride; p.out_choff = L.out_choff; p.cout_real = L.cout_real;
+    if (sparse_da && i == 6) p.out = const_cast<float *>(h->feat_cur);
+    if (sparse_da && i == 7) p.in = h->feat_cur;
     p.B = n; p.H = L.H; p.W = L.W;
     const int part = f0 > 0 ? 1 : 0;
     // first frame of this part: byte offsets (bf16 activations are 2-byte elements behind the float pointers)
@@ -839,8 +866,8 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
       return reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + elems * (h->bf16 ? 2 : 4));
     };
     if (f0 > 0) {
-      p.in = shift(L.in, (size_t)f0 * L.H * L.W * L.in_stride);
-      p.out = const_cast<float *>(shift(L.out, (size_t)f0 * (L.pool ? (L.H / 2) * (L.W / 2) : L.H * L.W) * L.out_stride));
+      p.in = shift(p.in, (size_t)f0 * L.H * L.W * L.in_stride);
+      p.out = const_cast<float *>(shift(p.out, (size_t)f0 * (L.pool ? (L.H / 2) * (L.W / 2) : L.H * L.W) * L.out_stride));
     }
     p.img = nullptr; p.w1a = nullptr; p.b1a = nullptr; p.tile_ctr = nullptr;
     if (i == 0 && fused) { p.img = d_images; p.w1a = h->d_w1a; p.b1a = h->d_b1a; }
@@ -870,11 +897,12 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
       // without a pool) -3...5 % on convPa|Da; 16-row tiles need 512 VGPRs + spills and lose 35 %: not the default.
       if (i == 7) {   // convPa | convDa: one launch, 512 output channels, bf16 (both 1x1 heads are bf16 GEMMs)
         p.out = reinterpret_cast<float *>(h->d_hd + (size_t)f0 * h->C * 512); p.out_stride = 512; p.out_choff = 0;
+        if (sparse_da) p.nblk = L.nblk / 2;   // convPa only: convDa runs gathered, behind the selection (da_gather_bf16.hip)
       }
       // Cin = 128: weights resident in registers (conv_bf16_rw.hip) when every workgroup of a 128-channel group gets enough
       // tiles; 4-row tiles, or 2-row tiles for the small launches (twice the tiles)
       if (L.cin == 128 && h->bf16_rw && h->d_wrw[i - 4] && L.W >= 32 && !(L.W & 1) && !(L.pool && (L.H & 1))) {
-        const int ncg = L.nblk / 2;
+        const int ncg = p.nblk / 2;
         const long wgs = std::max(8L * ncg, (long)((h->num_cus > 0 ? h->num_cus : 256) / (8 * ncg)) * 8 * ncg) / ncg;
         const long t4 = (long)p.tiles_x * ((L.H + 3) / 4) * n, t2 = (long)p.tiles_x * ((L.H + 1) / 2) * n;
         int tr = t4 >= (long)h->rw_min4 * wgs ? 4 : t2 >= (long)h->rw_min2 * wgs ? 2 : 0;
@@ -957,7 +985,6 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   // per-stage events (SPFE_STAGE_TIMING=1) the launch order stays the table's order.
   // Synchronous calls only: in the pipelined modes the side chain runs beside the NEXT batch anyway, and the deferred order
   // measured 0.3 ... 0.7 % slower there.
-  const bool sparse = h->sparse_db && h->d_db_list;
   const bool defer_db = !sparse && !(h->timing && h->timing_all) && h->defer_db && !((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode);
   const int nlayers = sparse ? 9 : 10;   // sparse: convDb is enqueue_post's gathered launch behind the selection
   // f32, >= 2 frames: conv1b for the whole batch (its work list divides evenly over the CUs), then everything behind it as
@@ -1000,6 +1027,8 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
 int launch_db_gathered(spfe_handle h, int n, hipStream_t s) {
   const ConvLayer &L = h->layers[9];
   const int max_total = n * h->db_cap;
+  if (h->bf16 && h->sparse_da_call)
+    HIP_TRY(spfe::launch_da_gather_bf16(h->feat_cur, h->d_wrw[3], h->layers[7].d_b, h->d_hd, h->d_db_list, h->d_db_total, max_total, n, h->hc, h->wc, h->num_cus, s));
   if (h->bf16) HIP_TRY(spfe::launch_head1x1_bf16_gather(h->d_hd, h->d_wdb, L.d_b, h->d_coarse, n * h->C, h->d_db_list, h->d_db_total, max_total, h->db_tiles_per_wg, s));
   else HIP_TRY(spfe::launch_head1x1_f32_gather(h->d_head, h->d_wdb32, L.d_b, h->d_coarse, n * h->C, h->d_db_list, h->d_db_total, max_total, h->db_tiles_per_wg, s));
   return SPFE_OK;
@@ -1008,6 +1037,19 @@ int launch_db_gathered(spfe_handle h, int n, hipStream_t s) {
 // The dense descriptor head over the last call's head activations (spfe_debug_read("coarse") after a sparse call).
 int launch_db_dense(spfe_handle h, int n, hipStream_t s) {
   const ConvLayer &L = h->layers[9];
+  if (h->bf16 && h->sparse_da_call) {   // convDa was gathered too: the same kernel over a list of ALL cells (a debug path)
+    const int all = n * h->C;
+    std::vector<int> cells((size_t)all + 1);
+    for (int i = 0; i < all; ++i) cells[i] = i;
+    cells[all] = all;
+    int *d_tmp = nullptr;
+    HIP_TRY(hipMalloc(&d_tmp, cells.size() * sizeof(int)));
+    hipError_t e = hipMemcpy(d_tmp, cells.data(), cells.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = spfe::launch_da_gather_bf16(h->feat_cur, h->d_wrw[3], h->layers[7].d_b, h->d_hd, d_tmp, d_tmp + all, all, n, h->hc, h->wc, h->num_cus, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_tmp);
+    HIP_TRY(e);
+  }
   if (h->bf16) HIP_TRY(spfe::launch_head1x1_bf16(h->d_hd, h->d_wdb, L.d_b, h->d_coarse, n * h->C, 256, s));
   else HIP_TRY(spfe::launch_head1x1_f32(h->d_head, h->d_wdb32, L.d_b, h->d_coarse, n * h->C, 256, s));
   return SPFE_OK;
@@ -1076,14 +1118,14 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
       HIP_TRY(hipStreamWaitEvent(s, h->ev_sel, 0));
       const int rc = launch_db_gathered(h, n, s);
       if (rc) return rc;
-      HIP_TRY(hipEventRecord(h->ev_dbs, s));
-      before_replay = h->ev_dbs;
+      HIP_TRY(hipEventRecord(h->ev_dbs[par], s));
+      before_replay = h->ev_dbs[par];
     } else {
       const int rc = launch_db_gathered(h, n, h->side);
       if (rc) return rc;
-      HIP_TRY(hipEventRecord(h->ev_dbs, h->side));
+      HIP_TRY(hipEventRecord(h->ev_dbs[par], h->side));
     }
-    h->dbs_recorded = true;
+    h->dbs_recorded[par] = true;
   }
   if (!desc_in_replay) {
     HIP_TRY(spfe::launch_desc(f, h->rl, n, H, W, h->side));
@@ -1185,7 +1227,7 @@ void spfe_destroy(spfe_handle h) {
   for (hipStream_t c : h->conv2_pool) (void)hipStreamDestroy(c);
   if (h->ev_db) (void)hipEventDestroy(h->ev_db);
   if (h->ev_sel) (void)hipEventDestroy(h->ev_sel);
-  if (h->ev_dbs) (void)hipEventDestroy(h->ev_dbs);
+  for (int i = 0; i < 2; ++i) if (h->ev_dbs[i]) (void)hipEventDestroy(h->ev_dbs[i]);
   (void)spfe_comm_destroy(h);
   for (auto &ps : h->pipe) {
     if (ps.ev_h2d) (void)hipEventDestroy(ps.ev_h2d);
@@ -1351,7 +1393,7 @@ long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size
   else if (nm == "cov_nxt") { src = h->cov.nxt + (size_t)frame * h->kmax; bytes = (size_t)h->kmax * 4; }
   else if (nm == "cov_workers") { src = h->cov.workers + (size_t)frame * h->kmax; bytes = (size_t)h->kmax * 4; }
   else if (nm == "cov_npop") { src = h->cov.npop + (size_t)frame * h->kmax; bytes = (size_t)h->kmax * 4; }
-  else if (nm == "feat") { src = h->act[7] + frame * C * 128; bytes = C * 128 * 4; bf16_src = h->bf16; }
+  else if (nm == "feat") { src = (h->feat_cur ? h->feat_cur : h->act[7]) + frame * C * 128; bytes = C * 128 * 4; bf16_src = h->bf16; }
   else if (nm.size() == 4 && nm.compare(0, 3, "act") == 0 && nm[3] >= '0' && nm[3] <= '7') {
     const int i = nm[3] - '0';
     if (i == 0 && h->act0_missing)
@@ -1372,7 +1414,7 @@ long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size
     const size_t n = bytes / 4;
     std::vector<unsigned short> tmp(n);
     const unsigned short *bsrc = reinterpret_cast<const unsigned short *>(
-        nm == "feat" ? (const void *)h->act[7] : (const void *)h->act[nm[3] - '0']) + (size_t)frame * n;
+        nm == "feat" || nm == "act7" ? (const void *)(h->feat_cur ? h->feat_cur : h->act[7]) : (const void *)h->act[nm[3] - '0']) + (size_t)frame * n;
     if (hipMemcpy(tmp.data(), bsrc, n * 2, hipMemcpyDeviceToHost) != hipSuccess)
       return fail(SPFE_EHIP, "debug read of '%s' failed", name);
     uint32_t *d32 = reinterpret_cast<uint32_t *>(dst);

@@ -64,6 +64,10 @@ hipError_t launch_head1x1_bf16(const void *in_bf16, const void *wpack, const flo
 // select_kernel's FrameBufs::db_list / db_total): "sparse convDb"
 hipError_t launch_head1x1_bf16_gather(const void *in_bf16, const void *wpack, const float *bias, float *out, int npix,
                                       const int *list, const int *total, int max_total, int tiles_per_wg, hipStream_t s);
+// convDa (3x3, 128 -> 256, ReLU) on the listed cells (da_gather_bf16.hip): feat = conv4b's output [B][hc][wc][128] bf16,
+// wpack = convPa|Da in conv_bf16_rw_pack_weights order, out = head activations [B * hc * wc][512] bf16 (channels 256..511)
+hipError_t launch_da_gather_bf16(const void *feat, const void *wpack, const float *bias, void *out, const int *list,
+                                 const int *total, int max_total, int B, int hc, int wc, int num_cus, hipStream_t s);
 size_t head_bf16_weight_bytes(int cout);
 void head_bf16_pack_weights(const unsigned short *Wb, int cout, unsigned char *dst);
 

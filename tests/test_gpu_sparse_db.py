@@ -42,17 +42,24 @@ def _tap_cells(kp_xy, H, W):
 @pytest.mark.parametrize("H,W,B,nf", [(240, 376, 2, 300), (480, 752, 3, 1000), (720, 1280, 2, 1000), (120, 160, 1, 1000),
                                       (136, 200, 2, 50)])
 def test_cell_list_is_the_union_of_the_taps_and_its_rows_are_the_dense_bits(monkeypatch, precision, H, W, B, nf):
-    monkeypatch.setenv("SPFE_SPARSE_DB", "1")
     blob = weights.synthetic(7, "dense")
     imgs = [synth.make_image(70 + i, H, W) for i in range(B)]
     C = (H // 8) * (W // 8)
+    monkeypatch.setenv("SPFE_SPARSE_DB", "0")       # the dense launches (convPa|Da, convDb) of another handle
+    ext = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=False, precision=precision)
+    ext.extract_batch(imgs)
+    dense = [ext.debug_read("coarse", i).reshape(C, 256).copy() for i in range(B)]
+    ext.close()
+    monkeypatch.setenv("SPFE_SPARSE_DB", "1")
     ext = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=False, precision=precision)
     frs = ext.extract_batch(imgs)
     raw = [ext.debug_read("coarse_sparse", i).reshape(C, 256).copy() for i in range(B)]
     total = int(ext.debug_read("db_total")[0])
     cells = ext.debug_read("db_list")[:total].copy()
-    dense = [ext.debug_read("coarse", i).reshape(C, 256).copy() for i in range(B)]   # (completes the map: dense launch)
+    full = [ext.debug_read("coarse", i).reshape(C, 256).copy() for i in range(B)]   # (completes the map on demand)
     ext.close()
+    for b in range(B):
+        assert np.array_equal(_bits(full[b]), _bits(dense[b]))
     assert len(set(cells.tolist())) == total
     for b in range(B):
         mine = np.sort(cells[(cells >= b * C) & (cells < (b + 1) * C)] - b * C)
