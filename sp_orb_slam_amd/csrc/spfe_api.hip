@@ -1618,7 +1618,12 @@ int spfe_submit_batch(spfe_handle h, const uint8_t *const *images, int stride, i
   // batch's convolutions until the previous batch's covariance had finished — tools/microbench/run_hosttrace.sh.)
   hipStream_t sc = h->side;
   {
-    static const int copy_mode = getenv("SPFE_PIPE_COPY_KERNEL") ? atoi(getenv("SPFE_PIPE_COPY_KERNEL")) : 1;
+    // f32 mode: a copy kernel of our own (2038 against 2000 ... 2028 frames/s with the runtime's copy at 752x480 x 8).  bf16
+    // mode: the runtime's copy engine — the kernel's 64 workgroups sit on the chip for the 0.2 ms the PCIe transfer takes,
+    // beside convolutions that are 4x shorter than the f32 ones: 6895 against 7990 frames/s at 1280x720 x 8 (= the
+    // device-resident rate)
+    static const int copy_env = getenv("SPFE_PIPE_COPY_KERNEL") ? atoi(getenv("SPFE_PIPE_COPY_KERNEL")) : -1;
+    const int copy_mode = copy_env >= 0 ? copy_env : (h->bf16 ? 0 : 1);
     if (copy_mode == 1) {          // a copy kernel of our own writing the pinned buffer
       const size_t n16 = ((size_t)n * h->rl.bytes + 15) / 16;
       hipLaunchKernelGGL(copy16_kernel, dim3(64), dim3(256), 0, sc, reinterpret_cast<uint4 *>(ps.h_rec),
