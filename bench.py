@@ -48,14 +48,15 @@ def path_tflops(ext, fps, H, W, B):
     nominal = FLOP_PER_FRAME[(H, W)]
     C = (H // 8) * (W // 8)
     try:
+        da = bool(ext.debug_read("da_gathered")[0])                  # (read first: reading db_total does not change it)
         frac = float(ext.debug_read("db_total")[0]) / float(B * C)   # the last call's list
         gathered = True
     except Exception:
-        frac, gathered = 1.0, False
-    executed = nominal - (1.0 - frac) * C * 2 * 256 * 256
+        frac, gathered, da = 1.0, False, False
+    executed = nominal - (1.0 - frac) * C * (2 * 256 * 256 + (2 * 9 * 128 * 256 if da else 0))
     return {"whole_path_tflops": round(fps * executed / 1e12, 2),
             "whole_path_tflops_dense_graph": round(fps * nominal / 1e12, 2),
-            "descriptor_head": {"gathered": gathered, "cells_computed_frac": round(frac, 4)}}
+            "descriptor_head": {"convDb_gathered": gathered, "convDa_gathered": da, "cells_computed_frac": round(frac, 4)}}
 
 
 def file_sha16(path):

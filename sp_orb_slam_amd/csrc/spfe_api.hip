@@ -140,6 +140,7 @@ struct spfe_handle_s {
   // sparse_da: conv4b's output exists twice (by ticket parity), so that the NEXT call's conv4b does not wait for this
   // call's gathered convDa, which runs behind the selection on the side stream
   float *act7_alt = nullptr;
+  float *d_wda32 = nullptr;          // f32 mode: convDa's weights in da_gather_f32.hip's order
   const float *feat_cur = nullptr;   // conv4b's output of the call being enqueued / of the last call
   // what the detector tail (launch stream) hands to the side chain exists twice, by ticket parity: batch i + 1's tail then
   // only has to wait for batch i - 1's side chain, not for batch i's (which runs beside batch i + 1's convolutions)
@@ -708,6 +709,20 @@ int build(spfe_handle h, const spfe_config *cfg) {
       if ((rc = dev_alloc(h, dst, w.size()))) return rc;
       HIP_TRY(hipMemcpy(*dst, w.data(), w.size() * 4, hipMemcpyHostToDevice));
     }
+    // convDa gathered as well (da_gather_f32.hip), pipelined calls included: 752x480 x 8, 19 k of 45 k cells listed: 122 us
+    // (two workgroups per CU) against the 210 us the dense launch loses without convDa — pipelined 2035 -> 2057 ... 2075
+    // frames/s, a single-frame call's p50 -1.4 %
+    h->sparse_da_mode = 2;
+    h->sparse_da = h->sparse_db && (size_t)B * C * 2048 < ((size_t)1 << 31);
+    if (const char *e = getenv("SPFE_SPARSE_DA")) h->sparse_da_mode = atoi(e);
+    h->sparse_da = h->sparse_da && h->sparse_da_mode != 0;
+    if (h->sparse_da) {
+      std::vector<float> w(spfe::da_gather_f32_weight_bytes() / 4);
+      spfe::da_gather_f32_pack_weights(blob.data() + blob_weight_offset(10), w.data());   // layer 10 = convDa
+      if ((rc = dev_alloc(h, &h->d_wda32, w.size()))) return rc;
+      HIP_TRY(hipMemcpy(h->d_wda32, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+      if ((rc = dev_alloc(h, &h->act7_alt, (size_t)B * C * 128))) return rc;
+    }
   }
   if (h->bf16) {  // both heads in bf16: convPa | convDa write bf16, convPb and convDb are head_bf16.hip's GEMMs
     if ((rc = dev_alloc(h, &h->d_hd, (size_t)B * C * 512))) return rc;
@@ -837,7 +852,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   const int n_all = n;
   hipStream_t const s_all = s;
   const bool sparse = h->sparse_db && h->d_db_list;   // the descriptor head (bf16: convDa too) runs gathered, in enqueue_post
-  const bool sparse_da = sparse && h->bf16 && h->sparse_da && (h->sparse_da_mode >= 2 || !((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode));
+  const bool sparse_da = sparse && h->sparse_da && (h->sparse_da_mode >= 2 || !((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode));
   h->sparse_da_call = sparse_da;
   const int par_db = (int)(h->ticket & 1);
   h->feat_cur = sparse_da && par_db ? h->act7_alt : h->act[7];
@@ -953,7 +968,8 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     bool small_tile = L.small_tile, tiny_tile = false;
     if (L.ks == 3 && h->small_maxh < 0) {
       const long tx = (L.W + 31) / 32;
-      const long items_big = tx * ((L.H + 7) / 8) * L.nblk * n, items_small = tx * ((L.H + 3) / 4) * L.nblk * n;
+      const long nblk_eff = i == 7 && sparse_da ? L.nblk / 2 : L.nblk;   // (convPa alone when convDa runs gathered)
+      const long items_big = tx * ((L.H + 7) / 8) * nblk_eff * n, items_small = tx * ((L.H + 3) / 4) * nblk_eff * n;
       const long g = h->num_cus > 0 ? h->num_cus : 256;
       const double cost_big = (double)((items_big + g - 1) / g) * 2.0 * 0.93;
       const double cost_small = (double)((items_small + g - 1) / g);
@@ -962,7 +978,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
       // CUs — one round of long items with CUs idle.  Half-height items cost 0.56 of a 4-row one (measured, batch 1:
       // conv4a / 4b 45 -> 27 us, convPa|Da 80 -> 64, conv3a 46 -> 38); at 8 frames per call the model keeps the taller tiles
       if (!L.pool && L.relu && !(i == 0 && fused) && h->tile2_auto) {
-        const long items_tiny = tx * ((L.H + 1) / 2) * L.nblk * n;
+        const long items_tiny = tx * ((L.H + 1) / 2) * nblk_eff * n;
         const double cost_tiny = (double)((items_tiny + g - 1) / g) * 0.56;
         tiny_tile = cost_tiny < (cost_small < cost_big ? cost_small : cost_big);
       }
@@ -974,6 +990,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     if (L.ks == 3 && !L.pool && L.relu && ((h->tile2_mask >> i) & 1)) tile_mode = 3;
     const int th = spfe::conv_tile_rows(tile_mode);
     p.tiles_x = (L.W + 31) / 32; p.tiles_y = (L.H + th - 1) / th; p.nblk = L.nblk;
+    if (i == 7 && sparse_da) p.nblk = L.nblk / 2;   // convPa only: convDa runs gathered, behind the selection (da_gather_f32.hip)
     p.num_cus = h->num_cus;
     HIP_TRY(spfe::launch_conv_f32(p, L.cin, L.ks, L.pool, L.relu, tile_mode, i == 0 ? (fused ? 2 : 1) : 0, s));
     STAGE_MARK(2 + i);
@@ -1029,6 +1046,8 @@ int launch_db_gathered(spfe_handle h, int n, hipStream_t s) {
   const int max_total = n * h->db_cap;
   if (h->bf16 && h->sparse_da_call)
     HIP_TRY(spfe::launch_da_gather_bf16(h->feat_cur, h->d_wrw[3], h->layers[7].d_b, h->d_hd, h->d_db_list, h->d_db_total, max_total, n, h->hc, h->wc, h->num_cus, s));
+  if (!h->bf16 && h->sparse_da_call)
+    HIP_TRY(spfe::launch_da_gather_f32(h->feat_cur, h->d_wda32, h->layers[7].d_b + 256, h->d_head, h->d_db_list, h->d_db_total, max_total, n, h->hc, h->wc, h->num_cus, s));
   if (h->bf16) HIP_TRY(spfe::launch_head1x1_bf16_gather(h->d_hd, h->d_wdb, L.d_b, h->d_coarse, n * h->C, h->d_db_list, h->d_db_total, max_total, h->db_tiles_per_wg, s));
   else HIP_TRY(spfe::launch_head1x1_f32_gather(h->d_head, h->d_wdb32, L.d_b, h->d_coarse, n * h->C, h->d_db_list, h->d_db_total, max_total, h->db_tiles_per_wg, s));
   return SPFE_OK;
@@ -1037,7 +1056,7 @@ int launch_db_gathered(spfe_handle h, int n, hipStream_t s) {
 // The dense descriptor head over the last call's head activations (spfe_debug_read("coarse") after a sparse call).
 int launch_db_dense(spfe_handle h, int n, hipStream_t s) {
   const ConvLayer &L = h->layers[9];
-  if (h->bf16 && h->sparse_da_call) {   // convDa was gathered too: the same kernel over a list of ALL cells (a debug path)
+  if (h->sparse_da_call) {   // convDa was gathered too: the same kernel over a list of ALL cells (a debug path)
     const int all = n * h->C;
     std::vector<int> cells((size_t)all + 1);
     for (int i = 0; i < all; ++i) cells[i] = i;
@@ -1045,7 +1064,9 @@ int launch_db_dense(spfe_handle h, int n, hipStream_t s) {
     int *d_tmp = nullptr;
     HIP_TRY(hipMalloc(&d_tmp, cells.size() * sizeof(int)));
     hipError_t e = hipMemcpy(d_tmp, cells.data(), cells.size() * sizeof(int), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = spfe::launch_da_gather_bf16(h->feat_cur, h->d_wrw[3], h->layers[7].d_b, h->d_hd, d_tmp, d_tmp + all, all, n, h->hc, h->wc, h->num_cus, s);
+    if (e == hipSuccess)
+      e = h->bf16 ? spfe::launch_da_gather_bf16(h->feat_cur, h->d_wrw[3], h->layers[7].d_b, h->d_hd, d_tmp, d_tmp + all, all, n, h->hc, h->wc, h->num_cus, s)
+                  : spfe::launch_da_gather_f32(h->feat_cur, h->d_wda32, h->layers[7].d_b + 256, h->d_head, d_tmp, d_tmp + all, all, n, h->hc, h->wc, h->num_cus, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(d_tmp);
     HIP_TRY(e);
@@ -1364,6 +1385,11 @@ long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size
   if (!h || !name || !dst) return fail(SPFE_EINVAL, "null argument");
   if (frame < 0 || frame >= h->B) return fail(SPFE_EINVAL, "frame %d out of range", frame);
   const size_t C = h->C, HW = (size_t)h->H * h->W;
+  if (std::string(name) == "da_gathered") {   // 1: the last call ran convDa on the listed cells only (host-side flag)
+    if (cap < sizeof(int)) return fail(SPFE_EINVAL, "buffer 'da_gathered' needs 4 bytes");
+    *reinterpret_cast<int *>(dst) = h->sparse_last && h->sparse_da_call ? 1 : 0;
+    return (long)sizeof(int);
+  }
   const void *src = nullptr;
   size_t bytes = 0;
   bool bf16_src = false;

@@ -74,6 +74,13 @@ void head_bf16_pack_weights(const unsigned short *Wb, int cout, unsigned char *d
 // f32 mode, the 1x1 heads (head_f32.hip): same shapes, in / out f32, bit-identical to conv_f32.hip's 1x1 path
 hipError_t launch_head1x1_f32(const float *in, const float *wpack, const float *bias, float *out, int npix, int cout,
                               hipStream_t s);
+// f32 mode, convDa (3x3, 128 -> 256, ReLU) on the listed cells (da_gather_f32.hip), bit-identical to conv_f32.hip's rows:
+// feat = conv4b's output [B][hc][wc][128], wpack = da_gather_f32_pack_weights(convDa's OIHW weights), bias = convDa's,
+// out = head activations [B * hc * wc][512] (channels 256..511 of the listed rows)
+hipError_t launch_da_gather_f32(const float *feat, const float *wpack, const float *bias, float *out, const int *list,
+                                const int *total, int max_total, int B, int hc, int wc, int num_cus, hipStream_t s);
+size_t da_gather_f32_weight_bytes();
+void da_gather_f32_pack_weights(const float *W, float *dst);
 hipError_t launch_head1x1_f32_gather(const float *in, const float *wpack, const float *bias, float *out, int npix,
                                      const int *list, const int *total, int max_total, int tiles_per_wg, hipStream_t s);
 size_t head_f32_weight_bytes(int cout);
