@@ -214,6 +214,11 @@ SPFE_API int spfe_view_record(spfe_handle h, const void *host_record, spfe_resul
 /* Test/diagnostic tap: copy an intermediate device buffer of frame `frame` of
  * the last call to host. Names: "semi" [hc][wc][65], "coarse" [hc][wc][256],
  * "heat_log" [H][W], "feat" [hc][wc][128], "act<i>" layer outputs.
+ * The descriptor branch (convDa, convDb: sp_extractor.cpp:99-100) computes only the rows of the coarse map that the
+ * emitted keypoints' bilinear taps read (:134-148 reads nothing else); "coarse" completes the map first (one dense
+ * pass over the last call's activations), "coarse_sparse" is the map as the call left it, "db_total" [1] int /
+ * "db_list" ints the cells it computed (b * hc * wc + cell; frame ignored), "da_gathered" [1] int whether convDa ran on
+ * those cells only as well.
  * Returns the number of bytes copied or a negative error. */
 SPFE_API long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size_t cap);
 
