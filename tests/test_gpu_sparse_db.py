@@ -107,3 +107,50 @@ def test_no_keypoints_no_cells(monkeypatch):
     assert total == len(_tap_cells(fr.kp_xy, H, W))
     if fr.K == 0:
         assert total == 0
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_gathered_branch_with_changing_batch_sizes_and_a_full_list(monkeypatch, precision):
+    """Calls of 3, 1, 2, 3 frames on one handle (the list, its total and the parity-double-buffered conv4b output are per
+    call), and num_features so large that the list holds every cell (4 kmax > C: capacity C)."""
+    H, W = 128, 168
+    blob = weights.synthetic(7, "dense")
+    sets = [[synth.make_image(40 + 7 * r + i, H, W) for i in range(n)] for r, n in enumerate((3, 1, 2, 3))]
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SPFE_SPARSE_DB", flag)
+        res = []
+        for nf in (120, 2000):
+            ext = SPExtractor(nf, H, W, blob, max_batch=3, with_heat=False, precision=precision)
+            for s in sets:
+                res += ext.extract_batch(s)
+            tickets = [ext.submit_batch(s) for s in sets[:3]]
+            for t in tickets:
+                res += ext.collect_batch(t)
+            ext.close()
+        out[flag] = res
+    assert len(out["0"]) == len(out["1"]) == 2 * (9 + 6)
+    for a, b in zip(out["0"], out["1"]):
+        assert a.K == b.K and np.array_equal(a.kp_xy, b.kp_xy)
+        assert np.array_equal(_bits(a.descriptors), _bits(b.descriptors))
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_gathered_branch_at_1920x1080(monkeypatch, precision):
+    """32,400 cells: the selection's large-frame path writes the list, the gathered kernels' 32-bit offsets hold."""
+    H, W = 1080, 1920
+    blob = weights.synthetic(7, "dense")
+    img = synth.make_image(11, H, W)
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SPFE_SPARSE_DB", flag)
+        ext = SPExtractor(1000, H, W, blob, with_heat=False, precision=precision)
+        out[flag] = ext.extract_batch([img])[0]
+        if flag == "1":
+            total = int(ext.debug_read("db_total")[0])
+            assert total == len(_tap_cells(out[flag].kp_xy, H, W))
+        ext.close()
+    a, b = out["0"], out["1"]
+    assert a.K == b.K and np.array_equal(a.kp_xy, b.kp_xy)
+    assert np.array_equal(_bits(a.descriptors), _bits(b.descriptors))
+    assert np.array_equal(_bits(a.cov2), _bits(b.cov2))
