@@ -11,9 +11,14 @@
 // Shape.  A work item is 64 listed cells x 64 output channels; a workgroup is 4 wavefronts = 2 cell halves x 2 channel
 // halves, one 32x32 accumulator each, 576 MFMAs per item.  K runs in 24 stages (chunk, dy): the stage's three taps of
 // A — [tap][4 channel quads][64 cells][4 floats], gathered — and of W — [tap][quad][64 channels][4] from a table packed in
-// that order — come L2 -> LDS with LDS-direct loads into a ring of three stages (two in flight), six 16-byte pieces per
-// thread and stage; one barrier per stage (24 MFMAs per wavefront).  A lane's 16-byte LDS read holds the operands of two
-// K steps (even / odd pairs of its quad).  The ring runs on across the workgroup's items.
+// that order — come L2 -> LDS with LDS-direct loads into a ring of two stages, six 16-byte pieces per thread and stage; one
+// barrier per stage (24 MFMAs per wavefront).  A lane's 16-byte LDS read holds the operands of two K steps (even / odd
+// pairs of its quad).  The ring runs on across the workgroup's items.
+//
+// What bounds it.  An output's K chain is 576 DEPENDENT MFMAs (one accumulator per wavefront): back to back they issue
+// every ~120 cycles, not 64 — a single frame's list (152 items, one per CU) takes 34 us whatever the prefetch depth, which
+// is this layer's floor at any batch size.  Throughput comes from other wavefronts on the same SIMD: 49 KB of LDS per
+// workgroup = three per CU; 752x480 x 8 (1204 items): 162 us with one workgroup per CU, 122 with two, 114 with three.
 #include <algorithm>
 #include <cstring>
 
@@ -33,14 +38,13 @@ constexpr int CELLS = 64, CH = 64;
 constexpr int NSTAGE = 24;                     // per item: 8 chunks of 16 channels x 3 tap rows
 constexpr int PART_BYTES = 3 * 4 * 1024;       // A (or W) of one stage: [3 taps][4 quads][64][16 bytes]
 constexpr int STAGE_BYTES = 2 * PART_BYTES;    // 24,576
-constexpr int RING = 3;                        // 73.7 KB + indices: two workgroups per CU, so that a SIMD has a second
-                                               // wavefront's MFMAs for the gaps of the first (one alone ran at half the MFMA rate)
+constexpr int RING = 2;                        // 49 KB + indices: three workgroups per CU (see above)
 constexpr int LDS_IDX = RING * STAGE_BYTES;    // [4][64] cell indices of the items in flight
 constexpr int LDS_TOTAL = LDS_IDX + 4 * CELLS * 4;
 
 // feat: [B][hc][wc][128] f32 (conv4b's output); wpack: da_gather_f32_pack_weights; bias: convDa's 256; out: [B * hc * wc][512]
 // f32 head activations, channels 256..511 written
-__global__ __launch_bounds__(256, 2) void da_gather_f32_kernel(const float *__restrict__ feat, const float *__restrict__ wpack,
+__global__ __launch_bounds__(256, 3) void da_gather_f32_kernel(const float *__restrict__ feat, const float *__restrict__ wpack,
                                                                const float *__restrict__ bias, float *__restrict__ out,
                                                                const int *__restrict__ list, const int *__restrict__ total,
                                                                int B, int hc, int wc) {
@@ -124,7 +128,6 @@ __global__ __launch_bounds__(256, 2) void da_gather_f32_kernel(const float *__re
     aim(item, g0);
   }
   issue(0);
-  issue(1);
   while (item < nitems) {
     f32x16 acc;
 #pragma unroll
@@ -132,24 +135,33 @@ __global__ __launch_bounds__(256, 2) void da_gather_f32_kernel(const float *__re
 #pragma unroll 1
     for (int st4 = 0; st4 < NSTAGE / RING; ++st4) {
 #pragma unroll
-      for (int slot = 0; slot < RING; ++slot) {   // (24 stages = 8 turns of the ring: an item starts at slot 0)
-        // two stages (12 or 13 loads) are in flight; the oldest must have landed: <= 6 outstanding
-        __builtin_amdgcn_s_waitcnt(0x0F70 | 6);    // vmcnt(6), expcnt / lgkmcnt untouched
+      for (int slot = 0; slot < RING; ++slot) {   // (24 stages = 12 turns of the ring: an item starts at slot 0)
+        // the stage issued one stage ago must have landed
+        __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0), expcnt / lgkmcnt untouched
         asm volatile("s_barrier" ::: "memory");     // ... for every wavefront; and everybody is done with the slot refilled next
                                                    // (not __syncthreads(): its fence would wait for ALL loads in flight)
-        issue((slot + 2) % RING);
+        issue((slot + 1) % RING);
         lds_char *const sb = lds + slot * STAGE_BYTES;
+        // 12 operand pairs (tap, quad) per stage, read two pairs ahead of their MFMAs (pinned: left alone, the scheduler sinks
+        // every read to its first use and the matrix pipe waits out an LDS round trip per pair)
+        f32x4 av[3], wv[3];
+        auto rd = [&](int i) {
+          av[i % 3] = *reinterpret_cast<lds_f4 *>(sb + (i / 4) * 4096 + (i % 4) * 1024 + a_lane);
+          wv[i % 3] = *reinterpret_cast<lds_f4 *>(sb + (i / 4) * 4096 + (i % 4) * 1024 + w_lane);
+        };
+        rd(0);
+        rd(1);
 #pragma unroll
-        for (int t3 = 0; t3 < 3; ++t3)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 a = *reinterpret_cast<lds_f4 *>(sb + t3 * 4096 + q * 1024 + a_lane);
-            const f32x4 w = *reinterpret_cast<lds_f4 *>(sb + t3 * 4096 + q * 1024 + w_lane);
-            const float a0 = hi ? a.y : a.x, a1 = hi ? a.w : a.z;
-            const float w0 = hi ? w.y : w.x, w1 = hi ? w.w : w.z;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w1, acc, 0, 0, 0);
-          }
+        for (int i = 0; i < 12; ++i) {
+          if (i + 2 < 12) rd(i + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          const f32x4 a = av[i % 3], w = wv[i % 3];
+          const float a0 = hi ? a.y : a.x, a1 = hi ? a.w : a.z;
+          const float w0 = hi ? w.y : w.x, w1 = hi ? w.w : w.z;
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w1, acc, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
     // D[cell][channel]: register r = cell (r & 3) + 8 (r >> 2) + 4 hi of this wavefront's 32, lane = channel
@@ -205,7 +217,7 @@ hipError_t launch_da_gather_f32(const float *feat, const float *wpack, const flo
     if (dev >= 0 && dev < 64) attr_done[dev] = true;
   }
   const int nitems = ((max_total + dagf::CELLS - 1) / dagf::CELLS) * 4;
-  int grid = 2 * (num_cus > 0 ? num_cus : 256);   // two workgroups per CU
+  int grid = 3 * (num_cus > 0 ? num_cus : 256);   // three workgroups per CU
   grid = std::max(1, std::min(grid, nitems));
   hipLaunchKernelGGL(k, dim3(grid), dim3(256), dagf::LDS_TOTAL, s, feat, wpack, bias, out, list, total, B, hc, wc);
   return hipGetLastError();
