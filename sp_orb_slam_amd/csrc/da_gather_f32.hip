@@ -15,10 +15,12 @@
 // barrier per stage (24 MFMAs per wavefront).  A lane's 16-byte LDS read holds the operands of two K steps (even / odd
 // pairs of its quad).  The ring runs on across the workgroup's items.
 //
-// What bounds it.  An output's K chain is 576 DEPENDENT MFMAs (one accumulator per wavefront): back to back they issue
-// every ~120 cycles, not 64 — a single frame's list (152 items, one per CU) takes 34 us whatever the prefetch depth, which
-// is this layer's floor at any batch size.  Throughput comes from other wavefronts on the same SIMD: 49 KB of LDS per
-// workgroup = three per CU; 752x480 x 8 (1204 items): 162 us with one workgroup per CU, 122 with two, 114 with three.
+// What bounds it.  One workgroup alone on a CU runs the stage loop at about half the MFMA rate (a barrier per 24 MFMAs, the
+// LDS-direct issue and the operand selects on a SIMD with no second wavefront to fill the gaps; NOT the accumulator
+// dependency: tools/microbench/mfma_chain_probe.hip — one dependent chain of v_mfma_f32_32x32x2_f32 issues every 64 cycles
+// like four independent ones): a single frame's list (152 items, one per CU) takes 34 us whatever the prefetch depth.
+// Throughput comes from other wavefronts on the same SIMD: 49 KB of LDS per workgroup = three per CU; 752x480 x 8 (1204
+// items): 162 us with one workgroup per CU, 122 with two, 114 with three.
 #include <algorithm>
 #include <cstring>
 
