@@ -57,9 +57,8 @@ int main() {
     hipLaunchKernelGGL(k, dim3(256), dim3(256), 0, 0, src, sink, clk, iters);
     hipDeviceSynchronize();
     unsigned long long c; hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
-    // s_memtime ticks at 100 MHz on this part: report ticks per instruction and, with the ~2.1 GHz shader clock, cycles
-    printf("%-10s %d chain(s): %.3f memtime ticks per MFMA of a chain's turn (x21 ~ cycles: %.0f)\n", name, nch,
-           (double)c / (iters * 8.0 * nch), (double)c / (iters * 8.0 * nch) * 21.0);
+    // (s_memtime ticks = shader cycles here: a 16-pass v_mfma_f32_32x32x2_f32 reads 64)
+    printf("%-10s %d chain(s): %.2f cycles per MFMA\n", name, nch, (double)c / (iters * 8.0 * nch));
   };
   run(chain<0, 1>, "32x32x2", 1); run(chain<0, 2>, "32x32x2", 2); run(chain<0, 4>, "32x32x2", 4);
   run(chain<1, 1>, "16x16x4", 1); run(chain<1, 2>, "16x16x4", 2); run(chain<1, 4>, "16x16x4", 4);

@@ -41,7 +41,7 @@ pmc bf16_720p_rw0_grbm "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE T
 python tools/rocpd_summary.py $out/pmc_bf16_720p_rw0_*/*.db > $out/pmc_summary_bf16_720p_rw0.txt 2>&1
 unset SPFE_BF16_RW
 # probes DESIGN.md leans on (built by tools/microbench/build_probes.sh in the build container)
-for pb in clock_probe conv_rw_plain; do
+for pb in clock_probe conv_rw_plain mfma_chain_probe; do
   [ -x tools/microbench/bin/$pb ] && { echo "== $pb"; if [ $pb = conv_rw_plain ]; then for a in "180 320 8 128 1 4 50" "90 160 8 512 0 4 50" "90 160 8 128 0 4 50" "90 160 8 128 0 2 50"; do tools/microbench/bin/$pb $a; done; else tools/microbench/bin/$pb; fi; } >> $out/probes.txt 2>&1
 done
 rm -rf $out/kt_*/ $out/pmc_*/   # the databases are large; the summaries are what is kept
