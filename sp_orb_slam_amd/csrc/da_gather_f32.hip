@@ -12,11 +12,11 @@
 // halves, one 32x32 accumulator each, 576 MFMAs per item.  K runs in 24 stages (chunk, dy): the stage's three taps of
 // A — [tap][4 channel quads][64 cells][4 floats], gathered — and of W — [tap][quad][64 channels][4] from a table packed in
 // that order — come L2 -> LDS with LDS-direct loads into a ring of two stages, six 16-byte pieces per thread and stage; one
-// barrier per stage (24 MFMAs per wavefront).  A lane's 16-byte LDS read holds the operands of two K steps (even / odd
-// pairs of its quad).  The ring runs on across the workgroup's items.
+// barrier per stage (24 MFMAs per wavefront).  A lane's piece holds the operands of two K steps (channels hi and 2 + hi of its
+// quad): one ds_read2_b32.  The ring runs on across the workgroup's items.
 //
 // What bounds it.  One workgroup alone on a CU runs the stage loop at about half the MFMA rate (a barrier per 24 MFMAs, the
-// LDS-direct issue and the operand selects on a SIMD with no second wavefront to fill the gaps; NOT the accumulator
+// LDS-direct issue on a SIMD with no second wavefront to fill the gaps, at the clock a short burst gets; NOT the accumulator
 // dependency: tools/microbench/mfma_chain_probe.hip — one dependent chain of v_mfma_f32_32x32x2_f32 issues every 64 cycles
 // like four independent ones): a single frame's list (152 items, one per CU) takes 34 us whatever the prefetch depth.
 // Throughput comes from other wavefronts on the same SIMD: 49 KB of LDS per workgroup = three per CU; 752x480 x 8 (1204
@@ -30,10 +30,9 @@ namespace spfe {
 namespace dagf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(3))) f32x4 lds_f4;
+typedef __attribute__((address_space(3))) float lds_f1;
 
 constexpr unsigned OOB = 0x80000000u;
 constexpr int CELLS = 64, CH = 64;
@@ -117,7 +116,7 @@ __global__ __launch_bounds__(256, 3) void da_gather_f32_kernel(const float *__re
   };
 
   // operands of this lane inside a stage part: A piece (quad q, cell 32 wm + l31), W piece (quad q, channel 32 wn + l31)
-  const unsigned a_lane = (unsigned)((32 * wm + l31) * 16), w_lane = (unsigned)(PART_BYTES + (32 * wn + l31) * 16);
+  const unsigned a_lane = (unsigned)((32 * wm + l31) * 16 + hi * 4), w_lane = (unsigned)(PART_BYTES + (32 * wn + l31) * 16 + hi * 4);
 
   float bias4[4];   // this lane's bias in each of the four 64-channel blocks (loaded here: a load inside the loop drains the ring)
 #pragma unroll
@@ -146,10 +145,14 @@ __global__ __launch_bounds__(256, 3) void da_gather_f32_kernel(const float *__re
         lds_char *const sb = lds + slot * STAGE_BYTES;
         // 12 operand pairs (tap, quad) per stage, read two pairs ahead of their MFMAs (pinned: left alone, the scheduler sinks
         // every read to its first use and the matrix pipe waits out an LDS round trip per pair)
-        f32x4 av[3], wv[3];
+        // (a lane's 16-byte piece holds channels e0..e3 of its quad; its K steps need e[hi] and e[2 + hi]: two dwords 8 bytes
+        // apart, one ds_read2_b32 — no selects between the MFMAs)
+        float a0v[3], a1v[3], w0v[3], w1v[3];
         auto rd = [&](int i) {
-          av[i % 3] = *reinterpret_cast<lds_f4 *>(sb + (i / 4) * 4096 + (i % 4) * 1024 + a_lane);
-          wv[i % 3] = *reinterpret_cast<lds_f4 *>(sb + (i / 4) * 4096 + (i % 4) * 1024 + w_lane);
+          const lds_f1 *ap = reinterpret_cast<const lds_f1 *>(sb + (i / 4) * 4096 + (i % 4) * 1024 + a_lane);
+          const lds_f1 *wp = reinterpret_cast<const lds_f1 *>(sb + (i / 4) * 4096 + (i % 4) * 1024 + w_lane);
+          a0v[i % 3] = ap[0]; a1v[i % 3] = ap[2];
+          w0v[i % 3] = wp[0]; w1v[i % 3] = wp[2];
         };
         rd(0);
         rd(1);
@@ -157,11 +160,8 @@ __global__ __launch_bounds__(256, 3) void da_gather_f32_kernel(const float *__re
         for (int i = 0; i < 12; ++i) {
           if (i + 2 < 12) rd(i + 2);
           __builtin_amdgcn_sched_barrier(0);
-          const f32x4 a = av[i % 3], w = wv[i % 3];
-          const float a0 = hi ? a.y : a.x, a1 = hi ? a.w : a.z;
-          const float w0 = hi ? w.y : w.x, w1 = hi ? w.w : w.z;
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w0, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w1, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[i % 3], w0v[i % 3], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[i % 3], w1v[i % 3], acc, 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
