@@ -553,6 +553,21 @@ def main():
             if (prec, h2, w2, 8) == (args.precision, H, W, B):
                 continue
             out[name] = device_leg(ctx, prec, h2, w2, 8, seed0, max(k2, args.steps), max(wu2, args.warmup), what)
+        # The headline workload with the reference's dense graph FULLY executed (SPFE_SPARSE_DB=0: convDa / convDb over the whole
+        # coarse map, as sp_extractor.cpp:99-100 runs them), for the reader who wants that number: the records are the same
+        # bits either way (tests/test_gpu_sparse_db.py); the default path computes the rows the keypoints read
+        prev_env = os.environ.get("SPFE_SPARSE_DB")
+        os.environ["SPFE_SPARSE_DB"] = "0"
+        try:
+            out["dense_descriptor_branch_b8"] = device_leg(
+                ctx, args.precision, H, W, B, 200, max(100, args.steps), max(10, args.warmup),
+                "the headline workload (%dx%d, %s, batch %d) with convDa / convDb computed on every cell (SPFE_SPARSE_DB=0)"
+                % (W, H, args.precision, B))
+        finally:
+            if prev_env is None:
+                os.environ.pop("SPFE_SPARSE_DB", None)
+            else:
+                os.environ["SPFE_SPARSE_DB"] = prev_env
     # batch-1 latency (configs[1] as written: one frame per call)
     if not args.no_latency:
         ext1 = SPExtractor(nf, H, W, blob, max_batch=1, device=local, with_heat=False, precision=args.precision)
