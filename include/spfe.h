@@ -55,6 +55,15 @@ extern "C" {
                                   reading the records.  Lets the latency-bound covariance of batch i overlap the
                                   convolutions of batch i+1.  Pass a different record buffer to consecutive calls. */
 
+#define SPFE_FLAG_DESC_BF16 4u /* the records (and spfe_result) carry the descriptors as bf16 [kmax][256] — the f32
+                                  descriptor of sp_extractor.cpp:512-513 rounded to nearest even — instead of f32: a record
+                                  shrinks from ~1.1 MB to ~0.6 MB (1000 features), and with it the D2H copy of the host
+                                  calls and the all-gather of the multi-GPU path.  spfe_result.desc is NULL then and
+                                  spfe_result.desc_bf16 is set; spfe_record_layout.desc_elem_bytes says which.  Everything
+                                  else in the record is unchanged.  The matching entry points that read descriptors from
+                                  records (spfe_match_records_device, spfe_match_patches_record_device,
+                                  spfe_track_dust_record_device) refuse such records with SPFE_EINVAL. */
+
 /* spfe_result.status / record header word 2 */
 #define SPFE_STATUS_COV_OVERFLOW 1 /* Set only when ONE covariance region has more pops than the device's last-resort list
                                       holds (SPFE_COV_FALLBACK_CAP, 4 M by default — the reference's own loop would spend
@@ -111,6 +120,7 @@ typedef struct {
   const float *semi_dust;   /* [H/8][W/8] raw dustbin logit (:106,448) */
   const float *heat;        /* [H][W] or NULL without SPFE_FLAG_HEAT (:467) */
   const float *heat_inv;    /* [H][W] or NULL without SPFE_FLAG_HEAT (:468) */
+  const uint16_t *desc_bf16; /* [K][256] bf16 bit patterns with SPFE_FLAG_DESC_BF16 (then desc is NULL), else NULL */
 } spfe_result;
 
 SPFE_API int spfe_create(const spfe_config *cfg, spfe_handle *out);
@@ -162,10 +172,11 @@ typedef struct {
   size_t off_resp; /* float [kmax] */
   size_t off_cov;  /* float [kmax][2] */
   size_t off_cinv; /* float [kmax][2] */
-  size_t off_desc; /* float [kmax][256] */
+  size_t off_desc; /* float [kmax][256]; bf16 [kmax][256] with SPFE_FLAG_DESC_BF16 */
   size_t off_occ;  /* int16 [H/8][W/8] */
   size_t off_dd;   /* float [H/8][W/8] dense_dust */
   size_t off_sd;   /* float [H/8][W/8] semi_dust */
+  int desc_elem_bytes; /* 4, or 2 with SPFE_FLAG_DESC_BF16 */
 } spfe_record_layout;
 
 SPFE_API int spfe_get_record_layout(spfe_handle h, spfe_record_layout *out);

@@ -81,8 +81,18 @@ __device__ __forceinline__ void desc_keypoint(const FrameBufs &f, const RecordLa
   const float nrm = sqrtf(sum256_wave(sq));
   float4 o;
   o.x = acc.x / nrm; o.y = acc.y / nrm; o.z = acc.z / nrm; o.w = acc.w / nrm;
-  float *desc = reinterpret_cast<float *>(rec + rl.off_desc);
-  *reinterpret_cast<float4 *>(desc + (size_t)i * SPFE_DESC_DIM + lane * 4) = o;
+  if (rl.desc_bf16) {   // SPFE_FLAG_DESC_BF16: the same descriptor, rounded to nearest even
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    uint2 pk;
+    pk.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){o.x, o.y}, bf16x2_));
+    pk.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){o.z, o.w}, bf16x2_));
+    unsigned short *d16 = reinterpret_cast<unsigned short *>(rec + rl.off_desc);
+    *reinterpret_cast<uint2 *>(d16 + (size_t)i * SPFE_DESC_DIM + lane * 4) = pk;
+  } else {
+    float *desc = reinterpret_cast<float *>(rec + rl.off_desc);
+    *reinterpret_cast<float4 *>(desc + (size_t)i * SPFE_DESC_DIM + lane * 4) = o;
+  }
   if (lane == 0) {
     float *resp = reinterpret_cast<float *>(rec + rl.off_resp);
     resp[i] = f.heat_inv[(size_t)b * H * W + (size_t)(int)y * W + (int)x];  // :271

@@ -253,15 +253,16 @@ int host_alloc(spfe_handle h, T **p, size_t count) {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-void make_layout(int kmax, int C, spfe::RecordLayout *r) {
+void make_layout(int kmax, int C, bool desc_bf16, spfe::RecordLayout *r) {
   size_t o = 0;
   r->kmax = kmax;
+  r->desc_bf16 = desc_bf16 ? 1 : 0;
   r->off_hdr = o; o += 16;
   r->off_xy = o; o = align_up(o + (size_t)kmax * 2 * 4, 16);
   r->off_resp = o; o = align_up(o + (size_t)kmax * 4, 16);
   r->off_cov = o; o = align_up(o + (size_t)kmax * 2 * 4, 16);
   r->off_cinv = o; o = align_up(o + (size_t)kmax * 2 * 4, 16);
-  r->off_desc = o; o = align_up(o + (size_t)kmax * SPFE_DESC_DIM * 4, 16);
+  r->off_desc = o; o = align_up(o + (size_t)kmax * SPFE_DESC_DIM * (desc_bf16 ? 2 : 4), 16);
   r->off_occ = o; o = align_up(o + (size_t)C * 2, 16);
   r->off_dd = o; o = align_up(o + (size_t)C * 4, 16);
   r->off_sd = o; o = align_up(o + (size_t)C * 4, 16);
@@ -629,7 +630,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
     if ((rc = dev_alloc(h, &h->cov.fb_q, (size_t)h->cov.fb_cap))) return rc;
     if ((rc = dev_alloc(h, &h->cov.fb_v, (size_t)h->cov.fb_cap))) return rc;
   }
-  make_layout(h->kmax, C, &h->rl);
+  make_layout(h->kmax, C, (cfg->flags & SPFE_FLAG_DESC_BF16) != 0, &h->rl);
   if ((rc = dev_alloc(h, &h->d_records, (size_t)B * h->rl.bytes))) return rc;
   HIP_TRY(hipMemset(h->d_records, 0, (size_t)B * h->rl.bytes));
 
@@ -1180,7 +1181,8 @@ void view_record(const spfe_handle h, const uint8_t *rec, const float *heat, con
   out->status = hdr[2];
   out->kp_xy = reinterpret_cast<const float *>(rec + r.off_xy);
   out->kp_response = reinterpret_cast<const float *>(rec + r.off_resp);
-  out->desc = reinterpret_cast<const float *>(rec + r.off_desc);
+  out->desc = r.desc_bf16 ? nullptr : reinterpret_cast<const float *>(rec + r.off_desc);
+  out->desc_bf16 = r.desc_bf16 ? reinterpret_cast<const uint16_t *>(rec + r.off_desc) : nullptr;
   out->cov2 = reinterpret_cast<const float *>(rec + r.off_cov);
   out->cov2_inv = reinterpret_cast<const float *>(rec + r.off_cinv);
   out->occ_grid = reinterpret_cast<const int16_t *>(rec + r.off_occ);
@@ -1279,6 +1281,7 @@ int spfe_get_record_layout(spfe_handle h, spfe_record_layout *o) {
   o->bytes = r.bytes; o->kmax = r.kmax; o->off_hdr = r.off_hdr; o->off_xy = r.off_xy;
   o->off_resp = r.off_resp; o->off_cov = r.off_cov; o->off_cinv = r.off_cinv;
   o->off_desc = r.off_desc; o->off_occ = r.off_occ; o->off_dd = r.off_dd; o->off_sd = r.off_sd;
+  o->desc_elem_bytes = r.desc_bf16 ? 2 : 4;
   return SPFE_OK;
 }
 
@@ -1917,6 +1920,7 @@ int patch_scratch(spfe_handle h) {
 
 int spfe_match_patches_record_device(spfe_handle h, const void *d_mp_desc, const void *d_mp_uv, int n_points,
                                      const void *d_record, float max_dist, void *d_kp_idx, void *stream) {
+  if (h && h->rl.desc_bf16) return fail(SPFE_EINVAL, "the records of this handle carry bf16 descriptors (SPFE_FLAG_DESC_BF16): this entry point reads f32 rows");
   if (!h || !d_record || !d_kp_idx) return fail(SPFE_EINVAL, "null argument");
   if (n_points < 0 || n_points > kPatchMax) return fail(SPFE_EINVAL, "n_points %d not in [0, %d]", n_points, kPatchMax);
   if (n_points == 0) return SPFE_OK;
@@ -1943,6 +1947,7 @@ int spfe_match_patches_record_device(spfe_handle h, const void *d_mp_desc, const
 int spfe_track_dust_record_device(spfe_handle h, const void *d_record, const void *d_points_xyz, const void *d_mp_desc, int n,
                                   const void *d_Tcw, const spfe_dust_params *prm, int min_inliers, float max_dist,
                                   void *d_dust_out, void *d_kp_idx, void *stream) {
+  if (h && h->rl.desc_bf16) return fail(SPFE_EINVAL, "the records of this handle carry bf16 descriptors (SPFE_FLAG_DESC_BF16): this entry point reads f32 rows");
   if (!h || !d_record || !d_Tcw || !prm || !d_dust_out || !d_kp_idx || (n > 0 && (!d_points_xyz || !d_mp_desc)))
     return fail(SPFE_EINVAL, "null argument");
   int rc = dust_check(h, n, prm);
@@ -2044,6 +2049,7 @@ size_t spfe_match_out_bytes(spfe_handle h) { return h ? (size_t)h->kmax * 8 : 0;
 
 int spfe_match_records_device(spfe_handle h, const void *d_query_records, const void *d_train_records, int n_pairs,
                               int cross_check, void *d_out, void *stream) {
+  if (h && h->rl.desc_bf16) return fail(SPFE_EINVAL, "the records of this handle carry bf16 descriptors (SPFE_FLAG_DESC_BF16): this entry point reads f32 rows");
   if (!h || !d_query_records || !d_train_records || !d_out) return fail(SPFE_EINVAL, "null argument");
   if (n_pairs < 1) return fail(SPFE_EINVAL, "n_pairs %d must be >= 1", n_pairs);
   HIP_TRY(hipSetDevice(h->cfg.device));

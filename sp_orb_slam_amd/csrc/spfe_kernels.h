@@ -118,6 +118,7 @@ struct RecordLayout {
   size_t bytes;
   int kmax;
   size_t off_hdr, off_xy, off_resp, off_cov, off_cinv, off_desc, off_occ, off_dd, off_sd;
+  int desc_bf16;   // SPFE_FLAG_DESC_BF16: descriptor rows are 256 bf16 (RNE of the f32 descriptor), not 256 f32
 };
 
 // scratch of the covariance kernels (cov.hip)

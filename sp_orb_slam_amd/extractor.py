@@ -20,6 +20,7 @@ LIB_PATH = os.path.join(_PKG, "libspfe.so")
 
 SPFE_FLAG_HEAT = 1
 SPFE_FLAG_ASYNC_COV = 2
+SPFE_FLAG_DESC_BF16 = 4   # records / results carry bf16 descriptors (RNE of the f32 ones)
 SPFE_PRECISION_F32 = 0
 SPFE_PRECISION_BF16 = 1
 NUM_PARAMS = 1300865
@@ -58,14 +59,15 @@ class _Result(C.Structure):
                 ("reserved", C.c_int), ("kp_xy", C.c_void_p),
                 ("kp_response", C.c_void_p), ("desc", C.c_void_p), ("cov2", C.c_void_p),
                 ("cov2_inv", C.c_void_p), ("occ_grid", C.c_void_p), ("dense_dust", C.c_void_p),
-                ("semi_dust", C.c_void_p), ("heat", C.c_void_p), ("heat_inv", C.c_void_p)]
+                ("semi_dust", C.c_void_p), ("heat", C.c_void_p), ("heat_inv", C.c_void_p),
+                ("desc_bf16", C.c_void_p)]
 
 
 class RecordLayout(C.Structure):
     _fields_ = [("bytes", C.c_size_t), ("kmax", C.c_int), ("off_hdr", C.c_size_t),
                 ("off_xy", C.c_size_t), ("off_resp", C.c_size_t), ("off_cov", C.c_size_t),
                 ("off_cinv", C.c_size_t), ("off_desc", C.c_size_t), ("off_occ", C.c_size_t),
-                ("off_dd", C.c_size_t), ("off_sd", C.c_size_t)]
+                ("off_dd", C.c_size_t), ("off_sd", C.c_size_t), ("desc_elem_bytes", C.c_int)]
 
 
 class _DustParams(C.Structure):
@@ -258,7 +260,12 @@ class FrameResult:
         self.keypoints = kps
         self.kp_xy = xy
         self.response = resp
-        self.descriptors = _as_np(r.desc, (K, 256), np.float32)
+        if r.desc:
+            self.descriptors = _as_np(r.desc, (K, 256), np.float32)
+            self.descriptors_bf16 = None
+        else:   # SPFE_FLAG_DESC_BF16: the record carries bf16 rows; `descriptors` is their exact widening to f32
+            self.descriptors_bf16 = _as_np(r.desc_bf16, (K, 256), np.uint16)
+            self.descriptors = (self.descriptors_bf16.astype(np.uint32) << 16).view(np.float32)
         self.cov2 = _as_np(r.cov2, (K, 2), np.float32)
         self.cov2_inv = _as_np(r.cov2_inv, (K, 2), np.float32)
         self.occ_grid = _as_np(r.occ_grid, (hc, wc), np.int16)
@@ -277,7 +284,7 @@ class SPExtractor:
     """
 
     def __init__(self, nfeatures, height, width, weights, max_batch=1, device=0, with_heat=True,
-                 async_cov=False, precision="f32"):
+                 async_cov=False, precision="f32", desc_bf16=False):
         self._h = C.c_void_p()
         self._lib = load_library()
         self.nfeatures, self.height, self.width = int(nfeatures), int(height), int(width)
@@ -289,7 +296,9 @@ class SPExtractor:
         self.precision = precision
         cfg.max_batch, cfg.device = self.max_batch, int(device)
         cfg.precision = SPFE_PRECISION_BF16 if precision == "bf16" else SPFE_PRECISION_F32
-        cfg.flags = (SPFE_FLAG_HEAT if with_heat else 0) | (SPFE_FLAG_ASYNC_COV if async_cov else 0)
+        cfg.flags = (SPFE_FLAG_HEAT if with_heat else 0) | (SPFE_FLAG_ASYNC_COV if async_cov else 0) | \
+            (SPFE_FLAG_DESC_BF16 if desc_bf16 else 0)
+        self.desc_bf16 = bool(desc_bf16)
         self.async_cov = bool(async_cov)
         keep = None
         if isinstance(weights, (str, bytes, os.PathLike)):

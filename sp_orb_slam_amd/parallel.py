@@ -41,8 +41,9 @@ class RecordLayout:
     """Python mirror of make_layout() in csrc/spfe_api.hip (checked against the
     library by tests): byte offsets inside one per-frame record."""
 
-    def __init__(self, height, width, num_features):
+    def __init__(self, height, width, num_features, desc_bf16=False):
         self.height, self.width = height, width
+        self.desc_bf16 = bool(desc_bf16)   # SPFE_FLAG_DESC_BF16: 2-byte descriptor elements
         self.kmax = num_features + 1
         self.cells = (height // 8) * (width // 8)
         o = 0
@@ -51,7 +52,7 @@ class RecordLayout:
         self.off_resp = o; o = _align(o + self.kmax * 4, 16)
         self.off_cov = o; o = _align(o + self.kmax * 2 * 4, 16)
         self.off_cinv = o; o = _align(o + self.kmax * 2 * 4, 16)
-        self.off_desc = o; o = _align(o + self.kmax * DESC_DIM * 4, 16)
+        self.off_desc = o; o = _align(o + self.kmax * DESC_DIM * (2 if self.desc_bf16 else 4), 16)
         self.off_occ = o; o = _align(o + self.cells * 2, 16)
         self.off_dd = o; o = _align(o + self.cells * 4, 16)
         self.off_sd = o; o = _align(o + self.cells * 4, 16)
@@ -78,7 +79,12 @@ class RecordLayout:
         put(self.off_resp, g("response"), np.float32)
         put(self.off_cov, g("cov2"), np.float32)
         put(self.off_cinv, g("cov2_inv"), np.float32)
-        put(self.off_desc, g("descriptors") if self._has(fr, "descriptors") else g("desc"), np.float32)
+        d = g("descriptors") if self._has(fr, "descriptors") else g("desc")
+        if self.desc_bf16:
+            u = np.ascontiguousarray(d, np.float32).view(np.uint32).astype(np.uint64)
+            put(self.off_desc, ((u + 0x7fff + ((u >> 16) & 1)) >> 16).astype(np.uint16), np.uint16)   # round to nearest even
+        else:
+            put(self.off_desc, d, np.float32)
         put(self.off_occ, g("occ_grid"), np.int16)
         put(self.off_dd, g("dense_dust"), np.float32)
         put(self.off_sd, g("semi_dust"), np.float32)
@@ -107,7 +113,8 @@ class RecordLayout:
                     response=get(self.off_resp, K, np.float32),
                     cov2=get(self.off_cov, K * 2, np.float32).reshape(K, 2),
                     cov2_inv=get(self.off_cinv, K * 2, np.float32).reshape(K, 2),
-                    desc=get(self.off_desc, K * DESC_DIM, np.float32).reshape(K, DESC_DIM),
+                    desc=((get(self.off_desc, K * DESC_DIM, np.uint16).astype(np.uint32) << 16).view(np.float32)
+                          if self.desc_bf16 else get(self.off_desc, K * DESC_DIM, np.float32)).reshape(K, DESC_DIM),
                     occ_grid=get(self.off_occ, hc * wc, np.int16).reshape(hc, wc),
                     dense_dust=get(self.off_dd, hc * wc, np.float32).reshape(hc, wc),
                     semi_dust=get(self.off_sd, hc * wc, np.float32).reshape(hc, wc))

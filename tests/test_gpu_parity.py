@@ -382,6 +382,14 @@ def test_python_record_layout_matches_library():
         for name in ("bytes", "kmax", "off_hdr", "off_xy", "off_resp", "off_cov", "off_cinv", "off_desc",
                      "off_occ", "off_dd", "off_sd"):
             assert getattr(lay, name) == getattr(ext.layout, name), name
+        assert ext.layout.desc_elem_bytes == 4
+        ext.close()
+        ext = SPExtractor(nf, H, W, weights.synthetic(7, "dense"), with_heat=False, desc_bf16=True)
+        lay = parallel.RecordLayout(H, W, nf, desc_bf16=True)
+        for name in ("bytes", "kmax", "off_hdr", "off_xy", "off_resp", "off_cov", "off_cinv", "off_desc",
+                     "off_occ", "off_dd", "off_sd"):
+            assert getattr(lay, name) == getattr(ext.layout, name), name
+        assert ext.layout.desc_elem_bytes == 2
         ext.close()
 
 
