@@ -60,9 +60,10 @@ extern "C" {
                                   shrinks from ~1.1 MB to ~0.6 MB (1000 features), and with it the D2H copy of the host
                                   calls and the all-gather of the multi-GPU path.  spfe_result.desc is NULL then and
                                   spfe_result.desc_bf16 is set; spfe_record_layout.desc_elem_bytes says which.  Everything
-                                  else in the record is unchanged.  The matching entry points that read descriptors from
-                                  records (spfe_match_records_device, spfe_match_patches_record_device,
-                                  spfe_track_dust_record_device) refuse such records with SPFE_EINVAL. */
+                                  else in the record is unchanged.  The entry points that read descriptors from records
+                                  (spfe_match_records_device, spfe_match_patches_record_device,
+                                  spfe_track_dust_record_device) widen the rows on load: distances are the f32 arithmetic
+                                  of the reference on those rounded values. */
 
 /* spfe_result.status / record header word 2 */
 #define SPFE_STATUS_COV_OVERFLOW 1 /* Set only when ONE covariance region has more pops than the device's last-resort list

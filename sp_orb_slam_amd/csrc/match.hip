@@ -44,6 +44,13 @@ __device__ __forceinline__ int side_count(const MatchSide &s, int pair) {
 __device__ __forceinline__ const float *side_desc(const MatchSide &s, int pair) {
   return reinterpret_cast<const float *>(s.base + (size_t)pair * s.stride + s.off_desc);
 }
+// four consecutive descriptor elements from element index e of a row block: f32 rows, or bf16 rows widened (exact)
+__device__ __forceinline__ float4 desc4(const float *rows, size_t e, int bf16) {
+  if (!bf16) return *reinterpret_cast<const float4 *>(rows + e);
+  const uint2 p = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(rows) + e);
+  return make_float4(__uint_as_float(p.x << 16), __uint_as_float(p.x & 0xffff0000u), __uint_as_float(p.y << 16),
+                     __uint_as_float(p.y & 0xffff0000u));
+}
 }  // namespace
 
 // excl (may be null): per row, only candidates with a (dist, column) key ABOVE excl[row] compete — with excl =
@@ -77,8 +84,8 @@ __global__ __launch_bounds__(256) void match_nn_kernel(MatchSide rows, MatchSide
     for (int i = tid; i < M_TILE * (M_KC / 4); i += 256) {
       const int row = i >> 4, k4 = i & 15;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f), u = v;
-      if (r0 + row < nr) v = *reinterpret_cast<const float4 *>(R + (size_t)(r0 + row) * M_DIM + k0 + k4 * 4);
-      if (c0 + row < nc) u = *reinterpret_cast<const float4 *>(Cd + (size_t)(c0 + row) * M_DIM + k0 + k4 * 4);
+      if (r0 + row < nr) v = desc4(R, (size_t)(r0 + row) * M_DIM + k0 + k4 * 4, rows.desc_bf16);
+      if (c0 + row < nc) u = desc4(Cd, (size_t)(c0 + row) * M_DIM + k0 + k4 * 4, cols.desc_bf16);
       *reinterpret_cast<float4 *>(&sR[row * M_PITCH + k4 * 4]) = v;
       *reinterpret_cast<float4 *>(&sC[row * M_PITCH + k4 * 4]) = u;
     }
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(256) void patch_dist_kernel(PatchArgs a, int *__res
     if (idx >= K) idx = -1;
     float dist = 3.0e38f;
     if (idx >= 0) {  // wave-uniform
-      const float4 k4 = *reinterpret_cast<const float4 *>(a.kp_desc + (size_t)idx * 256 + lane * 4);
+      const float4 k4 = desc4(a.kp_desc, (size_t)idx * 256 + lane * 4, a.kp_desc_bf16);
       const float d0 = m4.x - k4.x, d1 = m4.y - k4.y, d2 = m4.z - k4.z, d3 = m4.w - k4.w;
       double s = (double)d0 * (double)d0;
       s = s + (double)d1 * (double)d1;

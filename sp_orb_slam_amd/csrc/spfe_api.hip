@@ -1920,7 +1920,6 @@ int patch_scratch(spfe_handle h) {
 
 int spfe_match_patches_record_device(spfe_handle h, const void *d_mp_desc, const void *d_mp_uv, int n_points,
                                      const void *d_record, float max_dist, void *d_kp_idx, void *stream) {
-  if (h && h->rl.desc_bf16) return fail(SPFE_EINVAL, "the records of this handle carry bf16 descriptors (SPFE_FLAG_DESC_BF16): this entry point reads f32 rows");
   if (!h || !d_record || !d_kp_idx) return fail(SPFE_EINVAL, "null argument");
   if (n_points < 0 || n_points > kPatchMax) return fail(SPFE_EINVAL, "n_points %d not in [0, %d]", n_points, kPatchMax);
   if (n_points == 0) return SPFE_OK;
@@ -1937,6 +1936,7 @@ int spfe_match_patches_record_device(spfe_handle h, const void *d_mp_desc, const
   a.occ = reinterpret_cast<const int16_t *>(rec + h->rl.off_occ);
   a.hc = h->hc; a.wc = h->wc;
   a.kp_desc = reinterpret_cast<const float *>(rec + h->rl.off_desc);
+  a.kp_desc_bf16 = h->rl.desc_bf16;
   a.k_ptr = reinterpret_cast<const int *>(rec + h->rl.off_hdr);
   a.k_imm = 0;
   HIP_TRY(spfe::launch_match_patches(a, h->kmax, max_dist, h->p_cidx, h->p_cdist,
@@ -1947,7 +1947,6 @@ int spfe_match_patches_record_device(spfe_handle h, const void *d_mp_desc, const
 int spfe_track_dust_record_device(spfe_handle h, const void *d_record, const void *d_points_xyz, const void *d_mp_desc, int n,
                                   const void *d_Tcw, const spfe_dust_params *prm, int min_inliers, float max_dist,
                                   void *d_dust_out, void *d_kp_idx, void *stream) {
-  if (h && h->rl.desc_bf16) return fail(SPFE_EINVAL, "the records of this handle carry bf16 descriptors (SPFE_FLAG_DESC_BF16): this entry point reads f32 rows");
   if (!h || !d_record || !d_Tcw || !prm || !d_dust_out || !d_kp_idx || (n > 0 && (!d_points_xyz || !d_mp_desc)))
     return fail(SPFE_EINVAL, "null argument");
   int rc = dust_check(h, n, prm);
@@ -1970,6 +1969,7 @@ int spfe_track_dust_record_device(spfe_handle h, const void *d_record, const voi
   a.occ = reinterpret_cast<const int16_t *>(rec + h->rl.off_occ);
   a.hc = h->hc; a.wc = h->wc;
   a.kp_desc = reinterpret_cast<const float *>(rec + h->rl.off_desc);
+  a.kp_desc_bf16 = h->rl.desc_bf16;
   a.k_ptr = reinterpret_cast<const int *>(rec + h->rl.off_hdr);
   a.k_imm = 0;
   a.in_view = dout + SPFE_DUST_OFF_INLIER;
@@ -2049,7 +2049,6 @@ size_t spfe_match_out_bytes(spfe_handle h) { return h ? (size_t)h->kmax * 8 : 0;
 
 int spfe_match_records_device(spfe_handle h, const void *d_query_records, const void *d_train_records, int n_pairs,
                               int cross_check, void *d_out, void *stream) {
-  if (h && h->rl.desc_bf16) return fail(SPFE_EINVAL, "the records of this handle carry bf16 descriptors (SPFE_FLAG_DESC_BF16): this entry point reads f32 rows");
   if (!h || !d_query_records || !d_train_records || !d_out) return fail(SPFE_EINVAL, "null argument");
   if (n_pairs < 1) return fail(SPFE_EINVAL, "n_pairs %d must be >= 1", n_pairs);
   HIP_TRY(hipSetDevice(h->cfg.device));
@@ -2060,6 +2059,7 @@ int spfe_match_records_device(spfe_handle h, const void *d_query_records, const 
                     h->kmax};
   spfe::MatchSide t{reinterpret_cast<const uint8_t *>(d_train_records), h->rl.bytes, h->rl.off_hdr, h->rl.off_desc,
                     h->kmax};
+  q.desc_bf16 = t.desc_bf16 = h->rl.desc_bf16;   // (records made with SPFE_FLAG_DESC_BF16: bf16 rows, widened on load)
   HIP_TRY(spfe::launch_match(q, t, n_pairs, cross_check != 0, h->m_best_t, h->m_best_q,
                              reinterpret_cast<uint8_t *>(d_out), (size_t)h->kmax * 8, s));
   return SPFE_OK;

@@ -172,6 +172,7 @@ struct MatchSide {
   const uint8_t *base;
   size_t stride, off_cnt, off_desc;
   int cap;
+  int desc_bf16 = 0;   // rows are 256 bf16 (records made with SPFE_FLAG_DESC_BF16): widened on load, distances in f32 on those values
 };
 // out: per pair `out_stride` bytes: int32 train_idx[query.cap] (-1 = none), float dist[query.cap].
 // best_t: [pairs][train.cap], best_q: [pairs][query.cap] scratch.
@@ -206,6 +207,7 @@ struct PatchArgs {
   const int16_t *occ;    // [hc][wc] keypoint index per cell, -1 = empty
   int hc, wc;
   const float *kp_desc;  // [K][256]
+  int kp_desc_bf16 = 0;  // ... as bf16 rows (a record made with SPFE_FLAG_DESC_BF16)
   const int *k_ptr;      // K on the device (a record header), or null -> k_imm
   int k_imm;
   // chained form (spfe_track_dust_record_device): map points whose in_view flag is 0 are skipped

@@ -42,7 +42,7 @@ def test_bf16_descriptors_are_the_rounded_f32_ones_and_nothing_else_changes(prec
     assert np.array_equal(one[1].view(np.uint32), sync[0].descriptors.view(np.uint32))   # operator(): the widened rows
 
 
-def test_device_records_with_bf16_descriptors_decode_and_the_matchers_refuse_them():
+def test_device_records_with_bf16_descriptors_decode_and_match():
     import torch
     H, W, nf, B = 240, 376, 200, 2
     blob = weights.synthetic(7, "dense")
@@ -68,7 +68,16 @@ def test_device_records_with_bf16_descriptors_decode_and_the_matchers_refuse_the
         assert np.array_equal(v.descriptors.view(np.uint32), want)
         assert np.array_equal(lay.pack(dict(d, descriptors=a[i].descriptors, response=d["response"]))[lay.off_desc:lay.off_occ],
                               rec[lay.off_desc:lay.off_occ])
+    # the record-reading matcher widens the rows on load: the oracle's brute-force matcher on the widened descriptors
+    from oracle import oracle
     d_out = torch.zeros(ext.match_out_bytes(), dtype=torch.uint8, device="cuda")
-    with pytest.raises(RuntimeError, match="bf16 descriptors"):
-        ext.match_records_device(d_rec.data_ptr(), d_rec.data_ptr(), 1, d_out.data_ptr())
+    rb = ext.record_bytes()
+    for cross in (True, False):
+        ext.match_records_device(d_rec.data_ptr() + rb, d_rec.data_ptr(), 1, d_out.data_ptr(), cross)
+        torch.cuda.synchronize()
+        q, t = ext.view_record(host[rb:2 * rb]), ext.view_record(host[:rb])
+        idx, dist = ext.decode_match_out(d_out.cpu().numpy())
+        ridx, rdist = oracle.match_bruteforce(q.descriptors, t.descriptors, cross)
+        assert np.array_equal(idx[:q.K], ridx)
+        assert np.array_equal(dist[:q.K].view(np.uint32), rdist.view(np.uint32))
     ext.close()

@@ -65,11 +65,13 @@ def test_patches_empty_and_thresholds(frame):
                               oracle.match_patches(desc, uv, fr.occ_grid, fr.descriptors, md))
 
 
-def test_patches_against_resident_record():
+@pytest.mark.parametrize("desc_bf16", [False, True])
+def test_patches_against_resident_record(desc_bf16):
+    """(desc_bf16: a record made with SPFE_FLAG_DESC_BF16 — its rows are widened on load; the oracle gets the widened rows)"""
     import torch
 
     H, W, nf = 240, 320, 600
-    ext = SPExtractor(nf, H, W, weights.synthetic(7, "dense"), with_heat=False)
+    ext = SPExtractor(nf, H, W, weights.synthetic(7, "dense"), with_heat=False, desc_bf16=desc_bf16)
     img = torch.from_numpy(synth.make_image(78, H, W)[None]).cuda()
     rec = torch.zeros(ext.record_bytes(), dtype=torch.uint8, device="cuda")
     s = torch.cuda.Stream()
