@@ -118,7 +118,17 @@ def run_timed(ext, sharded, d_img, stream, steps, warmup, world, dist, torch):
     return dt
 
 
-def roofline_of(precision, stages, H, W, B, traffic):
+def conv1b_rows(ext, precision):
+    """Rows per tile of the f32 conv1b instantiation the last call launched (8 or 16): part of the kernel's name."""
+    if precision != "f32":
+        return 8
+    try:
+        return int(ext.debug_read("conv1b_tile_rows")[0])
+    except Exception:
+        return 8
+
+
+def roofline_of(precision, stages, H, W, B, traffic, tile_rows=8):
     t_conv1b = stages.get("conv1b", 0.0) * 1e-3
     bf16 = precision == "bf16"
     # bf16: the dominant kernel computes conv1a (9 taps, 1 -> 64 channels) as well, in its producer waves
@@ -126,7 +136,7 @@ def roofline_of(precision, stages, H, W, B, traffic):
     ach = (flop * B / t_conv1b / 1e12) if t_conv1b > 0 else None
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     return {"bound": "mfma", "kernel": ("conv_bf16_ws_kernel<true,2> (conv1b with conv1a computed by its producer waves)" if bf16 else
-                                        "conv_f32_kernel<1,64,3,16,4,1,2,2,true,true> (conv1b)"),
+                                        "conv_f32_kernel<1,64,3,16,4,1,%d,2,true,true> (conv1b, %d-row tiles)" % (tile_rows // 4, tile_rows)),
             "achieved": round(ach, 2) if ach else None, "peak": peak, "unit": "TFLOP/s",
             "frac": round(ach / peak, 4) if ach else None, "traffic": traffic,
             "kernel_ms": round(t_conv1b * 1e3, 4)}
@@ -170,7 +180,7 @@ def device_leg(ctx, precision, H, W, B, seed0, steps, warmup, what):
     fps = B * steps / dt
     out = {"what": "%s, %d timed steps after %d untimed" % (what, steps, warmup),
            "value": round(fps, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 4), "dtype": precision,
-           "roofline": roofline_of(precision, st, H, W, B, traffic_of(precision, H, W, B)),
+           "roofline": roofline_of(precision, st, H, W, B, traffic_of(precision, H, W, B), conv1b_rows(ext, precision)),
            "records_ok": ok}
     out.update(path_tflops(ext, fps, H, W, B))
     ext.close()
@@ -500,7 +510,7 @@ def main():
                        "gather": ("none (1 GPU)" if world == 1 else
                                   "ncclAllGather inside libspfe (spfe_allgather_records)" if getattr(sharded, "_native", False)
                                   else "torch.distributed all_gather_into_tensor")},
-            "roofline": roofline_of(args.precision, stages, H, W, B, traffic_of(args.precision, H, W, B)),
+            "roofline": roofline_of(args.precision, stages, H, W, B, traffic_of(args.precision, H, W, B), conv1b_rows(ext, args.precision)),
         }
         out.update(path_tflops(ext, fps, H, W, B))
 

@@ -100,7 +100,7 @@ struct EpiCtx {  // the tile whose outputs are being stored
 template <int MT, int NT, bool POOL, bool RELU, int E>
 __device__ __forceinline__ void epi_store(const EpiCtx<NT> &e, const f32x16 (&acc)[MT][NT]) {
   // C layout of the 32x32 MFMA: column (N) = lane&31, row (M) = (r&3)+8*(r>>2)+4*(lane>>5)
-  constexpr int NEPI_ = POOL ? NT * 8 : MT * NT * 16;
+  constexpr int NEPI_ = POOL ? (MT / 2) * NT * 8 : MT * NT * 16;
   if constexpr (E >= NEPI_) {
     return;
   } else if constexpr (!POOL) {
@@ -111,10 +111,10 @@ __device__ __forceinline__ void epi_store(const EpiCtx<NT> &e, const f32x16 (&ac
     const unsigned off = (xr < e.xlim && i < e.ylim) ? e.obase[j] + i * e.rowstep + xr * e.pixstep : SPFE_OOB;
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), e.rout, off, 0, 0);
   } else {
-    constexpr int j = E / 8, r = 2 * (E % 8);
+    constexpr int ip = E / (NT * 8), j = (E / 8) % NT, r = 2 * (E % 8), i0 = 2 * ip;   // pooled row ip = rows 2 ip, 2 ip + 1 of this wave
     constexpr int xr = (r & 3) + 8 * (r >> 2);
-    float v00 = acc[0][j][r] + e.bias[j], v01 = acc[0][j][r + 1] + e.bias[j];
-    float v10 = acc[1][j][r] + e.bias[j], v11 = acc[1][j][r + 1] + e.bias[j];
+    float v00 = acc[i0][j][r] + e.bias[j], v01 = acc[i0][j][r + 1] + e.bias[j];
+    float v10 = acc[i0 + 1][j][r] + e.bias[j], v11 = acc[i0 + 1][j][r + 1] + e.bias[j];
     if (RELU) {
       v00 = v00 > 0.0f ? v00 : 0.0f;
       v01 = v01 > 0.0f ? v01 : 0.0f;
@@ -124,7 +124,7 @@ __device__ __forceinline__ void epi_store(const EpiCtx<NT> &e, const f32x16 (&ac
     const float m0 = v00 > v01 ? v00 : v01;
     const float m1 = v10 > v11 ? v10 : v11;
     const float v = m0 > m1 ? m0 : m1;
-    const unsigned off = (xr < e.xlim && 0 < e.ylim) ? e.obase[j] + (xr >> 1) * e.pixstep : SPFE_OOB;
+    const unsigned off = (xr < e.xlim && i0 < e.ylim) ? e.obase[j] + ip * e.rowstep + (xr >> 1) * e.pixstep : SPFE_OOB;
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), e.rout, off, 0, 0);
   }
 }
@@ -202,7 +202,7 @@ __device__ __forceinline__ void k_steps(float (&a)[2][MT], float (&bb)[2][NT], f
     constexpr int NLDA = FUSE ? 0 : NITER;  // fused: the input pieces are computed, not loaded
     constexpr int NLD = NLDA + NWITER;
     constexpr int L0 = 1, W0 = NSTEP - NLD - 1;
-    constexpr int NEPI = POOL ? NT * 8 : MT * NT * 16;       // stores per wave per tile
+    constexpr int NEPI = POOL ? (MT / 2) * NT * 8 : MT * NT * 16;       // stores per wave per tile
     constexpr int EPS = (NEPI + (NSTEP - 3)) / (NSTEP - 2);  // stores per step
     constexpr int cur = STEP & 1, nxt = cur ^ 1;
     static_assert(L0 + NLD <= W0, "loads and LDS writes of a stage must not overlap");
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_f32_kernel(ConvParams p)
   static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
   constexpr int NTHR = 64 * WM * WN;
   static_assert(WN * NT == 2, "64 output channels per workgroup");
-  static_assert(!POOL || MT == 2, "pooling needs two rows per wave");
+  static_assert(!POOL || MT % 2 == 0, "pooling needs row pairs per wave");
   static_assert((KC * PLANE) % 4 == 0 && BUF % 4 == 0, "weight slabs must stay 16B aligned");
   constexpr int Q = KC / 4;  // float4 per pixel per chunk
   constexpr int NITEM = G::ROWS * G::COLS * Q;
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_f32_kernel(ConvParams p)
   }
   // the last tile's outputs: nothing left to hide them under
   {
-    constexpr int NEPI = POOL ? NT * 8 : MT * NT * 16;
+    constexpr int NEPI = POOL ? (MT / 2) * NT * 8 : MT * NT * 16;
     auto flush = [&](const f32x16(&acc)[MT][NT]) {
       [&]<int... E>(std::integer_sequence<int, E...>) {
         (epi_store<MT, NT, POOL, RELU, E>(epi, acc), ...);
@@ -639,7 +639,7 @@ static hipError_t launch_one(const ConvParams &p, hipStream_t s) {
 }
 
 int conv_kc(int ksize) { return ksize == 3 ? 16 : 64; }
-int conv_tile_rows(int tile_mode) { return tile_mode == 1 ? 4 : (tile_mode == 2 ? 16 : (tile_mode == 3 ? 2 : 8)); }
+int conv_tile_rows(int tile_mode) { return tile_mode == 1 ? 4 : (tile_mode == 2 || tile_mode == 4 ? 16 : (tile_mode == 3 ? 2 : 8)); }
 
 hipError_t launch_conv_f32(const ConvParams &p, int cin, int ksize, bool pool, bool relu,
                            int tile_mode, int layer_tag, hipStream_t s) {
@@ -649,6 +649,8 @@ hipError_t launch_conv_f32(const ConvParams &p, int cin, int ksize, bool pool, b
     if (cin == 128) return launch_one<0, 128, 3, 16, 2, 2, 1, 1, false, true>(p, s);  // a 4-row item per CU leaves CUs idle
     return hipErrorInvalidValue;
   }
+  if (tile_mode == 4 && ksize == 3 && relu && pool && cin == 64 && layer_tag == 1)   // conv1b, 16-row tiles of 4 waves x 4 rows
+    return launch_one<1, 64, 3, 16, 4, 1, 4, 2, true, true>(p, s);
   if (tile_mode == 2 && ksize == 3 && relu) {  // 16-row tiles, 8 waves (two per SIMD)
     if (layer_tag == 1 && cin == 64 && pool) return launch_one<1, 64, 3, 16, 8, 1, 2, 2, true, true>(p, s);  // conv1b
     if (cin == 64 && pool) return launch_one<0, 64, 3, 16, 8, 1, 2, 2, true, true>(p, s);

@@ -178,6 +178,8 @@ struct spfe_handle_s {
   unsigned tile2_mask = 0;   // SPFE_TILE2_MASK: f32 layers forced onto 2-row tiles (probe knob)
   bool tile2_auto = true;    // SPFE_TILE2_AUTO=0: never choose 2-row tiles
   unsigned tile16_mask = 0;  // f32 layers (bit i = conv layer i of enqueue()) on 16-row / 8-wave tiles
+  int conv1b_tile_rows = 8;  // rows per tile of the last call's conv1b launch (f32; spfe_debug_read("conv1b_tile_rows"))
+  int tile16x4 = 1;          // SPFE_TILE16X4: conv1b on 16-row tiles of 4 wavefronts x 4 rows (0 never, 1 by the cost model, 2 always)
   bool fuse1a = false;  // f32: conv1a computed inside conv1b (opt-in: SPFE_FUSE_CONV1A=1; measured perf-neutral)
   bool fuse1a_bf16 = true;  // bf16: conv1a computed by the producer waves of the wave-specialised conv1b (SPFE_BF16_FUSE_CONV1A=0 to split)
   uint8_t *dust_scratch = nullptr;   // spfe_align_dust: dust map | points | pose | output block (device)
@@ -508,6 +510,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
     const char *menv = getenv("SPFE_TILE16_MASK");
     if (menv) h->tile16_mask = (unsigned)strtoul(menv, nullptr, 0);
     if (const char *m2 = getenv("SPFE_TILE2_MASK")) h->tile2_mask = (unsigned)strtoul(m2, nullptr, 0);
+    if (const char *m4 = getenv("SPFE_TILE16X4")) h->tile16x4 = atoi(m4);
     if (const char *a2 = getenv("SPFE_TILE2_AUTO")) h->tile2_auto = atoi(a2) != 0;
     const char *wenv = getenv("SPFE_BF16_WS_MASK");
     if (wenv) h->ws_mask = (unsigned)strtoul(wenv, nullptr, 0) & 0xfu;
@@ -987,9 +990,20 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     if (i == 0 && fused) small_tile = false;  // the fused first layer exists for 8-row tiles only
     int tile_mode = small_tile ? 1 : 0;
     if (L.ks == 3 && !(i == 0 && fused) && ((h->tile16_mask >> i) & 1)) tile_mode = 2;
-    if (tiny_tile && tile_mode != 2) tile_mode = 3;
+    // conv1b: 16-row tiles of 4 wavefronts x 4 rows x 64 channels (6 operand reads per 8 MFMAs instead of 8; bit-identical):
+    // measured on conv1b 2.2 ... 2.5 % per tile (640x480: 0.863 -> 0.882 of peak; 752x480: the coarser list costs 45 -> 46
+    // round equivalents and it still gains 0.3 %; whole path +0.6 ... 0.8 %) — taken when its rounds are not more than 2.5 %
+    // longer than the 8-row list's.  SPFE_TILE16X4=0: never, 2: always
+    if (i == 0 && !fused && L.pool && h->tile16x4 && (tile_mode == 0 || h->tile16x4 >= 2)) {
+      const long g = h->num_cus > 0 ? h->num_cus : 256;
+      const long tx = (L.W + 31) / 32;
+      const long r8 = (tx * ((L.H + 7) / 8) * n + g - 1) / g, r16 = (tx * ((L.H + 15) / 16) * n + g - 1) / g;
+      if (2.0 * r16 * 0.975 < (double)r8 || h->tile16x4 >= 2) tile_mode = 4;
+    }
+    if (tiny_tile && tile_mode != 2 && tile_mode != 4) tile_mode = 3;
     if (L.ks == 3 && !L.pool && L.relu && ((h->tile2_mask >> i) & 1)) tile_mode = 3;
     const int th = spfe::conv_tile_rows(tile_mode);
+    if (i == 0) h->conv1b_tile_rows = th;
     p.tiles_x = (L.W + 31) / 32; p.tiles_y = (L.H + th - 1) / th; p.nblk = L.nblk;
     if (i == 7 && sparse_da) p.nblk = L.nblk / 2;   // convPa only: convDa runs gathered, behind the selection (da_gather_f32.hip)
     p.num_cus = h->num_cus;
@@ -1388,6 +1402,11 @@ long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size
   if (!h || !name || !dst) return fail(SPFE_EINVAL, "null argument");
   if (frame < 0 || frame >= h->B) return fail(SPFE_EINVAL, "frame %d out of range", frame);
   const size_t C = h->C, HW = (size_t)h->H * h->W;
+  if (std::string(name) == "conv1b_tile_rows") {   // f32: which conv1b instantiation the last call launched (8 or 16 rows per tile)
+    if (cap < sizeof(int)) return fail(SPFE_EINVAL, "buffer 'conv1b_tile_rows' needs 4 bytes");
+    *reinterpret_cast<int *>(dst) = h->conv1b_tile_rows;
+    return (long)sizeof(int);
+  }
   if (std::string(name) == "da_gathered") {   // 1: the last call ran convDa on the listed cells only (host-side flag)
     if (cap < sizeof(int)) return fail(SPFE_EINVAL, "buffer 'da_gathered' needs 4 bytes");
     *reinterpret_cast<int *>(dst) = h->sparse_last && h->sparse_da_call ? 1 : 0;

@@ -695,6 +695,26 @@ def test_f32_two_row_tiles_are_bit_identical(monkeypatch, H, W, B):
             assert np.array_equal(a.cov2, b.cov2)
 
 
+@pytest.mark.parametrize("H,W,B", [(240, 376, 2), (120, 168, 3), (136, 200, 1), (480, 752, 1), (24, 40, 2)])
+def test_f32_conv1b_16_row_tiles_are_bit_identical(monkeypatch, H, W, B):
+    """conv1b on 16-row tiles (4 wavefronts x 4 rows x 64 channels: the cost model's choice for the large launches; forced
+    here) against the 8-row tiles: the pooled output act1 and everything behind it are the same bits, ragged heights
+    (120 = 7.5 tiles, 136 = 8.5, 24 = 1.5) included."""
+    blob = weights.synthetic(7, "dense")
+    imgs = [synth.make_image(90 + i, H, W) for i in range(B)]
+    out = {}
+    for flag in ("0", "2"):
+        monkeypatch.setenv("SPFE_TILE16X4", flag)
+        ext = SPExtractor(200, H, W, blob, max_batch=B, with_heat=False)
+        frs = ext.extract_batch(imgs)
+        out[flag] = (frs, [ext.debug_read(nm, i) for i in range(B) for nm in ("act1", "semi", "feat")])
+        ext.close()
+    for a, b in zip(out["0"][1], out["2"][1]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for a, b in zip(out["0"][0], out["2"][0]):
+        assert np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.descriptors, b.descriptors)
+
+
 def test_debug_read_follows_the_double_buffered_tail_outputs():
     """heat_log / cell_score exist twice (by ticket parity, so that the next batch's detector tail does not wait for this
     batch's side chain): debug_read must hand out the set the LAST call wrote, whichever parity that was."""
