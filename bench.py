@@ -118,28 +118,38 @@ def run_timed(ext, sharded, d_img, stream, steps, warmup, world, dist, torch):
     return dt
 
 
-def conv1b_rows(ext, precision):
-    """Rows per tile of the f32 conv1b instantiation the last call launched (8 or 16): part of the kernel's name."""
+def conv1b_rows(ext, precision, H=0, B=0):
+    """(rows per tile of the f32 conv1b instantiation the last call launched — 8 or 16, part of the kernel's name —, share of
+    conv1b's work in that launch): large launches whose work list divides neither way run the first k tile rows of the batch
+    as 16-row tiles and the rest as 8-row tiles in a second launch; the in-region events then bracket the 16-row KERNEL."""
     if precision != "f32":
-        return 8
+        return 8, 1.0
     try:
-        return int(ext.debug_read("conv1b_tile_rows")[0])
+        rows = int(ext.debug_read("conv1b_tile_rows")[0])
+        k = int(ext.debug_read("conv1b_split_rows")[0])
     except Exception:
-        return 8
+        return 8, 1.0
+    if k > 0 and H and B:
+        ty16 = (H + 15) // 16
+        # (exact share in output rows: a frame's last tile row may be half a tile)
+        f, r = divmod(k, ty16)
+        return rows, (f * H + min(16 * r, H)) / float(B * H)
+    return rows, 1.0
 
 
-def roofline_of(precision, stages, H, W, B, traffic, tile_rows=8):
+def roofline_of(precision, stages, H, W, B, traffic, tile=(8, 1.0)):
+    tile_rows, share = tile
     t_conv1b = stages.get("conv1b", 0.0) * 1e-3
     bf16 = precision == "bf16"
     # bf16: the dominant kernel computes conv1a (9 taps, 1 -> 64 channels) as well, in its producer waves
-    flop = conv1b_flop(H, W) + (2 * H * W * 64 * 9 if bf16 else 0)
+    flop = (conv1b_flop(H, W) + (2 * H * W * 64 * 9 if bf16 else 0)) * share
     ach = (flop * B / t_conv1b / 1e12) if t_conv1b > 0 else None
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     return {"bound": "mfma", "kernel": ("conv_bf16_ws_kernel<true,2> (conv1b with conv1a computed by its producer waves)" if bf16 else
                                         "conv_f32_kernel<1,64,3,16,4,1,%d,2,true,true> (conv1b, %d-row tiles)" % (tile_rows // 4, tile_rows)),
             "achieved": round(ach, 2) if ach else None, "peak": peak, "unit": "TFLOP/s",
             "frac": round(ach / peak, 4) if ach else None, "traffic": traffic,
-            "kernel_ms": round(t_conv1b * 1e3, 4)}
+            "kernel_ms": round(t_conv1b * 1e3, 4), "share_of_conv1b_in_this_launch": round(share, 4)}
 
 
 def parity_of(rec, ref, bf16):
@@ -180,7 +190,7 @@ def device_leg(ctx, precision, H, W, B, seed0, steps, warmup, what):
     fps = B * steps / dt
     out = {"what": "%s, %d timed steps after %d untimed" % (what, steps, warmup),
            "value": round(fps, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 4), "dtype": precision,
-           "roofline": roofline_of(precision, st, H, W, B, traffic_of(precision, H, W, B), conv1b_rows(ext, precision)),
+           "roofline": roofline_of(precision, st, H, W, B, traffic_of(precision, H, W, B), conv1b_rows(ext, precision, H, B)),
            "records_ok": ok}
     out.update(path_tflops(ext, fps, H, W, B))
     ext.close()
@@ -510,7 +520,7 @@ def main():
                        "gather": ("none (1 GPU)" if world == 1 else
                                   "ncclAllGather inside libspfe (spfe_allgather_records)" if getattr(sharded, "_native", False)
                                   else "torch.distributed all_gather_into_tensor")},
-            "roofline": roofline_of(args.precision, stages, H, W, B, traffic_of(args.precision, H, W, B), conv1b_rows(ext, args.precision)),
+            "roofline": roofline_of(args.precision, stages, H, W, B, traffic_of(args.precision, H, W, B), conv1b_rows(ext, args.precision, H, B)),
         }
         out.update(path_tflops(ext, fps, H, W, B))
 

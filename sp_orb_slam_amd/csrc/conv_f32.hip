@@ -357,8 +357,9 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_f32_kernel(ConvParams p)
   // speed depends on it).  Each XCD owns one contiguous eighth of the work list
   // (64-channel blocks of a tile adjacent), its workgroups interleave inside it.
   const int total = p.nblk * p.tiles_x * p.tiles_y * p.B;
+  const int first = p.item_lo, count = (p.item_hi > 0 ? p.item_hi : total) - first;   // this launch's part of the list
   const int xcd = blockIdx.x & 7, gi = blockIdx.x >> 3, gper = gridDim.x >> 3;
-  const int lo = (int)((long)total * xcd / 8), hi_w = (int)((long)total * (xcd + 1) / 8);
+  const int lo = first + (int)((long)count * xcd / 8), hi_w = first + (int)((long)count * (xcd + 1) / 8);
   int w = lo + gi;
   if (w >= hi_w) return;
 

@@ -178,8 +178,10 @@ struct spfe_handle_s {
   unsigned tile2_mask = 0;   // SPFE_TILE2_MASK: f32 layers forced onto 2-row tiles (probe knob)
   bool tile2_auto = true;    // SPFE_TILE2_AUTO=0: never choose 2-row tiles
   unsigned tile16_mask = 0;  // f32 layers (bit i = conv layer i of enqueue()) on 16-row / 8-wave tiles
+  int conv1b_split_rows = -1; // ... and, when that launch was cut in a 16-row and an 8-row part, the 16-row part's tile rows ("conv1b_split_rows")
   int conv1b_tile_rows = 8;  // rows per tile of the last call's conv1b launch (f32; spfe_debug_read("conv1b_tile_rows"))
-  int tile16x4 = 1;          // SPFE_TILE16X4: conv1b on 16-row tiles of 4 wavefronts x 4 rows (0 never, 1 by the cost model, 2 always)
+  int tile16x4 = 1;          // SPFE_TILE16X4: conv1b on 16-row tiles of 4 wavefronts x 4 rows (0 never, 1 by the cost model — possibly
+                             // cut in a 16-row and an 8-row launch —, 2 always in one launch, 3 cost model without the cut)
   bool fuse1a = false;  // f32: conv1a computed inside conv1b (opt-in: SPFE_FUSE_CONV1A=1; measured perf-neutral)
   bool fuse1a_bf16 = true;  // bf16: conv1a computed by the producer waves of the wave-specialised conv1b (SPFE_BF16_FUSE_CONV1A=0 to split)
   uint8_t *dust_scratch = nullptr;   // spfe_align_dust: dust map | points | pose | output block (device)
@@ -993,20 +995,52 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     // conv1b: 16-row tiles of 4 wavefronts x 4 rows x 64 channels (6 operand reads per 8 MFMAs instead of 8; bit-identical):
     // measured on conv1b 2.2 ... 2.5 % per tile (640x480: 0.863 -> 0.882 of peak; 752x480: the coarser list costs 45 -> 46
     // round equivalents and it still gains 0.3 %; whole path +0.6 ... 0.8 %) — taken when its rounds are not more than 2.5 %
-    // longer than the 8-row list's.  SPFE_TILE16X4=0: never, 2: always
-    if (i == 0 && !fused && L.pool && h->tile16x4 && (tile_mode == 0 || h->tile16x4 >= 2)) {
+    // longer than the 8-row list's.  SPFE_TILE16X4=0: never, 2: always (one launch)
+    // ... and when neither list divides well, BOTH: the first k tile rows (of 16) of the batch as 16-row tiles, the rest as
+    // 8-row tiles in a second launch — 752x480 x 8: 224 of 240 tile rows = 21 rounds exactly + 768 eight-row tiles = 3
+    // rounds exactly = 45 round equivalents, 42 of them at the 16-row rate (46 with 16-row tiles alone).  SPFE_TILE16X4=3:
+    // no second launch
+    long split16_rows = -1;   // >= 0: conv1b in two launches, 16-row tiles for the first split16_rows tile rows of the batch
+    if (i == 0 && !fused && L.pool && h->tile16x4 && (tile_mode == 0 || h->tile16x4 == 2)) {
       const long g = h->num_cus > 0 ? h->num_cus : 256;
-      const long tx = (L.W + 31) / 32;
-      const long r8 = (tx * ((L.H + 7) / 8) * n + g - 1) / g, r16 = (tx * ((L.H + 15) / 16) * n + g - 1) / g;
-      if (2.0 * r16 * 0.975 < (double)r8 || h->tile16x4 >= 2) tile_mode = 4;
+      const long tx = (L.W + 31) / 32, ty8 = (L.H + 7) / 8, ty16 = (L.H + 15) / 16;
+      const long r8 = (tx * ty8 * n + g - 1) / g, r16 = (tx * ty16 * n + g - 1) / g;
+      const double c8 = (double)r8, c16 = 2.0 * r16 * 0.975;
+      double best = c8 < c16 ? c8 : c16;
+      if (c16 < c8 || h->tile16x4 == 2) tile_mode = 4;
+      if (h->tile16x4 == 1 && r8 >= 8)   // (large launches only: the second launch costs a kernel boundary)
+        for (long k = ty16 * n - 1; k > 0 && k >= ty16 * n - 4 * ty16; --k) {
+          const long f = k / ty16, r = k % ty16;                    // frames before f whole, r tile rows of frame f
+          const long rows8 = (ty8 - std::min(2 * r, ty8)) + (n - f - 1) * ty8;
+          const double c = 2.0 * ((tx * k + g - 1) / g) * 0.975 + (double)((tx * rows8 + g - 1) / g) + 0.3;
+          if (c < best - 0.2) { best = c; split16_rows = k; }
+        }
     }
     if (tiny_tile && tile_mode != 2 && tile_mode != 4) tile_mode = 3;
     if (L.ks == 3 && !L.pool && L.relu && ((h->tile2_mask >> i) & 1)) tile_mode = 3;
     const int th = spfe::conv_tile_rows(tile_mode);
-    if (i == 0) h->conv1b_tile_rows = th;
+    if (i == 0) { h->conv1b_tile_rows = th; h->conv1b_split_rows = (int)split16_rows; }
     p.tiles_x = (L.W + 31) / 32; p.tiles_y = (L.H + th - 1) / th; p.nblk = L.nblk;
     if (i == 7 && sparse_da) p.nblk = L.nblk / 2;   // convPa only: convDa runs gathered, behind the selection (da_gather_f32.hip)
     p.num_cus = h->num_cus;
+    if (split16_rows > 0) {   // conv1b: 16-row tiles for the first split16_rows tile rows, 8-row tiles for the rest
+      const int ty8 = (L.H + 7) / 8, ty16 = (L.H + 15) / 16;
+      const long f = split16_rows / ty16, r = split16_rows % ty16;
+      spfe::ConvParams p16 = p;
+      p16.tiles_y = ty16;
+      p16.item_lo = 0; p16.item_hi = (int)(p.tiles_x * split16_rows);
+      HIP_TRY(spfe::launch_conv_f32(p16, L.cin, L.ks, L.pool, L.relu, 4, 1, s));
+      // SPFE_STAGE_TIMING=2 brackets the dominant KERNEL: the 16-row launch (split16_rows of the batch's tile rows), not the pair
+      const bool kernel_bracket = h->timing && !h->timing_all;
+      if (kernel_bracket) HIP_TRY(hipEventRecord(h->ev[2], s));
+      p.tiles_y = ty8;
+      p.item_lo = (int)((f * ty8 + std::min<long>(2 * r, ty8)) * p.tiles_x);
+      p.item_hi = p.tiles_x * ty8 * n;
+      h->conv1b_tile_rows = 16;
+      HIP_TRY(spfe::launch_conv_f32(p, L.cin, L.ks, L.pool, L.relu, 0, 1, s));
+      if (!kernel_bracket) STAGE_MARK(2 + i);
+      return SPFE_OK;
+    }
     HIP_TRY(spfe::launch_conv_f32(p, L.cin, L.ks, L.pool, L.relu, tile_mode, i == 0 ? (fused ? 2 : 1) : 0, s));
     STAGE_MARK(2 + i);
     return SPFE_OK;
@@ -1402,6 +1436,11 @@ long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size
   if (!h || !name || !dst) return fail(SPFE_EINVAL, "null argument");
   if (frame < 0 || frame >= h->B) return fail(SPFE_EINVAL, "frame %d out of range", frame);
   const size_t C = h->C, HW = (size_t)h->H * h->W;
+  if (std::string(name) == "conv1b_split_rows") {
+    if (cap < sizeof(int)) return fail(SPFE_EINVAL, "buffer 'conv1b_split_rows' needs 4 bytes");
+    *reinterpret_cast<int *>(dst) = h->conv1b_split_rows;
+    return (long)sizeof(int);
+  }
   if (std::string(name) == "conv1b_tile_rows") {   // f32: which conv1b instantiation the last call launched (8 or 16 rows per tile)
     if (cap < sizeof(int)) return fail(SPFE_EINVAL, "buffer 'conv1b_tile_rows' needs 4 bytes");
     *reinterpret_cast<int *>(dst) = h->conv1b_tile_rows;

@@ -26,11 +26,15 @@ struct ConvParams {
   const float *w1a, *b1a;
   // conv_bf16_ws.hip: nblk * 8 tile counters (one per XCD and 64-channel block), zero before the launch
   int *tile_ctr;
+  // conv_f32.hip: the launch walks work items [item_lo, item_hi) of the list (frame, tile row, tile column, 64-channel
+  // block); item_hi = 0: the whole list.  (conv1b's list is cut in two launches with different tile heights, spfe_api.hip.)
+  int item_lo = 0, item_hi = 0;
 };
 
 // cin: 64/128/256; ksize: 3 or 1; pool/relu: fused epilogue; small_tile: 4-row
 // tiles (more workgroups for the low-resolution layers).
-// tile_mode: 0 = 8-row tiles (4 waves), 1 = 4-row tiles, 2 = 16-row tiles (8 waves, two per SIMD)
+// tile_mode: 0 = 8-row tiles (4 waves), 1 = 4-row tiles, 2 = 16-row tiles (8 waves, two per SIMD), 3 = 2-row tiles,
+// 4 = 16-row tiles of 4 waves x 4 rows (conv1b)
 hipError_t launch_conv_f32(const ConvParams &p, int cin, int ksize, bool pool, bool relu,
                            int tile_mode, int layer_tag, hipStream_t s);
 int conv_kc(int ksize);        // K-chunk the kernel stages per barrier (16 for 3x3, 64 for 1x1)

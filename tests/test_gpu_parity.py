@@ -715,6 +715,29 @@ def test_f32_conv1b_16_row_tiles_are_bit_identical(monkeypatch, H, W, B):
         assert np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.descriptors, b.descriptors)
 
 
+@pytest.mark.parametrize("H,W,B,rows", [(480, 752, 8, 224), (488, 752, 8, None), (720, 1280, 4, None)])
+def test_f32_conv1b_cut_in_a_16_row_and_an_8_row_launch_is_bit_identical(monkeypatch, H, W, B, rows):
+    """Large launches whose work list divides neither way: the first k tile rows of the batch as 16-row tiles, the rest as
+    8-row tiles in a second launch (752x480 x 8: k = 224 of 240).  Same bits as 8-row tiles alone — the frame the cut goes
+    through and a height that is not a multiple of 16 included."""
+    blob = weights.synthetic(7, "dense")
+    imgs = [synth.make_image(130 + i, H, W) for i in range(B)]
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SPFE_TILE16X4", flag)
+        ext = SPExtractor(100, H, W, blob, max_batch=B, with_heat=False)
+        ext.extract_batch(imgs)
+        out[flag] = [ext.debug_read("act1", i) for i in range(B)] + [ext.debug_read("semi", B - 1)]
+        if flag == "1":
+            k = int(ext.debug_read("conv1b_split_rows")[0])
+            if rows is not None:
+                assert k == rows
+            out["k"] = k
+        ext.close()
+    for a, b in zip(out["0"], out["1"]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def test_debug_read_follows_the_double_buffered_tail_outputs():
     """heat_log / cell_score exist twice (by ticket parity, so that the next batch's detector tail does not wait for this
     batch's side chain): debug_read must hand out the set the LAST call wrote, whichever parity that was."""

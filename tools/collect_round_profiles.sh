@@ -22,7 +22,7 @@ for n in f32 bf16_720p bf16_752 bf16_720p_rw0; do
 done
 [ -f $R/probes.txt ] && { echo "# profiles/${pre}_probes.txt — tools/microbench probes run on the GPU box by tools/profile_round.sh (clock_probe: MFMAs only, operands in registers: the clock ceiling; conv_rw_plain: conv_bf16_rw.hip stand-alone on random data; mfma_chain_probe: dependent f32 MFMA chains, 16x16x4 against the fmaf chain)"; cat $R/probes.txt; } > profiles/${pre}_probes.txt
 for f in $R/bench_*.json; do b=$(basename $f); case $b in bench_under_trace*) ;; *) cp $f profiles/${pre}_$b;; esac; done
-python tools/make_traffic_json.py profiles/${pre}_pmc_f32.txt "conv_f32_kernel<1,64,3,16,4,1," 480 752 8 conv_f32.hip > profiles/conv1b_traffic.json
+python tools/make_traffic_json.py profiles/${pre}_pmc_f32.txt "conv_f32_kernel<1,64,3,16,4,1,4,2" 480 752 8 conv_f32.hip share=0.93333 > profiles/conv1b_traffic.json
 python tools/make_traffic_json.py profiles/${pre}_pmc_bf16_752.txt "conv_bf16_ws_kernel<true,2>" 480 752 8 conv_bf16_ws.hip conv1a_mfma.h > profiles/conv1b_bf16_traffic.json
 python tools/make_traffic_json.py profiles/${pre}_pmc_bf16_720p.txt "conv_bf16_ws_kernel<true,2>" 720 1280 8 conv_bf16_ws.hip conv1a_mfma.h > profiles/conv1b_bf16_720p_traffic.json
 ls profiles | grep "^$pre" | wc -l

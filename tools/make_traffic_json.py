@@ -14,7 +14,9 @@ import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 summ, kern, H, W, B = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
-srcs = sys.argv[6:]
+srcs = [a for a in sys.argv[6:] if not a.startswith("share=")]
+# share=<x>: the measured launch covers that part of conv1b's output rows (the f32 list is cut in a 16-row and an 8-row launch)
+share = float(([a[6:] for a in sys.argv[6:] if a.startswith("share=")] or ["1"])[0])
 vals = {}
 for line in open(summ):
     if kern in line:
@@ -26,10 +28,10 @@ el = 4 if "f32" in kern else 2
 if "true,2" in kern:   # conv1a fused into the producers: the kernel reads the u8 image, not conv1a's activation
     alg = B * (H * W + (H // 2) * (W // 2) * 64 * el) + 64 * 576 * el + 64 * 16 * 2 + 64 * 4
 else:
-    alg = B * (H * W * 64 * el + (H // 2) * (W // 2) * 64 * el) + 64 * 576 * el
+    alg = share * B * (H * W * 64 * el + (H // 2) * (W // 2) * 64 * el) + 64 * 576 * el
 out = {
     "kernel": "%s (conv1b), %d frames %dx%d per launch" % (kern, B, W, H),
-    "workload_hwb": [H, W, B],
+    "workload_hwb": [H, W, B], "share_of_conv1b_in_this_launch": share,
     "fetch_size_kb_max_dispatch": fetch_kb, "write_size_kb_max_dispatch": write_kb,
     "fetch_correction": "x2 (gfx950: 128-B requests tallied at 64 B, MI355X_MICROARCH.md HBM section)",
     "hbm_bytes_per_launch": int((2 * fetch_kb + write_kb) * 1024),
