@@ -254,7 +254,7 @@ def frontend_chain_leg(ctx, H, W, nframes):
     (PoseOptimizationDust + patch-wise association at the alignment's projections, tracker_dust.cpp:92-172); only the pose
     block and the keypoint indices come back.  Returns (json object, what the CPU block needs for the parity check)."""
     import numpy as np
-    from sp_orb_slam_amd import track_scene as ts
+    from tools import track_scene as ts
     from sp_orb_slam_amd import weights
     from sp_orb_slam_amd.extractor import DUST_OUT_BYTES
     torch, SPExtractor, nf = ctx["torch"], ctx["SPExtractor"], ctx["nf"]
@@ -345,7 +345,7 @@ def frontend_chain_parity(fc, nf):
     """CPU block: the oracle chain on the kept frames of the front-end leg."""
     import numpy as np
     from oracle import oracle
-    from sp_orb_slam_amd import track_scene as ts
+    from tools import track_scene as ts
     from sp_orb_slam_amd import parallel
     lay = parallel.RecordLayout(fc["H"], fc["W"], nf)
     ok, detail = True, {}
@@ -674,7 +674,7 @@ def main():
 
         # SURVEY.md §8(f) rank 3 (outside the timed region): direct dust alignment, 160 map points against the
         # dense_dust of frame 0's resident record (optimizer_dust.cpp:170-294: 40 LM iterations)
-        from sp_orb_slam_amd import dust_scene
+        from tools import dust_scene
         from sp_orb_slam_amd.extractor import DUST_MAX_POINTS, DUST_OUT_BYTES
         extd = SPExtractor(nf, H, W, blob, max_batch=1, device=local, with_heat=False)
         dsc = dust_scene.make_scene(0, H=H, W=W, n_points=160, cx=W / 2 - 8.8, cy=H / 2 + 8.4)

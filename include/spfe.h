@@ -75,6 +75,12 @@ extern "C" {
                                       frame; a frame that exhausts those (or whose hills leave the staged window) is redone
                                       sequentially by cov_fallback_kernel.  The library has no host compute routine. */
 
+/* ABI of this header.  Bumped whenever a struct below changes size or layout or an entry point changes its signature
+ * (4: spfe_result.desc_bf16, spfe_record_layout.desc_elem_bytes — round 3 — and this check).  A caller built against an older
+ * header would hand the library arrays of the wrong stride; spfe_check_abi(SPFE_ABI_VERSION, sizeof(spfe_config),
+ * sizeof(spfe_result), sizeof(spfe_record_layout)) refuses that up front (the C++ adaptor and the Python loader call it). */
+#define SPFE_ABI_VERSION 4
+
 #define SPFE_DESC_DIM 256
 #define SPFE_NUM_PARAMS 1300865 /* sp_extractor.cpp:16-43; order = register_module order :46-62 */
 
@@ -186,8 +192,10 @@ SPFE_API int spfe_extract_batch_device(spfe_handle h, const void *d_images, int 
                               void *stream);
 /* (Batches of >= 2 frames issue the layers behind conv1b as two half batches, the second on a library-owned stream that must
  * not share a hardware queue with `stream`: the first call that brings a new `stream` measures that with two 150 us spin
- * kernels and synchronises `stream` once while doing so.  SPFE_F32_SPLIT=0 / SPFE_F32_SPLIT_PROBE=0 switch the split / the
- * measurement off.) */
+ * kernels that time-stamp themselves on the device clock, and synchronises `stream` once while doing so (a stream under
+ * capture is not probed: no split).  The answer is kept per hipStream_t value for the life of the handle — a stream destroyed
+ * and re-created at the same address inherits it (a performance matter only).  spfe_debug_read("split_streams") reports the
+ * outcome.  SPFE_F32_SPLIT=0 / SPFE_F32_SPLIT_PROBE=0 switch the split / the measurement off.) */
 /* Ticket of the most recent spfe_extract_batch_device call on this handle (0, 1, 2, ...), and the
  * ordering point for SPFE_FLAG_ASYNC_COV: makes `stream` (NULL = the handle's stream) wait until the
  * records of call `ticket` (one of the last 4 calls) are complete.  Without the flag the call itself
@@ -391,6 +399,8 @@ SPFE_API int spfe_math_probe(const float *in, float *out_exp, float *out_log, in
 
 SPFE_API const char *spfe_last_error(void);
 SPFE_API const char *spfe_version(void);
+SPFE_API int spfe_abi_version(void); /* SPFE_ABI_VERSION of the header the library was built from */
+SPFE_API int spfe_check_abi(int abi_version, size_t sizeof_config, size_t sizeof_result, size_t sizeof_record_layout);
 
 #ifdef __cplusplus
 }

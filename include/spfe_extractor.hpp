@@ -38,6 +38,9 @@ class ExtractorCV {
   ExtractorCV(int nfeatures, int height, int width, const std::string &weights_path, int device = 0,
               bool with_heat = true)
       : height_(height), width_(width) {
+    // this translation unit's view of spfe.h against the library's (struct strides, entry points)
+    if (spfe_check_abi(SPFE_ABI_VERSION, sizeof(spfe_config), sizeof(spfe_result), sizeof(spfe_record_layout)) != SPFE_OK)
+      throw std::runtime_error(std::string("libspfe: ") + spfe_last_error());
     spfe_config cfg{};
     cfg.height = height;
     cfg.width = width;

@@ -240,6 +240,8 @@ hipError_t launch_head1x1_bf16(const void *in_bf16, const void *wpack, const flo
 hipError_t launch_head1x1_bf16_gather(const void *in_bf16, const void *wpack, const float *bias, float *out, int npix,
                                       const int *list, const int *total, int max_total, int tiles_per_wg, hipStream_t s) {
   if (!list || !total) return hipErrorInvalidValue;
+  // the kernel forms a listed row's byte offset (row index x 1024) in 32 bits, with 0x80000000 as its out-of-range marker
+  if ((long long)npix * 1024 >= (1ll << 31)) return hipErrorInvalidValue;
   return launch_head<256, true>(in_bf16, 256, wpack, bias, out, npix, list, total, max_total, 0, tiles_per_wg, s);
 }
 

@@ -251,6 +251,8 @@ hipError_t launch_head1x1_f32(const float *in, const float *wpack, const float *
 hipError_t launch_head1x1_f32_gather(const float *in, const float *wpack, const float *bias, float *out, int npix,
                                      const int *list, const int *total, int max_total, int tiles_per_wg, hipStream_t s) {
   if (!list || !total) return hipErrorInvalidValue;
+  // the kernel forms a listed row's byte offset (row index x 2048) in 32 bits, with 0x80000000 as its out-of-range marker
+  if ((long long)npix * 2048 >= (1ll << 31)) return hipErrorInvalidValue;
   return launch_head_f32<256, true>(in, 256, wpack, bias, out, npix, list, total, max_total, 0, tiles_per_wg, s);
 }
 

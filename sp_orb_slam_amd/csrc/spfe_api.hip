@@ -103,6 +103,10 @@ struct spfe_handle_s {
   struct Conv2Choice { hipStream_t for_stream, conv2; bool ok; };
   std::vector<Conv2Choice> conv2_known;    // per launch stream seen so far: the candidate that shares no hardware queue with it
   bool conv2_ok = false;                   // or with the side stream (ok = false: none found, no split on that stream)
+  long long *probe_stamp = nullptr;        // pinned: the queue probe's device time stamps
+  bool split_last = false;                 // the last call issued the layers behind conv1b as two half batches
+  int split_probe = -3;                    // outcome of the last probe: 1 free queue found, 0 none, -1 not measurable, -2 stream
+                                           // under capture, 2 probe switched off (first candidate trusted), -3 never probed
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int desc_in_replay = 1;   // SPFE_DESC_IN_REPLAY
   int f32_split = 2;   // parts (0 = off)
@@ -504,6 +508,9 @@ int build(spfe_handle h, const spfe_config *cfg) {
   h->sparse_db = !h->bf16 || h->C >= 10000;
   h->db_tiles_per_wg = h->bf16 ? 4 : 1;
   if (const char *e = getenv("SPFE_SPARSE_DB")) h->sparse_db = atoi(e) != 0;
+  // the gathered kernels form row byte offsets in 32 bits (the head activations' rows are 2048 / 1024 bytes, 0x80000000 is their
+  // out-of-range marker): batches beyond that take the dense head (the launchers refuse them as well)
+  if ((size_t)cfg->max_batch * h->C * (h->bf16 ? 1024 : 2048) >= ((size_t)1 << 31)) h->sparse_db = false;
   if (const char *e = getenv("SPFE_DB_TILES_PER_WG")) h->db_tiles_per_wg = atoi(e);
   if (const char *de = getenv("SPFE_DEFER_DB")) h->defer_db = atoi(de) != 0;
   {
@@ -765,7 +772,9 @@ int launch_db_gathered(spfe_handle h, int n, hipStream_t s);
 // D2H of the records by a kernel of our own that writes the pinned (device-mapped) host buffer: 8.9 MB in ~0.18 ms, no LDS,
 // fits beside the persistent convolution workgroups; the runtime's own D2H path cost 0.36 ms more per batch in the pipeline
 // (SPFE_PIPE_COPY_KERNEL=0 selects it)
-__global__ void copy16_kernel(uint4 *dst, const uint4 *src, size_t n16) {
+}  // namespace
+namespace spfe {   // (named, so that kernel traces show them: an anonymous namespace prints as "(anonymous namespace)::")
+__global__ void copy_records_kernel(uint4 *dst, const uint4 *src, size_t n16) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
   __threadfence_system();
 }
@@ -773,43 +782,69 @@ __global__ void copy16_kernel(uint4 *dst, const uint4 *src, size_t n16) {
 // ---- which stream for the second half batch?  HIP maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default;
 // the assignment depends on what else the process has created), and two streams on ONE queue run their kernels one after the
 // other: a second-half stream that shares the launch stream's queue (or the side stream's, whose kernels wait for events)
-// turns the +2 % of the split into -3 %.  The runtime offers no query, so the library measures: two 150 us spin kernels, one
-// on each stream, take 150 us together on different queues and 300 us on the same one.  Once per launch stream (the first
-// call that brings it synchronises that stream), up to four candidates; without a free queue the split stays off.
-__global__ void spin_kernel(long long ticks) {   // wall_clock64: 100 MHz
+// turns the +2 % of the split into -3 %.  The runtime offers no query, so the library measures — on the DEVICE clock: two
+// 150 us spin kernels, one per stream, each writing the wall_clock64 (100 MHz, one counter for the whole device) of its first
+// and last instruction.  On different queues the two intervals overlap; on one queue the second starts when the first has
+// ended.  No host timer is involved, so a preempted host thread cannot change the answer; the outcome is
+// readable through spfe_debug_read("split_streams").  Once per launch stream (the first call that brings it synchronises that
+// stream), up to four candidates; without a free queue — or when the stream is being captured — the split stays off.
+__global__ void queue_probe_spin_kernel(long long ticks, long long *stamp) {
   const long long t0 = wall_clock64();
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+  if (threadIdx.x == 0) { stamp[0] = t0; stamp[1] = wall_clock64(); }
 }
+__global__ void zero_tile_counters_kernel(int *p, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
+}
+}  // namespace spfe
 namespace {
-bool streams_share_a_queue(hipStream_t a, hipStream_t b) {
+// 1 = the two streams share a hardware queue, 0 = they do not, -1 = could not be measured (error / ambiguous twice)
+int streams_share_a_queue(hipStream_t a, hipStream_t b, long long *h_stamp /* pinned, 4 entries */) {
   constexpr long long kTicks = 15000;   // 150 us
-  if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return true;
-  double best = 1e9;
-  for (int rep = 0; rep < 2; ++rep) {   // (first launch of the kernel includes its code load)
-    const auto t0 = std::chrono::steady_clock::now();
-    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, kTicks);
-    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, kTicks);
-    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return true;
-    best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+  if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return -1;
+  for (int rep = 0; rep < 3; ++rep) {   // (rep 0 includes the kernel's code load: its stamps are not used)
+    for (int i = 0; i < 4; ++i) h_stamp[i] = 0;
+    hipLaunchKernelGGL(spfe::queue_probe_spin_kernel, dim3(1), dim3(64), 0, a, kTicks, h_stamp);
+    hipLaunchKernelGGL(spfe::queue_probe_spin_kernel, dim3(1), dim3(64), 0, b, kTicks, h_stamp + 2);
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return -1;
+    if (rep == 0) continue;
+    const long long a0 = h_stamp[0], a1 = h_stamp[1], b0 = h_stamp[2], b1 = h_stamp[3];
+    if (a1 <= a0 || b1 <= b0) continue;   // (a stamp did not arrive: try once more)
+    // overlap of the two intervals against the spin length: none = one queue; more than half = two queues
+    const long long ov = std::min(a1, b1) - std::max(a0, b0);
+    if (ov <= kTicks / 10) return 1;
+    if (ov >= kTicks / 2) return 0;
   }
-  return best > 240.0;
+  return -1;
 }
 int pick_conv2(spfe_handle h, hipStream_t s) {
   for (const auto &k : h->conv2_known)
-    if (k.for_stream == s) { h->conv2 = k.conv2; h->conv2_ok = k.ok; return SPFE_OK; }
+    if (k.for_stream == s) { h->conv2 = k.conv2; h->conv2_ok = k.ok; h->split_probe = k.ok ? 1 : 0; return SPFE_OK; }
   if (h->conv2_known.size() >= 16) { h->conv2_ok = false; return SPFE_OK; }   // (a caller that keeps making streams: no split)
   h->conv2_ok = false;
+  {   // a stream under capture cannot be synchronised or probed: no split for this call, and no answer is remembered
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { h->split_probe = -2; return SPFE_OK; }
+  }
   struct Remember {   // whatever the outcome below, it is this stream's answer from now on
     spfe_handle h; hipStream_t s;
     ~Remember() { h->conv2_known.push_back({s, h->conv2, h->conv2_ok}); }
   } remember{h, s};
+  if (!h->probe_stamp) {
+    void *q = nullptr;
+    HIP_TRY(hipHostMalloc(&q, 4 * sizeof(long long), hipHostMallocDefault));
+    h->host_allocs.push_back(q);
+    h->probe_stamp = reinterpret_cast<long long *>(q);
+  }
   if (const char *e = getenv("SPFE_F32_SPLIT_PROBE"))   // 0: trust the first candidate (no measurement, no synchronisation)
     if (atoi(e) == 0) {
       if (h->conv2_pool.empty()) { hipStream_t c; HIP_TRY(hipStreamCreateWithFlags(&c, hipStreamNonBlocking)); h->conv2_pool.push_back(c); }
       h->conv2 = h->conv2_pool[0];
       h->conv2_ok = true;
+      h->split_probe = 2;
       return SPFE_OK;
     }
+  h->split_probe = 0;
   for (int k = 0; k < 4; ++k) {
     if ((int)h->conv2_pool.size() <= k) {
       hipStream_t c = nullptr;
@@ -817,18 +852,17 @@ int pick_conv2(spfe_handle h, hipStream_t s) {
       h->conv2_pool.push_back(c);
     }
     hipStream_t c = h->conv2_pool[k];
-    if (!streams_share_a_queue(c, s) && !streams_share_a_queue(c, h->side)) {
+    const int q1 = streams_share_a_queue(c, s, h->probe_stamp);
+    const int q2 = q1 == 0 ? streams_share_a_queue(c, h->side, h->probe_stamp) : q1;
+    if (q1 < 0 || q2 < 0) h->split_probe = -1;   // (could not be measured: counts as shared)
+    if (q1 == 0 && q2 == 0) {
       h->conv2 = c;
       h->conv2_ok = true;
+      h->split_probe = 1;
       break;
     }
   }
   return SPFE_OK;
-}
-}  // namespace
-
-__global__ void zero_ints_kernel(int *p, int n) {
-  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
 }
 
 // Enqueue the whole path for n frames already in device memory.
@@ -840,7 +874,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   // (a kernel of our own, not hipMemsetAsync: the runtime's fill is a blit that queues behind its other blits — the
   // pipelined host path's D2H copy of the PREVIOUS batch — and held the whole next batch back by 0.6 ms at 752x480 bf16)
   if (h->d_tile_ctr) {
-    hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(256), 0, s, h->d_tile_ctr, 8 * 64);
+    hipLaunchKernelGGL(spfe::zero_tile_counters_kernel, dim3(1), dim3(256), 0, s, h->d_tile_ctr, 8 * 64);
     HIP_TRY(hipGetLastError());
   }
   const bool fused = !h->bf16 && h->fuse1a;  // f32: conv1b computes conv1a's outputs itself
@@ -1062,6 +1096,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     if (rcp) return rcp;
     split = h->conv2_ok;
   }
+  h->split_last = split;
   if (split) {
     int rc = run_layer(0);
     if (rc) return rc;
@@ -1245,7 +1280,16 @@ void view_record(const spfe_handle h, const uint8_t *rec, const float *heat, con
 extern "C" {
 
 const char *spfe_last_error(void) { return g_err.c_str(); }
-const char *spfe_version(void) { return "spfe 0.2 (gfx950, f32-mfma + bf16-mfma)"; }
+const char *spfe_version(void) { return "spfe 0.4 abi 4 (gfx950, f32-mfma + bf16-mfma)"; }
+int spfe_abi_version(void) { return SPFE_ABI_VERSION; }
+int spfe_check_abi(int abi_version, size_t sizeof_config, size_t sizeof_result, size_t sizeof_record_layout) {
+  if (abi_version != SPFE_ABI_VERSION)
+    return fail(SPFE_EINVAL, "ABI mismatch: the caller was built against spfe.h ABI %d, this library is ABI %d", abi_version, SPFE_ABI_VERSION);
+  if (sizeof_config != sizeof(spfe_config) || sizeof_result != sizeof(spfe_result) || sizeof_record_layout != sizeof(spfe_record_layout))
+    return fail(SPFE_EINVAL, "ABI mismatch: struct sizes config %zu / result %zu / record_layout %zu, library %zu / %zu / %zu",
+                sizeof_config, sizeof_result, sizeof_record_layout, sizeof(spfe_config), sizeof(spfe_result), sizeof(spfe_record_layout));
+  return SPFE_OK;
+}
 const char *spfe_stage_name(int i) { return (i >= 0 && i < NSTAGE) ? kStageNames[i] : ""; }
 
 int spfe_create(const spfe_config *cfg, spfe_handle *out) {
@@ -1446,6 +1490,12 @@ long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size
     *reinterpret_cast<int *>(dst) = h->conv1b_tile_rows;
     return (long)sizeof(int);
   }
+  if (std::string(name) == "split_streams") {   // [2] int: outcome of the queue probe (see spfe_handle_s::split_probe), and whether the last call ran as two half batches
+    if (cap < 2 * sizeof(int)) return fail(SPFE_EINVAL, "buffer 'split_streams' needs 8 bytes");
+    reinterpret_cast<int *>(dst)[0] = h->split_probe;
+    reinterpret_cast<int *>(dst)[1] = h->split_last ? 1 : 0;
+    return (long)(2 * sizeof(int));
+  }
   if (std::string(name) == "da_gathered") {   // 1: the last call ran convDa on the listed cells only (host-side flag)
     if (cap < sizeof(int)) return fail(SPFE_EINVAL, "buffer 'da_gathered' needs 4 bytes");
     *reinterpret_cast<int *>(dst) = h->sparse_last && h->sparse_da_call ? 1 : 0;
@@ -1488,7 +1538,8 @@ long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size
     const int lh[8] = {1, 2, 2, 4, 4, 8, 8, 8};
     const int lc[8] = {64, 64, 64, 64, 128, 128, 128, 128};
     const size_t per = (size_t)(h->H / lh[i]) * (h->W / lh[i]) * lc[i];
-    src = h->act[i] + frame * per; bytes = per * 4; bf16_src = h->bf16;
+    // (conv4b's output exists twice, by ticket parity, when convDa runs gathered: "act7" is the last call's, like "feat")
+    src = (i == 7 && h->feat_cur ? h->feat_cur : h->act[i]) + frame * per; bytes = per * 4; bf16_src = h->bf16;
   } else return fail(SPFE_EINVAL, "unknown debug buffer '%s'", name);
   if (bytes > cap) return fail(SPFE_EINVAL, "buffer '%s' needs %zu bytes, cap %zu", name, bytes, cap);
   // both streams: with SPFE_FLAG_ASYNC_COV heat / heat_inv are written on the side stream
@@ -1713,7 +1764,7 @@ int spfe_submit_batch(spfe_handle h, const uint8_t *const *images, int stride, i
     const int copy_mode = copy_env >= 0 ? copy_env : (h->bf16 && h->C >= 10000 ? 0 : 1);   // (bf16 752x480: kernel 11,560, engine 11,250)
     if (copy_mode == 1) {          // a copy kernel of our own writing the pinned buffer
       const size_t n16 = ((size_t)n * h->rl.bytes + 15) / 16;
-      hipLaunchKernelGGL(copy16_kernel, dim3(64), dim3(256), 0, sc, reinterpret_cast<uint4 *>(ps.h_rec),
+      hipLaunchKernelGGL(spfe::copy_records_kernel, dim3(64), dim3(256), 0, sc, reinterpret_cast<uint4 *>(ps.h_rec),
                          reinterpret_cast<const uint4 *>(ps.d_rec), n16);
       HIP_TRY(hipGetLastError());
     } else if (copy_mode != 2) {   // (2: no copy at all, timing probe)
@@ -1722,9 +1773,9 @@ int spfe_submit_batch(spfe_handle h, const uint8_t *const *images, int stride, i
   }
   if (want) {
     const size_t m16 = (size_t)n * H * W * 4 / 16;   // (H, W multiples of 8)
-    hipLaunchKernelGGL(copy16_kernel, dim3(64), dim3(256), 0, sc, reinterpret_cast<uint4 *>(ps.h_heat_inv),
+    hipLaunchKernelGGL(spfe::copy_records_kernel, dim3(64), dim3(256), 0, sc, reinterpret_cast<uint4 *>(ps.h_heat_inv),
                        reinterpret_cast<const uint4 *>(h->d_heat_inv), m16);
-    hipLaunchKernelGGL(copy16_kernel, dim3(64), dim3(256), 0, sc, reinterpret_cast<uint4 *>(ps.h_heat),
+    hipLaunchKernelGGL(spfe::copy_records_kernel, dim3(64), dim3(256), 0, sc, reinterpret_cast<uint4 *>(ps.h_heat),
                        reinterpret_cast<const uint4 *>(h->d_heat), m16);
     HIP_TRY(hipGetLastError());
   }

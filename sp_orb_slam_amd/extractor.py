@@ -24,6 +24,7 @@ SPFE_FLAG_DESC_BF16 = 4   # records / results carry bf16 descriptors (RNE of the
 SPFE_PRECISION_F32 = 0
 SPFE_PRECISION_BF16 = 1
 NUM_PARAMS = 1300865
+ABI_VERSION = 4           # SPFE_ABI_VERSION of include/spfe.h these ctypes structures mirror
 _ERRORS = {-1: "SPFE_EINVAL", -2: "SPFE_EEMPTY", -3: "SPFE_EHIP", -4: "SPFE_EWEIGHTS"}
 
 # every symbol include/spfe.h declares (tests check that the library exports all)
@@ -33,7 +34,7 @@ ABI_SYMBOLS = [
     "spfe_wait_records",
     "spfe_view_record", "spfe_debug_read", "spfe_stage_times", "spfe_stage_reset",
     "spfe_stage_name",
-    "spfe_math_probe", "spfe_last_error", "spfe_version",
+    "spfe_math_probe", "spfe_last_error", "spfe_version", "spfe_abi_version", "spfe_check_abi",
     "spfe_match", "spfe_match_records_device", "spfe_match_out_bytes",
     "spfe_match_patches", "spfe_match_patches_record_device",
     "spfe_set_staging", "spfe_extract_staged", "spfe_extract_batch_staged", "spfe_stage_batch_device",
@@ -214,6 +215,15 @@ def load_library():
     L.spfe_comm_count.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.spfe_last_error.restype = C.c_char_p
     L.spfe_version.restype = C.c_char_p
+    # the structures above mirror include/spfe.h by hand: a library built from another header revision is refused here,
+    # not discovered as overrun arrays later
+    try:
+        L.spfe_check_abi.restype = C.c_int
+        L.spfe_check_abi.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t]
+    except AttributeError:
+        raise SpfeError("libspfe.so at %s predates spfe_check_abi (ABI < %d): rebuild it" % (LIB_PATH, ABI_VERSION))
+    if L.spfe_check_abi(ABI_VERSION, C.sizeof(_Config), C.sizeof(_Result), C.sizeof(RecordLayout)) != 0:
+        raise SpfeError(L.spfe_last_error().decode())
     _lib = L
     return L
 

@@ -27,7 +27,7 @@ import scipy.linalg
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", ".."))
-from sp_orb_slam_amd import dust_scene  # noqa: E402  (scene generator only: points, poses, a dust map)
+from tools import dust_scene  # noqa: E402  (scene generator only: points, poses, a dust map)
 
 F = np.float32
 

@@ -21,6 +21,21 @@ def test_header_symbols_exported():
         assert hasattr(lib, name), name
 
 
+def test_abi_check_refuses_a_caller_built_against_another_header():
+    """spfe_result / spfe_record_layout grew in round 3; a caller with the old strides must be refused up front."""
+    import ctypes as C
+    L = extractor.load_library()   # (itself calls spfe_check_abi with the ctypes mirrors' sizes)
+    assert L.spfe_abi_version() == extractor.ABI_VERSION
+    sizes = (C.sizeof(extractor._Config), C.sizeof(extractor._Result), C.sizeof(extractor.RecordLayout))
+    assert L.spfe_check_abi(extractor.ABI_VERSION, *sizes) == 0
+    assert L.spfe_check_abi(extractor.ABI_VERSION - 1, *sizes) == -1
+    assert b"ABI" in L.spfe_last_error()
+    assert L.spfe_check_abi(extractor.ABI_VERSION, sizes[0], sizes[1] - 8, sizes[2]) == -1   # round 2's spfe_result
+    # the header and the Python mirror name the same revision
+    hdr = open(os.path.join(ROOT, "include", "spfe.h")).read()
+    assert "#define SPFE_ABI_VERSION %d" % extractor.ABI_VERSION in hdr
+
+
 def test_library_reports_version_and_stage_names():
     L = extractor.load_library()
     assert b"gfx950" in L.spfe_version()

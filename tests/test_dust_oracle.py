@@ -5,7 +5,7 @@ the edge (types_dust_tracking.cpp:37-140)."""
 import numpy as np
 
 from oracle import oracle
-from sp_orb_slam_amd import dust_scene
+from tools import dust_scene
 
 
 def _bilinear(d, x, y):

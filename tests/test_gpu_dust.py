@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 
 from oracle import oracle
-from sp_orb_slam_amd import dust_scene, synth, weights
+from sp_orb_slam_amd import synth, weights
+from tools import dust_scene
 from sp_orb_slam_amd.extractor import DUST_OUT_BYTES, SPExtractor, SpfeError
 
 pytestmark = pytest.mark.gpu

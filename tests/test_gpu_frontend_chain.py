@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle
-from sp_orb_slam_amd import track_scene as ts
+from tools import track_scene as ts
 from sp_orb_slam_amd import weights
 from sp_orb_slam_amd.extractor import DUST_OUT_BYTES, SPExtractor
 

@@ -11,7 +11,7 @@ import sys
 
 
 def short(name):
-    name = re.sub(r"\[clone.*", "", name)
+    name = re.sub(r"\[clone.*", "", name).replace("(anonymous namespace)::", "")
     m = re.match(r"void (spfe::(?:\w+::)*\w+)<(.*)>\(", name)
     if m:
         args = m.group(2).replace(" ", "")
