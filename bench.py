@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
 """bench.py — frames/sec of the SuperPoint extraction path on MI355X.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (for N > 1 launched by
-torch.distributed.run, one rank per GPU).  A step = one pass of the whole hot
+Contract: `python bench.py --gpus N --steps K --warmup W`.  For N > 1 the ranks are one process per GPU under
+torch.distributed.run — launched by the caller (the driver's form) or, when the environment carries no rendezvous
+(RANK / WORLD_SIZE unset), BY THIS SCRIPT: it re-executes itself under `torch.distributed.run --nproc-per-node N`, so a
+plain `python bench.py --gpus 8` can never run on one GPU and print `n_gpus: 1`.  An N > 1 run exits non-zero — and
+prints no JSON line — when fewer than N devices are visible, when two ranks sit on the same device, or when the
+library's RCCL communicator reports another rank count than N (SPFE_BENCH_BACKEND=gloo, the shared-GPU dry run of the
+tests, lifts the device checks).  A step = one pass of the whole hot
 path (u8 frames resident in HBM -> fixed-stride keypoint/descriptor records in
 HBM, plus the RCCL all-gather of the records when N > 1) over a batch of
 FRAMES_PER_GPU frames per GPU.  Prints ONE JSON line on rank 0.
@@ -391,6 +396,37 @@ def multi_gpu_legs(ctx, args, ext, sharded, d_img, stream, frames_lo, B, H, W):
         res["parity_gathered_detail"] = det
     # (2) the collective alone: events on the stream it runs on
     res_g = sharded.time_gather(20)
+    # (2b) where the collective runs: the library's side stream, right behind the covariance kernels of the batch it gathers
+    # (default: the headline above) against a communication stream of its own that waits for the batch's event
+    # (SPFE_COMM_OWN_STREAM=1).  With N > 1 the side-stream form puts batch i + 1's selection / descriptors / covariance behind
+    # batch i's gather — i.e. behind the slowest rank; the own-stream form can land on the compute stream's hardware queue.
+    # Both on THIS box, same handle, communicator re-made in between.
+    ab = None
+    if getattr(sharded, "_native", False) and not args.no_comm_ab:
+        ab = {}
+        k3, w3 = max(args.steps, 50), max(args.warmup, 5)
+        prev = os.environ.get("SPFE_COMM_OWN_STREAM")
+        for name, val in (("own_stream", "1"), ("side_stream", "0")):
+            torch.cuda.synchronize()
+            dist.barrier()
+            ext.comm_destroy()
+            os.environ["SPFE_COMM_OWN_STREAM"] = val
+            sh3 = parallel.ShardedExtractor(ext, world, rank, B)
+            if not getattr(sh3, "_native", False):
+                ab[name] = None
+                continue
+            dt3 = run_timed(ext, sh3, d_img, stream, k3, w3, world, dist, torch)
+            r3 = sh3.decode(world * B - 1)
+            ab[name] = {"value": round(world * B * k3 / dt3, 2), "unit": "frames/s", "ms_per_step": round(dt3 / k3 * 1e3, 4),
+                        "steps": k3, "records_ok": bool(0 < r3.K <= nf + 1 and r3.status == 0), "rccl_ranks": sh3.comm_ranks()["library"]}
+            sharded = sh3   # (the handle's communicator is this one now: the legs below use it)
+        if prev is None:
+            os.environ.pop("SPFE_COMM_OWN_STREAM", None)
+        else:
+            os.environ["SPFE_COMM_OWN_STREAM"] = prev
+        ab["what"] = ("the headline's schedule with ncclAllGather on a communication stream of its own (own_stream, "
+                      "SPFE_COMM_OWN_STREAM=1) and on the library's side stream behind the batch's covariance (side_stream, the "
+                      "default), %d timed steps each after %d untimed, same handle" % (k3, w3))
     # (3) the host-side alternative: no gather, every rank copies ITS shard to its own pinned host buffer
     nbytes = B * ext.record_bytes()
     pinned = [torch.zeros(nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
@@ -407,13 +443,46 @@ def multi_gpu_legs(ctx, args, ext, sharded, d_img, stream, frames_lo, B, H, W):
         res["allgather_ms"] = res_g["ms"]
         res["allgather"] = res_g
         res["rccl_ranks"] = sharded.comm_ranks()
+        if ab is not None:
+            res["comm_stream_ab"] = ab
         res["host_alt"] = {"what": "no collective: each rank D2H-copies its own %d records (%d bytes) to pinned host memory on a "
                                    "copy stream behind the batch's covariance (SURVEY.md 8e: the SLAM consumer is on the host), "
                                    "%d timed steps" % (B, nbytes, k2),
                            "value": round(world * B * k2 / dt2, 2), "unit": "frames/s",
                            "ms_per_step": round(dt2 / k2 * 1e3, 4), "records_ok": bool(0 < own.K <= nf + 1 and own.status == 0)}
         res["host_alt_ms"] = res["host_alt"]["ms_per_step"]
-    return res
+    try:
+        lib_ranks = sharded.comm_ranks()["library"]   # (of the communicator the handle holds NOW)
+    except Exception as e:
+        lib_ranks = "error: %s" % e
+    return res, lib_ranks
+
+
+def self_launch(args):
+    """`--gpus N` (N > 1) without a rendezvous in the environment: re-execute under torch.distributed.run, one rank per GPU,
+    exactly as the driver would have (same flags, 127.0.0.1 rendezvous, a free port).  Never returns."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without RANK / WORLD_SIZE in the environment: launching %d ranks: %s"
+          % (args.gpus, args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def die(msg, dist=None):
+    """An N > 1 run that is not what --gpus asked for: no JSON line, a message, a non-zero exit on every rank."""
+    print("bench.py: FATAL: " + msg, file=sys.stderr, flush=True)
+    if dist is not None and dist.is_initialized():
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
+    os._exit(3)
 
 
 def main():
@@ -437,12 +506,19 @@ def main():
     ap.add_argument("--no-aten", action="store_true", help="skip the ATen-CPU baseline")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host-path legs")
     ap.add_argument("--no-parity", action="store_true", help="N > 1: skip the oracle check of the gathered records")
+    ap.add_argument("--no-comm-ab", action="store_true", help="N > 1: skip the comm-stream A/B leg (gather on the library's side "
+                    "stream vs on a stream of its own, SPFE_COMM_OWN_STREAM)")
     ap.add_argument("--latency-calls", type=int, default=1000)
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
                     help="f32: BASELINE configs[1]/[2] (bit-exact path, the headline); bf16: configs[3] (all twelve "
                          "convolutions, the two 1x1 heads included, as bf16 MFMA GEMMs with f32 accumulation; softmax, "
                          "NMS, descriptor sampling and covariance stay f32)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    have_rdzv = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not have_rdzv:
+        self_launch(args)
 
     # timed region: HIP events around the dominant kernel only (two per step); the full per-stage table
     # comes from a separate short pass below (sixteen events per step cost 1-2 % of the throughput)
@@ -455,13 +531,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:   # (a 1-rank environment with --gpus 8 is refused too: never a smaller run than asked for)
+        die("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # SPFE_BENCH_BACKEND=gloo: dry run of the N > 1 flow on a box with fewer GPUs than ranks (ranks share
     # a device, the collective goes through gloo); the real runs use RCCL ("nccl"), one rank per GPU
     backend = os.environ.get("SPFE_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        die("no GPU visible")
     if backend != "nccl":
-        local = local % max(1, torch.cuda.device_count())
+        local = local % max(1, ndev)
+    elif world > 1 and ndev < world:
+        die("--gpus %d but only %d device(s) visible: one rank per GPU is the contract (SPFE_BENCH_BACKEND=gloo is the "
+            "shared-GPU dry run)" % (world, ndev))
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -469,6 +551,14 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        if backend == "nccl":
+            # N ranks on N DISTINCT devices: every rank's (bus id, device uuid) through the process group
+            pr = torch.cuda.get_device_properties(local)
+            me = "%s/%s" % (getattr(pr, "pci_bus_id", local), getattr(pr, "uuid", local))
+            ids = [None] * world
+            dist.all_gather_object(ids, me)
+            if len(set(ids)) != world:
+                die("%d ranks but only %d distinct devices: %s" % (world, len(set(ids)), ids), dist)
 
     from sp_orb_slam_amd import parallel, synth, weights
     from sp_orb_slam_amd.extractor import SPExtractor
@@ -527,7 +617,9 @@ def main():
     if world > 1:
         # ---- N > 1: self-verification legs (every rank takes part), then ONE line, a barrier, and only then teardown
         os.environ["SPFE_STAGE_TIMING"] = "0"
-        res = multi_gpu_legs(ctx, args, ext, sharded, d_img, stream, lo, B, H, W)
+        res, lib_ranks = multi_gpu_legs(ctx, args, ext, sharded, d_img, stream, lo, B, H, W)
+        if lib_ranks is not None and lib_ranks != world:   # (every rank checks its own communicator: all leave together)
+            die("the library's RCCL communicator reports %s ranks, --gpus %d" % (lib_ranks, world), dist)
         if rank == 0:
             out.update(res)
             print(json.dumps(out), flush=True)

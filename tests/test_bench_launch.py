@@ -1,0 +1,39 @@
+"""CPU: `python bench.py --gpus N` launches its own ranks and never degrades to a smaller run.
+The compute is not reached here (no GPU): what is checked is the launch and the refusal."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+def _run(args, env):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True,
+                          text=True, timeout=300)
+
+
+def test_gpus_2_without_a_rendezvous_launches_two_ranks_and_fails_loudly_without_gpus():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-box test (the GPU form is tests/test_gpu_bench_two_ranks.py)")
+    out = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], _env())
+    assert "launching 2 ranks" in out.stderr and "--nproc-per-node 2" in out.stderr
+    assert out.returncode != 0                                       # torch.distributed.run's exit code comes back
+    assert "FATAL: no GPU visible" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]   # no line, not a line with n_gpus 1
+
+
+def test_a_rendezvous_that_disagrees_with_gpus_is_refused():
+    out = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], _env(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
+    assert out.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    out = _run(["--gpus", "0"], _env())
+    assert out.returncode != 0

@@ -16,13 +16,51 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+SMALL = ["--steps", "3", "--warmup", "1", "--height", "240", "--width", "320", "--frames-per-gpu", "3", "--num-features", "200",
+         "--no-cpu-baseline", "--no-match", "--no-latency", "--no-stage-table"]
+
+
+def _clean_env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", **kw)
+    return env
+
+
+def test_plain_python_bench_gpus_2_launches_two_ranks_itself():
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run used to read WORLD_SIZE = 1, run on one
+    GPU and print n_gpus 1 with rc 0.  It now re-executes itself under torch.distributed.run (gloo dry run: two ranks, one GPU)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, cwd=ROOT,
+                         env=_clean_env(SPFE_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["parity_gathered"] is True
+    assert "launching 2 ranks" in out.stderr
+
+
+def test_bench_gpus_2_on_a_one_gpu_box_fails_loudly():
+    """... and without the dry-run flag, on a box with fewer GPUs than ranks, it must not print a line at all."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, cwd=ROOT,
+                         env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "only 1 device(s) visible" in out.stderr
+    # a rendezvous that disagrees with --gpus is refused as well (WORLD_SIZE = 1, --gpus 2)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, cwd=ROOT,
+                         env=dict(_clean_env(), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
 def test_bench_two_ranks_one_gpu():
     env = dict(os.environ, SPFE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "3", "--warmup", "1", "--height", "240", "--width", "320",
-           "--frames-per-gpu", "3", "--num-features", "200",
-           "--no-cpu-baseline", "--no-match", "--no-latency", "--no-stage-table"]
+           "--gpus", "2"] + SMALL
     t0 = time.time()
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
