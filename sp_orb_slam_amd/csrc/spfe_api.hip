@@ -125,6 +125,11 @@ struct spfe_handle_s {
   unsigned char *d_wdb = nullptr, *d_wpb = nullptr;   // bf16 mode: convDb / convPb weights, head_bf16.hip layout
   float *d_wdb32 = nullptr, *d_wpb32 = nullptr;       // f32 mode: the same for head_f32.hip (SPFE_F32_HEADS=1; default: generic kernel)
   bool f32_heads = false;
+  // f32: convPb and the detector tail in one launch (pbtail_f32.hip): the two full 32-channel tiles on the MFMA, the dustbin
+  // channel as the contract's fmaf chain on the VALU, the tail on the logits while they are still in LDS.  SPFE_PBTAIL=0:
+  // convPb as a launch of the generic kernel + tail_kernel (same bits)
+  bool pbtail = true;
+  float *d_wpb_dust = nullptr;                        // convPb's row 64 (the dustbin channel), [256]
   // "sparse convDb": the descriptor head runs BEHIND the selection, on the cells some emitted keypoint's bilinear taps read
   // (<= 4 per keypoint: 28 % of a 1280x720 frame at 1000 keypoints), gathered through select_kernel's list; d_coarse keeps
   // the dense layout, only the rows anybody reads are written.  SPFE_SPARSE_DB=0: the dense head in the launch stream.
@@ -712,8 +717,15 @@ int build(spfe_handle h, const spfe_config *cfg) {
     // measured 63 + 38.5 us per eight 752x480 frames against 72 + 35.5 for the generic kernel (matrix-bound: 47 us at the peak)
     const char *fe = getenv("SPFE_F32_HEADS");
     if (fe) h->f32_heads = atoi(fe) != 0;
+    if (const char *e = getenv("SPFE_PBTAIL")) h->pbtail = atoi(e) != 0;
+    if (h->f32_heads) h->pbtail = false;
+    if (h->pbtail) {
+      const float *Wp = blob.data() + blob_weight_offset(9);   // layer 9 = convPb, [65][256]
+      if ((rc = dev_alloc(h, &h->d_wpb_dust, 256))) return rc;
+      HIP_TRY(hipMemcpy(h->d_wpb_dust, Wp + (size_t)64 * 256, 256 * 4, hipMemcpyHostToDevice));
+    }
     for (int which = 0; which < 2; ++which) {
-      if (!h->f32_heads && !(which == 0 && h->sparse_db)) continue;   // (the gathered descriptor head is head_f32.hip's kernel)
+      if (!h->f32_heads && !(which == 0 && h->sparse_db) && !(which == 1 && h->pbtail)) continue;   // (the gathered descriptor head is head_f32.hip's kernel; pbtail_f32.hip reads convPb's table)
       const int lid = which ? 9 : 11;
       const spfe_layer_t &Ld = SPFE_LAYERS[lid];
       std::vector<float> w(spfe::head_f32_weight_bytes(Ld.cout) / 4, 0.0f);
@@ -766,7 +778,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
 #define STAGE_MARK(i) \
   do { if (h->timing && (h->timing_all || (i) == 1 || (i) == 2)) HIP_TRY(hipEventRecord(h->ev[i], s)); } while (0)
 
-int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const std::function<int()> *conv_db = nullptr, bool sparse = false);
+int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const std::function<int()> *conv_db = nullptr, bool sparse = false, bool fused_pb = false);
 int launch_db_gathered(spfe_handle h, int n, hipStream_t s);
 
 // D2H of the records by a kernel of our own that writes the pinned (device-mapped) host buffer: 8.9 MB in ~0.18 ms, no LDS,
@@ -999,6 +1011,10 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
       STAGE_MARK(2 + i);
       return SPFE_OK;
     }
+    if (!h->bf16 && i == 8 && h->pbtail) {   // convPb runs inside the detector tail's launch (enqueue_post, pbtail_f32.hip)
+      STAGE_MARK(2 + i);
+      return SPFE_OK;
+    }
     if (!h->bf16 && i >= 8 && h->f32_heads) {  // convPb / convDb in f32: head_f32.hip (weights in registers)
       if (i == 8) HIP_TRY(spfe::launch_head1x1_f32(h->d_head, h->d_wpb32, L.d_b, h->d_semi, n * h->C, 65, s));
       else HIP_TRY(spfe::launch_head1x1_f32(h->d_head, h->d_wdb32, L.d_b, h->d_coarse, n * h->C, 256, s));
@@ -1112,16 +1128,16 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
         }
     HIP_TRY(hipEventRecord(h->ev_join, h->conv2));
     HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
-    return enqueue_post(h, n, d_records, s, nullptr, sparse);
+    return enqueue_post(h, n, d_records, s, nullptr, sparse, !h->bf16 && h->pbtail);
   }
   for (int i = 0; i < (defer_db ? 9 : nlayers); ++i) {
     const int rc = run_layer(i);
     if (rc) return rc;
   }
   if (sparse) STAGE_MARK(2 + 9);   // ("convDb" reads 0 on the launch stream: the gathered head is part of post_side)
-  if (!defer_db) return enqueue_post(h, n, d_records, s, nullptr, sparse);
+  if (!defer_db) return enqueue_post(h, n, d_records, s, nullptr, sparse, !h->bf16 && h->pbtail);
   const std::function<int()> conv_db = [&]() -> int { return run_layer(9); };
-  return enqueue_post(h, n, d_records, s, &conv_db);
+  return enqueue_post(h, n, d_records, s, &conv_db, false, !h->bf16 && h->pbtail);
 }
 
 // The descriptor head on select_kernel's cell list (stream `s`, behind the selection of the same call).
@@ -1162,7 +1178,7 @@ int launch_db_dense(spfe_handle h, int n, hipStream_t s) {
 
 // Detector tail, selection, descriptors, covariance for n frames whose semi /
 // coarse maps are in the handle's buffers.
-int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const std::function<int()> *conv_db, bool sparse) {
+int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const std::function<int()> *conv_db, bool sparse, bool fused_pb) {
   const int H = h->H, W = h->W;
   spfe::FrameBufs f{};
   f.semi = h->d_semi; f.coarse = h->d_coarse;
@@ -1188,8 +1204,42 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
     if (h->rec_of[prev] == d_records || old_order) HIP_TRY(hipStreamWaitEvent(s, h->ev_cov[prev], 0));
   }
   h->rec_of[slot] = d_records;
-  HIP_TRY(spfe::launch_tail(f, h->rl, n, H, W, s));
+  if (fused_pb) HIP_TRY(spfe::launch_pbtail_f32(h->d_head, h->d_wpb32, h->d_wpb_dust, h->layers[8].d_b, h->d_semi, f, h->rl, n, H, W, s));
+  else HIP_TRY(spfe::launch_tail(f, h->rl, n, H, W, s));
   STAGE_MARK(12);
+  // Synchronous calls with the gathered descriptor branch (a single frame's operator(): BASELINE configs[1]): the detector
+  // branch is the critical path — tail -> selection -> covariance walk / classify / link / replay, a chain of latency-bound
+  // kernels — and every cross-stream event hop on it costs ~13 us (measured on a batch-1 kernel timeline: tail -> side stream
+  // 13.6 us, head -> replay 12.6 us), as much as the kernels it orders.  So the chain stays on the LAUNCH stream, without a
+  // hop, and the descriptor branch (gathered convDa / convDb + sampling: needs the selection's cell list, shorter than the
+  // covariance chain) takes the side stream: one hop at its start, beside the covariance kernels, and a join at the end that
+  // has long been signalled.  (Round 3 ran it the other way round and let the replay launch carry the sampling: the replay
+  // then waited for the gathered head — 28 us of a 0.80 ms call.)  SPFE_INLINE_CHAIN=0 restores that order.
+  static const bool inline_env = !(getenv("SPFE_INLINE_CHAIN") && atoi(getenv("SPFE_INLINE_CHAIN")) == 0);
+  if (inline_env && sparse && !conv_db && !((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode) && !(h->timing && h->timing_all)) {
+    if (h->cov_inflight) {   // (a pipelined call's chain still on the side stream — it owns heat_inv and the covariance scratch)
+      HIP_TRY(hipStreamWaitEvent(s, h->ev_cov[(h->ticket + spfe_handle_s::NTICKET - 1) % spfe_handle_s::NTICKET], 0));
+      h->cov_inflight = false;
+    }
+    STAGE_MARK(13);
+    HIP_TRY(spfe::launch_select(f, h->rl, n, H, W, h->cfg.num_features, s, &h->cov, h->rl.kmax));
+    HIP_TRY(hipEventRecord(h->ev_sel, s));
+    HIP_TRY(hipStreamWaitEvent(h->side, h->ev_sel, 0));
+    int rc = launch_db_gathered(h, n, h->side);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(h->ev_dbs[par], h->side));
+    h->dbs_recorded[par] = true;
+    HIP_TRY(spfe::launch_desc(f, h->rl, n, H, W, h->side));
+    HIP_TRY(hipEventRecord(h->ev_desc, h->side));
+    h->desc_recorded = true;
+    HIP_TRY(spfe::launch_cov(f, h->rl, h->cov, n, H, W, s, false, nullptr));
+    HIP_TRY(hipStreamWaitEvent(s, h->ev_desc, 0));    // the join: records complete in `s` order
+    HIP_TRY(hipEventRecord(h->ev_cov[slot], s));
+    h->cov_inflight = false;
+    h->ticket++;
+    h->last_n = n;
+    return SPFE_OK;
+  }
   // Everything that only the finished record needs — selection (one latency-bound workgroup per frame), heat
   // normalisation (input of the covariance), descriptor sampling, covariance — goes to the side stream, ordered
   // after this call's detector tail: small kernels that run beside the next call's convolutions.

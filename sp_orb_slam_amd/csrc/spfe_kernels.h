@@ -155,6 +155,11 @@ hipError_t launch_cov(const FrameBufs &f, const RecordLayout &r, const CovScratc
                       hipStream_t s, bool with_desc = false, hipEvent_t before_replay = nullptr);
 
 int tail_parts(int H, int W);  // min/max partials per frame written by the tail kernel
+// f32 mode: convPb (1x1, 256 -> 65) + the detector tail in one launch (pbtail_f32.hip), bit-identical to convPb through
+// conv_f32.hip followed by launch_tail.  head = [B * C][512] f32 (channels 0..255 = ReLU(convPa)); wpack =
+// head_f32_pack_weights(convPb's weights, 65); wdust = convPb's row 64 [256]; bias [>= 65]; semi [B][C][65] is written too
+hipError_t launch_pbtail_f32(const float *head, const float *wpack, const float *wdust, const float *bias, float *semi,
+                             const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s);
 hipError_t launch_tail(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s);
 // with_heat_norm: the heat normalisation (launch_heat_norm) rides in the neighbour-mask launch in front of the selection
 hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H, int W,

@@ -758,3 +758,34 @@ def test_debug_read_follows_the_double_buffered_tail_outputs():
     two(b, None)
     assert np.array_equal(two.debug_read("heat_log").view(np.uint32), ref["heat_log"].view(np.uint32))
     two.close()
+
+
+@pytest.mark.parametrize("H,W,B", [(480, 752, 1), (240, 376, 3), (136, 200, 2), (24, 40, 2), (64, 96, 1)])
+def test_f32_convPb_inside_the_tail_launch_is_bit_identical(monkeypatch, H, W, B):
+    """pbtail_f32.hip (round 4): convPb's two full channel tiles on the MFMA, its dustbin channel as an fmaf chain on the VALU,
+    the detector tail on the logits while they sit in LDS — against convPb as a launch of the generic kernel + tail_kernel
+    (SPFE_PBTAIL=0).  Same logits (all 65 channels), same heat maps, dust maps, scores and records; frames whose cell count
+    is not a multiple of the 32-cell tile (5640, 1410, 425, 15, 96) and batches included.  Both against the oracle."""
+    nf = 300
+    blob = weights.synthetic(7, "dense")
+    imgs = [synth.make_image(170 + i, H, W) for i in range(B)]
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SPFE_PBTAIL", flag)
+        ext = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=True)
+        frs = ext.extract_batch(imgs)
+        out[flag] = (frs, [ext.debug_read(nm, i) for i in range(B) for nm in ("semi", "heat_log", "cell_score")])
+        ext.close()
+    for a, b in zip(out["0"][1], out["1"][1]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for a, b in zip(out["0"][0], out["1"][0]):
+        assert a.K == b.K and np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.descriptors, b.descriptors)
+        assert np.array_equal(a.cov2, b.cov2) and np.array_equal(a.occ_grid, b.occ_grid)
+        assert np.array_equal(a.dense_dust, b.dense_dust) and np.array_equal(a.semi_dust, b.semi_dust)
+        assert np.array_equal(a.heat, b.heat) and np.array_equal(a.heat_inv, b.heat_inv)
+    ref = oracle.extract(blob, imgs[B - 1], nf)
+    last = out["1"][0][B - 1]
+    assert last.K == ref["K"] and np.array_equal(last.kp_xy, ref["kp_xy"])
+    assert np.array_equal(last.descriptors.view(np.uint32), ref["desc"].view(np.uint32))
+    assert np.array_equal(last.semi_dust.view(np.uint32), ref["semi_dust"].view(np.uint32))
+    assert np.array_equal(last.heat.view(np.uint32), ref["heat"].view(np.uint32))
