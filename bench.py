@@ -693,6 +693,18 @@ def main():
             if (prec, h2, w2, 8) == (args.precision, H, W, B):
                 continue
             out[name] = device_leg(ctx, prec, h2, w2, 8, seed0, max(k2, args.steps), max(wu2, args.warmup), what)
+        # The headline workload with the SPARSE synthetic detector (~1-2 k candidates per frame in isolated peaks — what a trained
+        # SuperPoint produces — instead of a candidate in every cell): the headline's cells_computed_frac, selection and
+        # covariance costs are properties of the dense detector; this is the other end
+        if args.detector == "dense":
+            blob_keep = ctx["blob"]
+            ctx["blob"] = weights.synthetic(7, "sparse")
+            try:
+                out["%s_sparse_detector_b%d" % (args.precision, B)] = device_leg(
+                    ctx, args.precision, H, W, B, 200, max(100, args.steps), max(10, args.warmup),
+                    "the headline workload (%dx%d, %s, batch %d) with the sparse synthetic detector weights" % (W, H, args.precision, B))
+            finally:
+                ctx["blob"] = blob_keep
         # The headline workload with the reference's dense graph FULLY executed (SPFE_SPARSE_DB=0: convDa / convDb over the whole
         # coarse map, as sp_extractor.cpp:99-100 runs them), for the reader who wants that number: the records are the same
         # bits either way (tests/test_gpu_sparse_db.py); the default path computes the rows the keypoints read

@@ -158,6 +158,13 @@ struct spfe_handle_s {
   uint8_t *d_cell_k[2] = {}, *d_cell_mask = nullptr;
   const uint8_t *rec_of[NTICKET] = {};   // record buffer of each ticket (same buffer twice in a row: the old ordering)
   int *d_kp_cell = nullptr;
+  int select_lean = 0;                // SPFE_SELECT_LEAN: 1 = select_kernel keeps 2 bytes a cell in LDS on every frame size, 0 = only
+                                      // above 16,384 cells (default), -1 = in pipelined calls.  Measured (round 4, same-box A/B, 8
+                                      // frames per call, pipelined): the lean form starts beside a convolution workgroup instead of
+                                      // waiting for a free CU, and that is NOT a gain — f32 752x480 2107 / 2116 -> 2085 / 2082
+                                      // frames/s (it now sits beside conv1b: 0.87 -> 0.83 of peak), bf16 1280x720 7687 / 7690 ->
+                                      // 7670 / 7684, bf16 752x480 14,888 / 14,908 -> 14,846 / 14,826: the selection's 390 us
+                                      // "overlapped" were waiting time off the critical path
   int *d_sel_slot = nullptr;          // frames of more than 16,384 cells: select_kernel's global scratch (tail_select.hip)
   uint16_t *d_sel_list = nullptr;
   uint8_t *d_records = nullptr;
@@ -614,9 +621,10 @@ int build(spfe_handle h, const spfe_config *cfg) {
     if ((rc = dev_alloc(h, &h->d_db_total, 16))) return rc;
     HIP_TRY(hipMemset(h->d_db_total, 0, 16 * sizeof(int)));
   }
-  if (spfe::select_big(H, W)) {
+  {   // select_kernel's global scratch: frames of more than 16,384 cells, and the lean form of pipelined calls
     if ((rc = dev_alloc(h, &h->d_sel_slot, (size_t)B * C))) return rc;
     if ((rc = dev_alloc(h, &h->d_sel_list, (size_t)B * C))) return rc;
+    if (const char *e = getenv("SPFE_SELECT_LEAN")) h->select_lean = atoi(e);
   }
   {
     const char *qenv = getenv("SPFE_COV_QCAP");
@@ -1222,7 +1230,7 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
       h->cov_inflight = false;
     }
     STAGE_MARK(13);
-    HIP_TRY(spfe::launch_select(f, h->rl, n, H, W, h->cfg.num_features, s, &h->cov, h->rl.kmax));
+    HIP_TRY(spfe::launch_select(f, h->rl, n, H, W, h->cfg.num_features, s, &h->cov, h->rl.kmax, h->select_lean == 1));
     HIP_TRY(hipEventRecord(h->ev_sel, s));
     HIP_TRY(hipStreamWaitEvent(h->side, h->ev_sel, 0));
     int rc = launch_db_gathered(h, n, h->side);
@@ -1247,7 +1255,11 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
   HIP_TRY(hipStreamWaitEvent(h->side, h->ev_post[slot], 0));
   STAGE_MARK(13);   // ("select" reads 0 on the launch stream: it is part of post_side)
   // (the heat normalisation rides in the selection's first launch: both depend on the detector tail only)
-  HIP_TRY(spfe::launch_select(f, h->rl, n, H, W, h->cfg.num_features, h->side, &h->cov, h->rl.kmax));
+  {
+    const bool pipelined = (h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode;
+    HIP_TRY(spfe::launch_select(f, h->rl, n, H, W, h->cfg.num_features, h->side, &h->cov, h->rl.kmax,
+                                h->select_lean == 1 || (h->select_lean < 0 && pipelined)));
+  }
   // Synchronous calls: the descriptor sampling rides in the covariance replay launch (the chain's longest kernel) instead of
   // standing in front of the chain; pipelined calls keep it early — the NEXT call's convDb waits for it, and behind a replay
   // that shares the chip with that call's convolutions it would wait too long (0.5 ms steps in bf16 mode).

@@ -162,12 +162,16 @@ hipError_t launch_pbtail_f32(const float *head, const float *wpack, const float 
                              const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s);
 hipError_t launch_tail(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s);
 // with_heat_norm: the heat normalisation (launch_heat_norm) rides in the neighbour-mask launch in front of the selection
+// lean: the form that keeps only the cell states and neighbour masks in LDS (2 bytes a cell; the per-cell private data in
+// FrameBufs::sel_slot / sel_list) also on frames that would fit the all-in-LDS form (9 bytes a cell: 64 KB at 752x480, 143 KB
+// at 1280x720 — a whole CU): a pipelined call's selection then starts beside a convolution workgroup instead of waiting for a CU
 hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H, int W,
-                         int num_features, hipStream_t s, const CovScratch *with_heat_norm = nullptr, int kmax_hn = 0);
+                         int num_features, hipStream_t s, const CovScratch *with_heat_norm = nullptr, int kmax_hn = 0,
+                         bool lean = false);
 // (also resets the covariance scratch: launch_cov must follow it)
 hipError_t launch_heat_norm(const FrameBufs &f, const CovScratch &cs, int kmax, int B, int H, int W, hipStream_t s);
 hipError_t launch_desc(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s);
-size_t select_lds_bytes(int H, int W);
+size_t select_lds_bytes(int H, int W, bool lean = false);
 bool select_big(int H, int W);     // more than 16,384 cells: per-cell private data in global scratch (FrameBufs::sel_slot / sel_list)
 size_t select_max_cells();         // 65,535
 

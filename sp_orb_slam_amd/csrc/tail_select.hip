@@ -213,10 +213,10 @@ constexpr int SELECT_SMALL_CELLS = 16384;   // (also the register-resident key p
 constexpr int SELECT_DB_WORDS = 2048 + 32;   // bitmap of the cells the descriptor head must compute (<= 65,535 cells) + scan scratch
 static size_t select_fixed_lds(int H) { return ((size_t)(H / 8) + 16) * 4 * 2 + 64 + 1024 * 4 + 64 + 64 + SELECT_DB_WORDS * 4; }
 bool select_big(int H, int W) { return (size_t)(H / 8) * (W / 8) > (size_t)SELECT_SMALL_CELLS; }
-size_t select_lds_bytes(int H, int W) {
+size_t select_lds_bytes(int H, int W, bool lean) {
   const size_t C = (size_t)(H / 8) * (W / 8);
   const size_t Cp = (C + 15) & ~(size_t)15;
-  if (select_big(H, W)) return Cp + Cp + select_fixed_lds(H);
+  if (lean || select_big(H, W)) return Cp + Cp + select_fixed_lds(H);
   return Cp * 4 + Cp * 2 + Cp + Cp + Cp + select_fixed_lds(H);
 }
 size_t select_max_cells() { return 65535; }   // 16-bit cell indices (sList, row_of), 64 cells per thread
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
   const bool cut = S > need;
   if (cut) {
     constexpr int KREG = 16;                       // cells per thread kept in registers (C <= 16384)
-    const bool in_regs = !BIG && C <= KREG * 1024;
+    const bool in_regs = C <= KREG * 1024;         // (BIG on a small frame — the lean form of pipelined calls — reads its scores once)
     uint32_t key[KREG];
     uint32_t kmin = 0xffffffffu, kmax = 0u;
 #pragma unroll
@@ -552,9 +552,9 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
 }
 
 hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H, int W,
-                         int num_features, hipStream_t s, const CovScratch *with_heat_norm, int kmax_hn) {
-  const size_t lds = select_lds_bytes(H, W);
-  const bool big = select_big(H, W);
+                         int num_features, hipStream_t s, const CovScratch *with_heat_norm, int kmax_hn, bool lean) {
+  const bool big = select_big(H, W) || (lean && f.sel_slot && f.sel_list);
+  const size_t lds = select_lds_bytes(H, W, big);
   if (lds > 160 * 1024 || (size_t)(H / 8) * (W / 8) > select_max_cells()) return hipErrorInvalidValue;
   if (big && (!f.sel_slot || !f.sel_list)) return hipErrorInvalidValue;
   if (lds > 64 * 1024) {

@@ -125,10 +125,10 @@ def compute_covariance(heat, kps):
             np.array(resp, np.float32))
 
 
-def extract(named, img, num_features):
-    """SPExtractor::operator() (:361-514)."""
+def extract(named, img, num_features, cuda_scalar_div=False):
+    """SPExtractor::operator() (:361-514).  cuda_scalar_div: tools/aten_path.forward's CUDA form of `pixels.div(W / 2.0)`."""
     H, W = img.shape
-    f = forward(named, img)
+    f = forward(named, img, cuda_scalar_div)
     pts = f["pixels_in"].T.copy()  # [N,2]  (:458)
     heat, heat_inv = to_heat(f["heat_log"])
     order = sort_desc(f["score"])
@@ -150,6 +150,11 @@ CASES = [
     ("g480x752_dense", 480, 752, 100, 7, "dense", 1000, False),
     ("g480x640_sparse", 480, 640, 1, 7, "sparse", 1000, False),
     ("g720x1280_sparse", 720, 1280, 300, 7, "sparse", 1000, False),   # BASELINE configs[3] size
+    # `pixels.div(W / 2.0)` (:137-138) as libtorch-1.6 CUDA evaluates it — a * (1.0f / b) — the device the reference
+    # hard-wires (:73): the form the oracle and the kernels pin.  W / 2 = 188 and 376: the reciprocal is
+    # inexact, so the two forms differ in the last bit of about a third of the sampling coordinates
+    ("g64x376_dense_cudadiv", 64, 376, 6, 7, "dense", 150, True),
+    ("g480x752_dense_cudadiv", 480, 752, 100, 7, "dense", 1000, False),
 ]
 
 
@@ -160,13 +165,19 @@ def main():
             continue
         img = synth.make_image(iseed, H, W)
         blob = weights.synthetic(wseed, det)
-        out = extract(weights.to_named_tensors(blob), img, nf)
-        meta = dict(H=H, W=W, image_seed=iseed, weight_seed=wseed, detector=det, num_features=nf)
+        cuda_div = name.endswith("_cudadiv")
+        out = extract(weights.to_named_tensors(blob), img, nf, cuda_div)
+        meta = dict(H=H, W=W, image_seed=iseed, weight_seed=wseed, detector=det, num_features=nf, cuda_scalar_div=int(cuda_div))
         keep = dict(image=img, kp_xy=out["kp_xy"].astype(np.int16), occ_grid=out["occ_grid"],
                     n_candidates=np.int32(len(out["score"])), response=out["response"],
                     cov2=out["cov2"], cov2_inv=out["cov2_inv"],
                     dense_dust=out["dense_dust"], semi_dust=out["semi_dust"], **{
                         "meta_" + k: np.array(v) for k, v in meta.items()})
+        if cuda_div:
+            # how much the fixture discriminates: the same frame through ATen-CPU's true division
+            cpu = forward(weights.to_named_tensors(blob), img, False)
+            keep["meta_desc_max_abs_diff_to_cpu_div_form"] = np.float32(np.abs(cpu["desc"] - out["desc"]).max())
+            keep["meta_desc_rows_differing_from_cpu_div_form"] = np.int32((np.abs(cpu["desc"] - out["desc"]).max(1) > 1e-7).sum())
         if full:
             keep.update(semi=out["semi"], coarse_raw=out["coarse_raw"], heat_log=out["heat_log"],
                         heat=out["heat"], heat_inv=out["heat_inv"], cand_xy=out["pixels_in"].T.copy(),

@@ -11,9 +11,16 @@ from oracle import oracle
 from sp_orb_slam_amd import synth, weights
 
 CASES = ["g64x96_dense", "g64x96_sparse", "g128x160_sparse", "g480x752_dense", "g480x640_sparse",
-         "g720x1280_sparse"]
+         "g720x1280_sparse", "g64x376_dense_cudadiv", "g480x752_dense_cudadiv"]
 
 DESC_TOL = 2e-5
+# Fixtures made with libtorch-CUDA's form of `pixels.div(W / 2.0)` (sp_extractor.cpp:137-138: a * (1.0f / b), tools/
+# aten_path.py cuda_scalar_div) — the form the oracle and the kernels pin (the reference hard-wires CUDA, :73).  End to end the
+# oracle lands within the convolutions' summation-order noise of them (measured 2.0e-7 ... 2.2e-7); against the ATen-CPU form
+# (true division; the fixtures above) the same frames read 5.4e-7 — the 2e-5 bar hid which form the oracle follows, this one
+# does not.  Stage level (golden coarse map in, descriptors out): 6e-8.
+DESC_TOL_CUDA_FORM = 3e-7
+DESC_TOL_CUDA_FORM_STAGE = 1e-7
 HEAT_TOL = 1e-5
 COV_RTOL = 1e-5
 
@@ -43,15 +50,31 @@ def test_oracle_matches_aten_golden(name, golden_dir):
         assert np.allclose(out["coarse"], g["coarse_raw"], rtol=1e-5, atol=2e-5)
         assert np.abs(out["heat"] - g["heat"]).max() <= HEAT_TOL
         assert np.abs(out["heat_inv"] - g["heat_inv"]).max() <= HEAT_TOL
-        assert np.abs(out["desc"] - g["kp_desc"]).max() <= DESC_TOL
+        assert np.abs(out["desc"] - g["kp_desc"]).max() <= (DESC_TOL_CUDA_FORM if name.endswith("_cudadiv") else DESC_TOL)
     else:
-        assert np.abs(out["desc"][::16] - g["kp_desc_sub"]).max() <= DESC_TOL
+        assert np.abs(out["desc"][::16] - g["kp_desc_sub"]).max() <= (DESC_TOL_CUDA_FORM if name.endswith("_cudadiv") else DESC_TOL)
         assert np.allclose(out["semi"][::7, ::9], g["semi_sub"], rtol=1e-5, atol=2e-5)
         assert np.allclose(out["coarse"][::13, ::11], g["coarse_sub"], rtol=1e-5, atol=2e-5)
         assert np.abs(out["heat"][out["heat"].shape[0] // 2] - g["heat_row"]).max() <= HEAT_TOL
 
 
-@pytest.mark.parametrize("name", ["g64x96_dense", "g64x96_sparse", "g128x160_sparse"])
+def test_sampling_coordinates_follow_the_cuda_scalar_division(golden_dir):
+    """the reciprocal form of `x / (W / 2)` confirmed by a fixture instead of hidden under 2e-5.  The
+    fixture's own record says how far ATen-CPU's true division is from it on this frame; the oracle's sampling stage, fed the
+    fixture's coarse map and candidates, must be an order of magnitude closer than that."""
+    g = np.load("%s/g64x376_dense_cudadiv.npz" % golden_dir)
+    H, W = int(g["meta_H"]), int(g["meta_W"])
+    assert int(g["meta_cuda_scalar_div"]) == 1
+    gap = float(g["meta_desc_max_abs_diff_to_cpu_div_form"])
+    assert gap >= 3e-7 and int(g["meta_desc_rows_differing_from_cpu_div_form"]) >= 5   # the two forms do differ here
+    d = oracle.sample_desc(g["coarse_raw"], H, W, g["cand_xy"][:, 0].copy(), g["cand_xy"][:, 1].copy())
+    err = float(np.abs(d - g["cand_desc"]).max())
+    assert err <= DESC_TOL_CUDA_FORM_STAGE and err * 3 < gap
+    g2 = np.load("%s/g480x752_dense_cudadiv.npz" % golden_dir)
+    assert float(g2["meta_desc_max_abs_diff_to_cpu_div_form"]) >= 5e-7 and int(g2["meta_desc_rows_differing_from_cpu_div_form"]) > 1000
+
+
+@pytest.mark.parametrize("name", ["g64x96_dense", "g64x96_sparse", "g128x160_sparse", "g64x376_dense_cudadiv"])
 def test_oracle_stages_against_golden(name, golden_dir):
     """Stage-by-stage, feeding each oracle stage the GOLDEN upstream data."""
     g = np.load("%s/%s.npz" % (golden_dir, name))
@@ -73,3 +96,19 @@ def test_oracle_stages_against_golden(name, golden_dir):
     cov, cinv, resp = oracle.covariance(g["heat_inv"], kx, ky)
     assert np.array_equal(resp, g["response"])
     assert np.allclose(cov, g["cov2"], rtol=COV_RTOL) and np.allclose(cinv, g["cov2_inv"], rtol=COV_RTOL)
+
+
+def test_flip_report_is_committed_and_says_what_survey_8c_expects(golden_dir):
+    """tests/golden/flip_report.json (tools/flip_report.py, build container): oracle vs the ATen-CPU op sequence over 64 seeded
+    frames x {640x480, 752x480, 1280x720} x {dense, sparse}.  SURVEY.md 8c: "report #cells with flipped argmax/threshold
+    (expected ~0 for margin > 1e-5)" — every flipped cell's own margin must be below 1e-5, and flips must be rare."""
+    import json
+    rep = json.load(open("%s/flip_report.json" % golden_dir))
+    assert set(rep["configs"]) == {"%s_%s" % (s, d) for s in ("640x480", "752x480", "1280x720") for d in ("dense", "sparse")}
+    for key, c in rep["configs"].items():
+        assert c["frames"] >= 64
+        cells = c["frames"] * c["cells_per_frame"]
+        assert c["arg_flips_total"] + c["thr_flips_total"] <= cells * 1e-5, key          # (measured: 7 of 3.3 M cells overall)
+        assert all(g < 1e-5 for g in c["flipped_cells_top2_gaps"] + c["flipped_cells_threshold_gaps"]), key
+        assert c["keypoints_on_one_side_only_total"] <= c["keypoints_total"] * 1e-4, key
+        assert c["logit_max_abs_diff"] < 5e-5, key

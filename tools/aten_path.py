@@ -17,8 +17,12 @@ import torch
 import torch.nn.functional as F
 
 
-def forward(named, img_u8):
-    """SPFrontend::forward (:79-159) + input conversion (:388), ATen-CPU, NCHW."""
+def forward(named, img_u8, cuda_scalar_div=False):
+    """SPFrontend::forward (:79-159) + input conversion (:388), ATen-CPU, NCHW.
+    cuda_scalar_div: evaluate `pixels.div(W / 2.0)` (:137-138) the way libtorch-1.6's CUDA kernel does — tensor / scalar is
+    `a * inv_b` with inv_b = accscalar_t(1.0) / b formed once in f32 (aten/src/ATen/native/cuda/BinaryMulDivKernel.cu,
+    div_kernel_cuda's is_cpu_scalar branch) — instead of ATen-CPU's true division.  The reference hard-wires CUDA (:73), so
+    this is the form the oracle and the kernels pin; the two differ in the last bit of some sampling coordinates."""
     H, W = img_u8.shape
     hc, wc = H // 8, W // 8
     t = {k: torch.from_numpy(v) for k, v in named.items()}
@@ -65,8 +69,12 @@ def forward(named, img_u8):
 
     heat_log = F.pixel_shuffle(torch.log(torch.clamp(nodust, 0.001)).unsqueeze(0), 8)
 
-    x_s = pixels_in[0].div(W / 2.0) - 1.0
-    y_s = pixels_in[1].div(H / 2.0) - 1.0
+    if cuda_scalar_div:
+        x_s = pixels_in[0] * float(np.float32(1.0) / np.float32(W / 2.0)) - 1.0
+        y_s = pixels_in[1] * float(np.float32(1.0) / np.float32(H / 2.0)) - 1.0
+    else:
+        x_s = pixels_in[0].div(W / 2.0) - 1.0
+        y_s = pixels_in[1].div(H / 2.0) - 1.0
     samp = torch.cat([x_s.unsqueeze(-1), y_s.unsqueeze(-1)], -1).unsqueeze(0).unsqueeze(0)
     n = pixels_in.shape[1]
     if n > 0:
@@ -78,6 +86,7 @@ def forward(named, img_u8):
                 coarse_raw=coarse_raw[0].permute(1, 2, 0).contiguous().numpy(),  # [hc,wc,256]
                 semi_dust=semi_dust.numpy().copy(), dense_dust=dense_dust.numpy().copy(),
                 pixels_in=pixels_in.numpy().copy(), score=score_sel.numpy().copy(),
+                score_map=score.numpy().copy(), argmax_map=indices.numpy().astype(np.int32),
                 desc=desc.numpy().T.copy(), heat_log=heat_log[0, 0].numpy().copy())
 
 
