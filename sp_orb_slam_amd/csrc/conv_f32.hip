@@ -747,6 +747,37 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const uint8_t *__restrict__
   }
 }
 
+// 2x2 / 2 max-pool of an NHWC f32 activation (a float4 of channels per lane).  Used when a POOLED layer of a single frame runs
+// as un-pooled 2-row tiles (spfe_api.hip): bias, ReLU and the maximum commute exactly (all monotonic), so pooling the stored
+// ReLU outputs gives the bits of the fused epilogue.
+__global__ __launch_bounds__(256) void pool2x2_f32_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, int B, int Ho,
+                                                          int Wo, int c4) {
+  const size_t n = (size_t)B * Ho * Wo * c4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % c4);
+    size_t t = i / c4;
+    const int x = (int)(t % Wo);
+    t /= Wo;
+    const int y = (int)(t % Ho), b = (int)(t / Ho);
+    const size_t W = (size_t)Wo * 2, base = (((size_t)b * Ho * 2 + 2 * y) * W + 2 * x) * c4 + c;
+    const float4 a = in[base], bq = in[base + c4], cq = in[base + W * c4], d = in[base + W * c4 + c4];
+    float4 o;
+    o.x = fmaxf(fmaxf(a.x, bq.x), fmaxf(cq.x, d.x));
+    o.y = fmaxf(fmaxf(a.y, bq.y), fmaxf(cq.y, d.y));
+    o.z = fmaxf(fmaxf(a.z, bq.z), fmaxf(cq.z, d.z));
+    o.w = fmaxf(fmaxf(a.w, bq.w), fmaxf(cq.w, d.w));
+    out[i] = o;
+  }
+}
+hipError_t launch_pool2x2_f32(const float *in, float *out, int B, int H, int W, int C, hipStream_t s) {
+  if ((H & 1) || (W & 1) || (C & 3)) return hipErrorInvalidValue;
+  const size_t n = (size_t)B * (H / 2) * (W / 2) * (C / 4);
+  const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pool2x2_f32_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4 *>(in),
+                     reinterpret_cast<float4 *>(out), B, H / 2, W / 2, C / 4);
+  return hipGetLastError();
+}
+
 hipError_t launch_conv1a(const uint8_t *img, const float *w9x64, const float *b64, float *out, int B,
                          int H, int W, hipStream_t s) {
   const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;

@@ -193,6 +193,12 @@ struct spfe_handle_s {
   int m_host_cap = 0;              // rows the host-API staging blocks / m_out hold
   unsigned tile2_mask = 0;   // SPFE_TILE2_MASK: f32 layers forced onto 2-row tiles (probe knob)
   bool tile2_auto = true;    // SPFE_TILE2_AUTO=0: never choose 2-row tiles
+  // f32, a single frame: a POOLED low-resolution layer (conv3b: 180 eight-row items on 256 CUs — one round of the longest
+  // items, 70 % of the CUs busy) as UN-pooled 2-row tiles (720 items: three rounds of quarter-size items) into a scratch
+  // buffer + a 2x2 max-pool pass (pool2x2_f32_kernel; bias / ReLU / max commute exactly: same bits).  SPFE_POOL_SPLIT:
+  // -1 cost model, 0 never, 1 wherever the shapes allow (tests)
+  int pool_split = -1;
+  float *d_unpooled = nullptr;   // [<= 2 frames][H / 4][W / 4][128]
   unsigned tile16_mask = 0;  // f32 layers (bit i = conv layer i of enqueue()) on 16-row / 8-wave tiles
   int conv1b_split_rows = -1; // ... and, when that launch was cut in a 16-row and an 8-row part, the 16-row part's tile rows ("conv1b_split_rows")
   int conv1b_tile_rows = 8;  // rows per tile of the last call's conv1b launch (f32; spfe_debug_read("conv1b_tile_rows"))
@@ -533,6 +539,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
     if (const char *m2 = getenv("SPFE_TILE2_MASK")) h->tile2_mask = (unsigned)strtoul(m2, nullptr, 0);
     if (const char *m4 = getenv("SPFE_TILE16X4")) h->tile16x4 = atoi(m4);
     if (const char *a2 = getenv("SPFE_TILE2_AUTO")) h->tile2_auto = atoi(a2) != 0;
+    if (const char *ps = getenv("SPFE_POOL_SPLIT")) h->pool_split = atoi(ps);
     const char *wenv = getenv("SPFE_BF16_WS_MASK");
     if (wenv) h->ws_mask = (unsigned)strtoul(wenv, nullptr, 0) & 0xfu;
     const char *f16env = getenv("SPFE_BF16_FUSE_CONV1A");
@@ -600,6 +607,8 @@ int build(spfe_handle h, const spfe_config *cfg) {
   for (int i = 0; i < 8; ++i)
     if ((rc = dev_alloc(h, &h->act[i], (size_t)B * lh[i] * lw[i] * lc[i]))) return rc;
   if ((rc = dev_alloc(h, &h->d_img, (size_t)B * H * W))) return rc;
+  if (!h->bf16 && h->pool_split != 0 && !(H & 15) && !(W & 15))   // (the un-pooled output of the largest pooled layer this serves: conv2b / conv3b of <= 2 frames)
+    if ((rc = dev_alloc(h, &h->d_unpooled, (size_t)std::min(B, 2) * (H / 2) * (W / 2) * 64))) return rc;
   if ((rc = dev_alloc(h, &h->d_head, (size_t)B * C * 512))) return rc;
   if ((rc = dev_alloc(h, &h->d_semi, (size_t)B * C * SPFE_SEMI_CH))) return rc;
   if ((rc = dev_alloc(h, &h->d_coarse, (size_t)B * C * SPFE_DESC_DIM))) return rc;
@@ -1046,6 +1055,28 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
         const double cost_tiny = (double)((items_tiny + g - 1) / g) * 0.56;
         tiny_tile = cost_tiny < (cost_small < cost_big ? cost_small : cost_big);
       }
+    }
+    // a pooled layer as un-pooled 2-row tiles + a pool pass (single frames; see spfe_handle_s::pool_split)
+    bool pool_split = false;
+    if (L.ks == 3 && L.pool && L.relu && i > 0 && i < 7 && h->d_unpooled && h->pool_split != 0 && n_all == 1 &&   // (one scratch buffer: single-frame calls)
+         !(L.H & 1) && !(L.W & 1) &&
+        (size_t)n * L.H * L.W * L.out_stride <= (size_t)std::min(h->B, 2) * (H / 2) * (W / 2) * 64) {
+      const long tx = (L.W + 31) / 32, g = h->num_cus > 0 ? h->num_cus : 256;
+      const long items_big = tx * ((L.H + 7) / 8) * L.nblk * n, items_small = tx * ((L.H + 3) / 4) * L.nblk * n;
+      const long items_tiny = tx * ((L.H + 1) / 2) * L.nblk * n;
+      const double cost_big = (double)((items_big + g - 1) / g) * 2.0 * 0.93, cost_small = (double)((items_small + g - 1) / g);
+      // (0.56: a 2-row item against a 4-row one, measured; 0.12: the pool pass — ~6 us against the ~50 us of a 4-row round at K = 1152)
+      const double cost_tiny = (double)((items_tiny + g - 1) / g) * 0.56 + 0.12;
+      pool_split = h->pool_split > 0 || cost_tiny < (cost_small < cost_big ? cost_small : cost_big) - 0.02;
+    }
+    if (pool_split) {
+      spfe::ConvParams q = p;
+      q.out = h->d_unpooled; q.out_stride = L.out_stride; q.out_choff = 0;
+      q.tiles_x = (L.W + 31) / 32; q.tiles_y = (L.H + 1) / 2; q.nblk = L.nblk; q.num_cus = h->num_cus;
+      HIP_TRY(spfe::launch_conv_f32(q, L.cin, L.ks, false, true, 3, 0, s));
+      HIP_TRY(spfe::launch_pool2x2_f32(h->d_unpooled, p.out, n, L.H, L.W, L.out_stride, s));
+      STAGE_MARK(2 + i);
+      return SPFE_OK;
     }
     if (i == 0 && fused) small_tile = false;  // the fused first layer exists for 8-row tiles only
     int tile_mode = small_tile ? 1 : 0;

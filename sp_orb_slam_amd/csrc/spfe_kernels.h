@@ -37,6 +37,8 @@ struct ConvParams {
 // 4 = 16-row tiles of 4 waves x 4 rows (conv1b)
 hipError_t launch_conv_f32(const ConvParams &p, int cin, int ksize, bool pool, bool relu,
                            int tile_mode, int layer_tag, hipStream_t s);
+// 2x2 / 2 max-pool of an NHWC f32 activation [B][H][W][C] -> [B][H/2][W/2][C] (H, W even, C % 4 == 0)
+hipError_t launch_pool2x2_f32(const float *in, float *out, int B, int H, int W, int C, hipStream_t s);
 int conv_kc(int ksize);        // K-chunk the kernel stages per barrier (16 for 3x3, 64 for 1x1)
 int conv_tile_rows(int tile_mode);
 

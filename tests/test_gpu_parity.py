@@ -789,3 +789,25 @@ def test_f32_convPb_inside_the_tail_launch_is_bit_identical(monkeypatch, H, W, B
     assert np.array_equal(last.descriptors.view(np.uint32), ref["desc"].view(np.uint32))
     assert np.array_equal(last.semi_dust.view(np.uint32), ref["semi_dust"].view(np.uint32))
     assert np.array_equal(last.heat.view(np.uint32), ref["heat"].view(np.uint32))
+
+
+@pytest.mark.parametrize("H,W", [(480, 752), (240, 368), (64, 96)])
+def test_f32_pooled_layer_as_unpooled_two_row_tiles_plus_a_pool_pass_is_bit_identical(monkeypatch, H, W):
+    """Single frames (round 4): conv2b / conv3b as UN-pooled 2-row tiles into a scratch buffer + pool2x2_f32_kernel
+    (SPFE_POOL_SPLIT=1: wherever the shapes allow; the cost model takes it for conv3b at 752x480) against the fused
+    bias / ReLU / 2x2-max epilogue (SPFE_POOL_SPLIT=0): the pooled activations and everything behind them are the same bits."""
+    blob = weights.synthetic(7, "dense")
+    img = synth.make_image(190, H, W)
+    out = {}
+    for flag in ("0", "1", "-1"):
+        monkeypatch.setenv("SPFE_POOL_SPLIT", flag)
+        ext = SPExtractor(300, H, W, blob, max_batch=1, with_heat=False)
+        fr = ext(img, None)
+        out[flag] = (ext.last, [ext.debug_read(nm, 0) for nm in ("act3", "act5", "semi", "feat")])
+        ext.close()
+    for flag in ("1", "-1"):
+        for a, b in zip(out["0"][1], out[flag][1]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        a, b = out["0"][0], out[flag][0]
+        assert a.K == b.K and np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.descriptors, b.descriptors)
+        assert np.array_equal(a.cov2, b.cov2)
