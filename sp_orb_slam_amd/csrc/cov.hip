@@ -310,6 +310,8 @@ struct CovFrame {
   int *ovf_slot, *novf, *ovf_q;   // overflow slots: pop lists of the walks that outgrew qcap
   float *ovf_v;
   float *nxy;                     // [kmax][2] position of nxt[j] (so that one load yields the next member AND its window)
+  int *nedges;                    // claim edges (lower claimant, dirty keypoint) found by the classification: count ...
+  int2 *edges;                    // ... and list [ecap] (null: the link kernel walks the pop lists itself)
   int K;
 };
 
@@ -338,6 +340,8 @@ __device__ __forceinline__ CovFrame cov_frame(const FrameBufs &f, const RecordLa
   c.ovf_q = cs.ovf_q + (size_t)b * cs.ovf_slots * cs.ovf_cap;
   c.ovf_v = cs.ovf_v + (size_t)b * cs.ovf_slots * cs.ovf_cap;
   c.nxy = cs.nxy + (size_t)b * rl.kmax * 2;
+  c.nedges = cs.counters + 4 * b + 3;
+  c.edges = cs.edges ? reinterpret_cast<int2 *>(cs.edges) + (size_t)b * cs.ecap : nullptr;
   return c;
 }
 
@@ -402,7 +406,24 @@ __global__ __launch_bounds__(64 * COV_WAVES) void cov_classify_kernel(FrameBufs 
   pop_list(c, cs, j, q, qv, cap);
   const int n = c.npop[j];
   int bad = 0;
-  for (int i = 1 + lane; i < n; i += 64) bad |= c.claim[q[i]] < j;  // claims were made by the previous kernel
+  for (int i0 = 1; i0 < n; i0 += 64) {   // claims were made by the previous kernel  (uniform trip count: ballots inside)
+    const int i = i0 + lane;
+    const int a = i < n ? c.claim[q[i]] : COV_INF;
+    bad |= a < j;
+    // the link kernel's input, while the claim is in a register: (lower claimant, this keypoint).  One entry per pixel
+    // (duplicates are harmless for a union); a frame with more edges than the list holds makes the link kernel walk the pop
+    // lists itself, as it used to (the count keeps counting)
+    if (c.edges) {   // (uniform) one atomic per wavefront pass: the edge lanes take consecutive entries
+      const unsigned long long em = __ballot(a < j);
+      if (em) {
+        int base = 0;
+        if (lane == __ffsll((long long)em) - 1) base = atomicAdd(c.nedges, __popcll(em));
+        base = __shfl(base, __ffsll((long long)em) - 1, 64);
+        const int e = base + __popcll(em & ((1ull << lane) - 1ull));
+        if (a < j && e < cs.ecap) c.edges[e] = make_int2(a, j);
+      }
+    }
+  }
   if (__ballot(bad) == 0) {
     for (int i = lane; i < n; i += 64) atomicMin(&c.done[q[i]], j);
   } else if (lane == 0) {
@@ -439,9 +460,28 @@ __global__ __launch_bounds__(LINK_THREADS) void cov_link_kernel(FrameBufs f, Rec
   // (a quarter-wavefront per dirty keypoint, its 16 lanes over the pixels: the phase is two dependent global round trips
   // per keypoint — pop list, then the claims of its pixels — and 64 groups keep four times as many of them in flight
   // as 16 wavefronts did)
+  auto unite = [&](int a, int bb) {   // hook the larger root under the smaller one
+    while (true) {
+      a = uf_find(parent, a);
+      bb = uf_find(parent, bb);
+      if (a == bb) break;
+      const int hi = a > bb ? a : bb, lo = a > bb ? bb : a;
+      const int old = atomicMin(&parent[hi], lo);
+      if (old == hi) break;
+      a = old;
+      bb = lo;
+    }
+  };
+  const int ne = c.edges ? *c.nedges : -1;
+  const bool from_edges = ne >= 0 && ne <= cs.ecap;   // the classification listed every claim edge: ONE global round trip
+  if (from_edges)
+    for (int e = tid; e < ne; e += LINK_THREADS) {
+      const int2 ed = c.edges[e];
+      unite(ed.x, ed.y);
+    }
   constexpr int GL = 16;
   const int gl = tid & (GL - 1), grp = tid / GL;
-  for (int d = grp; d < nd; d += LINK_THREADS / GL) {
+  for (int d = grp; d < (from_edges ? 0 : nd); d += LINK_THREADS / GL) {
     const int j = c.dirty[d];
     int *q; float *qv; int cap;
     pop_list(c, cs, j, q, qv, cap);
@@ -469,6 +509,33 @@ __global__ __launch_bounds__(LINK_THREADS) void cov_link_kernel(FrameBufs f, Rec
   // — a bitonic sort in LDS — and the successor / the component's first member (the replay kernel's
   // worker) are the neighbours in the sorted order.
   int *key = smem_i + 2 * K;   // [P], P = next power of two >= nd (<= 2 K)
+  if (nd <= LINK_THREADS) {
+    // few dirty keypoints (a frame has a few hundred at most on the dense synthetic detector, none on a trained one): every
+    // thread owns one and scans the others' (root, index) keys in LDS — broadcast reads, no barrier — for its successor in
+    // the component and for "am I the first": the 36 barrier-separated passes of the bitonic sort below were most of this
+    // kernel's 25 us on a single frame
+    int myj = -1, myroot = -1;
+    if (tid < nd) {
+      myj = c.dirty[tid];
+      myroot = parent[myj];
+      key[tid] = (myroot << 15) | myj;
+    }
+    __syncthreads();
+    if (tid < nd) {
+      int jn = 0x7fff, first = 1;
+      for (int e = 0; e < nd; ++e) {
+        const int ke = key[e], je = ke & 0x7fff;
+        const bool same = (ke >> 15) == myroot;
+        jn = same && je > myj && je < jn ? je : jn;
+        first &= !(same && je < myj);
+      }
+      jn = jn == 0x7fff ? -1 : jn;
+      c.nxt[myj] = jn;
+      if (jn >= 0) { c.nxy[2 * myj] = c.kp_xy[2 * jn]; c.nxy[2 * myj + 1] = c.kp_xy[2 * jn + 1]; }
+      if (first) c.workers[atomicAdd(c.nworkers, 1)] = myj;
+    }
+    return;
+  }
   int P = 1;
   while (P < nd) P <<= 1;
   for (int d = tid; d < P; d += LINK_THREADS) {

@@ -649,6 +649,10 @@ int build(spfe_handle h, const spfe_config *cfg) {
     if ((rc = dev_alloc(h, &h->cov.nxy, (size_t)B * h->kmax * 2))) return rc;
     if ((rc = dev_alloc(h, &h->cov.workers, (size_t)B * h->kmax))) return rc;
     if ((rc = dev_alloc(h, &h->cov.counters, (size_t)B * 4))) return rc;
+    h->cov.ecap = 32 * h->kmax;   // (~24 pops per keypoint on the dense synthetic detector, a quarter of the keypoints dirty)
+    if (getenv("SPFE_COV_EDGES") && atoi(getenv("SPFE_COV_EDGES")) == 0) h->cov.ecap = 0;   // A/B: the link kernel walks the pop lists
+    if (const char *e = getenv("SPFE_COV_ECAP")) h->cov.ecap = std::max(0, atoi(e));        // (tests: a list that overflows)
+    if (h->cov.ecap && (rc = dev_alloc(h, &h->cov.edges, (size_t)B * h->cov.ecap * 2))) return rc;
     const char *oenv = getenv("SPFE_COV_OVF_SLOTS"), *cenv = getenv("SPFE_COV_OVF_CAP");
     h->cov.ovf_slots = oenv ? atoi(oenv) : 16;
     h->cov.ovf_cap = cenv ? atoi(cenv) : 16384;

@@ -138,7 +138,9 @@ struct CovScratch {
   int *nxt;       // [B][kmax] next dirty member of the same component (ascending) or -1
   float *nxy;     // [B][kmax][2] keypoint position of nxt
   int *workers;   // [B][kmax] lowest dirty member of each component
-  int *counters;  // [B][4] number of dirty keypoints, number of components, overflow slots taken
+  int *counters;  // [B][4] number of dirty keypoints, number of components, overflow slots taken, claim edges listed
+  int *edges;     // [B][ecap] int2 (lower claimant, dirty keypoint): the union-find's input, written by the classification (or null)
+  int ecap;
   int qcap;
   // walks that outgrow qcap redo themselves in one of ovf_slots per-frame slots of ovf_cap entries
   int *ovf_slot;  // [B][kmax] slot of the keypoint's pop list, or -1

@@ -10,7 +10,7 @@ import pytest
 
 from oracle import oracle
 from sp_orb_slam_amd.extractor import SPExtractor
-from sp_orb_slam_amd import weights
+from sp_orb_slam_amd import synth, weights
 
 pytestmark = pytest.mark.gpu
 f32 = np.float32
@@ -331,3 +331,26 @@ def test_full_extraction_1080p_matches_oracle():
 def test_frames_beyond_65535_cells_are_refused():
     with pytest.raises(Exception):
         SPExtractor(1000, 2160, 3840, _blob())
+
+
+@pytest.mark.parametrize("env", [{"SPFE_COV_EDGES": "0"}, {"SPFE_COV_ECAP": "40"}, {}])
+def test_covariance_link_from_the_classifications_edge_list_equals_the_pop_list_walk(monkeypatch, env):
+    """Round 4: the classification lists the claim edges (lower claimant, dirty keypoint) while it has the claims in registers,
+    and the link kernel unites from that list (one global round trip) and builds the chains by an all-pairs scan instead of a
+    bitonic sort.  Against the pop-list walk (SPFE_COV_EDGES=0), and with a list too short for the frame (SPFE_COV_ECAP=40:
+    the link kernel must notice and walk the pop lists): covariances bitwise equal to the sequential oracle's either way."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    H, W, nf = 240, 376, 400
+    blob = weights.synthetic(7, "dense")
+    imgs = [synth.make_image(210 + i, H, W) for i in range(2)]
+    ext = SPExtractor(nf, H, W, blob, max_batch=2, with_heat=False)
+    frs = ext.extract_batch(imgs)
+    for fr, img in zip(frs, imgs):
+        ref = oracle.extract(blob, img, nf)
+        assert fr.K == ref["K"] and fr.status == 0
+        assert np.array_equal(fr.cov2.view(np.uint32), ref["cov2"].view(np.uint32))
+        assert np.array_equal(fr.cov2_inv.view(np.uint32), ref["cov2_inv"].view(np.uint32))
+    nd = np.frombuffer(ext.debug_read("cov_counters", 0).tobytes(), np.int32)
+    assert nd[0] > 10          # the frame has dirty keypoints: the link stage did work
+    ext.close()
