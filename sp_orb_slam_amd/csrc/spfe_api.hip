@@ -62,6 +62,7 @@ int fail(int code, const char *fmt, ...) {
                   __LINE__);                                                            \
   } while (0)
 
+constexpr int kKcAuto = 0;   // layers the K-chain kernel takes by default on single frames (set from measurements)
 constexpr int NSTAGE = 15;
 const char *kStageNames[NSTAGE] = {"conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b",
                                    "conv4a", "conv4b", "convPaDa", "convPb", "convDb", "tail",
@@ -198,6 +199,12 @@ struct spfe_handle_s {
   // buffer + a 2x2 max-pool pass (pool2x2_f32_kernel; bias / ReLU / max commute exactly: same bits).  SPFE_POOL_SPLIT:
   // -1 cost model, 0 never, 1 wherever the shapes allow (tests)
   int pool_split = -1;
+  // f32, a single frame: the low-resolution layers without a pool (conv3a, conv4a, conv4b, convPa [| convDa]) on the K-chain
+  // kernel (conv_f32_kc.hip, v_mfma_f32_16x16x4_f32: every output's fmaf chain advances 4 k per 32-cycle issue and the layer is
+  // cut into 16 x 16 chains, 3 per wavefront, so that every SIMD has work).  SPFE_KC: -1 = the layers it measured faster on,
+  // 0 = never, else a mask of conv layer indices (bit 3 = conv3a, 5 = conv4a, 6 = conv4b, 7 = convPa | Da)
+  int kc_mask = -1;
+  float *d_wkc[8] = {};      // their weights in conv_f32_kc_pack_weights order
   float *d_unpooled = nullptr;   // [<= 2 frames][H / 4][W / 4][128]
   unsigned tile16_mask = 0;  // f32 layers (bit i = conv layer i of enqueue()) on 16-row / 8-wave tiles
   int conv1b_split_rows = -1; // ... and, when that launch was cut in a 16-row and an 8-row part, the 16-row part's tile rows ("conv1b_split_rows")
@@ -540,6 +547,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
     if (const char *m4 = getenv("SPFE_TILE16X4")) h->tile16x4 = atoi(m4);
     if (const char *a2 = getenv("SPFE_TILE2_AUTO")) h->tile2_auto = atoi(a2) != 0;
     if (const char *ps = getenv("SPFE_POOL_SPLIT")) h->pool_split = atoi(ps);
+    if (const char *km = getenv("SPFE_KC")) h->kc_mask = (int)strtol(km, nullptr, 0);
     const char *wenv = getenv("SPFE_BF16_WS_MASK");
     if (wenv) h->ws_mask = (unsigned)strtoul(wenv, nullptr, 0) & 0xfu;
     const char *f16env = getenv("SPFE_BF16_FUSE_CONV1A");
@@ -733,6 +741,22 @@ int build(spfe_handle h, const spfe_config *cfg) {
     if (const char *e = getenv("SPFE_SPARSE_DA")) h->sparse_da_mode = atoi(e);
     h->sparse_da = h->sparse_da && h->sparse_da_mode != 0;
     if (h->sparse_da && (rc = dev_alloc(h, &h->act7_alt, (size_t)B * C * 128))) return rc;
+  }
+  if (!h->bf16 && h->kc_mask != 0) {   // the K-chain kernel's weight tables (conv_f32_kc.hip): conv3a, conv4a, conv4b, convPa | convDa
+    const int kl[4] = {3, 5, 6, 7};
+    for (int q = 0; q < 4; ++q) {
+      const int i = kl[q];
+      const int l0 = specs[i].l0, l1 = specs[i].l1, nl = specs[i].nl;
+      const spfe_layer_t &La = SPFE_LAYERS[l0];
+      const int cout = La.cout + (nl == 2 ? SPFE_LAYERS[l1].cout : 0);
+      if (!spfe::conv_f32_kc_supports(h->layers[i].H, h->layers[i].W, La.cin, cout)) continue;
+      std::vector<float> wsrc((size_t)cout * La.cin * 9), wdst((size_t)cout * La.cin * 9);
+      memcpy(wsrc.data(), blob.data() + blob_weight_offset(l0), (size_t)La.cout * La.cin * 9 * 4);
+      if (nl == 2) memcpy(wsrc.data() + (size_t)La.cout * La.cin * 9, blob.data() + blob_weight_offset(l1), (size_t)SPFE_LAYERS[l1].cout * La.cin * 9 * 4);
+      spfe::conv_f32_kc_pack_weights(wsrc.data(), La.cin, cout, wdst.data());
+      if ((rc = dev_alloc(h, &h->d_wkc[i], wdst.size()))) return rc;
+      HIP_TRY(hipMemcpy(h->d_wkc[i], wdst.data(), wdst.size() * 4, hipMemcpyHostToDevice));
+    }
   }
   if (!h->bf16) {  // f32 heads with register-resident weights (head_f32.hip), bit-identical to the generic kernel — opt-in:
     // measured 63 + 38.5 us per eight 752x480 frames against 72 + 35.5 for the generic kernel (matrix-bound: 47 us at the peak)
@@ -1039,6 +1063,14 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     if (!h->bf16 && i >= 8 && h->f32_heads) {  // convPb / convDb in f32: head_f32.hip (weights in registers)
       if (i == 8) HIP_TRY(spfe::launch_head1x1_f32(h->d_head, h->d_wpb32, L.d_b, h->d_semi, n * h->C, 65, s));
       else HIP_TRY(spfe::launch_head1x1_f32(h->d_head, h->d_wdb32, L.d_b, h->d_coarse, n * h->C, 256, s));
+      STAGE_MARK(2 + i);
+      return SPFE_OK;
+    }
+    if (!h->bf16 && L.ks == 3 && !L.pool && L.relu && i < 8 && h->d_wkc[i] && n_all == 1 && !(i == 0 && fused) &&
+        (h->kc_mask > 0 ? ((h->kc_mask >> i) & 1) != 0 : h->kc_mask < 0 && ((kKcAuto >> i) & 1))) {
+      const int cout = i == 7 && sparse_da ? L.cout_real / 2 : L.cout_real;   // (convPa alone when convDa runs gathered)
+      p.B = n; p.H = L.H; p.W = L.W;
+      HIP_TRY(spfe::launch_conv_f32_kc(p, L.cin, cout, h->d_wkc[i], L.d_b, s));
       STAGE_MARK(2 + i);
       return SPFE_OK;
     }

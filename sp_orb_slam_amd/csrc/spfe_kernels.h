@@ -37,6 +37,13 @@ struct ConvParams {
 // 4 = 16-row tiles of 4 waves x 4 rows (conv1b)
 hipError_t launch_conv_f32(const ConvParams &p, int cin, int ksize, bool pool, bool relu,
                            int tile_mode, int layer_tag, hipStream_t s);
+// The K-chain kernel (conv_f32_kc.hip): 3x3 / pad 1 / bias / ReLU / no pool on v_mfma_f32_16x16x4_f32 for a single frame's
+// low-resolution layers (width <= 192 pixels); p.in / p.out / strides / B / H / W as for launch_conv_f32; wpack =
+// conv_f32_kc_pack_weights([cout][cin][9]), bias = [cout] in channel order; bit-identical to launch_conv_f32
+hipError_t launch_conv_f32_kc(const ConvParams &p, int cin, int cout, const float *wpack, const float *bias, hipStream_t s);
+bool conv_f32_kc_supports(int H, int W, int cin, int cout);
+size_t conv_f32_kc_weight_bytes(int cin, int cout);
+void conv_f32_kc_pack_weights(const float *W, int cin, int cout, float *dst);
 // 2x2 / 2 max-pool of an NHWC f32 activation [B][H][W][C] -> [B][H/2][W/2][C] (H, W even, C % 4 == 0)
 hipError_t launch_pool2x2_f32(const float *in, float *out, int B, int H, int W, int C, hipStream_t s);
 int conv_kc(int ksize);        // K-chunk the kernel stages per barrier (16 for 3x3, 64 for 1x1)

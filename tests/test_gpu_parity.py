@@ -811,3 +811,26 @@ def test_f32_pooled_layer_as_unpooled_two_row_tiles_plus_a_pool_pass_is_bit_iden
         a, b = out["0"][0], out[flag][0]
         assert a.K == b.K and np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.descriptors, b.descriptors)
         assert np.array_equal(a.cov2, b.cov2)
+
+
+@pytest.mark.parametrize("H,W", [(480, 752), (480, 640), (136, 200), (64, 96), (720, 1280), (24, 40)])
+def test_f32_k_chain_kernel_on_mfma_16x16x4_is_bit_identical(monkeypatch, H, W):
+    """conv_f32_kc.hip (round 4): a single frame's conv3a / conv4a / conv4b / convPa on v_mfma_f32_16x16x4_f32 — 16 x 16 output
+    chains, 4 k per MFMA in ascending order — against conv_f32.hip's v_mfma_f32_32x32x2_f32 tiles (SPFE_KC=0): the K order per
+    output is the arithmetic contract's either way, so every activation, logit and record is the same bits.  Widths that are
+    not multiples of 16 (94, 25, 12, 5), odd heights (17, 3), one and two rows per strip, and a frame whose conv3a is too wide
+    for the kernel (1280x720: it keeps the other kernel there) included."""
+    blob = weights.synthetic(7, "dense")
+    img = synth.make_image(230, H, W)
+    out = {}
+    for flag in ("0", "0xE8"):
+        monkeypatch.setenv("SPFE_KC", flag)
+        ext = SPExtractor(300, H, W, blob, max_batch=1, with_heat=False)
+        ext(img, None)
+        out[flag] = (ext.last, [ext.debug_read(nm, 0) for nm in ("act4", "act6", "feat", "semi", "coarse")])
+        ext.close()
+    for a, b in zip(out["0"][1], out["0xE8"][1]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    a, b = out["0"][0], out["0xE8"][0]
+    assert a.K == b.K and np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.descriptors, b.descriptors)
+    assert np.array_equal(a.cov2, b.cov2)
