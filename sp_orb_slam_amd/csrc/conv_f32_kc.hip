@@ -15,28 +15,32 @@
 //
 // Shape.  A workgroup = (frame, strip of R image rows, 16 output channels); R = 2 when two rows are <= 12 pixel groups of
 // 16 (752x480 / 8: 94 px = 6 groups), else 1.  Its <= 12 chains (R x groups) are dealt to 4 wavefronts, 3 each.  Per K chunk
-// of 16 input channels the halo strip ([16 ch][R + 2 rows][16 G + 2 px], channel-major: an A operand — 16 px x 4 channels —
-// is 4 runs of 16 consecutive floats, plane stride = 16 mod 32 banks: conflict-free) and the chunk's 144 x 16 weights
-// ([tap][k][16 ch]: a B operand is 64 consecutive floats) sit in LDS, double buffered; the next chunk travels global ->
-// registers -> LDS under the current chunk's 108 MFMAs per wavefront; one barrier per chunk.  One B read feeds three MFMAs.
+// of 16 input channels the halo strip (1 KB blocks of 16 consecutive halo pixels x the chunk's 4 channel quads, as the
+// LDS-direct loads deliver them: an A operand — 16 px x 4 channels — is 64 dwords 16 bytes apart, a 2-way bank conflict)
+// and the chunk's 144 x 16 weights ([tap][k][16 ch]: a B operand is 64 consecutive floats) sit in LDS, double buffered; the
+// next chunk travels L2 -> LDS (buffer_load ... lds) under the current chunk's 108 MFMAs per wavefront, one block per MFMA
+// gap; one barrier per chunk.  One B read feeds three MFMAs.
 // K order: chunk -> tap -> channel (4 per MFMA, ascending): the contract's.  Accumulation starts from C = 0; out = max(acc
 // + bias, 0).  Same bits as conv_f32.hip (tests/test_gpu_parity.py::test_f32_k_chain_kernel_on_mfma_16x16x4_is_bit_identical).
 //
-// STATUS: opt-in (SPFE_KC=<layer mask>), NOT the default — measured on a single 752x480 frame (rocprofv3, round 4):
-//   conv4a / conv4b   conv_f32.hip 2-row tiles 22.8 us   this kernel 26.6 us      convPa 42 -> 40 us      conv3a 35 -> 62 us
-// What the measurements say (each an ablation build run on the GPU box):
-//   1. the matrix loop itself does what the arithmetic promised: with the staging removed the 2,880 chains of conv4a take 11 us
+// STATUS: opt-in (SPFE_KC=<layer mask>), NOT the default.  Measured on single frames (round 4; stage events, which read ~5 us
+// high; same-box A/B against conv_f32.hip's 2-row tiles):
+//   752x480   conv4a / conv4b 27.0 -> 29.2 us   convPa 45.4 -> 40.6 us (p50 of the call: +-0)   conv3a 39.6 -> 62.9 us
+//   640x480   convPa 45.3 -> 40.2 us (p50 0.681 -> 0.674 ms)          1280x720   convPa 80 -> 108 us
+// What the ablation builds said on the way (each run on the GPU box):
+//   1. the matrix loop does what the arithmetic promised: with the staging removed the 2,880 chains of conv4a take 11 us
 //      (the layer's roofline is 10.6) — once every operand read sits ALONE in an MFMA gap, two K steps ahead (four reads in
-//      one gap: 16 extra cycles per MFMA; reads issued where they are used: 3x slower);
-//   2. staging in the SAME wavefront doubles it (35 us) with or without memory traffic (all loads out of range: same time): a
-//      buffer_load or a staging ds_write between MFMAs holds a lone wavefront's in-order stream for 100+ cycles each
-//      (MI355X_MICROARCH.md prices an LDS-DMA piece at 60 - 185), 56 of them per 108 MFMAs;
-//   3. so the staging moved to four producer wavefronts (this file) — and a 512-thread workgroup pays ~19 us before its FIRST
-//      barrier completes on this stack (workgroups that return before the barrier: 5 us; one barrier or nine: the same 24 us;
-//      1 KB or 70 KB of LDS: the same; the round-2 note on conv_bf16_ws.hip's "8 us more start-up" is the same effect), which
-//      is more than the kernel saves on a layer that lasts 23 us.
-// The next step would be LDS-direct staging in a 256-thread workgroup (no VGPR round trip, no ds_write: 13 instead of 56
-// staging instructions per chunk); not built.
+//      one gap: +16 cycles per MFMA; reads issued where they are used: 3x slower);
+//   2. staging through registers in the SAME wavefront (10 buffer loads + 43 ds_writes per chunk) doubles the kernel — with or
+//      without memory traffic (every load out of range: same time): a VMEM or LDS-store instruction between MFMAs holds a lone
+//      wavefront's in-order stream for 100+ cycles (MI355X_MICROARCH.md prices an LDS-DMA piece at 60 - 185);
+//   3. four producer wavefronts beside four consumers (512-thread workgroups) removed that — and paid ~19 us before the FIRST
+//      barrier of the workgroup completes on this stack (workgroups that return before it: 5 us; one barrier or nine: the same
+//      24 us; 1 KB or 70 KB of LDS: the same; round 2's "8 us more start-up" of conv_bf16_ws.hip is the same effect);
+//   4. hence this form: 256 threads, LDS-direct staging (13 instead of 53 staging instructions per wavefront and chunk, no
+//      VGPR round trip).  It still pays ~1 us per chunk for them, which a second co-resident workgroup hides (convPa: 480
+//      workgroups, two per CU: faster) and a lone one does not (conv4a: 240 workgroups: slower).
+// So bit-exact f32 at batch 1 is bounded by staging issue cost, not by the chain latency the 16x16x4 form removes.
 #include <cstdlib>
 #include <cstring>
 
@@ -51,7 +55,7 @@ constexpr unsigned OOB = 0x80000000u;
 constexpr int KC = 16, TAPS = 9, NCO = 16;           // K chunk (input channels), taps, output channels per workgroup
 constexpr int WCHUNK = TAPS * KC * NCO;              // floats of a chunk's weight slab
 constexpr int MAXG = 12, MAXCH = 3;                  // pixel groups per strip, chains per wavefront
-constexpr int A_PIECES = 10, W_PIECES = 3;           // float4 pieces per thread and chunk (halo: 4 x 98 px x 4 quads at R = 2, G = 6; 3 x 194 x 4 at R = 1, G = 12)
+constexpr int A_PASSES = 10, W_PASSES = 3;           // LDS-direct blocks (1 KB) per wavefront and chunk: halo <= 37 blocks (3 x 194 px at R = 1, G = 12; 25 at R = 2, G = 6), weights 9
 
 struct Params {
   const float *in;       // [B][H][W][in_stride], channels [0, cin)
@@ -61,18 +65,15 @@ struct Params {
   int in_stride, out_stride, out_choff;
   int B, H, W, cin, cout;
   int R, G;              // rows per strip, pixel groups of 16 per row
-  int rowp, plane;       // LDS row pitch (16 G + 2) and channel-plane pitch (floats; = 16 mod 32)
 };
 
-__global__ __launch_bounds__(512, 2) void conv_f32_kc_kernel(Params p) {
-  extern __shared__ __attribute__((aligned(16))) float smem_kc[];
-  // 8 wavefronts, two per SIMD: 0..3 CONSUMERS (operand reads + MFMAs, nothing else), 4..7 PRODUCERS (the next chunk:
-  // global loads -> registers -> LDS).  In ONE instruction stream the 13 loads and 43 staging stores of a chunk cost the lone
-  // wavefront of a SIMD as much issue time as its 108 MFMAs (measured: 35 us against 16 without them, memory traffic or not —
-  // a VMEM / LDS-store instruction between MFMAs holds the in-order stream for 100+ cycles); in a second wavefront they run
-  // beside the matrix stream.
-  const int tid = threadIdx.x & 255, lane = tid & 63;
-  const bool producer = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) char lds_char;
+
+__global__ __launch_bounds__(256, 2) void conv_f32_kc_kernel(Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_kc[];
+  lds_char *const lds = (lds_char *)smem_kc;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int px = lane & 15, kk = lane >> 4;
   const int H = p.H, W = p.W, R = p.R, G = p.G;
@@ -84,110 +85,90 @@ __global__ __launch_bounds__(512, 2) void conv_f32_kc_kernel(Params p) {
   const int b = wg / nstrip;
   const int y0 = strip * R;
   const int nchunk = p.cin / KC;
-  const int ABUF = KC * p.plane;                 // floats of a halo buffer
-  const int BUF = ABUF + WCHUNK + 4;             // (+ a spare float4: the dummy destination of unused weight pieces)
+  const int hrows = R + 2, hcols = 16 * G + 2;
+  const int npix = hrows * hcols, nblk = (npix + 15) >> 4;   // halo blocks of 16 pixels = 1 KB per K chunk
+  const int HBYTES = nblk * 1024, BUFB = HBYTES + WCHUNK * 4;
+  const unsigned pixb = (unsigned)p.in_stride * 4u;
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.in + (size_t)b * H * W * p.in_stride), 0, (unsigned)((size_t)H * W * pixb), 0x00020000);
+  const float *wbase = p.wpack + (size_t)cg * nchunk * WCHUNK;
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wbase), 0, (unsigned)((size_t)nchunk * WCHUNK * 4), 0x00020000);
+  (void)rin; (void)rw;   // (the host pass of hipcc does not see the uses below)
 
-  if (producer) {
-    const unsigned pixb = (unsigned)p.in_stride * 4u;
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(p.in + (size_t)b * H * W * p.in_stride), 0, (unsigned)((size_t)H * W * pixb), 0x00020000);
-    const float *wbase = p.wpack + (size_t)cg * nchunk * WCHUNK;
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wbase), 0, (unsigned)((size_t)nchunk * WCHUNK * 4), 0x00020000);
-    // staging geometry: halo pieces (a float4 = 4 channels of one halo pixel) and weight pieces of a chunk.  16 consecutive
-    // lanes = 16 consecutive halo pixels of one channel quad, the four quads in the wavefront's four lane groups: a load
-    // instruction touches 16 x 64 contiguous bytes, a staging store 16 consecutive banks per plane
-    const int hrows = R + 2, hcols = 16 * G + 2;
-    const int npix = hrows * hcols;
-    unsigned aoff[A_PIECES];   // byte offset of the piece's pixel in the frame (+ quad), or OOB
-    int adst[A_PIECES];        // float index in the halo buffer (quad's first plane); unused piece: the planes' last pad floats
+  // ---- staging: LDS-direct.  Halo block blk = 16 consecutive pixels of the flattened halo strip x the chunk's 4 channel
+  // quads: lane (quad q = lane >> 4, pixel pp = lane & 15) fetches the 16 bytes (pixel, quad) and they land at
+  // blk * 1024 + q * 256 + pp * 16 — no VGPR round trip, no ds_write.  Wavefront w issues blocks w, w + 4, ...; a chunk's
+  // weight slab is 9 more 1 KB blocks, already in LDS order in memory.
+  unsigned aoff[A_PASSES];   // byte offset of this lane's (pixel, quad) in the frame, or OOB (padding, past the strip)
 #pragma unroll
-    for (int it = 0; it < A_PIECES; ++it) {
-      const int i = tid + it * 256;
-      const int q = (i >> 4) & 3, pix = (i >> 6) * 16 + (i & 15);
-      const int hr = pix / hcols, hcx = pix - hr * hcols;
-      const int gy = y0 + hr - 1, gx = hcx - 1;
-      const bool used = pix < npix;
-      const bool in = used && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-      aoff[it] = in ? (unsigned)(gy * W + gx) * pixb + (unsigned)q * 16u : OOB;
-      adst[it] = used ? (4 * q) * p.plane + hr * p.rowp + hcx : p.plane - 1;
-    }
-    // two register sets: chunk c + 1 is in flight (global -> registers) while chunk c goes registers -> LDS, so a store waits
-    // for loads issued a whole chunk earlier (with one set the producers' round trip — 2 us under load — was the chunk time)
-    f32x4 va[2][A_PIECES], vw[2][W_PIECES];
-    auto issue = [&](int chunk, f32x4 (&a)[A_PIECES], f32x4 (&w)[W_PIECES]) {
-      const bool ok = chunk < nchunk;   // (past the end: out-of-range loads, no branch — the compiler keeps count of what is in flight)
-#pragma unroll
-      for (int it = 0; it < A_PIECES; ++it) {
-        const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, aoff[it] == OOB || !ok ? OOB : aoff[it] + (unsigned)chunk * (KC * 4), 0, 0);
-        a[it] = __builtin_bit_cast(f32x4, v);
-      }
-#pragma unroll
-      for (int it = 0; it < W_PIECES; ++it) {
-        const int i = tid + it * 256;
-        const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, i < WCHUNK / 4 && ok ? (unsigned)(chunk * WCHUNK + 4 * i) * 4u : OOB, 0, 0);
-        w[it] = __builtin_bit_cast(f32x4, v);
-      }
-    };
-    auto stage = [&](int chunk, const f32x4 (&a)[A_PIECES], const f32x4 (&w)[W_PIECES]) {
-      float *buf = smem_kc + (chunk & 1) * BUF;   // (last read by the consumers during chunk - 2: they are past barrier chunk - 1)
-#pragma unroll
-      for (int it = 0; it < A_PIECES; ++it) {
-        float *d = buf + adst[it];
-        d[0] = a[it].x; d[p.plane] = a[it].y; d[2 * p.plane] = a[it].z; d[3 * p.plane] = a[it].w;
-      }
-#pragma unroll
-      for (int it = 0; it < W_PIECES; ++it) {
-        const int i = tid + it * 256;
-        reinterpret_cast<f32x4 *>(buf + ABUF)[i < WCHUNK / 4 ? i : WCHUNK / 4] = w[it];
-      }
-    };
-    issue(0, va[0], vw[0]);
-    for (int chunk = 0; chunk < nchunk; chunk += 2) {
-      issue(chunk + 1, va[1], vw[1]);
-      stage(chunk, va[0], vw[0]);
-      __syncthreads();   // barrier `chunk`: chunk is in LDS
-      if (chunk + 1 < nchunk) {   // (uniform)
-        issue(chunk + 2, va[0], vw[0]);
-        stage(chunk + 1, va[1], vw[1]);
-        __syncthreads();
-      }
-    }
-    __syncthreads();     // (the consumers' last barrier)
-    return;
+  for (int it = 0; it < A_PASSES; ++it) {
+    const int blk = wave + 4 * it;
+    const int P = blk * 16 + px;
+    const int hr = P / hcols, hcx = P - hr * hcols;
+    const int gy = y0 + hr - 1, gx = hcx - 1;
+    const bool in = blk < nblk && P < npix && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    aoff[it] = in ? (unsigned)(gy * W + gx) * pixb + (unsigned)kk * 16u : OOB;
   }
+  auto dma_a = [&](int it, int chunk, int buf) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int blk = wave + 4 * it;
+    if (blk < nblk)   // (wave-uniform)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void *)(lds + buf * BUFB + blk * 1024), 16,
+                                               aoff[it] == OOB || chunk >= nchunk ? OOB : aoff[it] + (unsigned)chunk * (KC * 4), 0, 0, 0);
+#endif
+  };
+  auto dma_w = [&](int it, int chunk, int buf) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int blk = wave + 4 * it;
+    if (blk < WCHUNK * 4 / 1024)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(lds + buf * BUFB + HBYTES + blk * 1024), 16,
+                                               chunk < nchunk ? (unsigned)(chunk * WCHUNK * 4 + blk * 1024 + lane * 16) : OOB, 0, 0, 0);
+#endif
+  };
 
-  // ---- consumers.  This wavefront's chains: chain c = wave + 4 j -> (row c / G, pixel group c % G) ----
+  // ---- this wavefront's chains: chain c = wave + 4 j -> (row c / G, pixel group c % G); per (chain, tap) the byte address
+  // of this lane's A element inside a halo buffer: pixel P -> (P >> 4) * 1024 + (P & 15) * 16, + kk * 4 (+ k4 * 256 per K step)
   const int nchain = R * G;
-  int abase[MAXCH];          // float index of (row, 16 grp + px) of the chain's top-left tap in plane kk
   bool have[MAXCH];
+  unsigned aaddr[MAXCH][TAPS];
 #pragma unroll
   for (int j = 0; j < MAXCH; ++j) {
     const int c = wave + 4 * j;
     have[j] = c < nchain;                        // (wave-uniform)
     const int cc = have[j] ? c : 0;
     const int row = cc / G, grp = cc - row * G;
-    abase[j] = kk * p.plane + row * p.rowp + 16 * grp + px;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const int P = (row + t / 3) * hcols + 16 * grp + px + t % 3;
+      aaddr[j][t] = (unsigned)((P >> 4) * 1024 + (P & 15) * 16 + kk * 4);
+    }
   }
-  const int wlane = kk * NCO + px;               // B operand: [tap][k][n] -> (tap * 16 + 4 k4 + kk) * 16 + n
+  const unsigned waddr = (unsigned)(HBYTES + (kk * NCO + px) * 4);   // B operand: [tap][k][n] -> ((tap * 16 + 4 k4 + kk) * 16 + n) * 4
+
+#pragma unroll
+  for (int it = 0; it < A_PASSES; ++it) dma_a(it, 0, 0);
+#pragma unroll
+  for (int it = 0; it < W_PASSES; ++it) dma_w(it, 0, 0);
   f32x4 acc[MAXCH];
 #pragma unroll
   for (int j = 0; j < MAXCH; ++j) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};   // the contract's chain starts from +0
-  __syncthreads();           // barrier 0: chunk 0 is in LDS
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wavefront's blocks of chunk 0 have landed
+  __syncthreads();
 #pragma unroll 1
   for (int chunk = 0; chunk < nchunk; ++chunk) {
-    const float *bufA = smem_kc + (chunk & 1) * BUF;
-    const float *bufW = bufA + ABUF;
+    const int cur = chunk & 1;
+    const unsigned boff = (unsigned)(cur * BUFB);
     // 36 K steps (tap, channel quad); the operands of step s + 2 — one B and three A values — are read while the MFMAs of
-    // step s issue, one read per MFMA gap (pinned: left alone, the scheduler sinks every read to its first use and each MFMA
-    // waits out an LDS round trip; four reads in ONE gap overran the 32-cycle shadow)
+    // step s issue, ONE read per MFMA gap (pinned: left alone, the scheduler sinks every read to its first use and each MFMA
+    // waits out an LDS round trip; four reads in one gap overran the 32-cycle shadow); the next chunk's LDS-direct blocks go
+    // out one per gap from gap 2 on
     float av[3][MAXCH], bw[3];
     auto rd = [&](int st, int slice) {
       const int slot = st % 3;
       const int tap = st >> 2, k4 = st & 3;
-      const int dy = tap / 3, dx = tap - 3 * dy;
-      const int ao = (4 * k4) * p.plane + dy * p.rowp + dx;
-      if (slice == 0) bw[slot] = bufW[(tap * KC + 4 * k4) * NCO + wlane];
-      av[slot][slice] = bufA[abase[slice] + ao];
+      if (slice == 0)
+        bw[slot] = *reinterpret_cast<const __attribute__((address_space(3))) float *>(lds + boff + waddr + (tap * KC + 4 * k4) * NCO * 4);
+      av[slot][slice] = *reinterpret_cast<const __attribute__((address_space(3))) float *>(lds + boff + aaddr[slice][tap] + k4 * 256);
     };
 #pragma unroll
     for (int j = 0; j < MAXCH; ++j) { rd(0, j); rd(1, j); }
@@ -198,12 +179,16 @@ __global__ __launch_bounds__(512, 2) void conv_f32_kc_kernel(Params p) {
 #pragma unroll
       for (int j = 0; j < MAXCH; ++j) {
         if (st + 2 < TAPS * 4) rd(st + 2, j);
+        const int g = 3 * st + j;
+        if (g >= 2 && g < 2 + A_PASSES) dma_a(g - 2, chunk + 1, cur ^ 1);
+        else if (g >= 2 + A_PASSES && g < 2 + A_PASSES + W_PASSES) dma_w(g - 2 - A_PASSES, chunk + 1, cur ^ 1);
         __builtin_amdgcn_sched_barrier(0);
         acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st % 3][j], bw[st % 3], acc[j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __syncthreads();         // barrier chunk + 1: chunk + 1 is in LDS, and this buffer may be refilled (by chunk + 2)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the next chunk's blocks (issued ~100 MFMAs ago) have landed
+    __syncthreads();                      // ... for every wavefront; and everybody is done reading this buffer
   }
 
   // ---- epilogue: D[pixel 4 kk + r][channel px] of each chain ----
@@ -254,13 +239,10 @@ hipError_t launch_conv_f32_kc(const ConvParams &cp, int cin, int cout, const flo
   p.B = cp.B; p.H = cp.H; p.W = cp.W; p.cin = cin; p.cout = cout;
   p.G = (cp.W + 15) / 16;
   p.R = 2 * p.G <= kc::MAXG && cp.H >= 2 ? 2 : 1;
-  p.rowp = 16 * p.G + 2;
-  const int raw = (p.R + 2) * p.rowp;
-  p.plane = raw + ((16 - raw % 32) + 32) % 32;   // = 16 mod 32: the four channel planes of an A operand on distinct bank halves
-  if (p.plane == raw) p.plane += 32;             // (at least one pad float per plane: the dummy destination of unused staging pieces)
-  if ((((p.R + 2) * p.rowp + 15) / 16) * 64 > kc::A_PIECES * 256) return hipErrorInvalidValue;
+  const int npix = (p.R + 2) * (16 * p.G + 2), nblk = (npix + 15) / 16;
+  if (nblk > 4 * kc::A_PASSES) return hipErrorInvalidValue;
   if ((size_t)cp.H * cp.W * cp.in_stride * 4 >= ((size_t)1 << 31)) return hipErrorInvalidValue;   // 32-bit offsets, OOB marker
-  const size_t lds = 2 * ((size_t)kc::KC * p.plane + kc::WCHUNK + 4) * sizeof(float);
+  const size_t lds = 2 * ((size_t)nblk * 1024 + kc::WCHUNK * 4);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   auto k = kc::conv_f32_kc_kernel;
   static bool attr_done[64] = {};
@@ -272,7 +254,7 @@ hipError_t launch_conv_f32_kc(const ConvParams &cp, int cin, int cout, const flo
     if (dev >= 0 && dev < 64) attr_done[dev] = true;
   }
   const int nstrip = (cp.H + p.R - 1) / p.R;
-  hipLaunchKernelGGL(k, dim3((unsigned)(cp.B * nstrip * (cout / kc::NCO))), dim3(512), lds, s, p);
+  hipLaunchKernelGGL(k, dim3((unsigned)(cp.B * nstrip * (cout / kc::NCO))), dim3(256), lds, s, p);
   return hipGetLastError();
 }
 

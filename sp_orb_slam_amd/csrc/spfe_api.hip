@@ -62,7 +62,7 @@ int fail(int code, const char *fmt, ...) {
                   __LINE__);                                                            \
   } while (0)
 
-constexpr int kKcAuto = 0;   // layers the K-chain kernel takes by default on single frames (set from measurements)
+constexpr int kKcAuto = 0;      // layers the K-chain kernel takes by default on single frames: none (measured, conv_f32_kc.hip's header)
 constexpr int NSTAGE = 15;
 const char *kStageNames[NSTAGE] = {"conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b",
                                    "conv4a", "conv4b", "convPaDa", "convPb", "convDb", "tail",
@@ -1067,7 +1067,11 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
       return SPFE_OK;
     }
     if (!h->bf16 && L.ks == 3 && !L.pool && L.relu && i < 8 && h->d_wkc[i] && n_all == 1 && !(i == 0 && fused) &&
-        (h->kc_mask > 0 ? ((h->kc_mask >> i) & 1) != 0 : h->kc_mask < 0 && ((kKcAuto >> i) & 1))) {
+        (h->kc_mask > 0 ? ((h->kc_mask >> i) & 1) != 0 : h->kc_mask < 0 && ((kKcAuto >> i) & 1) &&
+         // ... where at least two of its workgroups share a CU (they fill each other's staging stalls: convPa of a 752x480
+         // frame, 480 workgroups, 45 -> 41 us; conv4a, 240 workgroups = one per CU, 27 -> 29 us: not taken)
+         (long)((L.H + (2 * ((L.W + 15) / 16) <= 12 ? 2 : 1) - 1) / (2 * ((L.W + 15) / 16) <= 12 ? 2 : 1)) *
+                 ((i == 7 && sparse_da ? L.cout_real / 2 : L.cout_real) / 16) * 2 >= 3L * (h->num_cus > 0 ? h->num_cus : 256))) {
       const int cout = i == 7 && sparse_da ? L.cout_real / 2 : L.cout_real;   // (convPa alone when convDa runs gathered)
       p.B = n; p.H = L.H; p.W = L.W;
       HIP_TRY(spfe::launch_conv_f32_kc(p, L.cin, cout, h->d_wkc[i], L.d_b, s));
