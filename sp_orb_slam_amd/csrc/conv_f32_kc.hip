@@ -34,9 +34,12 @@
 //   2. staging through registers in the SAME wavefront (10 buffer loads + 43 ds_writes per chunk) doubles the kernel — with or
 //      without memory traffic (every load out of range: same time): a VMEM or LDS-store instruction between MFMAs holds a lone
 //      wavefront's in-order stream for 100+ cycles (MI355X_MICROARCH.md prices an LDS-DMA piece at 60 - 185);
-//   3. four producer wavefronts beside four consumers (512-thread workgroups) removed that — and paid ~19 us before the FIRST
-//      barrier of the workgroup completes on this stack (workgroups that return before it: 5 us; one barrier or nine: the same
-//      24 us; 1 KB or 70 KB of LDS: the same; round 2's "8 us more start-up" of conv_bf16_ws.hip is the same effect);
+//   3. four producer wavefronts beside four consumers (512-thread workgroups) removed that — and that build spent ~19 us
+//      before its FIRST barrier completed (workgroups that returned before it: 5 us; one barrier or nine: the same 24 us; 1 KB
+//      or 70 KB of LDS: the same).  NOT a property of 512-thread workgroups as such: a stand-alone probe (tools/microbench/
+//      barrier_probe.hip: 256 / 512 / 1024 threads, 16 ... 180 live registers, with and without 70 KB of dynamic LDS, half the
+//      wavefronts leaving first, a producer / consumer role split with LDS and global traffic) runs every case in the same
+//      6 us.  The cause in that build was not found; the form was dropped for the one below;
 //   4. hence this form: 256 threads, LDS-direct staging (13 instead of 53 staging instructions per wavefront and chunk, no
 //      VGPR round trip).  It still pays ~1 us per chunk for them, which a second co-resident workgroup hides (convPa: 480
 //      workgroups, two per CU: faster) and a lone one does not (conv4a: 240 workgroups: slower).

@@ -8,3 +8,4 @@ F="--offload-arch=gfx950 -O3 -std=c++20 -ffp-contract=off -mllvm -amdgpu-atomic-
 /opt/rocm/bin/hipcc $F -mllvm -amdgpu-mfma-vgpr-form tools/microbench/conv_rw_probe.hip -o tools/microbench/bin/conv_rw_plain
 /opt/rocm/bin/hipcc $F -mllvm -amdgpu-mfma-vgpr-form -DRW_PROBE tools/microbench/conv_rw_probe.hip -o tools/microbench/bin/conv_rw_probe_a0
 /opt/rocm/bin/hipcc $F tools/microbench/mfma_chain_probe.hip -o tools/microbench/bin/mfma_chain_probe
+/opt/rocm/bin/hipcc $F tools/microbench/barrier_probe.hip -o tools/microbench/bin/barrier_probe
