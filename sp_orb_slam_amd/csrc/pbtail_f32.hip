@@ -40,7 +40,7 @@ constexpr int IN_STRIDE = 512;          // head activations: [cell][ReLU(convPa)
 __global__ __launch_bounds__(256, 2) void pbtail_f32_kernel(const float *__restrict__ head, const float *__restrict__ wpack,
                                                             const float *__restrict__ wdust, const float *__restrict__ bias,
                                                             float *__restrict__ semi_out, FrameBufs f, RecordLayout rl, int H,
-                                                            int W, int nparts) {
+                                                            int W, int nparts, int b0) {
   __shared__ __attribute__((aligned(16))) char sA[PT_BYTES];
   __shared__ __attribute__((aligned(16))) float sW[256];
   __shared__ float sm[PT * SPFE_SEMI_CH];
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, 2) void pbtail_f32_kernel(const float *__restr
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
-  const int b = blockIdx.y;
+  const int b = blockIdx.y + b0;   // (b0: the first frame of this launch's part of the batch)
   const int cell0 = blockIdx.x * PT;                      // first cell of this workgroup, inside frame b
   const int ncell = C - cell0 < PT ? C - cell0 : PT;      // (>= 1 by the grid)
   lds_char *const lds = (lds_char *)sA;
@@ -168,10 +168,10 @@ __global__ __launch_bounds__(256, 2) void pbtail_f32_kernel(const float *__restr
 
 // head: the f32 head activations [B * C][512]; wpack / wdust / bias: convPb's (see the kernel); semi: [B][C][65]
 hipError_t launch_pbtail_f32(const float *head, const float *wpack, const float *wdust, const float *bias, float *semi,
-                             const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s) {
+                             const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s, int b0) {
   const int nparts = tail_parts(H, W);
   if ((size_t)(H / 8) * (W / 8) * IN_STRIDE * 4 >= ((size_t)1 << 32)) return hipErrorInvalidValue;   // (32-bit SRD offsets inside a frame)
-  hipLaunchKernelGGL(pbtail_f32_kernel, dim3(nparts, B), dim3(256), 0, s, head, wpack, wdust, bias, semi, f, r, H, W, nparts);
+  hipLaunchKernelGGL(pbtail_f32_kernel, dim3(nparts, B), dim3(256), 0, s, head, wpack, wdust, bias, semi, f, r, H, W, nparts, b0);
   return hipGetLastError();
 }
 

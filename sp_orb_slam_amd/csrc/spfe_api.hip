@@ -823,7 +823,9 @@ int build(spfe_handle h, const spfe_config *cfg) {
 #define STAGE_MARK(i) \
   do { if (h->timing && (h->timing_all || (i) == 1 || (i) == 2)) HIP_TRY(hipEventRecord(h->ev[i], s)); } while (0)
 
-int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const std::function<int()> *conv_db = nullptr, bool sparse = false, bool fused_pb = false);
+int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const std::function<int()> *conv_db = nullptr, bool sparse = false, bool fused_pb = false, bool tail_done = false);
+spfe::FrameBufs frame_bufs(spfe_handle h, uint8_t *d_records, bool sparse);
+int tail_waits(spfe_handle h, uint8_t *d_records, hipStream_t s);
 int launch_db_gathered(spfe_handle h, int n, hipStream_t s);
 
 // D2H of the records by a kernel of our own that writes the pinned (device-mapped) host buffer: 8.9 MB in ~0.18 ms, no LDS,
@@ -953,6 +955,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   h->sparse_da_call = sparse_da;
   const int par_db = (int)(h->ticket & 1);
   h->feat_cur = sparse_da && par_db ? h->act7_alt : h->act[7];
+  bool tail_per_half = false;   // set below, when the layers behind conv1b run as two half batches
   auto run_layer = [&](int i, int f0 = 0, int nfr = -1, hipStream_t s_use = nullptr) -> int {
     const ConvLayer &L = h->layers[i];
     hipStream_t s = s_use ? s_use : s_all;
@@ -1056,7 +1059,11 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
       STAGE_MARK(2 + i);
       return SPFE_OK;
     }
-    if (!h->bf16 && i == 8 && h->pbtail) {   // convPb runs inside the detector tail's launch (enqueue_post, pbtail_f32.hip)
+    if (!h->bf16 && i == 8 && h->pbtail) {   // convPb runs inside the detector tail's launch (pbtail_f32.hip)
+      if (tail_per_half) {   // two half batches on two streams: each half's tail right behind its convPa, beside the other half's layers
+        const spfe::FrameBufs fb = frame_bufs(h, d_records, sparse);
+        HIP_TRY(spfe::launch_pbtail_f32(h->d_head, h->d_wpb32, h->d_wpb_dust, h->layers[8].d_b, h->d_semi, fb, h->rl, n, H, W, s, f0));
+      }
       STAGE_MARK(2 + i);
       return SPFE_OK;
     }
@@ -1193,6 +1200,15 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   }
   h->split_last = split;
   if (split) {
+    // The detector tail rides in convPb's launch, and with the halves on two streams each half's tail can run right behind its
+    // convPa instead of behind the join (SPFE_TAIL_PER_HALF=0: behind the join) — what it must wait for (the side chain two
+    // tickets back) is waited for HERE, on the launch stream in front of conv1b; the second stream forks behind conv1b
+    static const bool tph_env = !(getenv("SPFE_TAIL_PER_HALF") && atoi(getenv("SPFE_TAIL_PER_HALF")) == 0);
+    tail_per_half = !h->bf16 && h->pbtail && tph_env;
+    if (tail_per_half) {
+      const int rcw = tail_waits(h, d_records, s);
+      if (rcw) return rcw;
+    }
     int rc = run_layer(0);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(h->ev_fork, s));
@@ -1207,7 +1223,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
         }
     HIP_TRY(hipEventRecord(h->ev_join, h->conv2));
     HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
-    return enqueue_post(h, n, d_records, s, nullptr, sparse, !h->bf16 && h->pbtail);
+    return enqueue_post(h, n, d_records, s, nullptr, sparse, !h->bf16 && h->pbtail, tail_per_half);
   }
   for (int i = 0; i < (defer_db ? 9 : nlayers); ++i) {
     const int rc = run_layer(i);
@@ -1255,26 +1271,25 @@ int launch_db_dense(spfe_handle h, int n, hipStream_t s) {
   return SPFE_OK;
 }
 
-// Detector tail, selection, descriptors, covariance for n frames whose semi /
-// coarse maps are in the handle's buffers.
-int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const std::function<int()> *conv_db, bool sparse, bool fused_pb) {
-  const int H = h->H, W = h->W;
+// The buffers of the call being enqueued (ticket h->ticket) as the tail / selection / covariance kernels see them.
+spfe::FrameBufs frame_bufs(spfe_handle h, uint8_t *d_records, bool sparse) {
   spfe::FrameBufs f{};
   f.semi = h->d_semi; f.coarse = h->d_coarse;
   if (sparse) { f.db_list = h->d_db_list; f.db_total = h->d_db_total; }
-  h->sparse_last = sparse;
   const int par = (int)(h->ticket & 1);
   f.heat_log = h->d_heat_log[par]; f.heat = h->d_heat; f.heat_inv = h->d_heat_inv;
   f.minmax = reinterpret_cast<uint32_t *>(h->d_minmax[par]);
   f.cell_score = h->d_cell_score[par]; f.cell_k = h->d_cell_k[par]; f.cell_mask = h->d_cell_mask; f.kp_cell = h->d_kp_cell;
   f.sel_slot = h->d_sel_slot; f.sel_list = h->d_sel_list;
   f.records = d_records; f.heat_consts = h->d_heat_consts;
-  if (h->timing && !h->ev) return fail(SPFE_EINVAL, "internal: no event set");
-  const int slot = (int)(h->ticket % spfe_handle_s::NTICKET);
-  // A side chain still in flight: heat_inv, the covariance scratch and everything else that only side-stream kernels
-  // touch is ordered by that stream.  This call's tail writes the buffers of its ticket parity — last read by the chain
-  // two tickets back — and the dust maps inside the record buffer, so it waits for the previous chain only when the
-  // caller passes the same record buffer twice in a row.
+  return f;
+}
+
+// What the detector tail of the call being enqueued must wait for (stream s).  A side chain still in flight: heat_inv, the
+// covariance scratch and everything else that only side-stream kernels touch is ordered by that stream.  This call's tail
+// writes the buffers of its ticket parity — last read by the chain two tickets back — and the dust maps inside the record
+// buffer, so it waits for the previous chain only when the caller passes the same record buffer twice in a row.
+int tail_waits(spfe_handle h, uint8_t *d_records, hipStream_t s) {
   if (h->cov_inflight) {
     const int NT = spfe_handle_s::NTICKET;
     if (h->ticket >= 2) HIP_TRY(hipStreamWaitEvent(s, h->ev_cov[(h->ticket - 2) % NT], 0));
@@ -1282,8 +1297,26 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
     static const bool old_order = getenv("SPFE_TAIL_WAITS_PREV") && atoi(getenv("SPFE_TAIL_WAITS_PREV"));   // A/B knob
     if (h->rec_of[prev] == d_records || old_order) HIP_TRY(hipStreamWaitEvent(s, h->ev_cov[prev], 0));
   }
+  return SPFE_OK;
+}
+
+// Detector tail, selection, descriptors, covariance for n frames whose semi /
+// coarse maps are in the handle's buffers.  tail_done: the detector tail (inside pbtail_f32_kernel) was launched per half
+// batch by enqueue(), behind tail_waits().
+int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const std::function<int()> *conv_db, bool sparse, bool fused_pb, bool tail_done) {
+  const int H = h->H, W = h->W;
+  spfe::FrameBufs f = frame_bufs(h, d_records, sparse);
+  h->sparse_last = sparse;
+  const int par = (int)(h->ticket & 1);
+  if (h->timing && !h->ev) return fail(SPFE_EINVAL, "internal: no event set");
+  const int slot = (int)(h->ticket % spfe_handle_s::NTICKET);
+  if (!tail_done) {
+    const int rcw = tail_waits(h, d_records, s);
+    if (rcw) return rcw;
+  }
   h->rec_of[slot] = d_records;
-  if (fused_pb) HIP_TRY(spfe::launch_pbtail_f32(h->d_head, h->d_wpb32, h->d_wpb_dust, h->layers[8].d_b, h->d_semi, f, h->rl, n, H, W, s));
+  if (tail_done) {}
+  else if (fused_pb) HIP_TRY(spfe::launch_pbtail_f32(h->d_head, h->d_wpb32, h->d_wpb_dust, h->layers[8].d_b, h->d_semi, f, h->rl, n, H, W, s));
   else HIP_TRY(spfe::launch_tail(f, h->rl, n, H, W, s));
   STAGE_MARK(12);
   // Synchronous calls with the gathered descriptor branch (a single frame's operator(): BASELINE configs[1]): the detector

@@ -170,7 +170,7 @@ int tail_parts(int H, int W);  // min/max partials per frame written by the tail
 // conv_f32.hip followed by launch_tail.  head = [B * C][512] f32 (channels 0..255 = ReLU(convPa)); wpack =
 // head_f32_pack_weights(convPb's weights, 65); wdust = convPb's row 64 [256]; bias [>= 65]; semi [B][C][65] is written too
 hipError_t launch_pbtail_f32(const float *head, const float *wpack, const float *wdust, const float *bias, float *semi,
-                             const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s);
+                             const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s, int b0 = 0);   // frames [b0, b0 + B) of the batch-wide buffers
 hipError_t launch_tail(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s);
 // with_heat_norm: the heat normalisation (launch_heat_norm) rides in the neighbour-mask launch in front of the selection
 // lean: the form that keeps only the cell states and neighbour masks in LDS (2 bytes a cell; the per-cell private data in

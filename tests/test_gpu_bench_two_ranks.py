@@ -78,3 +78,17 @@ def test_bench_two_ranks_one_gpu():
     assert d["host_alt"]["value"] > 0 and d["host_alt"]["records_ok"] and d["host_alt_ms"] > 0
     # teardown: both ranks left through the final barriers (no rank exits while rank 0 is still printing)
     assert "Traceback" not in out.stderr
+
+
+def test_scale_sweep_script_dry_run(tmp_path):
+    """tools/scale_sweep.sh (the N = 1, 2, 4, 8 curve of SCALE_rNN.json) on one GPU: N = 1 and N = 2 (gloo dry run), small frames —
+    one JSON line per N in scale.jsonl, the N = 2 line from two ranks, the summary table printed."""
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "scale_sweep.sh"), str(tmp_path), "--height", "240", "--width", "320",
+                          "--frames-per-gpu", "3", "--num-features", "200", "--no-cpu-baseline", "--no-stage-table", "--no-comm-ab"],
+                         cwd=ROOT, env=_clean_env(SPFE_BENCH_BACKEND="gloo", MAXN="2", STEPS="3", WARMUP="1"), capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = [json.loads(l) for l in open(tmp_path / "scale.jsonl")]
+    assert [r["n_gpus"] for r in rows] == [1, 2]
+    assert rows[1]["parity_gathered"] is True and rows[1]["config"]["parallelism"] == "dp2"
+    assert "N=1" in out.stdout and "N=2" in out.stdout

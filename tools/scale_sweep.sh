@@ -6,6 +6,7 @@
 # line in the output IS an N-GPU measurement.  The N > 1 lines carry `parity_gathered`, `allgather_ms`, `rccl_ranks`,
 # `comm_stream_ab` (gather on the library's side stream vs a stream of its own) and `host_alt`.
 #   usage: tools/scale_sweep.sh [outdir] [extra bench.py flags ...]      e.g.  tools/scale_sweep.sh gpurun_out/scale --precision bf16
+#   env: STEPS / WARMUP (default 20 / 5), MAXN (largest N tried), SPFE_BENCH_BACKEND=gloo (dry run: ranks share the GPUs there are)
 # N = 1 runs the driver's command line (--steps 20 --warmup 5), so its `value` is BENCH_rNN.json's.
 out=${1:-gpurun_out/scale}; shift
 cd "$(dirname "$0")/.." && mkdir -p "$out"
@@ -13,6 +14,7 @@ ngpu=$(python -c 'import torch; print(torch.cuda.device_count())' 2>/dev/null ||
 echo "scale_sweep: $ngpu GPU(s) visible" >&2
 : > "$out/scale.jsonl"
 for n in 1 2 4 8; do
+  if [ -n "$MAXN" ] && [ "$n" -gt "$MAXN" ]; then continue; fi
   if [ "$n" -gt "$ngpu" ] && [ -z "$SPFE_BENCH_BACKEND" ]; then echo "scale_sweep: skipping N=$n (only $ngpu GPUs)" >&2; continue; fi
   extra=""; [ "$n" -eq 1 ] && extra="--no-bf16-leg --no-match --no-host-path --no-latency --no-aten"
   python bench.py --gpus "$n" --steps "${STEPS:-20}" --warmup "${WARMUP:-5}" $extra "$@" > "$out/bench_n$n.json" 2> "$out/bench_n$n.err"
