@@ -573,16 +573,22 @@ __global__ __launch_bounds__(LINK_THREADS) void cov_link_kernel(FrameBufs f, Rec
 // desc_first >= 0: blocks from that index on are not replay workers but the descriptor sampling of the frame's keypoints, one
 // wavefront each (desc_body.h) — synchronous calls: the sampling is needed by the finished record only, so it runs beside the
 // longest kernel of the chain instead of in front of the chain.
-__global__ __launch_bounds__(64 * COV_WAVES) void cov_replay_kernel(FrameBufs f, RecordLayout rl, CovScratch cs,
-                                                                    int H, int W, int desc_first) {
-  __shared__ WaveMem s_mem[COV_WAVES];
+// WV wavefronts (= components) per workgroup.  2 (21 KB of LDS) fits beside an f32 convolution workgroup; 8 (83 KB) packs a
+// frame's ~120 live workers into ~15 workgroups, so that in bf16 pipelined calls — where a register-resident-weights
+// convolution workgroup needs every register of its CU and cannot start on a CU that hosts ONE side-chain wavefront — the
+// replay holds ~120 CUs' worth of nothing instead of a wavefront on nearly every CU (launch_cov).
+template <int WV>
+__global__ __launch_bounds__(64 * WV) void cov_replay_kernel(FrameBufs f, RecordLayout rl, CovScratch cs,
+                                                              int H, int W, int desc_first) {
+  extern __shared__ __attribute__((aligned(16))) char s_replay_raw[];
+  WaveMem *const s_mem = reinterpret_cast<WaveMem *>(s_replay_raw);
   const int b = blockIdx.y, lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (desc_first >= 0 && (int)blockIdx.x >= desc_first) {
-    desc_keypoint(f, rl, H, W, b, ((int)blockIdx.x - desc_first) * COV_WAVES + wv, lane);
+    desc_keypoint(f, rl, H, W, b, ((int)blockIdx.x - desc_first) * WV + wv, lane);
     return;
   }
-  const int widx = blockIdx.x * COV_WAVES + wv;
+  const int widx = blockIdx.x * WV + wv;
   const CovFrame c = cov_frame(f, rl, cs, b, H, W);
   if ((c.hdr[2] & 1) || widx >= *c.nworkers) return;
   int j = c.workers[widx];
@@ -749,8 +755,28 @@ __global__ __launch_bounds__(256) void cov_fallback_kernel(FrameBufs f, RecordLa
 
 size_t cov_link_lds(int kmax) { return (size_t)kmax * 4 * sizeof(int); }   // parent, leader, 2 K sort keys
 
+template <int WV>
+static hipError_t launch_replay(const FrameBufs &f, const RecordLayout &r, const CovScratch &cs, int B, int H, int W, hipStream_t s,
+                                bool with_desc) {
+  const size_t lds = sizeof(WaveMem) * WV;
+  auto k = cov_replay_kernel<WV>;
+  if (lds > 64 * 1024) {
+    static bool attr_done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      if (dev >= 0 && dev < 64) attr_done[dev] = true;
+    }
+  }
+  const int nb = (r.kmax + WV - 1) / WV;
+  hipLaunchKernelGGL(k, dim3(with_desc ? 2 * nb : nb, B), dim3(64 * WV), lds, s, f, r, cs, H, W, with_desc ? nb : -1);
+  return hipGetLastError();
+}
+
 hipError_t launch_cov(const FrameBufs &f, const RecordLayout &r, const CovScratch &cs, int B, int H, int W,
-                      hipStream_t s, bool with_desc, hipEvent_t before_replay) {
+                      hipStream_t s, bool with_desc, hipEvent_t before_replay, int replay_waves) {
   // claim / done / counters / ovf_slot were reset by heat_norm_kernel (the kernel in front of this stage)
   hipError_t e = hipSuccess;
   const dim3 grid((r.kmax + COV_WAVES - 1) / COV_WAVES, B), block(64 * COV_WAVES);
@@ -768,8 +794,8 @@ hipError_t launch_cov(const FrameBufs &f, const RecordLayout &r, const CovScratc
     e = hipStreamWaitEvent(s, before_replay, 0);
     if (e != hipSuccess) return e;
   }
-  const int nb = (r.kmax + COV_WAVES - 1) / COV_WAVES;
-  hipLaunchKernelGGL(cov_replay_kernel, dim3(with_desc ? 2 * nb : nb, B), block, 0, s, f, r, cs, H, W, with_desc ? nb : -1);
+  e = replay_waves >= 8 ? launch_replay<8>(f, r, cs, B, H, W, s, with_desc) : launch_replay<COV_WAVES>(f, r, cs, B, H, W, s, with_desc);
+  if (e != hipSuccess) return e;
   // (one workgroup that returns at once unless a record carries the overflow bit: ~2 us at the end of the chain)
   if (cs.fb_q) hipLaunchKernelGGL(cov_fallback_kernel, dim3(1), dim3(256), 0, s, f, r, cs, B, H, W);
   return hipGetLastError();

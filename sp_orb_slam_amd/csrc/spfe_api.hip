@@ -253,7 +253,9 @@ struct spfe_handle_s {
   bool bf16_dyn = true;          // SPFE_BF16_DYN_QUEUE
   int tile16_min_items = 3;      // SPFE_BF16_TILE16_MIN_ITEMS (0 = 8-row tiles only)
   int tile_rows_big = 12;        // SPFE_BF16_TILE_ROWS (12 | 16)
-  int *d_tile_ctr = nullptr;     // [8 layers][16] tile-queue counters, zeroed once per enqueue()
+  int *d_tile_ctr = nullptr;     // [8 layers][16] tile-queue counters, zero at the start of every enqueue(): cleared by the previous
+                                 // call's detector tail (a launch of its own cost 9 us between two 1 ms steps), or by a launch when that did not happen
+  bool tile_ctr_clean = false;
   bool act0_missing = false;  // the last call computed conv1a inside conv1b
   bool bf16 = false;  // SPFE_PRECISION_BF16: all twelve convolutions (1x1 heads included) as bf16 GEMMs with f32 accumulation; f32 tail
   // per-stage timing: a ring of event sets, one set per enqueue() call
@@ -932,10 +934,11 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   STAGE_MARK(0);
   // (a kernel of our own, not hipMemsetAsync: the runtime's fill is a blit that queues behind its other blits — the
   // pipelined host path's D2H copy of the PREVIOUS batch — and held the whole next batch back by 0.6 ms at 752x480 bf16)
-  if (h->d_tile_ctr) {
+  if (h->d_tile_ctr && !h->tile_ctr_clean) {
     hipLaunchKernelGGL(spfe::zero_tile_counters_kernel, dim3(1), dim3(256), 0, s, h->d_tile_ctr, 8 * 64);
     HIP_TRY(hipGetLastError());
   }
+  h->tile_ctr_clean = false;   // (until this call's tail has been enqueued)
   const bool fused = !h->bf16 && h->fuse1a;  // f32: conv1b computes conv1a's outputs itself
   // bf16: when conv1b takes the wave-specialised kernel, its producer waves compute conv1a (no conv1a launch, no act0)
   const int grid_ws0 = std::max(16, (h->num_cus > 0 ? h->num_cus : 256) & ~15);
@@ -1317,7 +1320,11 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
   h->rec_of[slot] = d_records;
   if (tail_done) {}
   else if (fused_pb) HIP_TRY(spfe::launch_pbtail_f32(h->d_head, h->d_wpb32, h->d_wpb_dust, h->layers[8].d_b, h->d_semi, f, h->rl, n, H, W, s));
-  else HIP_TRY(spfe::launch_tail(f, h->rl, n, H, W, s));
+  else {
+    HIP_TRY(spfe::launch_tail(f, h->rl, n, H, W, s, h->d_tile_ctr, h->d_tile_ctr ? 8 * 64 : 0));
+    static const bool zit = !(getenv("SPFE_ZERO_IN_TAIL") && atoi(getenv("SPFE_ZERO_IN_TAIL")) == 0);   // A/B knob
+    if (h->d_tile_ctr && zit) h->tile_ctr_clean = true;
+  }
   STAGE_MARK(12);
   // Synchronous calls with the gathered descriptor branch (a single frame's operator(): BASELINE configs[1]): the detector
   // branch is the critical path — tail -> selection -> covariance walk / classify / link / replay, a chain of latency-bound
@@ -1403,7 +1410,15 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
     HIP_TRY(hipEventRecord(h->ev_desc, h->side));  // d_coarse may be overwritten after this (next call's convDb)
     h->desc_recorded = true;
   }
-  HIP_TRY(spfe::launch_cov(f, h->rl, h->cov, n, H, W, h->side, desc_in_replay, before_replay));
+  {
+    // bf16 pipelined calls: fat replay workgroups (8 components each), so that the previous batch's replay holds ~120 CUs
+    // instead of a wavefront on nearly every CU — a register-resident-weights convolution workgroup of THIS batch needs a
+    // whole CU's registers (SPFE_REPLAY_WAVES=2|8 overrides)
+    static const int rw_env = getenv("SPFE_REPLAY_WAVES") ? atoi(getenv("SPFE_REPLAY_WAVES")) : 0;
+    // (measured, same-box A/B, 8 frames per call: bf16 1280x720 +0.7 %, bf16 752x480 -1.8 %, f32 -1 %: large bf16 frames only)
+    const int rwv = rw_env ? rw_env : (h->bf16 && !sync_call && h->C >= 10000 ? 8 : 2);
+    HIP_TRY(spfe::launch_cov(f, h->rl, h->cov, n, H, W, h->side, desc_in_replay, before_replay, rwv));
+  }
   if (desc_in_replay) {
     HIP_TRY(hipEventRecord(h->ev_desc, h->side));
     h->desc_recorded = true;
@@ -2074,7 +2089,10 @@ int spfe_allgather_records(spfe_handle h, long ticket, const void *d_local, void
   // on the side stream the gather simply follows the batch's covariance kernels (and everything enqueued there since:
   // gather batch i before enqueueing batch i + 1); a stream of its own waits for exactly this batch's records.  Either
   // way the gather of batch i runs beside the convolutions of batch i + 1
-  if (h->comm_own_stream) HIP_TRY(hipStreamWaitEvent(h->comm_stream, h->ev_cov[ticket % spfe_handle_s::NTICKET], 0));
+  // (always: in pipelined calls the covariance kernels sit on the side stream in front of the gather and the event has been
+  // recorded there — a wait that is satisfied when it is reached; in synchronous calls the chain runs on the launch stream
+  // (round 4) and this wait is what orders the gather behind it)
+  HIP_TRY(hipStreamWaitEvent(h->comm_stream, h->ev_cov[ticket % spfe_handle_s::NTICKET], 0));
   const size_t count = (size_t)frames_per_rank * h->rl.bytes;   // bytes as ncclUint8; RCCL counts are size_t
   const ncclResult_t r = h->p_ncclAllGather(d_local, d_all, count, ncclUint8, h->comm, h->comm_stream);
   if (r != ncclSuccess) return fail(SPFE_EHIP, "ncclAllGather(%zu bytes per rank): %s", count, h->p_ncclGetErrorString(r));

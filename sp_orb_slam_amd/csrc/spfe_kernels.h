@@ -162,8 +162,9 @@ struct CovScratch {
 };
 size_t cov_link_lds(int kmax);
 // with_desc: the descriptor sampling (launch_desc) as extra wavefronts of the replay launch, behind `before_replay` if given
+// replay_waves: components per replay workgroup, 2 (default) or 8 (bf16 pipelined calls: see cov.hip)
 hipError_t launch_cov(const FrameBufs &f, const RecordLayout &r, const CovScratch &cs, int B, int H, int W,
-                      hipStream_t s, bool with_desc = false, hipEvent_t before_replay = nullptr);
+                      hipStream_t s, bool with_desc = false, hipEvent_t before_replay = nullptr, int replay_waves = 2);
 
 int tail_parts(int H, int W);  // min/max partials per frame written by the tail kernel
 // f32 mode: convPb (1x1, 256 -> 65) + the detector tail in one launch (pbtail_f32.hip), bit-identical to convPb through
@@ -171,7 +172,8 @@ int tail_parts(int H, int W);  // min/max partials per frame written by the tail
 // head_f32_pack_weights(convPb's weights, 65); wdust = convPb's row 64 [256]; bias [>= 65]; semi [B][C][65] is written too
 hipError_t launch_pbtail_f32(const float *head, const float *wpack, const float *wdust, const float *bias, float *semi,
                              const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s, int b0 = 0);   // frames [b0, b0 + B) of the batch-wide buffers
-hipError_t launch_tail(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s);
+// zero_ints / nzero: ints the kernel also clears (the bf16 convolutions' tile-queue counters, for the next call)
+hipError_t launch_tail(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s, int *zero_ints = nullptr, int nzero = 0);
 // with_heat_norm: the heat normalisation (launch_heat_norm) rides in the neighbour-mask launch in front of the selection
 // lean: the form that keeps only the cell states and neighbour masks in LDS (2 bytes a cell; the per-cell private data in
 // FrameBufs::sel_slot / sel_list) also on frames that would fit the all-in-LDS form (9 bytes a cell: 64 KB at 752x480, 143 KB

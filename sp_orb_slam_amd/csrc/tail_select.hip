@@ -23,7 +23,10 @@ namespace spfe {
 
 // The wave first copies its 16 x 65 contiguous logits into LDS with coalesced loads, each lane then reads its 16 (+ the
 // dustbin).  min/max of the log-heat: one partial per workgroup (no atomics, no init).
-__global__ __launch_bounds__(TAIL_THREADS) void tail_kernel(FrameBufs f, RecordLayout rl, int H, int W, int nparts) {
+__global__ __launch_bounds__(TAIL_THREADS) void tail_kernel(FrameBufs f, RecordLayout rl, int H, int W, int nparts, int *zero_ints, int nzero) {
+  // (the bf16 convolutions' tile-queue counters, for the NEXT call: every convolution of this call is behind us in stream order)
+  if (zero_ints && blockIdx.x == 0 && blockIdx.y == 0)
+    for (int i = threadIdx.x; i < nzero; i += TAIL_THREADS) zero_ints[i] = 0;
   constexpr int CPW = 16, NW = TAIL_THREADS / 64;  // cells per wave, waves per workgroup
   const int wc = W >> 3, hc = H >> 3, C = hc * wc;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -67,9 +70,9 @@ int tail_parts(int H, int W) {  // workgroups (= min/max partials) per frame, of
   return (C + TAIL_CELLS_PER_WG - 1) / TAIL_CELLS_PER_WG;
 }
 
-hipError_t launch_tail(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s) {
+hipError_t launch_tail(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s, int *zero_ints, int nzero) {
   const int nparts = tail_parts(H, W);
-  hipLaunchKernelGGL(tail_kernel, dim3(nparts, B), dim3(TAIL_THREADS), 0, s, f, r, H, W, nparts);
+  hipLaunchKernelGGL(tail_kernel, dim3(nparts, B), dim3(TAIL_THREADS), 0, s, f, r, H, W, nparts, zero_ints, nzero);
   return hipGetLastError();
 }
 

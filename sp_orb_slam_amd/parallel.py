@@ -224,19 +224,26 @@ class ShardedExtractor:
         self.gathered = None
         self._gathered_event = None
         self._pending = None
+        self._lazy_ticket = None
+        self._consumer = None
         self._calls = 0
         self._gathers = 0
 
     def _complete(self, ticket, k, stream):
+        import os
+
         import torch
 
         if not self._collective:
-            # no gather: `gathered` is this rank's own buffer.  Its completion point still has to be an
-            # event: decode() copies on torch's CURRENT stream, which is not ordered after `stream`
-            self.ext.wait_records(ticket, stream.cuda_stream)
-            ev = torch.cuda.Event()
-            ev.record(stream)
-            self.gathered, self._gathered_event = self.local[k], ev
+            # no gather: `gathered` is this rank's own buffer, complete when the library's covariance event of that ticket has
+            # fired.  Nothing is put on the compute stream here: a wait + an event record per step are two barrier packets
+            # between two steps — ~20 us of an idle compute queue on a kernel timeline (round 4) — and nobody needs the
+            # ordering until a consumer shows up: sync() / decode() / flush() establish it then.  (Buffer reuse is ordered by
+            # the library itself: a call's detector tail waits for the side chain two tickets back.)
+            self.gathered, self._gathered_event = self.local[k], None
+            self._lazy_ticket = ticket
+            if os.environ.get("SPFE_LAZY_ORDER") == "0":   # A/B knob: the per-step wait + record on the compute stream
+                self._settle(stream)
             return
         out = self.all[self._gathers % 2]
         self._gathers += 1
@@ -296,8 +303,23 @@ class ShardedExtractor:
         self.sync(stream)
         return self.gathered
 
+    def _settle(self, stream):
+        """Non-collective path: turn the pending ticket into an event on `stream` (see _complete)."""
+        import torch
+
+        if self._lazy_ticket is not None:
+            if not stream.cuda_stream:   # the legacy default stream's handle is 0, which the C ABI reads as "the handle's own stream"
+                if self._consumer is None:
+                    self._consumer = torch.cuda.Stream()
+                stream = self._consumer
+            self.ext.wait_records(self._lazy_ticket, stream.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            self._gathered_event, self._lazy_ticket = ev, None
+
     def sync(self, stream):
         """Make `stream` wait until `gathered` is complete."""
+        self._settle(stream)
         if self._gathered_event is not None:
             stream.wait_event(self._gathered_event)
 
@@ -361,6 +383,9 @@ class ShardedExtractor:
 
     def decode(self, frame):
         """Host copy + decode of global frame `frame` of the last completed batch."""
+        import torch
+
+        self._settle(torch.cuda.current_stream())
         if self._gathered_event is not None:
             self._gathered_event.synchronize()
         rb = self.rec_bytes
