@@ -401,7 +401,7 @@ def frontend_chain_parity(fc, nf):
     return bool(ok), detail
 
 
-def multi_gpu_legs(ctx, args, ext, sharded, d_img, stream, frames_lo, B, H, W):
+def multi_gpu_legs(ctx, args, ext, sharded, d_img, stream, frames_lo, B, H, W, emit_partial=None):
     """N > 1: what makes the line prove itself.  Collective calls are made by EVERY rank, in the same order."""
     import numpy as np
     torch, dist, parallel = ctx["torch"], ctx["dist"], ctx["parallel"]
@@ -424,6 +424,11 @@ def multi_gpu_legs(ctx, args, ext, sharded, d_img, stream, frames_lo, B, H, W):
         res["parity_gathered_detail"] = det
     # (2) the collective alone: events on the stream it runs on
     res_g = sharded.time_gather(20)
+    # what took part in the HEADLINE's collective (read before the A/B leg below re-makes the communicator)
+    try:
+        ranks_headline = sharded.comm_ranks()
+    except Exception as e:
+        ranks_headline = {"library": "error: %s" % e, "process_group": world, "backend": None}
     # (2b) where the collective runs: the library's side stream, right behind the covariance kernels of the batch it gathers
     # (default: the headline above) against a communication stream of its own that waits for the batch's event
     # (SPFE_COMM_OWN_STREAM=1).  With N > 1 the side-stream form puts batch i + 1's selection / descriptors / covariance behind
@@ -431,27 +436,51 @@ def multi_gpu_legs(ctx, args, ext, sharded, d_img, stream, frames_lo, B, H, W):
     # Both on THIS box, same handle, communicator re-made in between.
     ab = None
     if getattr(sharded, "_native", False) and not args.no_comm_ab:
+        # This leg destroys and re-creates the library's communicator twice.  Should a rank get stuck in it (it has never run
+        # on more than one GPU), the measurement above must not be lost with it: a watchdog on every rank lets rank 0 print the
+        # line as far as it got and ends the process (exit code 0: the headline is complete and verified at that point).
+        import threading
+        done_ab = threading.Event()
+
+        def watchdog():
+            if done_ab.wait(float(os.environ.get("SPFE_COMM_AB_TIMEOUT", "150"))):
+                return
+            if rank == 0 and emit_partial is not None:
+                part = dict(res)
+                part["allgather_ms"] = res_g["ms"]
+                part["allgather"] = res_g
+                part["comm_stream_ab"] = {"error": "the comm-stream A/B leg did not finish within its time limit; line printed without it"}
+                emit_partial(part)
+            os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
         ab = {}
         k3, w3 = max(args.steps, 50), max(args.warmup, 5)
         prev = os.environ.get("SPFE_COMM_OWN_STREAM")
-        for name, val in (("own_stream", "1"), ("side_stream", "0")):
-            torch.cuda.synchronize()
-            dist.barrier()
-            ext.comm_destroy()
-            os.environ["SPFE_COMM_OWN_STREAM"] = val
-            sh3 = parallel.ShardedExtractor(ext, world, rank, B)
-            if not getattr(sh3, "_native", False):
-                ab[name] = None
-                continue
-            dt3 = run_timed(ext, sh3, d_img, stream, k3, w3, world, dist, torch)
-            r3 = sh3.decode(world * B - 1)
-            ab[name] = {"value": round(world * B * k3 / dt3, 2), "unit": "frames/s", "ms_per_step": round(dt3 / k3 * 1e3, 4),
-                        "steps": k3, "records_ok": bool(0 < r3.K <= nf + 1 and r3.status == 0), "rccl_ranks": sh3.comm_ranks()["library"]}
-            sharded = sh3   # (the handle's communicator is this one now: the legs below use it)
+        try:
+          for name, val in (("own_stream", "1"), ("side_stream", "0")):
+              torch.cuda.synchronize()
+              dist.barrier()
+              ext.comm_destroy()
+              os.environ["SPFE_COMM_OWN_STREAM"] = val
+              sh3 = parallel.ShardedExtractor(ext, world, rank, B)
+              if not getattr(sh3, "_native", False):
+                  ab[name] = None
+                  continue
+              dt3 = run_timed(ext, sh3, d_img, stream, k3, w3, world, dist, torch)
+              r3 = sh3.decode(world * B - 1)
+              ab[name] = {"value": round(world * B * k3 / dt3, 2), "unit": "frames/s", "ms_per_step": round(dt3 / k3 * 1e3, 4),
+                          "steps": k3, "records_ok": bool(0 < r3.K <= nf + 1 and r3.status == 0), "rccl_ranks": sh3.comm_ranks()["library"]}
+              sharded = sh3   # (the handle's communicator is this one now: the legs below use it)
+        except Exception as e:
+            # a rank that fails alone leaves the others inside a collective: no rank may move on to the next leg's barriers —
+            # every rank ends through its watchdog, rank 0 printing the line as far as it got
+            print("bench.py: rank %d: comm-stream A/B leg failed: %s: %s" % (rank, type(e).__name__, e), file=sys.stderr, flush=True)
+            threading.Event().wait()
         if prev is None:
             os.environ.pop("SPFE_COMM_OWN_STREAM", None)
         else:
             os.environ["SPFE_COMM_OWN_STREAM"] = prev
+        done_ab.set()
         ab["what"] = ("the headline's schedule with ncclAllGather on a communication stream of its own (own_stream, "
                       "SPFE_COMM_OWN_STREAM=1) and on the library's side stream behind the batch's covariance (side_stream, the "
                       "default), %d timed steps each after %d untimed, same handle" % (k3, w3))
@@ -470,7 +499,7 @@ def multi_gpu_legs(ctx, args, ext, sharded, d_img, stream, frames_lo, B, H, W):
     if rank == 0:
         res["allgather_ms"] = res_g["ms"]
         res["allgather"] = res_g
-        res["rccl_ranks"] = sharded.comm_ranks()
+        res["rccl_ranks"] = ranks_headline
         if ab is not None:
             res["comm_stream_ab"] = ab
         res["host_alt"] = {"what": "no collective: each rank D2H-copies its own %d records (%d bytes) to pinned host memory on a "
@@ -479,11 +508,7 @@ def multi_gpu_legs(ctx, args, ext, sharded, d_img, stream, frames_lo, B, H, W):
                            "value": round(world * B * k2 / dt2, 2), "unit": "frames/s",
                            "ms_per_step": round(dt2 / k2 * 1e3, 4), "records_ok": bool(0 < own.K <= nf + 1 and own.status == 0)}
         res["host_alt_ms"] = res["host_alt"]["ms_per_step"]
-    try:
-        lib_ranks = sharded.comm_ranks()["library"]   # (of the communicator the handle holds NOW)
-    except Exception as e:
-        lib_ranks = "error: %s" % e
-    return res, lib_ranks
+    return res, ranks_headline["library"]
 
 
 def self_launch(args):
@@ -645,7 +670,11 @@ def main():
     if world > 1:
         # ---- N > 1: self-verification legs (every rank takes part), then ONE line, a barrier, and only then teardown
         os.environ["SPFE_STAGE_TIMING"] = "0"
-        res, lib_ranks = multi_gpu_legs(ctx, args, ext, sharded, d_img, stream, lo, B, H, W)
+        def emit_partial(part):
+            line = dict(out)
+            line.update(part)
+            print(json.dumps(line), flush=True)
+        res, lib_ranks = multi_gpu_legs(ctx, args, ext, sharded, d_img, stream, lo, B, H, W, emit_partial)
         if lib_ranks is not None and lib_ranks != world:   # (every rank checks its own communicator: all leave together)
             die("the library's RCCL communicator reports %s ranks, --gpus %d" % (lib_ranks, world), dist)
         if rank == 0:

@@ -288,6 +288,24 @@ int host_alloc(spfe_handle h, T **p, size_t count) {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Order stream `s` behind `ev` — but only if `ev` has not fired yet.  A wait is a barrier packet in the compute queue and
+// costs ~10 us of idle queue whether or not the event is long done (measured on kernel timelines of the pipelined steps:
+// conv1a -> [wait] -> conv1b 12 us apart); the waits below guard buffers against work TWO batches back, which in steady state
+// finished long ago: one hipEventQuery on the host replaces the packet.  (Not under stream capture: a query is illegal there,
+// and a captured wait is a graph edge, not a packet.)
+hipError_t wait_if_pending(hipStream_t s, hipEvent_t ev) {
+  static const bool always = getenv("SPFE_ALWAYS_WAIT") && atoi(getenv("SPFE_ALWAYS_WAIT")) != 0;   // A/B knob
+  if (!always) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
+      const hipError_t q = hipEventQuery(ev);
+      if (q == hipSuccess) return hipSuccess;
+      if (q != hipErrorNotReady) (void)hipGetLastError();   // (e.g. an event never recorded: fall through to the wait)
+    }
+  }
+  return hipStreamWaitEvent(s, ev, 0);
+}
+
 void make_layout(int kmax, int C, bool desc_bf16, spfe::RecordLayout *r) {
   size_t o = 0;
   r->kmax = kmax;
@@ -965,12 +983,12 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     const int n = nfr < 0 ? n_all : nfr;
     // convDb overwrites the coarse descriptor map the PREVIOUS call's descriptor sampling reads on
     // the side stream (pipelined callers): order it after that, by event, not by timing
-    if (i == 9 && h->desc_recorded) HIP_TRY(hipStreamWaitEvent(s, h->ev_desc, 0));
+    if (i == 9 && h->desc_recorded) HIP_TRY(wait_if_pending(s, h->ev_desc));
     // convPa | convDa overwrite the head activations the PREVIOUS call's gathered descriptor head reads (side stream).
     // sparse_da: the dense launch writes convPa's channels only, the gathered convDa / convDb touch the others; what the
     // gathered convDa reads is conv4b's output — kept twice, so conv4b waits for the call TWO tickets back
-    if (!sparse_da && i == 7 && h->dbs_recorded[par_db ^ 1]) HIP_TRY(hipStreamWaitEvent(s, h->ev_dbs[par_db ^ 1], 0));
-    if (sparse_da && i == 6 && h->dbs_recorded[par_db]) HIP_TRY(hipStreamWaitEvent(s, h->ev_dbs[par_db], 0));
+    if (!sparse_da && i == 7 && h->dbs_recorded[par_db ^ 1]) HIP_TRY(wait_if_pending(s, h->ev_dbs[par_db ^ 1]));
+    if (sparse_da && i == 6 && h->dbs_recorded[par_db]) HIP_TRY(wait_if_pending(s, h->ev_dbs[par_db]));
     spfe::ConvParams p;
     p.in = L.in; p.in_stride = L.in_stride; p.in_choff = L.in_choff;
     p.wpack = L.d_w; p.bias = L.d_b;
@@ -1295,10 +1313,10 @@ spfe::FrameBufs frame_bufs(spfe_handle h, uint8_t *d_records, bool sparse) {
 int tail_waits(spfe_handle h, uint8_t *d_records, hipStream_t s) {
   if (h->cov_inflight) {
     const int NT = spfe_handle_s::NTICKET;
-    if (h->ticket >= 2) HIP_TRY(hipStreamWaitEvent(s, h->ev_cov[(h->ticket - 2) % NT], 0));
+    if (h->ticket >= 2) HIP_TRY(wait_if_pending(s, h->ev_cov[(h->ticket - 2) % NT]));
     const int prev = (int)((h->ticket + NT - 1) % NT);
     static const bool old_order = getenv("SPFE_TAIL_WAITS_PREV") && atoi(getenv("SPFE_TAIL_WAITS_PREV"));   // A/B knob
-    if (h->rec_of[prev] == d_records || old_order) HIP_TRY(hipStreamWaitEvent(s, h->ev_cov[prev], 0));
+    if (h->rec_of[prev] == d_records || old_order) HIP_TRY(wait_if_pending(s, h->ev_cov[prev]));
   }
   return SPFE_OK;
 }
