@@ -815,6 +815,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
     }
   }
   if (h->bf16) {  // both heads in bf16: convPa | convDa write bf16, convPb and convDb are head_bf16.hip's GEMMs
+    if (const char *e = getenv("SPFE_PBTAIL")) h->pbtail = atoi(e) != 0;   // (convPb inside the tail's launch: pbtail_bf16.hip)
     if ((rc = dev_alloc(h, &h->d_hd, (size_t)B * C * 512))) return rc;
     for (int which = 0; which < 2; ++which) {
       const int lid = which ? 9 : 11;
@@ -1075,7 +1076,8 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     }
     if (h->bf16 && i >= 8) {  // convPb (65 logits) and convDb (256 descriptor channels): bf16 GEMMs over all cells of the batch
       const unsigned short *hd = h->d_hd + (size_t)f0 * h->C * 512;
-      if (i == 8) HIP_TRY(spfe::launch_head1x1_bf16(hd, h->d_wpb, L.d_b, h->d_semi + (size_t)f0 * h->C * SPFE_SEMI_CH, n * h->C, 65, s));
+      if (i == 8 && h->pbtail) {}   // (inside the detector tail's launch: pbtail_bf16.hip, enqueue_post)
+      else if (i == 8) HIP_TRY(spfe::launch_head1x1_bf16(hd, h->d_wpb, L.d_b, h->d_semi + (size_t)f0 * h->C * SPFE_SEMI_CH, n * h->C, 65, s));
       else HIP_TRY(spfe::launch_head1x1_bf16(hd, h->d_wdb, L.d_b, h->d_coarse + (size_t)f0 * h->C * SPFE_DESC_DIM, n * h->C, 256, s));
       STAGE_MARK(2 + i);
       return SPFE_OK;
@@ -1244,16 +1246,16 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
         }
     HIP_TRY(hipEventRecord(h->ev_join, h->conv2));
     HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
-    return enqueue_post(h, n, d_records, s, nullptr, sparse, !h->bf16 && h->pbtail, tail_per_half);
+    return enqueue_post(h, n, d_records, s, nullptr, sparse, h->pbtail, tail_per_half);
   }
   for (int i = 0; i < (defer_db ? 9 : nlayers); ++i) {
     const int rc = run_layer(i);
     if (rc) return rc;
   }
   if (sparse) STAGE_MARK(2 + 9);   // ("convDb" reads 0 on the launch stream: the gathered head is part of post_side)
-  if (!defer_db) return enqueue_post(h, n, d_records, s, nullptr, sparse, !h->bf16 && h->pbtail);
+  if (!defer_db) return enqueue_post(h, n, d_records, s, nullptr, sparse, h->pbtail);
   const std::function<int()> conv_db = [&]() -> int { return run_layer(9); };
-  return enqueue_post(h, n, d_records, s, &conv_db, false, !h->bf16 && h->pbtail);
+  return enqueue_post(h, n, d_records, s, &conv_db, false, h->pbtail);
 }
 
 // The descriptor head on select_kernel's cell list (stream `s`, behind the selection of the same call).
@@ -1337,7 +1339,11 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
   }
   h->rec_of[slot] = d_records;
   if (tail_done) {}
-  else if (fused_pb) HIP_TRY(spfe::launch_pbtail_f32(h->d_head, h->d_wpb32, h->d_wpb_dust, h->layers[8].d_b, h->d_semi, f, h->rl, n, H, W, s));
+  else if (fused_pb && h->bf16) {
+    HIP_TRY(spfe::launch_pbtail_bf16(h->d_hd, h->d_wpb, h->layers[8].d_b, h->d_semi, f, h->rl, n, H, W, s, 0, h->d_tile_ctr, h->d_tile_ctr ? 8 * 64 : 0));
+    static const bool zit = !(getenv("SPFE_ZERO_IN_TAIL") && atoi(getenv("SPFE_ZERO_IN_TAIL")) == 0);   // A/B knob
+    if (h->d_tile_ctr && zit) h->tile_ctr_clean = true;
+  } else if (fused_pb) HIP_TRY(spfe::launch_pbtail_f32(h->d_head, h->d_wpb32, h->d_wpb_dust, h->layers[8].d_b, h->d_semi, f, h->rl, n, H, W, s));
   else {
     HIP_TRY(spfe::launch_tail(f, h->rl, n, H, W, s, h->d_tile_ctr, h->d_tile_ctr ? 8 * 64 : 0));
     static const bool zit = !(getenv("SPFE_ZERO_IN_TAIL") && atoi(getenv("SPFE_ZERO_IN_TAIL")) == 0);   // A/B knob
@@ -1359,8 +1365,12 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
       h->cov_inflight = false;
     }
     STAGE_MARK(13);
-    HIP_TRY(spfe::launch_select(f, h->rl, n, H, W, h->cfg.num_features, s, &h->cov, h->rl.kmax, h->select_lean == 1));
-    HIP_TRY(hipEventRecord(h->ev_sel, s));
+    // (the event the side stream waits for is the selection's own completion signal: a hipEventRecord here put a marker
+    // packet between the selection and the covariance walk — 7.6 us on the chain; SPFE_SEL_EXT_EVENT=0: that record)
+    static const bool sel_ext = !(getenv("SPFE_SEL_EXT_EVENT") && atoi(getenv("SPFE_SEL_EXT_EVENT")) == 0);
+    HIP_TRY(spfe::launch_select(f, h->rl, n, H, W, h->cfg.num_features, s, &h->cov, h->rl.kmax, h->select_lean == 1,
+                                sel_ext ? h->ev_sel : nullptr));
+    if (!sel_ext) HIP_TRY(hipEventRecord(h->ev_sel, s));
     HIP_TRY(hipStreamWaitEvent(h->side, h->ev_sel, 0));
     int rc = launch_db_gathered(h, n, h->side);
     if (rc) return rc;

@@ -171,7 +171,12 @@ int tail_parts(int H, int W);  // min/max partials per frame written by the tail
 // conv_f32.hip followed by launch_tail.  head = [B * C][512] f32 (channels 0..255 = ReLU(convPa)); wpack =
 // head_f32_pack_weights(convPb's weights, 65); wdust = convPb's row 64 [256]; bias [>= 65]; semi [B][C][65] is written too
 hipError_t launch_pbtail_f32(const float *head, const float *wpack, const float *wdust, const float *bias, float *semi,
-                             const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s, int b0 = 0);   // frames [b0, b0 + B) of the batch-wide buffers
+                             const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s, int b0 = 0);
+// bf16 mode: the same fusion (pbtail_bf16.hip), bit-identical to launch_head1x1_bf16(.., 65, ..) followed by launch_tail.
+// head = [B * C][512] bf16; wpack = head_bf16_pack_weights(convPb, 65); zero_ints / nzero as launch_tail's
+hipError_t launch_pbtail_bf16(const void *head, const void *wpack, const float *bias, float *semi, const FrameBufs &f,
+                              const RecordLayout &r, int B, int H, int W, hipStream_t s, int b0 = 0, int *zero_ints = nullptr,
+                              int nzero = 0);   // frames [b0, b0 + B) of the batch-wide buffers
 // zero_ints / nzero: ints the kernel also clears (the bf16 convolutions' tile-queue counters, for the next call)
 hipError_t launch_tail(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s, int *zero_ints = nullptr, int nzero = 0);
 // with_heat_norm: the heat normalisation (launch_heat_norm) rides in the neighbour-mask launch in front of the selection
@@ -180,7 +185,7 @@ hipError_t launch_tail(const FrameBufs &f, const RecordLayout &r, int B, int H, 
 // at 1280x720 — a whole CU): a pipelined call's selection then starts beside a convolution workgroup instead of waiting for a CU
 hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H, int W,
                          int num_features, hipStream_t s, const CovScratch *with_heat_norm = nullptr, int kmax_hn = 0,
-                         bool lean = false);
+                         bool lean = false, hipEvent_t done = nullptr);
 // (also resets the covariance scratch: launch_cov must follow it)
 hipError_t launch_heat_norm(const FrameBufs &f, const CovScratch &cs, int kmax, int B, int H, int W, hipStream_t s);
 hipError_t launch_desc(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s);

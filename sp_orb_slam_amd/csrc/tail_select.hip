@@ -11,6 +11,8 @@
 //                     for the emitted keypoints only          (:102-103, :134-148)
 // Float steps follow include/spfe_exact_math.h so every integer decision is
 // bit-identical to the CPU oracle given identical logits.
+#include <hip/hip_ext.h>
+
 #include "spfe_kernels.h"
 #include "../../include/spfe_exact_math.h"
 
@@ -555,7 +557,8 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
 }
 
 hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H, int W,
-                         int num_features, hipStream_t s, const CovScratch *with_heat_norm, int kmax_hn, bool lean) {
+                         int num_features, hipStream_t s, const CovScratch *with_heat_norm, int kmax_hn, bool lean,
+                         hipEvent_t done) {
   const bool big = select_big(H, W) || (lean && f.sel_slot && f.sel_list);
   const size_t lds = select_lds_bytes(H, W, big);
   if (lds > 160 * 1024 || (size_t)(H / 8) * (W / 8) > select_max_cells()) return hipErrorInvalidValue;
@@ -573,7 +576,12 @@ hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H
   } else {
     hipLaunchKernelGGL(nms_mask_kernel, dim3(((H / 8) * (W / 8) + 255) / 256, B), dim3(256), 0, s, f, H / 8, W / 8);
   }
-  if (big) hipLaunchKernelGGL(select_kernel<true>, dim3(B), dim3(1024), lds, s, f, r, H, W, num_features);
+  // `done`: the event rides on the selection's own dispatch packet (its completion signal) instead of a marker packet behind
+  // it — a hipEventRecord between two kernels of a latency chain costs the stream ~7 us (spfe_api.hip, enqueue_post)
+  if (done) {
+    if (big) hipExtLaunchKernelGGL(select_kernel<true>, dim3(B), dim3(1024), (unsigned)lds, s, nullptr, done, 0, f, r, H, W, num_features);
+    else hipExtLaunchKernelGGL(select_kernel<false>, dim3(B), dim3(1024), (unsigned)lds, s, nullptr, done, 0, f, r, H, W, num_features);
+  } else if (big) hipLaunchKernelGGL(select_kernel<true>, dim3(B), dim3(1024), lds, s, f, r, H, W, num_features);
   else hipLaunchKernelGGL(select_kernel<false>, dim3(B), dim3(1024), lds, s, f, r, H, W, num_features);
   return hipGetLastError();
 }

@@ -267,3 +267,32 @@ def test_two_stream_half_batches_are_bit_identical(monkeypatch):
             assert a.status == 0 and b.status == 0 and a.K == b.K and np.array_equal(a.kp_xy, b.kp_xy)
             assert np.array_equal(a.descriptors.view(np.uint32), b.descriptors.view(np.uint32))
             assert np.array_equal(a.cov2.view(np.uint32), b.cov2.view(np.uint32)) and np.array_equal(a.occ_grid, b.occ_grid)
+
+
+@pytest.mark.parametrize("H,W,B", [(720, 1280, 2), (480, 752, 3), (136, 200, 2), (24, 40, 2), (64, 96, 1)])
+def test_bf16_convPb_inside_the_tail_launch_is_bit_identical(monkeypatch, H, W, B):
+    """pbtail_bf16.hip (round 4): convPb's three channel tiles on the bf16 MFMA and the detector tail on the logits while
+    they sit in LDS, one launch, in its two forms (2 / 4 wavefronts per workgroup) — against head1x1_bf16_kernel<65> +
+    tail_kernel (SPFE_PBTAIL=0).  Same logits (all 65 channels), heat maps, dust maps, scores and records; cell counts that
+    are not multiples of the 32-cell tile (14400, 5640, 425, 15, 96) and batches included.  Twice per extractor: the
+    tile-queue counters the launch clears feed the next call."""
+    nf = 300
+    blob = weights.synthetic(7, "dense")
+    imgs = [synth.make_image(270 + i, H, W) for i in range(B)]
+    out = {}
+    for flag in ("0", "2", "4"):
+        monkeypatch.setenv("SPFE_PBTAIL", "0" if flag == "0" else "1")
+        monkeypatch.setenv("SPFE_PBTAIL_WAVES", flag)
+        ext = SPExtractor(nf, H, W, blob, max_batch=B, precision="bf16", with_heat=True)
+        ext.extract_batch(imgs[::-1])
+        frs = ext.extract_batch(imgs)
+        out[flag] = (frs, [ext.debug_read(nm, i) for i in range(B) for nm in ("semi", "heat_log", "cell_score")])
+        ext.close()
+    for flag in ("2", "4"):
+        for a, b in zip(out["0"][1], out[flag][1]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        for a, b in zip(out["0"][0], out[flag][0]):
+            assert a.K == b.K and np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.descriptors, b.descriptors)
+            assert np.array_equal(a.cov2, b.cov2) and np.array_equal(a.occ_grid, b.occ_grid)
+            assert np.array_equal(a.dense_dust, b.dense_dust) and np.array_equal(a.semi_dust, b.semi_dust)
+            assert np.array_equal(a.heat, b.heat) and np.array_equal(a.heat_inv, b.heat_inv)
