@@ -407,28 +407,74 @@ def multi_gpu_legs(ctx, args, ext, sharded, d_img, stream, frames_lo, B, H, W, e
     torch, dist, parallel = ctx["torch"], ctx["dist"], ctx["parallel"]
     world, rank, nf = ctx["world"], ctx["rank"], ctx["nf"]
     res = {}
+    # No leg below may cost the line.  These legs run collectives (and one re-makes communicators) on a topology this code has
+    # never met before the driver's run, while the headline above is complete and checked at this point.  So a watchdog on every
+    # rank holds a deadline for all the legs together (SPFE_LEGS_TIMEOUT, 300 s) and a nearer one for the comm-stream A/B leg
+    # (SPFE_COMM_AB_TIMEOUT, 150 s): on expiry rank 0 prints the line as far as it got and every rank leaves through
+    # os._exit(0).  A rank that FAILS inside a leg must not tear the others down either (torchrun would, and the line with
+    # them): it reports on stderr and waits for its watchdog — the other ranks reach theirs inside the next collective.
+    import threading
+    import time
+    wd = {"deadline": time.monotonic() + float(os.environ.get("SPFE_LEGS_TIMEOUT", "300")), "leg": "parity_gathered", "gather": None}
+
+    def watchdog():
+        while time.monotonic() < wd["deadline"]:
+            time.sleep(0.25)
+            if wd.get("done"):
+                return
+        if rank == 0 and emit_partial is not None:
+            part = dict(res)
+            if wd["gather"] is not None:
+                part["allgather_ms"] = wd["gather"]["ms"]
+                part["allgather"] = wd["gather"]
+            part["legs_incomplete"] = "leg '%s' did not finish within its time limit; line printed without it and the legs behind it" % wd["leg"]
+            if wd["leg"] == "comm_stream_ab":
+                part["comm_stream_ab"] = {"error": "the comm-stream A/B leg did not finish within its time limit; line printed without it"}
+            emit_partial(part)
+        os._exit(0)
+    threading.Thread(target=watchdog, daemon=True).start()
+
+    def inject(leg):   # (tests: SPFE_BENCH_FAIL_LEG=<leg>:<rank> makes that rank fail there)
+        if os.environ.get("SPFE_BENCH_FAIL_LEG") == "%s:%d" % (leg, rank):
+            raise RuntimeError("injected failure")
+
+    def failed(leg, e):
+        print("bench.py: rank %d: leg %s failed: %s: %s" % (rank, leg, type(e).__name__, e), file=sys.stderr, flush=True)
+        threading.Event().wait()   # (until the watchdog ends the process)
+
     # (1) a frame computed on ANOTHER rank, as it arrived through the gather of the timed region
     if rank == 0 and not args.no_parity:
-        from oracle import oracle
-        from sp_orb_slam_amd import synth
-        bf16 = args.precision == "bf16"
-        oracle.set_num_threads(min(32, os.cpu_count() or 1))
-        det = {}
-        ok = True
-        for g in (B, 0, world * B - 1):                      # rank 1's first frame, our own, the last rank's last
-            ref = oracle.extract(ctx["blob"], synth.make_image(200 + g, H, W), nf)
-            p, d = parity_of(sharded.decode(g), ref, bf16)
-            det["frame_%d_from_rank_%d" % (g, g // B)] = d
-            ok = ok and p
-        res["parity_gathered"] = bool(ok)
-        res["parity_gathered_detail"] = det
+        try:
+            from oracle import oracle
+            from sp_orb_slam_amd import synth
+            bf16 = args.precision == "bf16"
+            oracle.set_num_threads(min(32, os.cpu_count() or 1))
+            det = {}
+            ok = True
+            for g in (B, 0, world * B - 1):                      # rank 1's first frame, our own, the last rank's last
+                ref = oracle.extract(ctx["blob"], synth.make_image(200 + g, H, W), nf)
+                p, d = parity_of(sharded.decode(g), ref, bf16)
+                det["frame_%d_from_rank_%d" % (g, g // B)] = d
+                ok = ok and p
+            res["parity_gathered"] = bool(ok)
+            res["parity_gathered_detail"] = det
+        except Exception as e:
+            failed("parity_gathered", e)
     # (2) the collective alone: events on the stream it runs on
-    res_g = sharded.time_gather(20)
+    wd["leg"] = "allgather"
+    try:
+        inject("allgather")
+        res_g = sharded.time_gather(20)
+    except Exception as e:
+        failed("allgather", e)
+    wd["gather"] = res_g
     # what took part in the HEADLINE's collective (read before the A/B leg below re-makes the communicator)
     try:
         ranks_headline = sharded.comm_ranks()
     except Exception as e:
         ranks_headline = {"library": "error: %s" % e, "process_group": world, "backend": None}
+    if rank == 0:
+        res["rccl_ranks"] = ranks_headline
     # (2b) where the collective runs: the library's side stream, right behind the covariance kernels of the batch it gathers
     # (default: the headline above) against a communication stream of its own that waits for the batch's event
     # (SPFE_COMM_OWN_STREAM=1).  With N > 1 the side-stream form puts batch i + 1's selection / descriptors / covariance behind
@@ -436,23 +482,9 @@ def multi_gpu_legs(ctx, args, ext, sharded, d_img, stream, frames_lo, B, H, W, e
     # Both on THIS box, same handle, communicator re-made in between.
     ab = None
     if getattr(sharded, "_native", False) and not args.no_comm_ab:
-        # This leg destroys and re-creates the library's communicator twice.  Should a rank get stuck in it (it has never run
-        # on more than one GPU), the measurement above must not be lost with it: a watchdog on every rank lets rank 0 print the
-        # line as far as it got and ends the process (exit code 0: the headline is complete and verified at that point).
-        import threading
-        done_ab = threading.Event()
-
-        def watchdog():
-            if done_ab.wait(float(os.environ.get("SPFE_COMM_AB_TIMEOUT", "150"))):
-                return
-            if rank == 0 and emit_partial is not None:
-                part = dict(res)
-                part["allgather_ms"] = res_g["ms"]
-                part["allgather"] = res_g
-                part["comm_stream_ab"] = {"error": "the comm-stream A/B leg did not finish within its time limit; line printed without it"}
-                emit_partial(part)
-            os._exit(0)
-        threading.Thread(target=watchdog, daemon=True).start()
+        wd["leg"] = "comm_stream_ab"
+        overall = wd["deadline"]
+        wd["deadline"] = min(overall, time.monotonic() + float(os.environ.get("SPFE_COMM_AB_TIMEOUT", "150")))
         ab = {}
         k3, w3 = max(args.steps, 50), max(args.warmup, 5)
         prev = os.environ.get("SPFE_COMM_OWN_STREAM")
@@ -472,36 +504,38 @@ def multi_gpu_legs(ctx, args, ext, sharded, d_img, stream, frames_lo, B, H, W, e
                           "steps": k3, "records_ok": bool(0 < r3.K <= nf + 1 and r3.status == 0), "rccl_ranks": sh3.comm_ranks()["library"]}
               sharded = sh3   # (the handle's communicator is this one now: the legs below use it)
         except Exception as e:
-            # a rank that fails alone leaves the others inside a collective: no rank may move on to the next leg's barriers —
-            # every rank ends through its watchdog, rank 0 printing the line as far as it got
-            print("bench.py: rank %d: comm-stream A/B leg failed: %s: %s" % (rank, type(e).__name__, e), file=sys.stderr, flush=True)
-            threading.Event().wait()
+            failed("comm_stream_ab", e)
         if prev is None:
             os.environ.pop("SPFE_COMM_OWN_STREAM", None)
         else:
             os.environ["SPFE_COMM_OWN_STREAM"] = prev
-        done_ab.set()
+        wd["deadline"] = overall
         ab["what"] = ("the headline's schedule with ncclAllGather on a communication stream of its own (own_stream, "
                       "SPFE_COMM_OWN_STREAM=1) and on the library's side stream behind the batch's covariance (side_stream, the "
                       "default), %d timed steps each after %d untimed, same handle" % (k3, w3))
+        if rank == 0:
+            res["comm_stream_ab"] = ab
+    wd["leg"] = "host_alt"
     # (3) the host-side alternative: no gather, every rank copies ITS shard to its own pinned host buffer
     nbytes = B * ext.record_bytes()
-    pinned = [torch.zeros(nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
-    cnt = [0]
+    try:
+        inject("host_alt")
+        pinned = [torch.zeros(nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        cnt = [0]
 
-    def d2h(out_unused, local):
-        pinned[cnt[0] % 2].copy_(local, non_blocking=True)
-        cnt[0] += 1
-    sh2 = parallel.ShardedExtractor(ext, world, rank, B, gather_fn=d2h)
-    k2 = max(args.steps, 50)
-    dt2 = run_timed(ext, sh2, d_img, stream, k2, max(args.warmup, 5), world, dist, torch)
-    own = ext.view_record(pinned[(cnt[0] - 1) % 2][:ext.record_bytes()].numpy())
+        def d2h(out_unused, local):
+            pinned[cnt[0] % 2].copy_(local, non_blocking=True)
+            cnt[0] += 1
+        sh2 = parallel.ShardedExtractor(ext, world, rank, B, gather_fn=d2h)
+        k2 = max(args.steps, 50)
+        dt2 = run_timed(ext, sh2, d_img, stream, k2, max(args.warmup, 5), world, dist, torch)
+        own = ext.view_record(pinned[(cnt[0] - 1) % 2][:ext.record_bytes()].numpy())
+    except Exception as e:
+        failed("host_alt", e)
+    wd["done"] = True
     if rank == 0:
         res["allgather_ms"] = res_g["ms"]
         res["allgather"] = res_g
-        res["rccl_ranks"] = ranks_headline
-        if ab is not None:
-            res["comm_stream_ab"] = ab
         res["host_alt"] = {"what": "no collective: each rank D2H-copies its own %d records (%d bytes) to pinned host memory on a "
                                    "copy stream behind the batch's covariance (SURVEY.md 8e: the SLAM consumer is on the host), "
                                    "%d timed steps" % (B, nbytes, k2),

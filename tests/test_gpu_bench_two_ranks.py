@@ -92,3 +92,19 @@ def test_scale_sweep_script_dry_run(tmp_path):
     assert [r["n_gpus"] for r in rows] == [1, 2]
     assert rows[1]["parity_gathered"] is True and rows[1]["config"]["parallelism"] == "dp2"
     assert "N=1" in out.stdout and "N=2" in out.stdout
+
+
+def test_a_rank_failing_inside_a_leg_does_not_cost_the_line():
+    """The legs behind the headline (gathered-frame parity, the collective alone, the comm-stream A/B, the host alternative) run
+    under a watchdog on every rank: rank 1 fails inside the last leg (injected), rank 0 waits for it in the leg's barrier — and
+    the line is still printed once, with what was measured, exit code 0."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, cwd=ROOT,
+                         env=_clean_env(SPFE_BENCH_BACKEND="gloo", SPFE_BENCH_FAIL_LEG="host_alt:1", SPFE_LEGS_TIMEOUT="25"),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["parity_gathered"] is True and d["allgather_ms"] > 0
+    assert "host_alt" in d["legs_incomplete"] and "host_alt" not in d
+    assert "leg host_alt failed" in out.stderr
