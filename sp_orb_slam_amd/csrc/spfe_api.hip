@@ -135,6 +135,7 @@ struct spfe_handle_s {
   // (<= 4 per keypoint: 28 % of a 1280x720 frame at 1000 keypoints), gathered through select_kernel's list; d_coarse keeps
   // the dense layout, only the rows anybody reads are written.  SPFE_SPARSE_DB=0: the dense head in the launch stream.
   bool sparse_db = true;
+  bool sparse_db_sync_only = false;   // ... in synchronous calls only (bf16 frames below 10,000 cells; SPFE_SPARSE_DB=2)
   bool sparse_last = false;      // the last call left d_coarse sparse (spfe_debug_read("coarse") completes it on demand)
   // ... and convDa with it (bf16 mode, da_gather_bf16.hip): the dense launch computes convPa only, the descriptor branch
   // runs on the listed cells from conv4b's output on.  SPFE_SPARSE_DA=0: convPa|Da dense, only convDb gathered.
@@ -550,9 +551,14 @@ int build(spfe_handle h, const spfe_config *cfg) {
   // f32 752x480 +0.4 ... 0.7 %, bf16 752x480 -2 ... 3 %: there the launch stream runs as two half batches on two streams, the
   // dense head (HBM-bound) hid completely beside the other half's convolutions (removing it altogether gains nothing), and
   // the gathered launch is pure extra work for the chip.  So: f32, and bf16 frames of >= 10,000 cells (= no two-stream split).
-  h->sparse_db = !h->bf16 || h->C >= 10000;
+  // SYNCHRONOUS calls of those small bf16 frames take the gathered branch all the same (round 4): there is no other half
+  // batch to hide the dense head beside, and the gathered form brings the inline chain with it (enqueue_post) — 752x480:
+  // a single frame's p50 0.287 -> 0.264 ... 0.274 ms, 8 frames per synchronous call +0.5 ... 0.8 %; 640x480: 0.311 -> 0.288
+  // ms, +2.4 %.  SPFE_SPARSE_DB = 0 never, 1 every call, 2 synchronous calls only
+  h->sparse_db = true;
+  h->sparse_db_sync_only = h->bf16 && h->C < 10000;
   h->db_tiles_per_wg = h->bf16 ? 4 : 1;
-  if (const char *e = getenv("SPFE_SPARSE_DB")) h->sparse_db = atoi(e) != 0;
+  if (const char *e = getenv("SPFE_SPARSE_DB")) { h->sparse_db = atoi(e) != 0; h->sparse_db_sync_only = atoi(e) == 2; }
   // the gathered kernels form row byte offsets in 32 bits (the head activations' rows are 2048 / 1024 bytes, 0x80000000 is their
   // out-of-range marker): batches beyond that take the dense head (the launchers refuse them as well)
   if ((size_t)cfg->max_batch * h->C * (h->bf16 ? 1024 : 2048) >= ((size_t)1 << 31)) h->sparse_db = false;
@@ -972,7 +978,8 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   // frames [f0, f0 + nfr) of the batch on stream `s` (the whole batch on the caller's stream by default)
   const int n_all = n;
   hipStream_t const s_all = s;
-  const bool sparse = h->sparse_db && h->d_db_list;   // the descriptor head (bf16: convDa too) runs gathered, in enqueue_post
+  // the descriptor head (bf16: convDa too) runs gathered, in enqueue_post
+  const bool sparse = h->sparse_db && h->d_db_list && !(h->sparse_db_sync_only && ((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode));
   const bool sparse_da = sparse && h->sparse_da && (h->sparse_da_mode >= 2 || !((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode));
   h->sparse_da_call = sparse_da;
   const int par_db = (int)(h->ticket & 1);
@@ -1367,7 +1374,11 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
     STAGE_MARK(13);
     // (the event the side stream waits for is the selection's own completion signal: a hipEventRecord here put a marker
     // packet between the selection and the covariance walk — 7.6 us on the chain; SPFE_SEL_EXT_EVENT=0: that record)
-    static const bool sel_ext = !(getenv("SPFE_SEL_EXT_EVENT") && atoi(getenv("SPFE_SEL_EXT_EVENT")) == 0);
+    static const bool sel_ext_env = !(getenv("SPFE_SEL_EXT_EVENT") && atoi(getenv("SPFE_SEL_EXT_EVENT")) == 0);
+    // (under stream capture the record it is: the stop event of an extended launch is not a capture node, the side stream
+    // would not join the capture and its kernels would run once, at capture time)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool sel_ext = sel_ext_env && hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
     HIP_TRY(spfe::launch_select(f, h->rl, n, H, W, h->cfg.num_features, s, &h->cov, h->rl.kmax, h->select_lean == 1,
                                 sel_ext ? h->ev_sel : nullptr));
     if (!sel_ext) HIP_TRY(hipEventRecord(h->ev_sel, s));

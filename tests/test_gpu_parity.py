@@ -11,6 +11,8 @@ The f32 MFMA path follows the same operation order as the oracle
 (include/spfe_exact_math.h), so the tests additionally report (and for the
 network outputs require) BITWISE equality.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -834,3 +836,19 @@ def test_f32_k_chain_kernel_on_mfma_16x16x4_is_bit_identical(monkeypatch, H, W):
     a, b = out["0"][0], out["0xE8"][0]
     assert a.K == b.K and np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.descriptors, b.descriptors)
     assert np.array_equal(a.cov2, b.cov2)
+
+
+@pytest.mark.parametrize("cfg", ["f32 1", "f32 4", "bf16 1", "bf16 3", "bf16 2 720 1280"])
+def test_a_synchronous_call_captured_into_a_hip_graph_replays_bit_identically(cfg):
+    """tools/graph_capture_check.py (its own process: a failed capture leaves the runtime in capture mode): one
+    spfe_extract_batch_device call captured on a torch stream — the library's side streams and its second convolution stream
+    fork from and join the capturing stream by events; the selection's extended-launch stop event (not a capture node) gives
+    way to a plain record; waits are never replaced by host-side event queries there — and replayed on three different frame
+    sets: every field of every record equals the direct call's."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "graph_capture_check.py")] + cfg.split(), cwd=root,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    assert "bit-identical to direct calls: True" in out.stdout

@@ -70,14 +70,20 @@ def test_cell_list_is_the_union_of_the_taps_and_its_rows_are_the_dense_bits(monk
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
-@pytest.mark.parametrize("H,W,B", [(240, 376, 3), (720, 1280, 2), (128, 168, 4)])
+@pytest.mark.parametrize("H,W,B", [(240, 376, 3), (720, 1280, 2), (128, 168, 4), (480, 752, 3)])
 def test_records_do_not_depend_on_the_descriptor_head_being_gathered(monkeypatch, precision, H, W, B):
-    """Synchronous calls (twice: the second runs behind the first's side chain) and the pipelined host path."""
+    """Synchronous calls (twice: the second runs behind the first's side chain) and the pipelined host path, then a
+    synchronous single frame again — on ONE handle.  SPFE_SPARSE_DB = 0 never / 1 every call / 2 synchronous calls only (the
+    default of bf16 frames below 10,000 cells since round 4: gathered and dense calls alternate on the handle) / unset."""
     blob = weights.synthetic(7, "dense")
     sets = [[synth.make_image(90 + 10 * r + i, H, W) for i in range(B)] for r in range(3)]
     out = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("SPFE_SPARSE_DB", flag)
+    for flag in ("0", "1", "2", None):
+        if flag is None:
+            monkeypatch.delenv("SPFE_SPARSE_DB", raising=False)
+            flag = "default"
+        else:
+            monkeypatch.setenv("SPFE_SPARSE_DB", flag)
         ext = SPExtractor(500, H, W, blob, max_batch=B, with_heat=False, precision=precision)
         sync = [ext.extract_batch(s) for s in sets[:2]]
         tickets = [ext.submit_batch(s) for s in sets]
@@ -86,7 +92,7 @@ def test_records_do_not_depend_on_the_descriptor_head_being_gathered(monkeypatch
         ext.close()
         out[flag] = [fr for frs in sync + pipe for fr in frs] + [one]
     assert len(out["0"]) == 5 * B + 1
-    for a, b in zip(out["0"], out["1"]):
+    for a, b in [ab for other in ("1", "2", "default") for ab in zip(out["0"], out[other])]:
         assert a.K == b.K and a.status == 0 and b.status == 0
         assert np.array_equal(a.kp_xy, b.kp_xy)
         assert np.array_equal(_bits(a.descriptors), _bits(b.descriptors))
