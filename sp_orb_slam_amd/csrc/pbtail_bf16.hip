@@ -52,14 +52,14 @@ __global__ __launch_bounds__(64 * NW) void pbtail_bf16_kernel(const unsigned sho
                                                           const unsigned char *__restrict__ wpack,
                                                           const float *__restrict__ bias, float *__restrict__ semi_out,
                                                           FrameBufs f, RecordLayout rl, int H, int W, int nparts, int b0,
-                                                          int *zero_ints, int nzero) {
+                                                          int *zero_ints, int nzero, int zstride) {
   // (the logits take the activations' place once both wavefronts have read their operands: 16 KB per workgroup, nine per CU)
   __shared__ __attribute__((aligned(16))) char sA[PT_BYTES];
   static_assert(PT * SPFE_SEMI_CH * 4 <= PT_BYTES, "the logits reuse the activation tile");
   float *const sm = reinterpret_cast<float *>(sA);
   __shared__ float smin[2], smax[2];
   if (zero_ints && blockIdx.x == 0 && blockIdx.y == 0)
-    for (int i = threadIdx.x; i < nzero; i += 64 * NW) zero_ints[i] = 0;
+    for (int i = threadIdx.x; i < nzero; i += 64 * NW) zero_ints[(i >> 5) * zstride + (i & 31)] = 0;   // runs of 32, zstride apart
   const int wc = W >> 3, hc = H >> 3, C = hc * wc;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -183,7 +183,8 @@ __global__ __launch_bounds__(64 * NW) void pbtail_bf16_kernel(const unsigned sho
 
 // head: the bf16 head activations [B * C][512]; wpack / bias: convPb's (see the kernel); semi: [B][C][65] f32
 hipError_t launch_pbtail_bf16(const void *head, const void *wpack, const float *bias, float *semi, const FrameBufs &f,
-                              const RecordLayout &r, int B, int H, int W, hipStream_t s, int b0, int *zero_ints, int nzero) {
+                              const RecordLayout &r, int B, int H, int W, hipStream_t s, int b0, int *zero_ints, int nzero,
+                              int zstride) {
   const int nparts = tail_parts(H, W);
   if ((size_t)(H / 8) * (W / 8) * IN_STRIDE * 2 >= ((size_t)1 << 32)) return hipErrorInvalidValue;   // (32-bit SRD offsets inside a frame)
   // few frames (one round of workgroups): four wavefronts share the load and the three channel tiles — the shorter chain
@@ -194,10 +195,10 @@ hipError_t launch_pbtail_bf16(const void *head, const void *wpack, const float *
   const bool four = force ? force == 4 : (long)nparts * B <= 1024;
   if (four)
     hipLaunchKernelGGL(pbtail_bf16_kernel<4>, dim3(nparts, B), dim3(256), 0, s, reinterpret_cast<const unsigned short *>(head),
-                       reinterpret_cast<const unsigned char *>(wpack), bias, semi, f, r, H, W, nparts, b0, zero_ints, nzero);
+                       reinterpret_cast<const unsigned char *>(wpack), bias, semi, f, r, H, W, nparts, b0, zero_ints, nzero, zstride);
   else
     hipLaunchKernelGGL(pbtail_bf16_kernel<2>, dim3(nparts, B), dim3(128), 0, s, reinterpret_cast<const unsigned short *>(head),
-                       reinterpret_cast<const unsigned char *>(wpack), bias, semi, f, r, H, W, nparts, b0, zero_ints, nzero);
+                       reinterpret_cast<const unsigned char *>(wpack), bias, semi, f, r, H, W, nparts, b0, zero_ints, nzero, zstride);
   return hipGetLastError();
 }
 

@@ -109,6 +109,10 @@ struct spfe_handle_s {
   int split_probe = -3;                    // outcome of the last probe: 1 free queue found, 0 none, -1 not measurable, -2 stream
                                            // under capture, 2 probe switched off (first candidate trusted), -3 never probed
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // pipelined calls: the launch stream does not wait for the second stream's half batch at the end of a step — the side chain
+  // does, and the launch stream only in front of the NEXT call's conv1b (its conv1a runs beside the other half's last kernels)
+  bool join_pending = false;
+  bool defer_join = true;   // SPFE_DEFER_JOIN=0: the join at the end of the step, on the launch stream
   int desc_in_replay = 1;   // SPFE_DESC_IN_REPLAY
   int f32_split = 2;   // parts (0 = off)
   int bf16_split = -1;  // SPFE_BF16_SPLIT: the same for the bf16 stack; -1 = frames of fewer than 10,000 cells (752x480: +2 %; 1280x720: +-0)
@@ -564,6 +568,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
   if ((size_t)cfg->max_batch * h->C * (h->bf16 ? 1024 : 2048) >= ((size_t)1 << 31)) h->sparse_db = false;
   if (const char *e = getenv("SPFE_DB_TILES_PER_WG")) h->db_tiles_per_wg = atoi(e);
   if (const char *de = getenv("SPFE_DEFER_DB")) h->defer_db = atoi(de) != 0;
+  if (const char *de = getenv("SPFE_DEFER_JOIN")) h->defer_join = atoi(de) != 0;
   {
     const char *fenv = getenv("SPFE_FUSE_CONV1A");
     h->fuse1a = fenv && atoi(fenv) != 0;
@@ -952,6 +957,15 @@ int pick_conv2(spfe_handle h, hipStream_t s) {
 }
 
 // Enqueue the whole path for n frames already in device memory.
+// (see spfe_handle_s::join_pending) orders `s` behind the half batch the last pipelined call left on the second stream
+int settle_join(spfe_handle h, hipStream_t s) {
+  if (h->join_pending) {
+    HIP_TRY(wait_if_pending(s, h->ev_join));
+    h->join_pending = false;
+  }
+  return SPFE_OK;
+}
+
 int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, hipStream_t s) {
   const int H = h->H, W = h->W;
   if (h->timing) h->ev = h->evpool.data() + (size_t)(h->calls % spfe_handle_s::EVSETS) * (NSTAGE + 1);
@@ -959,6 +973,8 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   STAGE_MARK(0);
   // (a kernel of our own, not hipMemsetAsync: the runtime's fill is a blit that queues behind its other blits — the
   // pipelined host path's D2H copy of the PREVIOUS batch — and held the whole next batch back by 0.6 ms at 752x480 bf16)
+  // bf16: conv1a is inside conv1b and the tile-queue counters may be in use by the half batch still running: the join first
+  if (h->bf16) { const int rcj = settle_join(h, s); if (rcj) return rcj; }
   if (h->d_tile_ctr && !h->tile_ctr_clean) {
     hipLaunchKernelGGL(spfe::zero_tile_counters_kernel, dim3(1), dim3(256), 0, s, h->d_tile_ctr, 8 * 64);
     HIP_TRY(hipGetLastError());
@@ -974,6 +990,9 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   h->act0_missing = fused || fused16;
   if (h->bf16 && !fused16) HIP_TRY(spfe::launch_conv1a_bf16(d_images, h->d_w1a_tab, h->d_b1a, h->act[0], n, H, W, s));
   else if (!h->bf16 && !fused) HIP_TRY(spfe::launch_conv1a(d_images, h->d_w1a, h->d_b1a, h->act[0], n, H, W, s));
+  // f32: conv1a (HBM-bound, reads the new frames, writes what conv1b of the last call has long read) runs beside the last
+  // kernels of the half batch on the second stream; everything behind it waits for that half
+  { const int rcj = settle_join(h, s); if (rcj) return rcj; }
   STAGE_MARK(1);
   // frames [f0, f0 + nfr) of the batch on stream `s` (the whole batch on the caller's stream by default)
   const int n_all = n;
@@ -1083,7 +1102,15 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     }
     if (h->bf16 && i >= 8) {  // convPb (65 logits) and convDb (256 descriptor channels): bf16 GEMMs over all cells of the batch
       const unsigned short *hd = h->d_hd + (size_t)f0 * h->C * 512;
-      if (i == 8 && h->pbtail) {}   // (inside the detector tail's launch: pbtail_bf16.hip, enqueue_post)
+      if (i == 8 && h->pbtail) {   // (inside the detector tail's launch: pbtail_bf16.hip; enqueue_post, or here per half batch)
+        if (tail_per_half) {
+          const spfe::FrameBufs fb = frame_bufs(h, d_records, sparse);
+          // (each half clears ITS tile-queue counters [layer][part][32] for the next call: the other half's may be in use)
+          HIP_TRY(spfe::launch_pbtail_bf16(h->d_hd, h->d_wpb, h->layers[8].d_b, h->d_semi, fb, h->rl, n, H, W, s, f0,
+                                           h->d_tile_ctr ? h->d_tile_ctr + 32 * part : nullptr, h->d_tile_ctr ? 8 * 32 : 0, 64));
+          if (h->d_tile_ctr) h->tile_ctr_clean = true;
+        }
+      }
       else if (i == 8) HIP_TRY(spfe::launch_head1x1_bf16(hd, h->d_wpb, L.d_b, h->d_semi + (size_t)f0 * h->C * SPFE_SEMI_CH, n * h->C, 65, s));
       else HIP_TRY(spfe::launch_head1x1_bf16(hd, h->d_wdb, L.d_b, h->d_coarse + (size_t)f0 * h->C * SPFE_DESC_DIM, n * h->C, 256, s));
       STAGE_MARK(2 + i);
@@ -1234,7 +1261,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     // convPa instead of behind the join (SPFE_TAIL_PER_HALF=0: behind the join) — what it must wait for (the side chain two
     // tickets back) is waited for HERE, on the launch stream in front of conv1b; the second stream forks behind conv1b
     static const bool tph_env = !(getenv("SPFE_TAIL_PER_HALF") && atoi(getenv("SPFE_TAIL_PER_HALF")) == 0);
-    tail_per_half = !h->bf16 && h->pbtail && tph_env;
+    tail_per_half = h->pbtail && tph_env;
     if (tail_per_half) {
       const int rcw = tail_waits(h, d_records, s);
       if (rcw) return rcw;
@@ -1252,7 +1279,12 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
           if ((rc = run_layer(i, f0, f1 - f0, (r & 1) ? h->conv2 : s))) return rc;
         }
     HIP_TRY(hipEventRecord(h->ev_join, h->conv2));
-    HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
+    // Pipelined calls whose tails ran per half: nothing on the launch stream needs the other half any more — the side chain
+    // waits for it (enqueue_post), the launch stream in front of the next call's conv1b (settle_join).  A step's last kernel
+    // — the second half's tail, ~20 us alone on the chip — and the event hop behind it (~13 us) leave the critical path
+    // (f32 752x480 x 8: 3735 us steps, +0.9 %).
+    if (tail_per_half && h->defer_join && ((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode)) h->join_pending = true;
+    else HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
     return enqueue_post(h, n, d_records, s, nullptr, sparse, h->pbtail, tail_per_half);
   }
   for (int i = 0; i < (defer_db ? 9 : nlayers); ++i) {
@@ -1403,6 +1435,7 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
   // after this call's detector tail: small kernels that run beside the next call's convolutions.
   HIP_TRY(hipEventRecord(h->ev_post[slot], s));
   HIP_TRY(hipStreamWaitEvent(h->side, h->ev_post[slot], 0));
+  if (h->join_pending) HIP_TRY(hipStreamWaitEvent(h->side, h->ev_join, 0));   // (the other half batch: its tail ran on the second stream)
   STAGE_MARK(13);   // ("select" reads 0 on the launch stream: it is part of post_side)
   // (the heat normalisation rides in the selection's first launch: both depend on the detector tail only)
   {
@@ -1552,6 +1585,7 @@ void spfe_destroy(spfe_handle h) {
   (void)hipSetDevice(h->cfg.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->side) (void)hipStreamSynchronize(h->side);
+  for (hipStream_t c : h->conv2_pool) (void)hipStreamSynchronize(c);
   for (int i = 0; i < spfe_handle_s::NTICKET; ++i) {
     if (h->ev_post[i]) (void)hipEventDestroy(h->ev_post[i]);
     if (h->ev_cov[i]) (void)hipEventDestroy(h->ev_cov[i]);
@@ -1616,6 +1650,7 @@ int spfe_postprocess(spfe_handle h, const float *semi, const float *coarse, int 
   if (n < 1 || n > h->B) return fail(SPFE_EINVAL, "batch %d not in [1, %d]", n, h->B);
   HIP_TRY(hipSetDevice(h->cfg.device));
   hipStream_t s = h->stream;
+  { const int rcj = settle_join(h, s); if (rcj) return rcj; }
   if (h->desc_recorded) HIP_TRY(hipStreamWaitEvent(s, h->ev_desc, 0));  // previous call's reader of d_coarse
   HIP_TRY(hipMemcpyAsync(h->d_semi, semi, (size_t)n * h->C * SPFE_SEMI_CH * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(h->d_coarse, coarse, (size_t)n * h->C * SPFE_DESC_DIM * 4, hipMemcpyHostToDevice, s));

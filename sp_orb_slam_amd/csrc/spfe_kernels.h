@@ -176,7 +176,7 @@ hipError_t launch_pbtail_f32(const float *head, const float *wpack, const float 
 // head = [B * C][512] bf16; wpack = head_bf16_pack_weights(convPb, 65); zero_ints / nzero as launch_tail's
 hipError_t launch_pbtail_bf16(const void *head, const void *wpack, const float *bias, float *semi, const FrameBufs &f,
                               const RecordLayout &r, int B, int H, int W, hipStream_t s, int b0 = 0, int *zero_ints = nullptr,
-                              int nzero = 0);   // frames [b0, b0 + B) of the batch-wide buffers
+                              int nzero = 0, int zstride = 32);   // (zero_ints: nzero ints in runs of 32, zstride apart)   // frames [b0, b0 + B) of the batch-wide buffers
 // zero_ints / nzero: ints the kernel also clears (the bf16 convolutions' tile-queue counters, for the next call)
 hipError_t launch_tail(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s, int *zero_ints = nullptr, int nzero = 0);
 // with_heat_norm: the heat normalisation (launch_heat_norm) rides in the neighbour-mask launch in front of the selection
