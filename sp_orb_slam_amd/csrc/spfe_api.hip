@@ -1049,6 +1049,14 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
         p.wpack = reinterpret_cast<const float *>(h->d_wws[i]);
         p.tile_ctr = h->d_tile_ctr + 64 * i + 32 * part;
         if (i == 0 && fused16) { p.img = d_images; p.w1a = reinterpret_cast<const float *>(h->d_w1a_tab); p.b1a = h->d_b1a; }
+        // (experiment knobs, pipelined calls: conv1b / all Cin = 64 layers on fewer workgroups than CUs, so that the previous
+        // batch's selection — 143 KB of LDS per workgroup, nothing fits beside this kernel's 158 KB — starts beside conv1b
+        // instead of behind it.  1280x720 x 8: conv1b on 224 workgroups +0.3 ... 2 % whole path with conv1b at 0.51 - 0.53 of
+        // peak instead of 0.57; 240 / 208 / 192: -2 / -1 / -3 %.  Not taken: HISTORY.md "Round 4")
+        static const int ws_grid0 = getenv("SPFE_BF16_CONV1B_GRID") ? atoi(getenv("SPFE_BF16_CONV1B_GRID")) : 0;
+        static const int ws_grid = getenv("SPFE_BF16_WS_GRID") ? atoi(getenv("SPFE_BF16_WS_GRID")) : 0;
+        if (((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode) && (i == 0 && ws_grid0 ? ws_grid0 : ws_grid) > 0)
+          p.num_cus = i == 0 && ws_grid0 ? ws_grid0 : ws_grid;
         HIP_TRY(spfe::launch_conv_bf16_ws(p, L.pool, i == 0 ? (fused16 ? 2 : 1) : 0, s));
         STAGE_MARK(2 + i);
         return SPFE_OK;
