@@ -296,3 +296,41 @@ def test_bf16_convPb_inside_the_tail_launch_is_bit_identical(monkeypatch, H, W, 
             assert np.array_equal(a.cov2, b.cov2) and np.array_equal(a.occ_grid, b.occ_grid)
             assert np.array_equal(a.dense_dust, b.dense_dust) and np.array_equal(a.semi_dust, b.semi_dust)
             assert np.array_equal(a.heat, b.heat) and np.array_equal(a.heat_inv, b.heat_inv)
+
+
+@pytest.mark.parametrize("prec,H,W,B", [("f32", 240, 376, 5), ("bf16", 240, 376, 5), ("bf16", 480, 752, 4), ("f32", 480, 752, 2)])
+def test_pipelined_steps_on_changing_frames_equal_synchronous_calls(prec, H, W, B):
+    """Twelve pipelined calls back to back, no synchronisation in between, every call on OTHER frames and into its own record
+    buffer — the schedule of round 4: two half batches on two streams, each half's tail behind its convPa, the launch stream
+    NOT waiting for the other half at the end of a step (its next conv1a runs beside that half's last kernels), tile-queue
+    counters cleared per half, waits skipped when their event has fired.  Every record of every call equals the one a
+    synchronous handle computes for the same frames: nothing of call i + 1 overtakes what call i still reads or writes."""
+    import torch
+    nf, steps = 300, 12
+    blob = weights.synthetic(7, "dense")
+    sets = [torch.from_numpy(np.stack([synth.make_image(400 + 7 * r + i, H, W) for i in range(B)])).cuda() for r in range(3)]
+    ref_ext = SPExtractor(nf, H, W, blob, max_batch=B, precision=prec, with_heat=False)
+    rb = ref_ext.record_bytes()
+    ref = []
+    for d in sets:
+        rec = torch.zeros(B * rb, dtype=torch.uint8, device="cuda")
+        ref_ext.extract_batch_device(d.data_ptr(), B, rec.data_ptr())
+        torch.cuda.synchronize()
+        ref.append([ref_ext.view_record(rec.cpu().numpy()[i * rb:(i + 1) * rb]) for i in range(B)])
+    ext = SPExtractor(nf, H, W, blob, max_batch=B, precision=prec, with_heat=False, async_cov=True)
+    recs = [torch.zeros(B * rb, dtype=torch.uint8, device="cuda") for _ in range(steps)]
+    stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for k in range(steps):
+        ext.extract_batch_device(sets[k % 3].data_ptr(), B, recs[k].data_ptr(), stream.cuda_stream)
+    ext.wait_records(ext.last_ticket(), stream.cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(steps):
+        host = recs[k].cpu().numpy()
+        for i in range(B):
+            a, b = ext.view_record(host[i * rb:(i + 1) * rb]), ref[k % 3][i]
+            assert a.status == 0 and a.K == b.K and a.K > 0, (k, i)
+            for name in ("kp_xy", "response", "descriptors", "cov2", "cov2_inv", "occ_grid", "dense_dust", "semi_dust"):
+                assert np.array_equal(getattr(a, name), getattr(b, name)), (k, i, name)
+    ext.close()
+    ref_ext.close()
