@@ -99,7 +99,7 @@ def test_a_rank_failing_inside_a_leg_does_not_cost_the_line():
     under a watchdog on every rank: rank 1 fails inside the last leg (injected), rank 0 waits for it in the leg's barrier — and
     the line is still printed once, with what was measured, exit code 0."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, cwd=ROOT,
-                         env=_clean_env(SPFE_BENCH_BACKEND="gloo", SPFE_BENCH_FAIL_LEG="host_alt:1", SPFE_LEGS_TIMEOUT="25"),
+                         env=_clean_env(SPFE_BENCH_BACKEND="gloo", SPFE_BENCH_FAIL_LEG="host_alt:1", SPFE_LEGS_TIMEOUT="40"),
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
