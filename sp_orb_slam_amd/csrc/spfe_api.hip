@@ -988,6 +988,19 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
                          (long)((W + 31) / 32) * ((H + 7) / 8) * n >= (long)ws_min * grid_ws0;
   const bool fused16 = ws_layer0 && h->fuse1a_bf16;
   h->act0_missing = fused || fused16;
+  // Pipelined two-half-batch steps: what the tails wait for (the side chain two tickets back: long finished, but the host
+  // runs many steps ahead of the device, so these are real wait packets) is waited for in FRONT of conv1a — the packets are
+  // then processed while the other half batch of the last step still runs, not between conv1a and conv1b with the chip idle.
+  // Predicted from the last call's schedule; a wrong guess only repeats the (satisfied) waits later.  SPFE_EARLY_WAITS=0: off
+  bool early_waits = false;
+  {
+    static const bool ew_env = !(getenv("SPFE_EARLY_WAITS") && atoi(getenv("SPFE_EARLY_WAITS")) == 0);
+    if (ew_env && h->split_last && h->pbtail && n >= 2 && ((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode) && !(h->timing && h->timing_all)) {
+      const int rcw = tail_waits(h, d_records, s);
+      if (rcw) return rcw;
+      early_waits = true;
+    }
+  }
   if (h->bf16 && !fused16) HIP_TRY(spfe::launch_conv1a_bf16(d_images, h->d_w1a_tab, h->d_b1a, h->act[0], n, H, W, s));
   else if (!h->bf16 && !fused) HIP_TRY(spfe::launch_conv1a(d_images, h->d_w1a, h->d_b1a, h->act[0], n, H, W, s));
   // f32: conv1a (HBM-bound, reads the new frames, writes what conv1b of the last call has long read) runs beside the last
@@ -1270,7 +1283,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     // tickets back) is waited for HERE, on the launch stream in front of conv1b; the second stream forks behind conv1b
     static const bool tph_env = !(getenv("SPFE_TAIL_PER_HALF") && atoi(getenv("SPFE_TAIL_PER_HALF")) == 0);
     tail_per_half = h->pbtail && tph_env;
-    if (tail_per_half) {
+    if (tail_per_half && !early_waits) {
       const int rcw = tail_waits(h, d_records, s);
       if (rcw) return rcw;
     }
