@@ -48,16 +48,24 @@ SPFE_DM void spfe_quat_from_rot(const double R[9], double q[4]) {
     q[1] = (R[2] - R[6]) * s;
     q[2] = (R[3] - R[1]) * s;
   } else {
+    /* i = index of the largest diagonal element, j = (i + 1) % 3, k = (j + 1) % 3 — the three cases written out (static
+     * indices: the kernel keeps R and q in registers) */
     int i = 0;
     if (R[4] > R[0]) i = 1;
-    if (R[8] > R[i * 3 + i]) i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    double s = sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0);
-    q[i] = 0.5 * s;
-    s = 0.5 / s;
-    q[3] = (R[k * 3 + j] - R[j * 3 + k]) * s;
-    q[j] = (R[j * 3 + i] + R[i * 3 + j]) * s;
-    q[k] = (R[k * 3 + i] + R[i * 3 + k]) * s;
+    if (R[8] > (i == 1 ? R[4] : R[0])) i = 2;
+#define SPFE_QFR_CASE(I, J, K)                                                   \
+  {                                                                              \
+    double s = sqrt(R[I * 3 + I] - R[J * 3 + J] - R[K * 3 + K] + 1.0);           \
+    q[I] = 0.5 * s;                                                              \
+    s = 0.5 / s;                                                                 \
+    q[3] = (R[K * 3 + J] - R[J * 3 + K]) * s;                                    \
+    q[J] = (R[J * 3 + I] + R[I * 3 + J]) * s;                                    \
+    q[K] = (R[K * 3 + I] + R[I * 3 + K]) * s;                                    \
+  }
+    if (i == 0) SPFE_QFR_CASE(0, 1, 2)
+    else if (i == 1) SPFE_QFR_CASE(1, 2, 0)
+    else SPFE_QFR_CASE(2, 0, 1)
+#undef SPFE_QFR_CASE
   }
 }
 
@@ -96,10 +104,11 @@ SPFE_DM void spfe_se3_oplus(spfe_se3 *T, const double upd[6]) {
   if (theta < 0.00001) {
     a = 1.0; b = 0.5; c1 = 0.5; c2 = 1.0 / 6.0;
   } else {
-    a = sin(theta) / theta;
-    b = (1.0 - cos(theta)) / (theta * theta);
+    const double st = sin(theta), ct = cos(theta);
+    a = st / theta;
+    b = (1.0 - ct) / (theta * theta);
     c1 = b;
-    c2 = (theta - sin(theta)) / (theta * theta * theta);
+    c2 = (theta - st) / (theta * theta * theta);
   }
   double R[9], V[9];
   for (int i = 0; i < 9; ++i) {
@@ -113,9 +122,6 @@ SPFE_DM void spfe_se3_oplus(spfe_se3 *T, const double upd[6]) {
   /* the SE3Quat(Quaternion, t) constructor normalises */
   spfe_se3_normalize(&E);
   /* result = E * T: t = E.t + E.r * T.t; r = E.r * T.r; normalizeRotation() */
-  spfe_se3 Z;
-  Z.q[0] = Z.q[1] = Z.q[2] = 0.0; Z.q[3] = 1.0;
-  Z.t[0] = Z.t[1] = Z.t[2] = 0.0;
   spfe_se3 Er = E;
   Er.t[0] = Er.t[1] = Er.t[2] = 0.0;
   double rt[3];
@@ -128,7 +134,6 @@ SPFE_DM void spfe_se3_oplus(spfe_se3 *T, const double upd[6]) {
   N.q[1] = a4[3] * b4[1] + a4[1] * b4[3] + a4[2] * b4[0] - a4[0] * b4[2];
   N.q[2] = a4[3] * b4[2] + a4[2] * b4[3] + a4[0] * b4[1] - a4[1] * b4[0];
   spfe_se3_normalize(&N);
-  (void)Z;
   *T = N;
 }
 
@@ -238,37 +243,85 @@ SPFE_DM void spfe_huber(double e2, double delta, double rho[3]) {
   }
 }
 
-/* (H + lambda I) x = b for the 6x6 pose block (LinearSolverDense: Eigen LDLT, solved when isPositive()).  Restated as
- * Cholesky.  H is a sum of rho1 * J^T J (positive semi-definite) and lambda >= 0, so the two disagree on one input only:
- * the ZERO matrix (no gradient anywhere and lambda = tau * 0), which LDLT calls positive and solves to x = 0 — one trial
- * with rho = 0, Terminate — and Cholesky rejects — ten failed trials, Terminate.  Either way the pose is untouched, the
- * edges are re-evaluated at it and optimize() reports one iteration (tests/golden/dust_flat.npz pins that).
- * H: full symmetric 6x6.  Returns 1 / 0. */
-SPFE_DM int spfe_solve6(const double H[36], double lambda, const double b[6], double x[6]) {
-  double L[36];
+/* ---- the sums over the edges: a FIXED-SHAPE tree, the same in the kernel and in the oracle ---------------------------
+ * g2o accumulates chi2 and the pose block's normal equations edge by edge (activeRobustChi2, constructQuadraticForm); its
+ * bits are not pinned by anything in /root/reference (g2o is not vendored).  Rounds 1-4 restated that as a strict
+ * edge-order chain, which a GPU can only run one lane per sum (27 chains of n dependent additions: 32 us per Levenberg
+ * iteration, slower than one host core).  The contract is now a tree a 256-thread workgroup evaluates in log time:
+ *   slot t (0 <= t < 256) = 0.0 + term(t) + term(t + 256) + ...            (ascending edge index, edges i < n only)
+ *   wave g (0 <= g < 4)   = halving tree over its 64 slots: for m = 32, 16, 8, 4, 2, 1: s[l] += s[l + m], l < m
+ *   total                 = ((wave 0 + wave 1) + wave 2) + wave 3
+ * (the kernel's cross-lane butterfly forms s[l] + s[l ^ m] in every lane: IEEE addition commutes, so lane 0's value — and
+ * every other lane's — is the halving tree's).  What is summed: SPFE_DUST_NSUM = 28 quantities per edge,
+ *   q[0]                     rho0 = Huber(err^2)                              (activeRobustChi2)
+ *   q[1 + i (i + 1) / 2 + j] (J[i] * rho1) * J[j], 0 <= j <= i < 6            (lower triangle of J^T (rho1 Omega) J, Omega = 1)
+ *   q[22 + j]                -((rho1 * J[j]) * err)                            (b -= J^T rho1 Omega e)
+ * The solver reads the lower triangle only (spfe_solve6); spfe_dust_unpack mirrors it. */
+#define SPFE_DUST_SLOTS 256
+#define SPFE_DUST_NSUM 28
+
+SPFE_DM void spfe_dust_terms(double err, const double J[6], double delta, double q[SPFE_DUST_NSUM]) {
+  double rho[3];
+  spfe_huber(err * err, delta, rho);
+  q[0] = rho[0];
   for (int i = 0; i < 6; ++i)
-    for (int j = 0; j <= i; ++j) {
+    for (int j = 0; j <= i; ++j) q[1 + i * (i + 1) / 2 + j] = (J[i] * rho[1]) * J[j];
+  for (int j = 0; j < 6; ++j) q[22 + j] = -((rho[1] * J[j]) * err);
+}
+
+SPFE_DM void spfe_dust_unpack(const double tot[SPFE_DUST_NSUM], double *chi, double H[36], double b[6]) {
+  *chi = tot[0];
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j <= i; ++j) H[i * 6 + j] = H[j * 6 + i] = tot[1 + i * (i + 1) / 2 + j];
+  for (int j = 0; j < 6; ++j) b[j] = tot[22 + j];
+}
+
+/* the tree over one quantity's 256 slot sums (host form; s is destroyed) */
+static inline double spfe_dust_tree_total(double s[SPFE_DUST_SLOTS]) {
+  for (int g = 0; g < 4; ++g)
+    for (int m = 32; m >= 1; m >>= 1)
+      for (int l = 0; l < m; ++l) s[64 * g + l] += s[64 * g + l + m];
+  return ((s[0] + s[64]) + s[128]) + s[192];
+}
+
+/* (H + lambda I) x = b for the 6x6 pose block (LinearSolverDense: Eigen LDLT, solved when isPositive()).  Restated as an
+ * unpivoted L D L^T with unit lower-triangular L — no square roots, ONE division per pivot (its reciprocal; everything else
+ * multiplies by it), no early exit: the kernel runs this on the critical path of every trial step, and a branch per pivot
+ * would stop the independent columns from overlapping.  Positive = every pivot D_j > 0 (what a Cholesky factorisation
+ * checks too).  H is a sum of rho1 * J^T J (positive semi-definite) and lambda >= 0, so this and Eigen's pivoted LDLT
+ * disagree on one input only: the ZERO matrix (no gradient anywhere and lambda = tau * 0), which Eigen calls positive and
+ * solves to x = 0 — one trial with rho = 0, Terminate — and this form rejects — ten failed trials, Terminate.  Either way the
+ * pose is untouched, the edges are re-evaluated at it and optimize() reports one iteration (tests/golden/dust_flat.npz
+ * pins that).  H: symmetric 6x6, the lower triangle is read.  Returns 1 / 0; x = 0 when 0 (the caller's gain ratio reads x).
+ *   U_ij = H_ij - sum_{k<j} L_ik U_jk (j <= i; U_jj = D_j, + lambda on the diagonal), L_ij = U_ij * (1 / D_j)
+ *   z = L^-1 b (forward), w = z / D (as z * (1 / D)), x = L^-T w (backward); sums in ascending k. */
+SPFE_DM int spfe_solve6(const double H[36], double lambda, const double b[6], double x[6]) {
+  double L[36], U[36], rD[6];
+  int ok = 1;
+  for (int j = 0; j < 6; ++j) {
+    for (int i = j; i < 6; ++i) {
       double s = H[i * 6 + j] + (i == j ? lambda : 0.0);
-      for (int k = 0; k < j; ++k) s -= L[i * 6 + k] * L[j * 6 + k];
-      if (i == j) {
-        if (!(s > 0.0)) return 0;
-        L[i * 6 + i] = sqrt(s);
-      } else {
-        L[i * 6 + j] = s / L[j * 6 + j];
-      }
+      for (int k = 0; k < j; ++k) s -= L[i * 6 + k] * U[j * 6 + k];
+      U[i * 6 + j] = s;
     }
-  double y[6];
+    ok &= U[j * 6 + j] > 0.0;
+    rD[j] = 1.0 / U[j * 6 + j];
+    for (int i = j + 1; i < 6; ++i) L[i * 6 + j] = U[i * 6 + j] * rD[j];
+  }
+  double z[6];
   for (int i = 0; i < 6; ++i) {
     double s = b[i];
-    for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * y[k];
-    y[i] = s / L[i * 6 + i];
+    for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * z[k];
+    z[i] = s;
   }
   for (int i = 5; i >= 0; --i) {
-    double s = y[i];
+    double s = z[i] * rD[i];
     for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * x[k];
-    x[i] = s / L[i * 6 + i];
+    x[i] = s;
   }
-  return 1;
+  if (!ok)
+    for (int i = 0; i < 6; ++i) x[i] = 0.0;
+  return ok;
 }
 
 /* Levenberg state + one trial's bookkeeping (OptimizationAlgorithmLevenberg::solve) */

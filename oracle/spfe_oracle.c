@@ -816,7 +816,9 @@ EXPORT float oracle_sum256(const float *v) { return spfe_sum256_host(v); }
  * Levenberg-Marquardt driver (SparseOptimizer::optimize(40), OptimizationAlgorithmLevenberg::solve,
  * BlockSolver_6_3 + LinearSolverDense on the single 6x6 pose block, RobustKernelHuber(0.9)).  g2o is a
  * catkin dependency that is NOT in /root/reference: PARITY UNPINNED — its published algorithm is restated
- * (arithmetic in include/spfe_dust_math.h, the control flow here), sequentially, edge by edge, as g2o loops.
+ * (arithmetic in include/spfe_dust_math.h, the control flow here).  The edges are visited in g2o's order; their
+ * contributions to chi2 / H / b are summed by the fixed-shape tree of include/spfe_dust_math.h (round 5: the shape the
+ * kernel evaluates in log time; before, a strict edge-order chain — neither is pinned by anything in /root/reference).
  *
  * dust [hc][wc] = Frame::dust_ (dense_dust_ of the extractor); pts [n][3] = MapPoint::GetWorldPos() floats;
  * Tcw_in / Tcw_out = Frame::mTcw, CV_32F 4x4 row-major; fx..cy = Frame::fx.. (floats, full resolution: the
@@ -824,18 +826,30 @@ EXPORT float oracle_sum256(const float *v) { return spfe_sum256_host(v); }
  * uv = dust_proj_u / dust_proj_v (:267-268; only meaningful for inliers).  Returns n_inlier (:258-270). */
 #include "../include/spfe_dust_math.h"
 
+/* the fixed-shape tree of include/spfe_dust_math.h over quantities q0 .. q0 + nq - 1 of the per-edge terms */
+static void dust_tree_sums(const double *terms /* [n][28] */, int n, int q0, int nq, double *out) {
+  for (int q = q0; q < q0 + nq; ++q) {
+    double slot[SPFE_DUST_SLOTS];
+    for (int t = 0; t < SPFE_DUST_SLOTS; ++t) {
+      slot[t] = 0.0;
+      for (int i = t; i < n; i += SPFE_DUST_SLOTS) slot[t] += terms[(size_t)i * SPFE_DUST_NSUM + q];
+    }
+    out[q] = spfe_dust_tree_total(slot);
+  }
+}
+
 static double dust_errors(const spfe_se3 *T, const float *pts, int n, double fx, double fy, double cx, double cy,
-                          const float *dust, int wc, int hc, double delta, spfe_dust_edge *ed) {
-  /* computeActiveErrors + activeRobustChi2: sum of rho[0] over the edges in insertion order */
-  double chi = 0.0;
+                          const float *dust, int wc, int hc, double delta, spfe_dust_edge *ed, double *terms) {
+  /* computeActiveErrors + activeRobustChi2: rho[0] of every edge, summed by the contract's tree */
+  const double J0[6] = {0, 0, 0, 0, 0, 0};
   for (int i = 0; i < n; ++i) {
     const double Xw[3] = {(double)pts[3 * i], (double)pts[3 * i + 1], (double)pts[3 * i + 2]};
     spfe_dust_error(T, Xw, fx, fy, cx, cy, dust, wc, hc, &ed[i]);
-    double rho[3];
-    spfe_huber(ed[i].err * ed[i].err, delta, rho);
-    chi += rho[0];
+    spfe_dust_terms(ed[i].err, J0, delta, terms + (size_t)i * SPFE_DUST_NSUM);
   }
-  return chi;
+  double tot[SPFE_DUST_NSUM];
+  dust_tree_sums(terms, n, 0, 1, tot);
+  return tot[0];
 }
 
 static int align_dust_core(const float *dust, int hc, int wc, const float *pts, int n, const float *Tcw_in,
@@ -847,22 +861,22 @@ static int align_dust_core(const float *dust, int hc, int wc, const float *pts, 
   spfe_se3 T;
   spfe_se3_from_f32(Tcw_in, &T);
   spfe_dust_edge *ed = (spfe_dust_edge *)calloc((size_t)(n > 0 ? n : 1), sizeof(spfe_dust_edge));
+  double *terms = (double *)calloc((size_t)(n > 0 ? n : 1) * SPFE_DUST_NSUM, sizeof(double));
   spfe_lm lm = {0.0, 2.0};
   int it_done = 0, ok = 1;
   for (int it = 0; it < max_iterations && ok && n > 0; ++it) {   /* no edges: nothing active, the pose is echoed */
-    double currentChi = dust_errors(&T, pts, n, fx, fy, cx, cy, dust, wc, hc, delta, ed);
-    /* buildSystem: linearizeOplus + constructQuadraticForm of every edge */
-    double H[36] = {0}, b[6] = {0};
+    double currentChi = dust_errors(&T, pts, n, fx, fy, cx, cy, dust, wc, hc, delta, ed, terms);
+    /* buildSystem: linearizeOplus + constructQuadraticForm of every edge, summed by the contract's tree */
+    double H[36], b[6], tot[SPFE_DUST_NSUM], chi_again;
     for (int i = 0; i < n; ++i) {
       const double Xw[3] = {(double)pts[3 * i], (double)pts[3 * i + 1], (double)pts[3 * i + 2]};
-      double J[6], rho[3];
+      double J[6];
       spfe_dust_jacobian(&T, Xw, fx, fy, cx, cy, dust, wc, hc, ed[i].level, J);
-      spfe_huber(ed[i].err * ed[i].err, delta, rho);
-      for (int j = 0; j < 6; ++j) {
-        b[j] -= (rho[1] * J[j]) * ed[i].err;
-        for (int k = 0; k < 6; ++k) H[j * 6 + k] += (J[j] * rho[1]) * J[k];
-      }
+      spfe_dust_terms(ed[i].err, J, delta, terms + (size_t)i * SPFE_DUST_NSUM);
     }
+    dust_tree_sums(terms, n, 0, SPFE_DUST_NSUM, tot);
+    spfe_dust_unpack(tot, &chi_again, H, b);
+    (void)chi_again;   /* q[0] of the build pass is the same rho0: the same tree, the same bits as currentChi */
     if (it == 0) {
       double maxDiagonal = 0;
       for (int j = 0; j < 6; ++j) maxDiagonal = fabs(H[j * 6 + j]) > maxDiagonal ? fabs(H[j * 6 + j]) : maxDiagonal;
@@ -876,7 +890,7 @@ static int align_dust_core(const float *dust, int hc, int wc, const float *pts, 
       double x[6] = {0, 0, 0, 0, 0, 0};
       const int ok2 = spfe_solve6(H, lm.lambda, b, x);
       if (ok2) spfe_se3_oplus(&T, x);
-      double tempChi = dust_errors(&T, pts, n, fx, fy, cx, cy, dust, wc, hc, delta, ed);
+      double tempChi = dust_errors(&T, pts, n, fx, fy, cx, cy, dust, wc, hc, delta, ed, terms);
       if (!ok2) tempChi = DBL_MAX;
       if (spfe_lm_judge(&lm, currentChi, tempChi, x, b, &rho)) currentChi = tempChi;   /* discardTop */
       else T = saved;                                                                    /* pop */
@@ -906,6 +920,7 @@ static int align_dust_core(const float *dust, int hc, int wc, const float *pts, 
   }
   if (iterations) *iterations = it_done;
   free(ed);
+  free(terms);
   return n_inlier;
 }
 

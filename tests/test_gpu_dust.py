@@ -1,8 +1,8 @@
 """GPU: direct "dust" alignment (spfe_align_dust, csrc/dust.hip) against the CPU oracle
 (oracle_align_dust — Optimizer::PoseOptimizationDust, optimizer_dust.cpp:170-294; g2o restated, PARITY UNPINNED).
 
-Both sides evaluate include/spfe_dust_math.h and sum the edges in the same order, so they differ only through
-the device's sin / cos / sqrt / division in the exponential map and the solve (<= 1 ulp each).  Tolerances:
+Both sides evaluate include/spfe_dust_math.h and sum the edges by the same fixed-shape tree (round 5), so they differ only
+through the device's sin / cos / sqrt / division in the exponential map and the solve (<= 1 ulp each).  Tolerances:
 pose 1e-5 (absolute, 4x4 float), projections 1e-3 cell, inlier flags equal except where chi2 is within 1e-6 of
 the 0.9 threshold, iteration count equal."""
 import numpy as np
@@ -38,7 +38,8 @@ def _compare(g, r, dust):
 
 @pytest.mark.parametrize("H,W,n,seed", [(480, 752, 160, 0), (480, 752, 200, 1), (480, 640, 97, 2), (720, 1280, 300, 3),
                                         (480, 752, 512, 4), (480, 752, 1, 5), (120, 160, 40, 6),
-                                        (1080, 1920, 160, 8)])   # (32,400 cells: the map no longer fits in LDS, read through L2)
+                                        (1080, 1920, 160, 8),     # 32,400 cells: the largest standard map that fits in LDS
+                                        (1440, 2560, 160, 9)])    # 57,600 cells: the map does not fit in LDS, read through L2
 def test_align_dust_matches_oracle(H, W, n, seed):
     sc = dust_scene.make_scene(seed, H=H, W=W, n_points=n, cx=W / 2 - 8.8, cy=H / 2 + 8.4)
     ext = SPExtractor(100, H, W, weights.synthetic(7, "dense"), with_heat=False)
