@@ -39,11 +39,92 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dens
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 
 
+CLOCK_PROBE = os.path.join(ROOT, "tools", "microbench", "bin", "clock_probe")
+_sustained = {}   # dtype -> {"tflops", "ghz"}: the last probe's figures (device of this rank)
+
+
+def clock_probe(device):
+    """Bare MFMA rate the part sustains per dtype, right now (tools/microbench/clock_probe --json: random operands, one
+    wavefront per SIMD on every CU, ~50 ms per dtype after a warm-up launch of the same length; its own process on the same
+    device).  The nominal-clock peaks (157.3 / 2500 TFLOP/s) assume 2.4 GHz; under dense MFMA the chip holds 1.9 - 2.2 GHz
+    depending on the box and on the dtype, so every `frac` of the line is printed beside `frac_of_sustained`.  Returns the
+    probe's dict, or {"error": ...}."""
+    import subprocess
+    if not os.path.exists(CLOCK_PROBE):
+        return {"error": "tools/microbench/bin/clock_probe not built (__graft_entry__.build())"}
+    try:
+        r = subprocess.run([CLOCK_PROBE, "--json", str(device)], capture_output=True, text=True, timeout=60)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:   # noqa: BLE001 — a diagnostic leg must not cost the line
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    for k in ("f32", "bf16"):
+        if k in d:
+            _sustained[k] = d[k]
+    return d
+
+
+class SclkSampler:
+    """Shader clock of the device during a timed region, read from the driver's sysfs node (pp_dpm_sclk: the line marked
+    `*` is the level the SMU reports) every ~2 ms by a thread — min / avg / max MHz, or None where the node is absent."""
+
+    def __init__(self, torch, device):
+        import glob
+        self.paths, self.samples, self._stop, self._th = [], [], False, None
+        try:   # the card whose PCI function (…/0000:BB:DD.F) carries this device's bus number
+            bus = int(getattr(torch.cuda.get_device_properties(device), "pci_bus_id"))
+        except Exception:   # noqa: BLE001
+            bus = None
+        cands = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        if bus is not None:
+            def bus_of(c):
+                parts = os.path.basename(os.path.realpath(os.path.dirname(c))).split(":")
+                try:
+                    return int(parts[1], 16)
+                except (IndexError, ValueError):
+                    return None
+            cands = [c for c in cands if bus_of(c) == bus] or cands
+        self.paths = cands[:1]
+
+    @staticmethod
+    def _read(path):
+        with open(path) as f:
+            for ln in f:
+                if "*" in ln:
+                    return float(ln.split(":")[1].strip().lower().replace("mhz", "").replace("*", "").strip())
+        return None
+
+    def start(self):
+        if not self.paths:
+            return
+        import threading
+
+        def run():
+            while not self._stop:
+                try:
+                    v = self._read(self.paths[0])
+                    if v:
+                        self.samples.append(v)
+                except Exception:   # noqa: BLE001
+                    return
+                time.sleep(0.002)
+        self._th = threading.Thread(target=run, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        self._stop = True
+        if self._th:
+            self._th.join(timeout=1.0)
+        if not self.samples:
+            return None
+        s = self.samples
+        return {"min": min(s), "avg": round(sum(s) / len(s), 1), "max": max(s), "samples": len(s), "source": self.paths[0]}
+
+
 def conv1b_flop(H, W):
     return 2 * H * W * 64 * 64 * 9
 
 
-def path_tflops(ext, fps, H, W, B):
+def path_tflops(ext, fps, H, W, B, precision=None):
     """Whole-path TFLOP/s = EXECUTED flops per frame x frames/s.  The descriptor head (convDb, 2 x 256 x 256 flops per coarse
     cell) runs on the cells the emitted keypoints' bilinear taps read only (libspfe's gathered head, on by default in f32
     mode and for bf16 frames of >= 10,000 cells): the rows it skips are not counted.  `dense_graph` is the reference's dense
@@ -59,9 +140,15 @@ def path_tflops(ext, fps, H, W, B):
     except Exception:
         frac, gathered, da = 1.0, False, False
     executed = nominal - (1.0 - frac) * C * (2 * 256 * 256 + (2 * 9 * 128 * 256 if da else 0))
-    return {"whole_path_tflops": round(fps * executed / 1e12, 2),
-            "whole_path_tflops_dense_graph": round(fps * nominal / 1e12, 2),
-            "descriptor_head": {"convDb_gathered": gathered, "convDa_gathered": da, "cells_computed_frac": round(frac, 4)}}
+    out = {"whole_path_tflops": round(fps * executed / 1e12, 2),
+           "whole_path_tflops_dense_graph": round(fps * nominal / 1e12, 2),
+           "descriptor_head": {"convDb_gathered": gathered, "convDa_gathered": da, "cells_computed_frac": round(frac, 4)}}
+    if precision:   # executed flops of the whole path against the nominal-clock MFMA peak and against what this box sustains
+        peak = PEAK_BF16_MFMA_TFLOPS if precision == "bf16" else PEAK_F32_MFMA_TFLOPS
+        sus = _sustained.get(precision)
+        out["whole_path_frac_of_peak"] = round(fps * executed / 1e12 / peak, 4)
+        out["whole_path_frac_of_sustained"] = round(fps * executed / 1e12 / sus["tflops"], 4) if sus else None
+    return out
 
 
 def file_sha16(path):
@@ -97,8 +184,9 @@ def traffic_of(precision, H, W, B):
     return stamped_traffic("conv1b_traffic.json", ["conv_f32.hip"], H, W, B)
 
 
-def run_timed(ext, sharded, d_img, stream, steps, warmup, world, dist, torch):
-    """W untimed + K timed steps bracketed by barrier + synchronize; returns seconds (max over ranks)."""
+def run_timed(ext, sharded, d_img, stream, steps, warmup, world, dist, torch, sampler=None):
+    """W untimed + K timed steps bracketed by barrier + synchronize; returns seconds (max over ranks).  `sampler`: an
+    SclkSampler started when the timed region starts (a host thread reading a sysfs node: nothing on the device)."""
     for _ in range(warmup):
         sharded.step(d_img, stream)
     sharded.flush(stream)
@@ -107,6 +195,8 @@ def run_timed(ext, sharded, d_img, stream, steps, warmup, world, dist, torch):
         dist.barrier()
     torch.cuda.synchronize()
     ext.stage_reset()
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     for _ in range(steps):
         sharded.step(d_img, stream)
@@ -150,10 +240,15 @@ def roofline_of(precision, stages, H, W, B, traffic, tile=(8, 1.0)):
     flop = (conv1b_flop(H, W) + (2 * H * W * 64 * 9 if bf16 else 0)) * share
     ach = (flop * B / t_conv1b / 1e12) if t_conv1b > 0 else None
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    sus = _sustained.get("bf16" if bf16 else "f32")
     return {"bound": "mfma", "kernel": ("conv_bf16_ws_kernel<true,2> (conv1b with conv1a computed by its producer waves)" if bf16 else
                                         "conv_f32_kernel<1,64,3,16,4,1,%d,2,true,true> (conv1b, %d-row tiles)" % (tile_rows // 4, tile_rows)),
             "achieved": round(ach, 2) if ach else None, "peak": peak, "unit": "TFLOP/s",
             "frac": round(ach / peak, 4) if ach else None, "traffic": traffic,
+            # the bare-MFMA rate this box sustained for this dtype in the probe nearest to this leg (clock_probe()): what the
+            # nominal-clock `peak` shrinks to under load here, and the kernel's fraction of THAT
+            "mfma_sustained_tflops": sus["tflops"] if sus else None, "mfma_sustained_ghz": sus["ghz"] if sus else None,
+            "frac_of_sustained": round(ach / sus["tflops"], 4) if (ach and sus) else None,
             "kernel_ms": round(t_conv1b * 1e3, 4), "share_of_conv1b_in_this_launch": round(share, 4)}
 
 
@@ -188,16 +283,19 @@ def device_leg(ctx, precision, H, W, B, seed0, steps, warmup, what):
                       async_cov=not ctx["sync_cov"], precision=precision)
     d = torch.from_numpy(synth.make_batch(seed0, B, H, W)).cuda()
     sh = parallel.ShardedExtractor(ext, 1, 0, B)
-    dt = run_timed(ext, sh, d, ctx["stream"], steps, warmup, 1, ctx["dist"], torch)
+    smp = SclkSampler(torch, ctx["local"])
+    dt = run_timed(ext, sh, d, ctx["stream"], steps, warmup, 1, ctx["dist"], torch, smp)
+    sclk = smp.stop()
     st = ext.stage_times()
     r = sh.decode(0)
     ok = bool(0 < r.K <= ctx["nf"] + 1 and r.status == 0)
     fps = B * steps / dt
+    clock_probe(ctx["local"])   # the rate the box sustains right behind this leg (-> roofline_of, path_tflops)
     out = {"what": "%s, %d timed steps after %d untimed" % (what, steps, warmup),
            "value": round(fps, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 4), "dtype": precision,
            "roofline": roofline_of(precision, st, H, W, B, traffic_of(precision, H, W, B), conv1b_rows(ext, precision, H, B)),
-           "records_ok": ok}
-    out.update(path_tflops(ext, fps, H, W, B))
+           "sclk_mhz": sclk, "records_ok": ok}
+    out.update(path_tflops(ext, fps, H, W, B, precision))
     ext.close()
     del d
     os.environ["SPFE_STAGE_TIMING"] = "0"
@@ -665,8 +763,13 @@ def main():
     ctx = dict(torch=torch, dist=dist, parallel=parallel, synth=synth, SPExtractor=SPExtractor, nf=nf, blob=blob, local=local,
                sync_cov=args.sync_cov, stream=stream, world=world, rank=rank)
 
-    dt = run_timed(ext, sharded, d_img, stream, args.steps, args.warmup, world, dist, torch)
+    smp = SclkSampler(torch, local) if rank == 0 else None
+    dt = run_timed(ext, sharded, d_img, stream, args.steps, args.warmup, world, dist, torch, smp)
+    sclk = smp.stop() if smp else None
     stages = ext.stage_times()
+    # the MFMA rate this box sustains per dtype, measured right behind the headline (rank 0's device; the other ranks idle
+    # in the barrier of the legs below meanwhile)
+    probe = clock_probe(local) if rank == 0 else None
 
     # sanity: the gathered records decode and carry the expected keypoint counts
     rec0 = sharded.decode(0)
@@ -698,8 +801,12 @@ def main():
                                   "ncclAllGather inside libspfe (spfe_allgather_records)" if getattr(sharded, "_native", False)
                                   else "torch.distributed all_gather_into_tensor")},
             "roofline": roofline_of(args.precision, stages, H, W, B, traffic_of(args.precision, H, W, B), conv1b_rows(ext, args.precision, H, B)),
+            # tools/microbench/clock_probe --json right behind the timed region: bare MFMA TFLOP/s and shader GHz per dtype on
+            # random operands (nominal: 157.3 / 2500 TFLOP/s at 2.4 GHz) — a slow box and a regression read differently here
+            "mfma_sustained": probe,
+            "sclk_mhz": sclk,   # the SMU's reported shader clock level during the timed region (sysfs pp_dpm_sclk), or null
         }
-        out.update(path_tflops(ext, fps, H, W, B))
+        out.update(path_tflops(ext, fps, H, W, B, args.precision))
 
     if world > 1:
         # ---- N > 1: self-verification legs (every rank takes part), then ONE line, a barrier, and only then teardown

@@ -31,6 +31,7 @@ int main(int argc, char **argv) {
   tracking::num_features = atoi(argv[5]);
   common::model_path = argv[1];
   const int calls = atoi(argv[6]), warm = atoi(argv[7]);
+  if (calls < 1 || warm < 0) return 2;   // (the percentiles below index a non-empty list)
   const int H = camera::height, W = camera::width;
   std::vector<unsigned char> pix((size_t)H * W);
   FILE *f = fopen(argv[2], "rb");
