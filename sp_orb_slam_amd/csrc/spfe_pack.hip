@@ -1,0 +1,549 @@
+// spfe_pack.hip — construction of a handle: the weight blob (register_module order, sp_extractor.cpp:46-62) packed into each
+// kernel family's device tables, the activation / scratch / record buffers, streams and events (SPExtractor's constructor,
+// /root/reference/orb_slam2/src/cv/sp_extractor.cpp:342-359).
+#include "spfe_host.h"
+
+namespace spfe_host {
+
+void make_layout(int kmax, int C, bool desc_bf16, spfe::RecordLayout *r) {
+  size_t o = 0;
+  r->kmax = kmax;
+  r->desc_bf16 = desc_bf16 ? 1 : 0;
+  r->off_hdr = o; o += 16;
+  r->off_xy = o; o = align_up(o + (size_t)kmax * 2 * 4, 16);
+  r->off_resp = o; o = align_up(o + (size_t)kmax * 4, 16);
+  r->off_cov = o; o = align_up(o + (size_t)kmax * 2 * 4, 16);
+  r->off_cinv = o; o = align_up(o + (size_t)kmax * 2 * 4, 16);
+  r->off_desc = o; o = align_up(o + (size_t)kmax * SPFE_DESC_DIM * (desc_bf16 ? 2 : 4), 16);
+  r->off_occ = o; o = align_up(o + (size_t)C * 2, 16);
+  r->off_dd = o; o = align_up(o + (size_t)C * 4, 16);
+  r->off_sd = o; o = align_up(o + (size_t)C * 4, 16);
+  r->bytes = align_up(o, 256);
+}
+
+// offsets into the flat blob (register_module order, sp_extractor.cpp:46-62)
+size_t blob_weight_offset(int l) {
+  size_t off = 0;
+  for (int i = 0; i < l; ++i) {
+    const spfe_layer_t &L = SPFE_LAYERS[i];
+    off += (size_t)L.cout * L.cin * L.ksize * L.ksize + L.cout;
+  }
+  return off;
+}
+
+// pack OIHW weights of one or two layers (concatenated along cout) into slabs
+// [nblk][chunk][n-tile(2)][tap][KC][32] (K order of spfe_exact_math.h) + padded bias
+int pack_layer(spfe_handle h, const float *blob, const int *lids, int nl, ConvLayer *out) {
+  const spfe_layer_t &L0 = SPFE_LAYERS[lids[0]];
+  const int cin = L0.cin, ks = L0.ksize, taps = ks * ks;
+  int cout = 0;
+  for (int i = 0; i < nl; ++i) cout += SPFE_LAYERS[lids[i]].cout;
+  const int kc = spfe::conv_kc(ks), nchunk = cin / kc, nblk = (cout + 63) / 64;
+  std::vector<float> w((size_t)nblk * nchunk * taps * kc * 64, 0.0f), bia((size_t)nblk * 64, 0.0f);
+  int co_base = 0;
+  for (int i = 0; i < nl; ++i) {
+    const spfe_layer_t &L = SPFE_LAYERS[lids[i]];
+    const float *W = blob + blob_weight_offset(lids[i]);
+    const float *Bv = W + (size_t)L.cout * L.cin * taps;
+    for (int co = 0; co < L.cout; ++co) {
+      const int g = co_base + co, nb = g / 64, j = g % 64;
+      bia[g] = Bv[co];
+      for (int ci = 0; ci < cin; ++ci) {
+        const int ch = ci / kc, c = ci % kc;
+        for (int t = 0; t < taps; ++t)
+          w[(((((size_t)nb * nchunk + ch) * 2 + j / 32) * taps + t) * kc + c) * 32 + j % 32] =
+              W[((size_t)co * cin + ci) * taps + t];
+      }
+    }
+    co_base += L.cout;
+  }
+  int rc;
+  if ((rc = dev_alloc(h, &out->d_w, w.size()))) return rc;
+  if ((rc = dev_alloc(h, &out->d_b, bia.size()))) return rc;
+  HIP_TRY(hipMemcpy(out->d_w, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(out->d_b, bia.data(), bia.size() * 4, hipMemcpyHostToDevice));
+  out->cin = cin;
+  out->cout_real = cout;
+  out->nblk = nblk;
+  out->ks = ks;
+  return SPFE_OK;
+}
+
+unsigned short host_bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+// bf16 slabs for conv_bf16.hip: [nblk][chunk of 32 channels][tap][n 64][80-byte row: 32 bf16 + pad],
+// each slab padded to conv_bf16_slab_bytes(); bias stays f32
+int pack_layer_bf16(spfe_handle h, const float *blob, const int *lids, int nl, ConvLayer *out) {
+  const spfe_layer_t &L0 = SPFE_LAYERS[lids[0]];
+  const int cin = L0.cin, taps = 9;
+  int cout = 0;
+  for (int i = 0; i < nl; ++i) cout += SPFE_LAYERS[lids[i]].cout;
+  const int nchunk = cin / 32, nblk = (cout + 63) / 64;
+  const size_t slab = spfe::conv_bf16_slab_bytes();
+  std::vector<unsigned char> w((size_t)nblk * nchunk * slab, 0);
+  std::vector<float> bia((size_t)nblk * 64, 0.0f);
+  int co_base = 0;
+  for (int i = 0; i < nl; ++i) {
+    const spfe_layer_t &L = SPFE_LAYERS[lids[i]];
+    const float *W = blob + blob_weight_offset(lids[i]);
+    const float *Bv = W + (size_t)L.cout * L.cin * taps;
+    for (int co = 0; co < L.cout; ++co) {
+      // row of the 64-channel block: even channels fill accumulator tile 0, odd ones tile 1 (the kernels pack a lane's
+      // channel pair into one dword store); the bias stays in channel order
+      const int g = co_base + co, nb = g / 64, c64 = g % 64, j = (c64 & 1) * 32 + (c64 >> 1);
+      bia[g] = Bv[co];
+      for (int ci = 0; ci < cin; ++ci) {
+        const int ch = ci / 32, c = ci % 32;
+        for (int t = 0; t < taps; ++t) {
+          const unsigned short v = host_bf16_rne(W[((size_t)co * cin + ci) * taps + t]);
+          // row (tap, cout) = 64 B: 4 pieces of 8 channels, piece g in slot g ^ ((cout >> 2) & 3) (conv_bf16.hip's LDS layout)
+          memcpy(&w[((size_t)nb * nchunk + ch) * slab + ((size_t)t * 64 + j) * 64 + (((c / 8) ^ ((j >> 2) & 3)) * 16) + (c % 8) * 2], &v, 2);
+        }
+      }
+    }
+    co_base += L.cout;
+  }
+  int rc;
+  unsigned char *dw = nullptr;
+  if ((rc = dev_alloc(h, &dw, w.size()))) return rc;
+  if ((rc = dev_alloc(h, &out->d_b, bia.size()))) return rc;
+  HIP_TRY(hipMemcpy(dw, w.data(), w.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(out->d_b, bia.data(), bia.size() * 4, hipMemcpyHostToDevice));
+  out->d_w = reinterpret_cast<float *>(dw);
+  out->cin = cin;
+  out->cout_real = cout;
+  out->nblk = nblk;
+  out->ks = 3;
+  return SPFE_OK;
+}
+
+// conv_bf16_ws.hip layout: [nblk][tap][cout 64][8 pieces of 8 cin, piece g in slot g ^ ((cout >> 1) & 7)]
+int pack_layer_bf16_ws(spfe_handle h, const float *blob, int lid, unsigned char **out) {
+  const spfe_layer_t &L = SPFE_LAYERS[lid];
+  if (L.cin != 64 || L.ksize != 3 || L.cout % 64) return fail(SPFE_EINVAL, "internal: layer %d is not a Cin = 64 3x3 layer", lid);
+  const size_t blk = spfe::conv_bf16_ws_weight_bytes();
+  std::vector<unsigned char> w((size_t)(L.cout / 64) * blk, 0);
+  const float *W = blob + blob_weight_offset(lid);
+  for (int co = 0; co < L.cout; ++co)
+    for (int ci = 0; ci < 64; ++ci)
+      for (int t = 0; t < 9; ++t) {
+        const unsigned short v = host_bf16_rne(W[((size_t)co * 64 + ci) * 9 + t]);
+        // row of the block: even channels fill accumulator tile 0, odd ones tile 1 (conv_bf16_ws.hip's epilogue
+        // packs a lane's channel pair into one dword store)
+        const int c64 = co % 64, j = (c64 & 1) * 32 + (c64 >> 1), slot = (ci / 8) ^ ((j >> 1) & 7);
+        memcpy(&w[(size_t)(co / 64) * blk + ((size_t)t * 64 + j) * 128 + slot * 16 + (ci % 8) * 2], &v, 2);
+      }
+  int rc;
+  if ((rc = dev_alloc(h, out, w.size()))) return rc;
+  HIP_TRY(hipMemcpy(*out, w.data(), w.size(), hipMemcpyHostToDevice));
+  return SPFE_OK;
+}
+
+// conv_bf16_rw.hip layout for a Cin = 128 layer (or two concatenated ones: convPa | convDa)
+int pack_layer_bf16_rw(spfe_handle h, const float *blob, const int *lids, int nl, unsigned char **out) {
+  int cout = 0;
+  for (int i = 0; i < nl; ++i) {
+    const spfe_layer_t &L = SPFE_LAYERS[lids[i]];
+    if (L.cin != 128 || L.ksize != 3) return fail(SPFE_EINVAL, "internal: layer %d is not a Cin = 128 3x3 layer", lids[i]);
+    cout += L.cout;
+  }
+  if (cout % 128) return fail(SPFE_EINVAL, "internal: %d output channels are not whole 128-channel groups", cout);
+  std::vector<unsigned short> wb((size_t)cout * 128 * 9);
+  size_t o = 0;
+  for (int i = 0; i < nl; ++i) {
+    const spfe_layer_t &L = SPFE_LAYERS[lids[i]];
+    const float *W = blob + blob_weight_offset(lids[i]);
+    for (size_t k = 0; k < (size_t)L.cout * 128 * 9; ++k) wb[o++] = host_bf16_rne(W[k]);
+  }
+  std::vector<unsigned char> w((size_t)(cout / 128) * spfe::conv_bf16_rw_weight_bytes());
+  spfe::conv_bf16_rw_pack_weights(wb.data(), cout, w.data());
+  int rc;
+  if ((rc = dev_alloc(h, out, w.size()))) return rc;
+  HIP_TRY(hipMemcpy(*out, w.data(), w.size(), hipMemcpyHostToDevice));
+  return SPFE_OK;
+}
+
+int load_blob(const spfe_config *cfg, std::vector<float> *blob) {
+  blob->resize(SPFE_NUM_PARAMS);
+  if (cfg->weights) {
+    memcpy(blob->data(), cfg->weights, (size_t)SPFE_NUM_PARAMS * 4);
+    return SPFE_OK;
+  }
+  if (!cfg->weights_path) return fail(SPFE_EWEIGHTS, "no weights: both weights and weights_path are NULL");
+  FILE *f = fopen(cfg->weights_path, "rb");
+  if (!f) return fail(SPFE_EWEIGHTS, "cannot open weight file %s", cfg->weights_path);
+  unsigned char head[16];
+  uint32_t ver = 0;
+  uint64_t n = 0;
+  bool ok = fread(head, 1, 16, f) == 16 && memcmp(head, "SPFW", 4) == 0;
+  if (ok) {
+    memcpy(&ver, head + 4, 4);
+    memcpy(&n, head + 8, 8);
+    ok = ver == 1 && n == SPFE_NUM_PARAMS && fread(blob->data(), 4, n, f) == n;
+  }
+  fclose(f);
+  if (!ok) return fail(SPFE_EWEIGHTS, "%s is not a valid SPFW v1 file with %d params", cfg->weights_path, SPFE_NUM_PARAMS);
+  return SPFE_OK;
+}
+
+int build(spfe_handle h, const spfe_config *cfg) {
+  h->cfg = *cfg;
+  h->H = cfg->height; h->W = cfg->width;
+  h->hc = h->H / 8; h->wc = h->W / 8; h->C = h->hc * h->wc;
+  h->kmax = cfg->num_features + 1;
+  h->B = cfg->max_batch;
+  h->bf16 = cfg->precision == SPFE_PRECISION_BF16;
+  const int H = h->H, W = h->W, B = h->B, C = h->C;
+  HIP_TRY(hipSetDevice(cfg->device));
+  {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    h->num_cus = prop.multiProcessorCount;
+    const char *genv = getenv("SPFE_CONV_GRID");
+    if (genv) h->num_cus = atoi(genv);
+  }
+  HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  {
+    // SPFE_SIDE_PRIORITY (probe knob): -1 = the side stream at the device's highest priority, 1 = lowest, unset / 0 = default
+    const char *pe = getenv("SPFE_SIDE_PRIORITY");
+    const int want = pe ? atoi(pe) : 0;
+    int lo = 0, hi = 0;   // (numerically: greatest priority = lowest value)
+    // SPFE_SIDE_CUS=N: the side stream (selection, descriptors, covariance) confined to the last N of the device's CUs
+    // (hipExtStreamCreateWithCUMask; mask bit i <-> CU i / 8 of XCD i % 8: tools/microbench/cumask_probe.hip), so that its
+    // long-lived small workgroups cannot sit on every CU while the convolutions of the next batch want whole CUs
+    const char *ce = getenv("SPFE_SIDE_CUS");
+    int side_cus = ce ? atoi(ce) : h->side_cus_default;
+    hipDeviceProp_t prop;
+    if (side_cus > 0 && hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount >= 64 &&
+        side_cus < prop.multiProcessorCount) {
+      const int ncu = prop.multiProcessorCount;
+      std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+      for (int b = ncu - side_cus; b < ncu; ++b) mask[b / 32] |= 1u << (b % 32);
+      if (hipExtStreamCreateWithCUMask(&h->side, (uint32_t)mask.size(), mask.data()) != hipSuccess) h->side = nullptr;
+    }
+    if (h->side) {
+    } else if (want && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+      HIP_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, want < 0 ? hi : lo));
+    else
+      HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+  }
+  for (int i = 0; i < spfe_handle_s::NTICKET; ++i) {
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_post[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_cov[i], hipEventDisableTiming));
+  }
+  HIP_TRY(hipEventCreateWithFlags(&h->ev_desc, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  if (const char *e = getenv("SPFE_F32_SPLIT")) h->f32_split = atoi(e);
+  if (const char *e = getenv("SPFE_DESC_IN_REPLAY")) h->desc_in_replay = atoi(e);
+  if (const char *e = getenv("SPFE_BF16_SPLIT")) h->bf16_split = atoi(e);
+  HIP_TRY(hipEventCreateWithFlags(&h->ev_db, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&h->ev_sel, hipEventDisableTiming));
+  for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&h->ev_dbs[i], hipEventDisableTiming));
+  // Measured, pipelined, 8 frames per call (same-box A/B): bf16 1280x720 +2.5 ... 3.8 % (7590 -> 7780, 7322 -> 7604 frames/s),
+  // f32 752x480 +0.4 ... 0.7 %, bf16 752x480 -2 ... 3 %: there the launch stream runs as two half batches on two streams, the
+  // dense head (HBM-bound) hid completely beside the other half's convolutions (removing it altogether gains nothing), and
+  // the gathered launch is pure extra work for the chip.  So: f32, and bf16 frames of >= 10,000 cells (= no two-stream split).
+  // SYNCHRONOUS calls of those small bf16 frames take the gathered branch all the same (round 4): there is no other half
+  // batch to hide the dense head beside, and the gathered form brings the inline chain with it (enqueue_post) — 752x480:
+  // a single frame's p50 0.287 -> 0.264 ... 0.274 ms, 8 frames per synchronous call +0.5 ... 0.8 %; 640x480: 0.311 -> 0.288
+  // ms, +2.4 %.  SPFE_SPARSE_DB = 0 never, 1 every call, 2 synchronous calls only
+  h->sparse_db = true;
+  h->sparse_db_sync_only = h->bf16 && h->C < 10000;
+  h->db_tiles_per_wg = h->bf16 ? 4 : 1;
+  if (const char *e = getenv("SPFE_SPARSE_DB")) { h->sparse_db = atoi(e) != 0; h->sparse_db_sync_only = atoi(e) == 2; }
+  // the gathered kernels form row byte offsets in 32 bits (the head activations' rows are 2048 / 1024 bytes, 0x80000000 is their
+  // out-of-range marker): batches beyond that take the dense head (the launchers refuse them as well)
+  if ((size_t)cfg->max_batch * h->C * (h->bf16 ? 1024 : 2048) >= ((size_t)1 << 31)) h->sparse_db = false;
+  if (const char *e = getenv("SPFE_DB_TILES_PER_WG")) h->db_tiles_per_wg = atoi(e);
+  if (const char *de = getenv("SPFE_DEFER_DB")) h->defer_db = atoi(de) != 0;
+  if (const char *de = getenv("SPFE_DEFER_JOIN")) h->defer_join = atoi(de) != 0;
+  {
+    const char *fenv = getenv("SPFE_FUSE_CONV1A");
+    h->fuse1a = fenv && atoi(fenv) != 0;
+    const char *menv = getenv("SPFE_TILE16_MASK");
+    if (menv) h->tile16_mask = (unsigned)strtoul(menv, nullptr, 0);
+    if (const char *m2 = getenv("SPFE_TILE2_MASK")) h->tile2_mask = (unsigned)strtoul(m2, nullptr, 0);
+    if (const char *m4 = getenv("SPFE_TILE16X4")) h->tile16x4 = atoi(m4);
+    if (const char *a2 = getenv("SPFE_TILE2_AUTO")) h->tile2_auto = atoi(a2) != 0;
+    if (const char *ps = getenv("SPFE_POOL_SPLIT")) h->pool_split = atoi(ps);
+    if (const char *km = getenv("SPFE_KC")) h->kc_mask = (int)strtol(km, nullptr, 0);
+    const char *wenv = getenv("SPFE_BF16_WS_MASK");
+    if (wenv) h->ws_mask = (unsigned)strtoul(wenv, nullptr, 0) & 0xfu;
+    const char *f16env = getenv("SPFE_BF16_FUSE_CONV1A");
+    if (f16env) h->fuse1a_bf16 = atoi(f16env) != 0;
+    // Synchronous calls (latency): the wave-specialised kernel wins from ~5 items per workgroup (batch 1 at 752x480: 0.43 ->
+    // 0.385 ms, conv1a fused).  Pipelined calls (SPFE_FLAG_ASYNC_COV): it holds all of a CU's LDS, the side-stream kernels of
+    // the previous batch cannot start beside it, and at 752x480 x 8 (0.65 ms steps) their chain becomes the critical path
+    // when the quarter-resolution layers take it too (12,450 -> 12,050 frames/s): those keep the higher bar.
+    // (the bar is picked per call: spfe_submit_batch pipelines on a handle created without the flag)
+    const char *ienv = getenv("SPFE_BF16_WS_MIN_ITEMS");
+    if (ienv) h->ws_min_items = h->ws_min_items_sync = atoi(ienv);
+    const char *t16env = getenv("SPFE_BF16_TILE16_MIN_ITEMS");
+    if (t16env) h->tile16_min_items = atoi(t16env);
+    const char *trenv = getenv("SPFE_BF16_TILE_ROWS");
+    if (trenv) h->tile_rows_big = atoi(trenv);
+    const char *denv = getenv("SPFE_BF16_DYN_QUEUE");
+    if (denv) h->bf16_dyn = atoi(denv) != 0;
+    if (const char *e = getenv("SPFE_BF16_RW")) h->bf16_rw = atoi(e) != 0;
+    if (const char *e = getenv("SPFE_BF16_RW_MIN4")) h->rw_min4 = atoi(e);
+    if (const char *e = getenv("SPFE_BF16_RW_ROWS3")) h->rw_rows3 = atoi(e);
+    if (const char *e = getenv("SPFE_BF16_RW_MIN2")) h->rw_min2 = atoi(e);
+  }
+  const char *tenv = getenv("SPFE_STAGE_TIMING");
+  h->timing = tenv && atoi(tenv) != 0;
+  h->timing_all = !(tenv && atoi(tenv) == 2);
+  if (h->timing) {
+    h->evpool.resize((size_t)spfe_handle_s::EVSETS * (NSTAGE + 1), nullptr);
+    for (auto &e : h->evpool) HIP_TRY(hipEventCreate(&e));
+  }
+
+  std::vector<float> blob;
+  int rc = load_blob(cfg, &blob);
+  if (rc) return rc;
+
+  // conv1a weights: [tap][64]
+  {
+    const float *Wt = blob.data() + blob_weight_offset(0);
+    std::vector<float> w(9 * 64), bv(64);
+    for (int co = 0; co < 64; ++co) {
+      for (int t = 0; t < 9; ++t) w[t * 64 + co] = Wt[co * 9 + t];
+      bv[co] = Wt[64 * 9 + co];
+    }
+    if ((rc = dev_alloc(h, &h->d_w1a, w.size()))) return rc;
+    if ((rc = dev_alloc(h, &h->d_b1a, bv.size()))) return rc;
+    HIP_TRY(hipMemcpy(h->d_w1a, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_b1a, bv.data(), bv.size() * 4, hipMemcpyHostToDevice));
+    if (h->bf16) {
+      // conv1a_mfma.h: [j 2][lane 64][e 8] = bf16(w[channel 32 j + (lane & 31)][tap 8 (lane >> 5) + e]), 0 for taps >= 9
+      std::vector<unsigned short> tab(2 * 64 * 8, 0);
+      for (int j = 0; j < 2; ++j)
+        for (int ln = 0; ln < 64; ++ln)
+          for (int e = 0; e < 8; ++e) {
+            const int t = 8 * (ln >> 5) + e, co = 32 * j + (ln & 31);
+            if (t < 9) tab[(j * 64 + ln) * 8 + e] = host_bf16_rne(Wt[co * 9 + t]);
+          }
+      if ((rc = dev_alloc(h, &h->d_w1a_tab, tab.size()))) return rc;
+      HIP_TRY(hipMemcpy(h->d_w1a_tab, tab.data(), tab.size() * 2, hipMemcpyHostToDevice));
+    }
+  }
+
+  // activations (NHWC f32).  act[0]=conv1a .. act[7]=conv4b
+  const int lh[8] = {H, H / 2, H / 2, H / 4, H / 4, H / 8, H / 8, H / 8};
+  const int lw[8] = {W, W / 2, W / 2, W / 4, W / 4, W / 8, W / 8, W / 8};
+  const int lc[8] = {64, 64, 64, 64, 128, 128, 128, 128};
+  for (int i = 0; i < 8; ++i)
+    if ((rc = dev_alloc(h, &h->act[i], (size_t)B * lh[i] * lw[i] * lc[i]))) return rc;
+  if ((rc = dev_alloc(h, &h->d_img, (size_t)B * H * W))) return rc;
+  if (!h->bf16 && h->pool_split != 0 && !(H & 15) && !(W & 15))   // (the un-pooled output of the largest pooled layer this serves: conv2b / conv3b of <= 2 frames)
+    if ((rc = dev_alloc(h, &h->d_unpooled, (size_t)std::min(B, 2) * (H / 2) * (W / 2) * 64))) return rc;
+  if ((rc = dev_alloc(h, &h->d_head, (size_t)B * C * 512))) return rc;
+  if ((rc = dev_alloc(h, &h->d_semi, (size_t)B * C * SPFE_SEMI_CH))) return rc;
+  if ((rc = dev_alloc(h, &h->d_coarse, (size_t)B * C * SPFE_DESC_DIM))) return rc;
+  for (int k = 0; k < 2; ++k) {
+    if ((rc = dev_alloc(h, &h->d_heat_log[k], (size_t)B * H * W))) return rc;
+    if ((rc = dev_alloc(h, &h->d_minmax[k], (size_t)B * spfe::tail_parts(h->H, h->W) * 2))) return rc;
+    if ((rc = dev_alloc(h, &h->d_cell_score[k], (size_t)B * C))) return rc;
+    if ((rc = dev_alloc(h, &h->d_cell_k[k], (size_t)B * C))) return rc;
+  }
+  if ((rc = dev_alloc(h, &h->d_heat_inv, (size_t)B * H * W))) return rc;
+  if (cfg->flags & SPFE_FLAG_HEAT)
+    if ((rc = dev_alloc(h, &h->d_heat, (size_t)B * H * W))) return rc;
+  if ((rc = dev_alloc(h, &h->d_heat_consts, (size_t)B * 4))) return rc;
+  if ((rc = dev_alloc(h, &h->d_cell_mask, (size_t)B * C))) return rc;
+  if ((rc = dev_alloc(h, &h->d_kp_cell, (size_t)B * h->kmax))) return rc;
+  if (h->sparse_db) {
+    h->db_cap = (int)std::min<size_t>((size_t)4 * h->kmax, (size_t)C);
+    if ((rc = dev_alloc(h, &h->d_db_list, (size_t)B * h->db_cap))) return rc;
+    if ((rc = dev_alloc(h, &h->d_db_total, 16))) return rc;
+    HIP_TRY(hipMemset(h->d_db_total, 0, 16 * sizeof(int)));
+  }
+  {   // select_kernel's global scratch: frames of more than 16,384 cells, and the lean form of pipelined calls
+    if ((rc = dev_alloc(h, &h->d_sel_slot, (size_t)B * C))) return rc;
+    if ((rc = dev_alloc(h, &h->d_sel_list, (size_t)B * C))) return rc;
+    if (const char *e = getenv("SPFE_SELECT_LEAN")) h->select_lean = atoi(e);
+  }
+  {
+    const char *qenv = getenv("SPFE_COV_QCAP");
+    h->cov.qcap = qenv ? atoi(qenv) : 1024;
+    if (h->cov.qcap < 16) h->cov.qcap = 16;
+    if ((rc = dev_alloc(h, &h->cov.claim, (size_t)B * H * W))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.done, (size_t)B * H * W))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.queue, (size_t)B * h->kmax * h->cov.qcap))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.qval, (size_t)B * h->kmax * h->cov.qcap))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.npop, (size_t)B * h->kmax))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.dirty, (size_t)B * h->kmax))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.nxt, (size_t)B * h->kmax))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.nxy, (size_t)B * h->kmax * 2))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.workers, (size_t)B * h->kmax))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.counters, (size_t)B * 4))) return rc;
+    h->cov.ecap = 32 * h->kmax;   // (~24 pops per keypoint on the dense synthetic detector, a quarter of the keypoints dirty)
+    if (getenv("SPFE_COV_EDGES") && atoi(getenv("SPFE_COV_EDGES")) == 0) h->cov.ecap = 0;   // A/B: the link kernel walks the pop lists
+    if (const char *e = getenv("SPFE_COV_ECAP")) h->cov.ecap = std::max(0, atoi(e));        // (tests: a list that overflows)
+    if (h->cov.ecap && (rc = dev_alloc(h, &h->cov.edges, (size_t)B * h->cov.ecap * 2))) return rc;
+    const char *oenv = getenv("SPFE_COV_OVF_SLOTS"), *cenv = getenv("SPFE_COV_OVF_CAP");
+    h->cov.ovf_slots = oenv ? atoi(oenv) : 16;
+    h->cov.ovf_cap = cenv ? atoi(cenv) : 16384;
+    if (h->cov.ovf_slots < 0) h->cov.ovf_slots = 0;
+    if (h->cov.ovf_cap < h->cov.qcap) h->cov.ovf_cap = h->cov.qcap;
+    if ((rc = dev_alloc(h, &h->cov.ovf_slot, (size_t)B * h->kmax))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.ovf_q, (size_t)B * h->cov.ovf_slots * h->cov.ovf_cap + 1))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.ovf_v, (size_t)B * h->cov.ovf_slots * h->cov.ovf_cap + 1))) return rc;
+    // the device-side last resort (cov.hip, cov_fallback_kernel): one list for the batch, 4 M pops by default (48 MB)
+    const char *fenv = getenv("SPFE_COV_FALLBACK_CAP");
+    h->cov.fb_cap = fenv ? atoi(fenv) : (1 << 22);
+    if (h->cov.fb_cap < 1024) h->cov.fb_cap = 1024;
+    if ((rc = dev_alloc(h, &h->cov.fb_q, (size_t)h->cov.fb_cap))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.fb_v, (size_t)h->cov.fb_cap))) return rc;
+  }
+  make_layout(h->kmax, C, (cfg->flags & SPFE_FLAG_DESC_BF16) != 0, &h->rl);
+  if ((rc = dev_alloc(h, &h->d_records, (size_t)B * h->rl.bytes))) return rc;
+  HIP_TRY(hipMemset(h->d_records, 0, (size_t)B * h->rl.bytes));
+
+  // the MFMA conv chain
+  struct Spec { int nl, l0, l1, src, dst; bool pool; };
+  // src/dst index into act[]; -1 = head buffer
+  const Spec specs[8] = {{1, 1, 0, 0, 1, true},  {1, 2, 0, 1, 2, false}, {1, 3, 0, 2, 3, true},
+                         {1, 4, 0, 3, 4, false}, {1, 5, 0, 4, 5, true},  {1, 6, 0, 5, 6, false},
+                         {1, 7, 0, 6, 7, false}, {2, 8, 10, 7, -1, false}};
+  const char *senv = getenv("SPFE_SMALL_TILE_MAXH");  // override of the per-call choice in enqueue()
+  const int small_maxh = senv ? atoi(senv) : -1;
+  h->small_maxh = small_maxh;
+  for (int i = 0; i < 8; ++i) {
+    ConvLayer &L = h->layers[i];
+    const int lids[2] = {specs[i].l0, specs[i].l1};
+    if (h->bf16) rc = pack_layer_bf16(h, blob.data(), lids, specs[i].nl, &L);
+    else rc = pack_layer(h, blob.data(), lids, specs[i].nl, &L);
+    if (rc) return rc;
+    L.pool = specs[i].pool;
+    L.relu = true;
+    L.H = lh[specs[i].src];
+    L.W = lw[specs[i].src];
+    L.small_tile = L.H <= small_maxh;
+    L.in = h->act[specs[i].src];
+    L.in_stride = lc[specs[i].src];
+    L.in_choff = 0;
+    if (specs[i].dst >= 0) { L.out = h->act[specs[i].dst]; L.out_stride = lc[specs[i].dst]; }
+    else { L.out = h->d_head; L.out_stride = 512; }
+    L.out_choff = 0;
+  }
+  {  // convPb: head[0:256] -> semi (65)
+    ConvLayer &L = h->layers[8];
+    const int lids[1] = {9};
+    if ((rc = pack_layer(h, blob.data(), lids, 1, &L))) return rc;
+    L.pool = false; L.relu = false; L.small_tile = true; L.H = H / 8; L.W = W / 8;
+    L.in = h->d_head; L.in_stride = 512; L.in_choff = 0;
+    L.out = h->d_semi; L.out_stride = SPFE_SEMI_CH; L.out_choff = 0;
+  }
+  {  // convDb: head[256:512] -> coarse (256)
+    ConvLayer &L = h->layers[9];
+    const int lids[1] = {11};
+    if ((rc = pack_layer(h, blob.data(), lids, 1, &L))) return rc;
+    L.pool = false; L.relu = false; L.small_tile = true; L.H = H / 8; L.W = W / 8;
+    L.in = h->d_head; L.in_stride = 512; L.in_choff = 256;
+    L.out = h->d_coarse; L.out_stride = SPFE_DESC_DIM; L.out_choff = 0;
+  }
+  if (h->bf16) {  // Cin = 64 layers selected for the wave-specialised kernel (conv1b by default)
+    for (int i = 0; i < 4; ++i)
+      if ((h->ws_mask >> i) & 1)
+        if ((rc = pack_layer_bf16_ws(h, blob.data(), specs[i].l0, &h->d_wws[i]))) return rc;
+    if (h->bf16_rw)
+      for (int i = 4; i < 8; ++i) {
+        const int lids2[2] = {specs[i].l0, specs[i].l1};   // (convPa | convDa for the last one)
+        if ((rc = pack_layer_bf16_rw(h, blob.data(), lids2, specs[i].nl, &h->d_wrw[i - 4]))) return rc;
+      }
+    if ((rc = dev_alloc(h, &h->d_tile_ctr, 8 * 64))) return rc;   // [layer][part of the batch][32]
+    h->sparse_da = h->sparse_db && h->d_wrw[3] && (size_t)B * C * 1024 < ((size_t)1 << 31);
+    // Measured at 1280x720 x 8 (da_gather_bf16.hip): 25 us alone against the 43 us the dense launch loses without convDa, a
+    // single-frame call's p50 0.357 -> 0.352 ms; but pipelined 7640 -> 7500 frames/s — a workgroup needs a whole CU (148 KB
+    // of LDS, 380 registers), so beside the next batch's convolutions it only starts where one of theirs has ended, and
+    // then holds that CU for its ~6 tiles.  So: synchronous calls only.
+    if (const char *e = getenv("SPFE_SPARSE_DA")) h->sparse_da_mode = atoi(e);
+    h->sparse_da = h->sparse_da && h->sparse_da_mode != 0;
+    if (h->sparse_da && (rc = dev_alloc(h, &h->act7_alt, (size_t)B * C * 128))) return rc;
+  }
+  if (!h->bf16 && h->kc_mask != 0) {   // the K-chain kernel's weight tables (conv_f32_kc.hip): conv3a, conv4a, conv4b, convPa | convDa
+    const int kl[4] = {3, 5, 6, 7};
+    for (int q = 0; q < 4; ++q) {
+      const int i = kl[q];
+      const int l0 = specs[i].l0, l1 = specs[i].l1, nl = specs[i].nl;
+      const spfe_layer_t &La = SPFE_LAYERS[l0];
+      const int cout = La.cout + (nl == 2 ? SPFE_LAYERS[l1].cout : 0);
+      if (!spfe::conv_f32_kc_supports(h->layers[i].H, h->layers[i].W, La.cin, cout)) continue;
+      std::vector<float> wsrc((size_t)cout * La.cin * 9), wdst((size_t)cout * La.cin * 9);
+      memcpy(wsrc.data(), blob.data() + blob_weight_offset(l0), (size_t)La.cout * La.cin * 9 * 4);
+      if (nl == 2) memcpy(wsrc.data() + (size_t)La.cout * La.cin * 9, blob.data() + blob_weight_offset(l1), (size_t)SPFE_LAYERS[l1].cout * La.cin * 9 * 4);
+      spfe::conv_f32_kc_pack_weights(wsrc.data(), La.cin, cout, wdst.data());
+      if ((rc = dev_alloc(h, &h->d_wkc[i], wdst.size()))) return rc;
+      HIP_TRY(hipMemcpy(h->d_wkc[i], wdst.data(), wdst.size() * 4, hipMemcpyHostToDevice));
+    }
+  }
+  if (!h->bf16) {  // f32 heads with register-resident weights (head_f32.hip), bit-identical to the generic kernel — opt-in:
+    // measured 63 + 38.5 us per eight 752x480 frames against 72 + 35.5 for the generic kernel (matrix-bound: 47 us at the peak)
+    const char *fe = getenv("SPFE_F32_HEADS");
+    if (fe) h->f32_heads = atoi(fe) != 0;
+    if (const char *e = getenv("SPFE_PBTAIL")) h->pbtail = atoi(e) != 0;
+    if (h->f32_heads) h->pbtail = false;
+    if (h->pbtail) {
+      const float *Wp = blob.data() + blob_weight_offset(9);   // layer 9 = convPb, [65][256]
+      if ((rc = dev_alloc(h, &h->d_wpb_dust, 256))) return rc;
+      HIP_TRY(hipMemcpy(h->d_wpb_dust, Wp + (size_t)64 * 256, 256 * 4, hipMemcpyHostToDevice));
+    }
+    for (int which = 0; which < 2; ++which) {
+      if (!h->f32_heads && !(which == 0 && h->sparse_db) && !(which == 1 && h->pbtail)) continue;   // (the gathered descriptor head is head_f32.hip's kernel; pbtail_f32.hip reads convPb's table)
+      const int lid = which ? 9 : 11;
+      const spfe_layer_t &Ld = SPFE_LAYERS[lid];
+      std::vector<float> w(spfe::head_f32_weight_bytes(Ld.cout) / 4, 0.0f);
+      spfe::head_f32_pack_weights(blob.data() + blob_weight_offset(lid), Ld.cout, w.data());
+      float **dst = which ? &h->d_wpb32 : &h->d_wdb32;
+      if ((rc = dev_alloc(h, dst, w.size()))) return rc;
+      HIP_TRY(hipMemcpy(*dst, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    }
+    // convDa gathered as well (da_gather_f32.hip), pipelined calls included: 752x480 x 8, 19 k of 45 k cells listed: 122 us
+    // (two workgroups per CU) against the 210 us the dense launch loses without convDa — pipelined 2035 -> 2057 ... 2075
+    // frames/s, a single-frame call's p50 -1.4 %
+    h->sparse_da_mode = 2;
+    h->sparse_da = h->sparse_db && (size_t)B * C * 2048 < ((size_t)1 << 31);
+    if (const char *e = getenv("SPFE_SPARSE_DA")) h->sparse_da_mode = atoi(e);
+    h->sparse_da = h->sparse_da && h->sparse_da_mode != 0;
+    if (h->sparse_da) {
+      std::vector<float> w(spfe::da_gather_f32_weight_bytes() / 4);
+      spfe::da_gather_f32_pack_weights(blob.data() + blob_weight_offset(10), w.data());   // layer 10 = convDa
+      if ((rc = dev_alloc(h, &h->d_wda32, w.size()))) return rc;
+      HIP_TRY(hipMemcpy(h->d_wda32, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+      if ((rc = dev_alloc(h, &h->act7_alt, (size_t)B * C * 128))) return rc;
+    }
+  }
+  if (h->bf16) {  // both heads in bf16: convPa | convDa write bf16, convPb and convDb are head_bf16.hip's GEMMs
+    if (const char *e = getenv("SPFE_PBTAIL")) h->pbtail = atoi(e) != 0;   // (convPb inside the tail's launch: pbtail_bf16.hip)
+    if ((rc = dev_alloc(h, &h->d_hd, (size_t)B * C * 512))) return rc;
+    for (int which = 0; which < 2; ++which) {
+      const int lid = which ? 9 : 11;
+      const spfe_layer_t &Ld = SPFE_LAYERS[lid];
+      const float *Wd = blob.data() + blob_weight_offset(lid);
+      std::vector<unsigned char> w(spfe::head_bf16_weight_bytes(Ld.cout), 0);
+      std::vector<unsigned short> wb((size_t)Ld.cout * Ld.cin);
+      for (size_t k = 0; k < wb.size(); ++k) wb[k] = host_bf16_rne(Wd[k]);
+      spfe::head_bf16_pack_weights(wb.data(), Ld.cout, w.data());
+      unsigned char **dst = which ? &h->d_wpb : &h->d_wdb;
+      if ((rc = dev_alloc(h, dst, w.size()))) return rc;
+      HIP_TRY(hipMemcpy(*dst, w.data(), w.size(), hipMemcpyHostToDevice));
+    }
+  }
+
+  // pinned host mirrors for the host-facing calls
+  if ((rc = host_alloc(h, &h->h_img, (size_t)B * H * W))) return rc;
+  if ((rc = host_alloc(h, &h->h_records, (size_t)B * h->rl.bytes))) return rc;
+  if ((rc = host_alloc(h, &h->h_heat_inv, (size_t)B * H * W))) return rc;
+  if (cfg->flags & SPFE_FLAG_HEAT)
+    if ((rc = host_alloc(h, &h->h_heat, (size_t)B * H * W))) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  return SPFE_OK;
+}
+
+}  // namespace spfe_host
