@@ -748,7 +748,7 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const uint8_t *__restrict__
 }
 
 // 2x2 / 2 max-pool of an NHWC f32 activation (a float4 of channels per lane).  Used when a POOLED layer of a single frame runs
-// as un-pooled 2-row tiles (spfe_api.hip): bias, ReLU and the maximum commute exactly (all monotonic), so pooling the stored
+// as un-pooled 2-row tiles (spfe_schedule.hip): bias, ReLU and the maximum commute exactly (all monotonic), so pooling the stored
 // ReLU outputs gives the bits of the fused epilogue.
 __global__ __launch_bounds__(256) void pool2x2_f32_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, int B, int Ho,
                                                           int Wo, int c4) {

@@ -16,7 +16,7 @@
 // Measured (1280x720 x 8, 22 k listed cells = 690 tiles x 2 groups on 256 workgroups): 25 us, of which the MFMA loops are
 // 6 x 1.1 us — they run at the LDS's full read rate (four wavefronts x one 1 KB fragment per 32-cycle MFMA = 128 B / clk),
 // so the LDS-direct loads of the next tile get no LDS write slots beside them and a tile costs its loads' round trip PLUS
-// its MFMAs (probe: without the loads 21 us, without the MFMAs 19 us).  Used for synchronous calls (spfe_api.hip).
+// its MFMAs (probe: without the loads 21 us, without the MFMAs 19 us).  Used for synchronous calls (spfe_schedule.hip).
 //
 // Arithmetic: conv_bf16_rw.hip's — mfma(cells, weights), v_mfma_f32_32x32x16_bf16, K order 32-channel chunk -> dx ->
 // 16-channel group -> dy, f32 accumulate, bias, ReLU, RNE to bf16 — so a listed row holds the bits the dense launch writes

@@ -184,14 +184,13 @@ __global__ __launch_bounds__(64 * NW) void pbtail_bf16_kernel(const unsigned sho
 // head: the bf16 head activations [B * C][512]; wpack / bias: convPb's (see the kernel); semi: [B][C][65] f32
 hipError_t launch_pbtail_bf16(const void *head, const void *wpack, const float *bias, float *semi, const FrameBufs &f,
                               const RecordLayout &r, int B, int H, int W, hipStream_t s, int b0, int *zero_ints, int nzero,
-                              int zstride) {
+                              int zstride, int force) {
   const int nparts = tail_parts(H, W);
   if ((size_t)(H / 8) * (W / 8) * IN_STRIDE * 2 >= ((size_t)1 << 32)) return hipErrorInvalidValue;   // (32-bit SRD offsets inside a frame)
   // few frames (one round of workgroups): four wavefronts share the load and the three channel tiles — the shorter chain
   // (single-frame calls: both forms within the +-4 us noise of the call's p50, 3 ... 8 us below the two launches); full
   // launches: two wavefronts, both on the tail (1280x720 x 8: 38.5 us against 41.5; the two launches it replaces: 17.3 +
-  // 26.0).  SPFE_PBTAIL_WAVES=2|4 forces one
-  const int force = getenv("SPFE_PBTAIL_WAVES") ? atoi(getenv("SPFE_PBTAIL_WAVES")) : 0;
+  // 26.0).  force = 2 | 4 (SPFE_PBTAIL=2|4, tests) takes that form
   const bool four = force ? force == 4 : (long)nparts * B <= 1024;
   if (four)
     hipLaunchKernelGGL(pbtail_bf16_kernel<4>, dim3(nparts, B), dim3(256), 0, s, reinterpret_cast<const unsigned short *>(head),

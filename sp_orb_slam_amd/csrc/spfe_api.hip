@@ -443,8 +443,7 @@ int spfe_submit_batch(spfe_handle h, const uint8_t *const *images, int stride, i
     // mode: the runtime's copy engine — the kernel's 64 workgroups sit on the chip for the 0.2 ms the PCIe transfer takes,
     // beside convolutions that are 4x shorter than the f32 ones: 6895 against 7990 frames/s at 1280x720 x 8 (= the
     // device-resident rate)
-    static const int copy_env = getenv("SPFE_PIPE_COPY_KERNEL") ? atoi(getenv("SPFE_PIPE_COPY_KERNEL")) : -1;
-    const int copy_mode = copy_env >= 0 ? copy_env : (h->bf16 && h->C >= 10000 ? 0 : 1);   // (bf16 752x480: kernel 11,560, engine 11,250)
+    const int copy_mode = h->pipe_copy_kernel >= 0 ? h->pipe_copy_kernel : (h->bf16 && h->C >= 10000 ? 0 : 1);   // (bf16 752x480: kernel 11,560, engine 11,250)
     if (copy_mode == 1) {          // a copy kernel of our own writing the pinned buffer
       const size_t n16 = ((size_t)n * h->rl.bytes + 15) / 16;
       hipLaunchKernelGGL(spfe::copy_records_kernel, dim3(64), dim3(256), 0, sc, reinterpret_cast<uint4 *>(ps.h_rec),

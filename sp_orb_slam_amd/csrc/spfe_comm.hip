@@ -61,6 +61,8 @@ int spfe_comm_init(spfe_handle h, const void *id, int rank, int world) {
   // a hardware queue waiting for the covariance event.  HIP maps streams onto a few hardware queues; a waiting stream that
   // lands on the compute stream's queue holds the NEXT batch's convolutions back (measured on the host path: half the
   // throughput).  SPFE_COMM_OWN_STREAM=1: a communication stream of its own that waits for the batch's event.
+  // (the one switch that is not the handle's but the communicator's: read each time one is made, so that ONE handle can run
+  // both forms — bench.py's comm_stream_ab leg)
   h->comm_own_stream = getenv("SPFE_COMM_OWN_STREAM") && atoi(getenv("SPFE_COMM_OWN_STREAM")) != 0;
   if (!h->comm_stream) {
     if (h->comm_own_stream) HIP_TRY(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));

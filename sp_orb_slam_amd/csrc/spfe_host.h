@@ -56,7 +56,6 @@ int fail(int code, const char *fmt, ...);
                   __LINE__);                                                            \
   } while (0)
 
-constexpr int kKcAuto = 0;      // layers the K-chain kernel takes by default on single frames: none (measured, conv_f32_kc.hip's header)
 constexpr int NSTAGE = 15;
 extern const char *const kStageNames[NSTAGE];
 
@@ -86,7 +85,7 @@ struct spfe_handle_s {
   static constexpr int NTICKET = 4;
   hipEvent_t ev_post[NTICKET] = {}, ev_cov[NTICKET] = {};
   hipEvent_t ev_db = nullptr;    // launch stream: this call's convDb is done (when it is launched behind the detector tail)
-  bool defer_db = true;          // SPFE_DEFER_DB=0: convDb in layer order
+  bool defer_db = true;          // synchronous dense calls: convDb launched behind the detector tail
   hipEvent_t ev_desc = nullptr;  // side stream: the last call's descriptor sampling (reader of d_coarse) is done
   // f32, batches of >= 2 frames: the layers behind conv1b run as TWO half batches on two streams (SPFE_F32_SPLIT), so that the
   // workgroups of one half's kernel fill the CUs the other half's kernel leaves idle in its last, partial round of work items.
@@ -108,9 +107,11 @@ struct spfe_handle_s {
   // does, and the launch stream only in front of the NEXT call's conv1b (its conv1a runs beside the other half's last kernels)
   bool join_pending = false;
   bool defer_join = true;   // SPFE_DEFER_JOIN=0: the join at the end of the step, on the launch stream
-  int desc_in_replay = 1;   // SPFE_DESC_IN_REPLAY
-  int f32_split = 2;   // parts (0 = off)
-  int bf16_split = -1;  // SPFE_BF16_SPLIT: the same for the bf16 stack; -1 = frames of fewer than 10,000 cells (752x480: +2 %; 1280x720: +-0)
+  int split_mode = -1;      // SPFE_SPLIT: -1 = f32 always, bf16 frames of fewer than 10,000 cells (752x480: +2 %; 1280x720: +-0); 0 never; 1 always
+  // the other schedule switches (read_switches(), spfe_pack.hip; README "Environment switches"), defaults = the product's order
+  bool inline_chain = true, tail_per_half = true, early_waits = true, sel_ext_event = true, zero_in_tail = true;
+  int replay_waves = 0;     // SPFE_REPLAY_WAVES: 0 = by workload
+  int sparse_db_env = -1, sparse_da_env = -1, pbtail_env = 1, fuse1a_env = -1, pipe_copy_kernel = -1, cov_ecap_env = -1;
   bool desc_recorded = false;
   long ticket = 0;          // calls so far; call t uses slot t % NTICKET
   bool cov_inflight = false;
@@ -143,7 +144,7 @@ struct spfe_handle_s {
   bool sparse_da_call = false;   // ... this / the last call
   int *d_db_list = nullptr, *d_db_total = nullptr;
   int db_cap = 0;                // list entries per frame: min(4 kmax, C)
-  int db_tiles_per_wg = 4;       // SPFE_DB_TILES_PER_WG: the gathered head's grid = listed tiles / this (a workgroup's weights: 128 KB)
+  int db_tiles_per_wg = 4;       // the gathered head's grid = listed tiles / this (a workgroup's weights: 128 KB)
   hipEvent_t ev_sel = nullptr;   // side stream: this call's selection (and its cell list) is done
   hipEvent_t ev_dbs[2] = {};     // by ticket parity: that call's gathered head (reader of the head activations / of conv4b's output) is done
   bool dbs_recorded[2] = {};
@@ -159,13 +160,9 @@ struct spfe_handle_s {
   uint8_t *d_cell_k[2] = {}, *d_cell_mask = nullptr;
   const uint8_t *rec_of[NTICKET] = {};   // record buffer of each ticket (same buffer twice in a row: the old ordering)
   int *d_kp_cell = nullptr;
-  int select_lean = 0;                // SPFE_SELECT_LEAN: 1 = select_kernel keeps 2 bytes a cell in LDS on every frame size, 0 = only
-                                      // above 16,384 cells (default), -1 = in pipelined calls.  Measured (round 4, same-box A/B, 8
-                                      // frames per call, pipelined): the lean form starts beside a convolution workgroup instead of
-                                      // waiting for a free CU, and that is NOT a gain — f32 752x480 2107 / 2116 -> 2085 / 2082
-                                      // frames/s (it now sits beside conv1b: 0.87 -> 0.83 of peak), bf16 1280x720 7687 / 7690 ->
-                                      // 7670 / 7684, bf16 752x480 14,888 / 14,908 -> 14,846 / 14,826: the selection's 390 us
-                                      // "overlapped" were waiting time off the critical path
+  // (select_kernel's 2-bytes-a-cell LDS form is for frames above 16,384 cells only.  Forced onto smaller frames in pipelined
+  // calls it starts beside a convolution workgroup instead of waiting for a free CU, and that measured as NOT a gain — f32
+  // 752x480 2107 / 2116 -> 2085 / 2082 frames/s, conv1b 0.87 -> 0.83 of peak: HISTORY.md "Round 4" — the switch is gone)
   int *d_sel_slot = nullptr;          // frames of more than 16,384 cells: select_kernel's global scratch (tail_select.hip)
   uint16_t *d_sel_list = nullptr;
   uint8_t *d_records = nullptr;
@@ -192,27 +189,20 @@ struct spfe_handle_s {
   size_t p_stage_bytes = 0;
   int m_pairs = 0, m_cap = 0;      // capacity of m_best_* ([pairs][cap])
   int m_host_cap = 0;              // rows the host-API staging blocks / m_out hold
-  unsigned tile2_mask = 0;   // SPFE_TILE2_MASK: f32 layers forced onto 2-row tiles (probe knob)
-  bool tile2_auto = true;    // SPFE_TILE2_AUTO=0: never choose 2-row tiles
+  unsigned tile2_mask = 0;   // SPFE_TILE2_MASK > 0: f32 layers forced onto 2-row tiles
+  bool tile2_auto = true;    // SPFE_TILE2_MASK=0: never choose 2-row tiles
   // f32, a single frame: a POOLED low-resolution layer (conv3b: 180 eight-row items on 256 CUs — one round of the longest
   // items, 70 % of the CUs busy) as UN-pooled 2-row tiles (720 items: three rounds of quarter-size items) into a scratch
   // buffer + a 2x2 max-pool pass (pool2x2_f32_kernel; bias / ReLU / max commute exactly: same bits).  SPFE_POOL_SPLIT:
   // -1 cost model, 0 never, 1 wherever the shapes allow (tests)
   int pool_split = -1;
-  // f32, a single frame: the low-resolution layers without a pool (conv3a, conv4a, conv4b, convPa [| convDa]) on the K-chain
-  // kernel (conv_f32_kc.hip, v_mfma_f32_16x16x4_f32: every output's fmaf chain advances 4 k per 32-cycle issue and the layer is
-  // cut into 16 x 16 chains, 3 per wavefront, so that every SIMD has work).  SPFE_KC: -1 = the layers it measured faster on,
-  // 0 = never, else a mask of conv layer indices (bit 3 = conv3a, 5 = conv4a, 6 = conv4b, 7 = convPa | Da)
-  int kc_mask = -1;
-  float *d_wkc[8] = {};      // their weights in conv_f32_kc_pack_weights order
   float *d_unpooled = nullptr;   // [<= 2 frames][H / 4][W / 4][128]
-  unsigned tile16_mask = 0;  // f32 layers (bit i = conv layer i of enqueue()) on 16-row / 8-wave tiles
   int conv1b_split_rows = -1; // ... and, when that launch was cut in a 16-row and an 8-row part, the 16-row part's tile rows ("conv1b_split_rows")
   int conv1b_tile_rows = 8;  // rows per tile of the last call's conv1b launch (f32; spfe_debug_read("conv1b_tile_rows"))
   int tile16x4 = 1;          // SPFE_TILE16X4: conv1b on 16-row tiles of 4 wavefronts x 4 rows (0 never, 1 by the cost model — possibly
                              // cut in a 16-row and an 8-row launch —, 2 always in one launch, 3 cost model without the cut)
   bool fuse1a = false;  // f32: conv1a computed inside conv1b (opt-in: SPFE_FUSE_CONV1A=1; measured perf-neutral)
-  bool fuse1a_bf16 = true;  // bf16: conv1a computed by the producer waves of the wave-specialised conv1b (SPFE_BF16_FUSE_CONV1A=0 to split)
+  bool fuse1a_bf16 = true;  // bf16: conv1a computed by the producer waves of the wave-specialised conv1b (SPFE_FUSE_CONV1A=0 to split)
   uint8_t *dust_scratch = nullptr;   // spfe_align_dust: dust map | points | pose | output block (device)
   uint8_t *dust_host = nullptr;      // pinned mirror of the output block
   // pipelined host path (spfe_submit_batch / spfe_collect_batch): NPIPE batches in flight, each with its own
@@ -249,7 +239,6 @@ struct spfe_handle_s {
   bool bf16_rw = true;           // SPFE_BF16_RW: register-resident-weights kernel for those layers
   int rw_rows3 = 1;              // SPFE_BF16_RW_ROWS3
   int rw_min4 = 3, rw_min2 = 2;  // ... 4-row tiles from this many tiles per workgroup, 2-row tiles from this many, else conv_bf16.hip
-  int side_cus_default = 0;      // SPFE_SIDE_CUS
   bool bf16_dyn = true;          // SPFE_BF16_DYN_QUEUE
   int tile16_min_items = 3;      // SPFE_BF16_TILE16_MIN_ITEMS (0 = 8-row tiles only)
   int tile_rows_big = 12;        // SPFE_BF16_TILE_ROWS (12 | 16)

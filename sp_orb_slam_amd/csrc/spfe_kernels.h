@@ -1,4 +1,4 @@
-// spfe_kernels.h — launch interface between the host pipeline (spfe_api.hip) and
+// spfe_kernels.h — launch interface between the host pipeline (spfe_schedule.hip) and
 // the gfx950 kernels.  Everything here is internal to libspfe.so.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -27,7 +27,7 @@ struct ConvParams {
   // conv_bf16_ws.hip: nblk * 8 tile counters (one per XCD and 64-channel block), zero before the launch
   int *tile_ctr;
   // conv_f32.hip: the launch walks work items [item_lo, item_hi) of the list (frame, tile row, tile column, 64-channel
-  // block); item_hi = 0: the whole list.  (conv1b's list is cut in two launches with different tile heights, spfe_api.hip.)
+  // block); item_hi = 0: the whole list.  (conv1b's list is cut in two launches with different tile heights, spfe_schedule.hip.)
   int item_lo = 0, item_hi = 0;
 };
 
@@ -37,13 +37,6 @@ struct ConvParams {
 // 4 = 16-row tiles of 4 waves x 4 rows (conv1b)
 hipError_t launch_conv_f32(const ConvParams &p, int cin, int ksize, bool pool, bool relu,
                            int tile_mode, int layer_tag, hipStream_t s);
-// The K-chain kernel (conv_f32_kc.hip): 3x3 / pad 1 / bias / ReLU / no pool on v_mfma_f32_16x16x4_f32 for a single frame's
-// low-resolution layers (width <= 192 pixels); p.in / p.out / strides / B / H / W as for launch_conv_f32; wpack =
-// conv_f32_kc_pack_weights([cout][cin][9]), bias = [cout] in channel order; bit-identical to launch_conv_f32
-hipError_t launch_conv_f32_kc(const ConvParams &p, int cin, int cout, const float *wpack, const float *bias, hipStream_t s);
-bool conv_f32_kc_supports(int H, int W, int cin, int cout);
-size_t conv_f32_kc_weight_bytes(int cin, int cout);
-void conv_f32_kc_pack_weights(const float *W, int cin, int cout, float *dst);
 // 2x2 / 2 max-pool of an NHWC f32 activation [B][H][W][C] -> [B][H/2][W/2][C] (H, W even, C % 4 == 0)
 hipError_t launch_pool2x2_f32(const float *in, float *out, int B, int H, int W, int C, hipStream_t s);
 int conv_kc(int ksize);        // K-chunk the kernel stages per barrier (16 for 3x3, 64 for 1x1)
@@ -176,7 +169,7 @@ hipError_t launch_pbtail_f32(const float *head, const float *wpack, const float 
 // head = [B * C][512] bf16; wpack = head_bf16_pack_weights(convPb, 65); zero_ints / nzero as launch_tail's
 hipError_t launch_pbtail_bf16(const void *head, const void *wpack, const float *bias, float *semi, const FrameBufs &f,
                               const RecordLayout &r, int B, int H, int W, hipStream_t s, int b0 = 0, int *zero_ints = nullptr,
-                              int nzero = 0, int zstride = 32);   // (zero_ints: nzero ints in runs of 32, zstride apart)   // frames [b0, b0 + B) of the batch-wide buffers
+                              int nzero = 0, int zstride = 32, int force = 0);   // (zero_ints: nzero ints in runs of 32, zstride apart; force: 2 | 4 wavefronts, 0 = by launch size)   // frames [b0, b0 + B) of the batch-wide buffers
 // zero_ints / nzero: ints the kernel also clears (the bf16 convolutions' tile-queue counters, for the next call)
 hipError_t launch_tail(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s, int *zero_ints = nullptr, int nzero = 0);
 // with_heat_norm: the heat normalisation (launch_heat_norm) rides in the neighbour-mask launch in front of the selection

@@ -191,8 +191,79 @@ int load_blob(const spfe_config *cfg, std::vector<float> *blob) {
   return SPFE_OK;
 }
 
+
+// Every environment switch libspfe.so reads — ONCE per handle, here, at spfe_create (README.md "Environment switches" lists
+// them with their tests).  A switch either selects between product paths that give the same bits (so that a test can put
+// two of them side by side), or sizes a capacity so that a test can reach an overflow path.  Nothing else in the library
+// calls getenv, and no value is cached across handles.
+static int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return e && *e ? (int)strtol(e, nullptr, 0) : dflt;
+}
+// "a,b,c": field k as an int, dflt where the field is missing or empty
+static int env_field(const char *name, int k, int dflt) {
+  const char *e = getenv(name);
+  if (!e) return dflt;
+  for (int i = 0; i < k; ++i) {
+    e = strchr(e, ',');
+    if (!e) return dflt;
+    ++e;
+  }
+  return (*e && *e != ',') ? (int)strtol(e, nullptr, 0) : dflt;
+}
+static void read_switches(spfe_handle h) {
+  // schedule
+  const int st = env_int("SPFE_STAGE_TIMING", 0);            // 1: events around every stage, 2: around the dominant kernel only
+  h->timing = st != 0;
+  h->timing_all = st != 2;
+  h->split_mode = env_int("SPFE_SPLIT", -1);                 // layers behind conv1b as two half batches: -1 by workload, 0 never, 1 always
+  h->inline_chain = env_int("SPFE_INLINE_CHAIN", 1) != 0;    // synchronous calls: detector chain on the launch stream
+  h->defer_join = env_int("SPFE_DEFER_JOIN", 1) != 0;        // pipelined two-half steps: the join in front of the NEXT conv1b
+  h->tail_per_half = env_int("SPFE_TAIL_PER_HALF", 1) != 0;  // ... each half's tail right behind its convPa
+  h->early_waits = env_int("SPFE_EARLY_WAITS", 1) != 0;      // ... the tails' waits in front of conv1a
+  h->sel_ext_event = env_int("SPFE_SEL_EXT_EVENT", 1) != 0;  // the selection's completion signal as the descriptor branch's event
+  h->replay_waves = env_int("SPFE_REPLAY_WAVES", 0);         // components per replay workgroup: 0 by workload, 2 | 8
+  h->zero_in_tail = env_int("SPFE_ZERO_IN_TAIL", 1) != 0;    // bf16 tile-queue counters cleared by the previous call's tail
+  // which branch
+  h->sparse_db_env = env_int("SPFE_SPARSE_DB", -1);          // gathered descriptor head: 0 never, 1 every call, 2 synchronous calls
+  h->sparse_da_env = env_int("SPFE_SPARSE_DA", -1);          // gathered convDa: 0 never, 1 synchronous calls, 2 pipelined too
+  h->pbtail_env = env_int("SPFE_PBTAIL", 1);                 // convPb inside the tail's launch: 0 off, 1 on, 2 | 4: on, bf16 form on that many wavefronts
+  h->f32_heads = env_int("SPFE_F32_HEADS", 0) != 0;          // dense f32 convPb / convDb on head_f32.hip
+  h->fuse1a_env = env_int("SPFE_FUSE_CONV1A", -1);           // conv1a inside conv1b: f32 default 0, bf16 default 1
+  // host path
+  h->pipe_copy_kernel = env_int("SPFE_PIPE_COPY_KERNEL", -1);   // D2H of a pipelined batch: -1 by precision, 0 runtime copy, 1 copy kernel
+  // (SPFE_COMM_OWN_STREAM — the all-gather on a stream of its own instead of the side stream — belongs to the communicator: read
+  // by spfe_comm_init, spfe_comm.hip, each time one is made)
+  // f32 tile shapes (bit-identical: the tile shape does not touch an output's K order)
+  h->tile16x4 = env_int("SPFE_TILE16X4", 1);                 // conv1b 16-row tiles: 0 never, 1 cost model (+ cut), 2 always, 3 model without the cut
+  {
+    const int m = env_int("SPFE_TILE2_MASK", -1);            // 2-row tiles: unset = cost model, 0 = never, else the layers forced onto them
+    h->tile2_auto = m < 0;
+    h->tile2_mask = m > 0 ? (unsigned)m : 0u;
+  }
+  h->pool_split = env_int("SPFE_POOL_SPLIT", -1);            // pooled layer as un-pooled 2-row tiles + pool pass: -1 model, 0 never, 1 wherever possible
+  // bf16 kernel selection (bit-identical kernels; which one takes a launch is a size decision)
+  h->ws_mask = (unsigned)env_field("SPFE_BF16_WS", 0, 15) & 0xfu;   // "mask[,min_items]": Cin = 64 layers that may take conv_bf16_ws.hip
+  if (getenv("SPFE_BF16_WS") && strchr(getenv("SPFE_BF16_WS"), ','))
+    h->ws_min_items = h->ws_min_items_sync = env_field("SPFE_BF16_WS", 1, h->ws_min_items);
+  h->bf16_dyn = env_int("SPFE_BF16_DYN_QUEUE", 1) != 0;      // conv_bf16.hip: work items in queue order
+  h->tile_rows_big = env_field("SPFE_BF16_TILE_ROWS", 0, 12);       // "rows[,min_items]": conv_bf16.hip's taller tiles (12 | 16), 0 items = never
+  h->tile16_min_items = env_field("SPFE_BF16_TILE_ROWS", 1, 3);
+  h->bf16_rw = env_field("SPFE_BF16_RW", 0, 1) != 0;         // "on[,min4,min2,rows3]": conv_bf16_rw.hip for the Cin = 128 layers
+  h->rw_min4 = env_field("SPFE_BF16_RW", 1, 3);
+  h->rw_min2 = env_field("SPFE_BF16_RW", 2, 2);
+  h->rw_rows3 = env_field("SPFE_BF16_RW", 3, 1);
+  // capacities of the covariance stage (tests reach the overflow paths): "qcap,ovf_slots,ovf_cap,fallback_cap,ecap"
+  h->cov.qcap = std::max(16, env_field("SPFE_COV_CAPS", 0, 1024));
+  h->cov.ovf_slots = std::max(0, env_field("SPFE_COV_CAPS", 1, 16));
+  h->cov.ovf_cap = std::max(h->cov.qcap, env_field("SPFE_COV_CAPS", 2, 16384));
+  h->cov.fb_cap = std::max(1024, env_field("SPFE_COV_CAPS", 3, 1 << 22));
+  h->cov_ecap_env = env_field("SPFE_COV_CAPS", 4, -1);       // -1: 32 x kmax; 0: no edge list (the link kernel walks the pop lists)
+}
+
 int build(spfe_handle h, const spfe_config *cfg) {
   h->cfg = *cfg;
+  read_switches(h);
   h->H = cfg->height; h->W = cfg->width;
   h->hc = h->H / 8; h->wc = h->W / 8; h->C = h->hc * h->wc;
   h->kmax = cfg->num_features + 1;
@@ -204,34 +275,11 @@ int build(spfe_handle h, const spfe_config *cfg) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
     h->num_cus = prop.multiProcessorCount;
-    const char *genv = getenv("SPFE_CONV_GRID");
-    if (genv) h->num_cus = atoi(genv);
   }
   HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  {
-    // SPFE_SIDE_PRIORITY (probe knob): -1 = the side stream at the device's highest priority, 1 = lowest, unset / 0 = default
-    const char *pe = getenv("SPFE_SIDE_PRIORITY");
-    const int want = pe ? atoi(pe) : 0;
-    int lo = 0, hi = 0;   // (numerically: greatest priority = lowest value)
-    // SPFE_SIDE_CUS=N: the side stream (selection, descriptors, covariance) confined to the last N of the device's CUs
-    // (hipExtStreamCreateWithCUMask; mask bit i <-> CU i / 8 of XCD i % 8: tools/microbench/cumask_probe.hip), so that its
-    // long-lived small workgroups cannot sit on every CU while the convolutions of the next batch want whole CUs
-    const char *ce = getenv("SPFE_SIDE_CUS");
-    int side_cus = ce ? atoi(ce) : h->side_cus_default;
-    hipDeviceProp_t prop;
-    if (side_cus > 0 && hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount >= 64 &&
-        side_cus < prop.multiProcessorCount) {
-      const int ncu = prop.multiProcessorCount;
-      std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-      for (int b = ncu - side_cus; b < ncu; ++b) mask[b / 32] |= 1u << (b % 32);
-      if (hipExtStreamCreateWithCUMask(&h->side, (uint32_t)mask.size(), mask.data()) != hipSuccess) h->side = nullptr;
-    }
-    if (h->side) {
-    } else if (want && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
-      HIP_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, want < 0 ? hi : lo));
-    else
-      HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-  }
+  // (measured and not kept: the side stream at another priority; confined to N CUs by hipExtStreamCreateWithCUMask — 64 CUs
+  // -15 %, 128 -2.5 %, 160 -0.8 % at bf16 1280x720: HISTORY.md "Round 4")
+  HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
   for (int i = 0; i < spfe_handle_s::NTICKET; ++i) {
     HIP_TRY(hipEventCreateWithFlags(&h->ev_post[i], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_cov[i], hipEventDisableTiming));
@@ -239,9 +287,6 @@ int build(spfe_handle h, const spfe_config *cfg) {
   HIP_TRY(hipEventCreateWithFlags(&h->ev_desc, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-  if (const char *e = getenv("SPFE_F32_SPLIT")) h->f32_split = atoi(e);
-  if (const char *e = getenv("SPFE_DESC_IN_REPLAY")) h->desc_in_replay = atoi(e);
-  if (const char *e = getenv("SPFE_BF16_SPLIT")) h->bf16_split = atoi(e);
   HIP_TRY(hipEventCreateWithFlags(&h->ev_db, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&h->ev_sel, hipEventDisableTiming));
   for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&h->ev_dbs[i], hipEventDisableTiming));
@@ -256,48 +301,17 @@ int build(spfe_handle h, const spfe_config *cfg) {
   h->sparse_db = true;
   h->sparse_db_sync_only = h->bf16 && h->C < 10000;
   h->db_tiles_per_wg = h->bf16 ? 4 : 1;
-  if (const char *e = getenv("SPFE_SPARSE_DB")) { h->sparse_db = atoi(e) != 0; h->sparse_db_sync_only = atoi(e) == 2; }
+  if (h->sparse_db_env >= 0) { h->sparse_db = h->sparse_db_env != 0; h->sparse_db_sync_only = h->sparse_db_env == 2; }
   // the gathered kernels form row byte offsets in 32 bits (the head activations' rows are 2048 / 1024 bytes, 0x80000000 is their
   // out-of-range marker): batches beyond that take the dense head (the launchers refuse them as well)
   if ((size_t)cfg->max_batch * h->C * (h->bf16 ? 1024 : 2048) >= ((size_t)1 << 31)) h->sparse_db = false;
-  if (const char *e = getenv("SPFE_DB_TILES_PER_WG")) h->db_tiles_per_wg = atoi(e);
-  if (const char *de = getenv("SPFE_DEFER_DB")) h->defer_db = atoi(de) != 0;
-  if (const char *de = getenv("SPFE_DEFER_JOIN")) h->defer_join = atoi(de) != 0;
-  {
-    const char *fenv = getenv("SPFE_FUSE_CONV1A");
-    h->fuse1a = fenv && atoi(fenv) != 0;
-    const char *menv = getenv("SPFE_TILE16_MASK");
-    if (menv) h->tile16_mask = (unsigned)strtoul(menv, nullptr, 0);
-    if (const char *m2 = getenv("SPFE_TILE2_MASK")) h->tile2_mask = (unsigned)strtoul(m2, nullptr, 0);
-    if (const char *m4 = getenv("SPFE_TILE16X4")) h->tile16x4 = atoi(m4);
-    if (const char *a2 = getenv("SPFE_TILE2_AUTO")) h->tile2_auto = atoi(a2) != 0;
-    if (const char *ps = getenv("SPFE_POOL_SPLIT")) h->pool_split = atoi(ps);
-    if (const char *km = getenv("SPFE_KC")) h->kc_mask = (int)strtol(km, nullptr, 0);
-    const char *wenv = getenv("SPFE_BF16_WS_MASK");
-    if (wenv) h->ws_mask = (unsigned)strtoul(wenv, nullptr, 0) & 0xfu;
-    const char *f16env = getenv("SPFE_BF16_FUSE_CONV1A");
-    if (f16env) h->fuse1a_bf16 = atoi(f16env) != 0;
-    // Synchronous calls (latency): the wave-specialised kernel wins from ~5 items per workgroup (batch 1 at 752x480: 0.43 ->
-    // 0.385 ms, conv1a fused).  Pipelined calls (SPFE_FLAG_ASYNC_COV): it holds all of a CU's LDS, the side-stream kernels of
-    // the previous batch cannot start beside it, and at 752x480 x 8 (0.65 ms steps) their chain becomes the critical path
-    // when the quarter-resolution layers take it too (12,450 -> 12,050 frames/s): those keep the higher bar.
-    // (the bar is picked per call: spfe_submit_batch pipelines on a handle created without the flag)
-    const char *ienv = getenv("SPFE_BF16_WS_MIN_ITEMS");
-    if (ienv) h->ws_min_items = h->ws_min_items_sync = atoi(ienv);
-    const char *t16env = getenv("SPFE_BF16_TILE16_MIN_ITEMS");
-    if (t16env) h->tile16_min_items = atoi(t16env);
-    const char *trenv = getenv("SPFE_BF16_TILE_ROWS");
-    if (trenv) h->tile_rows_big = atoi(trenv);
-    const char *denv = getenv("SPFE_BF16_DYN_QUEUE");
-    if (denv) h->bf16_dyn = atoi(denv) != 0;
-    if (const char *e = getenv("SPFE_BF16_RW")) h->bf16_rw = atoi(e) != 0;
-    if (const char *e = getenv("SPFE_BF16_RW_MIN4")) h->rw_min4 = atoi(e);
-    if (const char *e = getenv("SPFE_BF16_RW_ROWS3")) h->rw_rows3 = atoi(e);
-    if (const char *e = getenv("SPFE_BF16_RW_MIN2")) h->rw_min2 = atoi(e);
-  }
-  const char *tenv = getenv("SPFE_STAGE_TIMING");
-  h->timing = tenv && atoi(tenv) != 0;
-  h->timing_all = !(tenv && atoi(tenv) == 2);
+  h->fuse1a = !h->bf16 && h->fuse1a_env > 0;                      // f32: opt-in (measured perf-neutral)
+  h->fuse1a_bf16 = h->bf16 && h->fuse1a_env != 0;                 // bf16: conv1b's producer waves compute conv1a
+  // bf16, Cin = 64 layers, the wave-specialised kernel's bar.  Synchronous calls (latency): it wins from ~5 items per workgroup
+  // (batch 1 at 752x480: 0.43 -> 0.385 ms, conv1a fused).  Pipelined calls (SPFE_FLAG_ASYNC_COV): it holds all of a CU's LDS, the
+  // side-stream kernels of the previous batch cannot start beside it, and at 752x480 x 8 (0.65 ms steps) their chain becomes
+  // the critical path when the quarter-resolution layers take it too (12,450 -> 12,050 frames/s): those keep the higher bar
+  // (the bar is picked per call: spfe_submit_batch pipelines on a handle created without the flag)
   if (h->timing) {
     h->evpool.resize((size_t)spfe_handle_s::EVSETS * (NSTAGE + 1), nullptr);
     for (auto &e : h->evpool) HIP_TRY(hipEventCreate(&e));
@@ -366,12 +380,8 @@ int build(spfe_handle h, const spfe_config *cfg) {
   {   // select_kernel's global scratch: frames of more than 16,384 cells, and the lean form of pipelined calls
     if ((rc = dev_alloc(h, &h->d_sel_slot, (size_t)B * C))) return rc;
     if ((rc = dev_alloc(h, &h->d_sel_list, (size_t)B * C))) return rc;
-    if (const char *e = getenv("SPFE_SELECT_LEAN")) h->select_lean = atoi(e);
   }
   {
-    const char *qenv = getenv("SPFE_COV_QCAP");
-    h->cov.qcap = qenv ? atoi(qenv) : 1024;
-    if (h->cov.qcap < 16) h->cov.qcap = 16;
     if ((rc = dev_alloc(h, &h->cov.claim, (size_t)B * H * W))) return rc;
     if ((rc = dev_alloc(h, &h->cov.done, (size_t)B * H * W))) return rc;
     if ((rc = dev_alloc(h, &h->cov.queue, (size_t)B * h->kmax * h->cov.qcap))) return rc;
@@ -382,22 +392,12 @@ int build(spfe_handle h, const spfe_config *cfg) {
     if ((rc = dev_alloc(h, &h->cov.nxy, (size_t)B * h->kmax * 2))) return rc;
     if ((rc = dev_alloc(h, &h->cov.workers, (size_t)B * h->kmax))) return rc;
     if ((rc = dev_alloc(h, &h->cov.counters, (size_t)B * 4))) return rc;
-    h->cov.ecap = 32 * h->kmax;   // (~24 pops per keypoint on the dense synthetic detector, a quarter of the keypoints dirty)
-    if (getenv("SPFE_COV_EDGES") && atoi(getenv("SPFE_COV_EDGES")) == 0) h->cov.ecap = 0;   // A/B: the link kernel walks the pop lists
-    if (const char *e = getenv("SPFE_COV_ECAP")) h->cov.ecap = std::max(0, atoi(e));        // (tests: a list that overflows)
+    h->cov.ecap = h->cov_ecap_env >= 0 ? h->cov_ecap_env : 32 * h->kmax;   // (~24 pops per keypoint on the dense synthetic detector, a quarter of the keypoints dirty)
     if (h->cov.ecap && (rc = dev_alloc(h, &h->cov.edges, (size_t)B * h->cov.ecap * 2))) return rc;
-    const char *oenv = getenv("SPFE_COV_OVF_SLOTS"), *cenv = getenv("SPFE_COV_OVF_CAP");
-    h->cov.ovf_slots = oenv ? atoi(oenv) : 16;
-    h->cov.ovf_cap = cenv ? atoi(cenv) : 16384;
-    if (h->cov.ovf_slots < 0) h->cov.ovf_slots = 0;
-    if (h->cov.ovf_cap < h->cov.qcap) h->cov.ovf_cap = h->cov.qcap;
     if ((rc = dev_alloc(h, &h->cov.ovf_slot, (size_t)B * h->kmax))) return rc;
     if ((rc = dev_alloc(h, &h->cov.ovf_q, (size_t)B * h->cov.ovf_slots * h->cov.ovf_cap + 1))) return rc;
     if ((rc = dev_alloc(h, &h->cov.ovf_v, (size_t)B * h->cov.ovf_slots * h->cov.ovf_cap + 1))) return rc;
     // the device-side last resort (cov.hip, cov_fallback_kernel): one list for the batch, 4 M pops by default (48 MB)
-    const char *fenv = getenv("SPFE_COV_FALLBACK_CAP");
-    h->cov.fb_cap = fenv ? atoi(fenv) : (1 << 22);
-    if (h->cov.fb_cap < 1024) h->cov.fb_cap = 1024;
     if ((rc = dev_alloc(h, &h->cov.fb_q, (size_t)h->cov.fb_cap))) return rc;
     if ((rc = dev_alloc(h, &h->cov.fb_v, (size_t)h->cov.fb_cap))) return rc;
   }
@@ -411,8 +411,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
   const Spec specs[8] = {{1, 1, 0, 0, 1, true},  {1, 2, 0, 1, 2, false}, {1, 3, 0, 2, 3, true},
                          {1, 4, 0, 3, 4, false}, {1, 5, 0, 4, 5, true},  {1, 6, 0, 5, 6, false},
                          {1, 7, 0, 6, 7, false}, {2, 8, 10, 7, -1, false}};
-  const char *senv = getenv("SPFE_SMALL_TILE_MAXH");  // override of the per-call choice in enqueue()
-  const int small_maxh = senv ? atoi(senv) : -1;
+  const int small_maxh = -1;   // (the 4- / 8-row choice is enqueue()'s, per call)
   h->small_maxh = small_maxh;
   for (int i = 0; i < 8; ++i) {
     ConvLayer &L = h->layers[i];
@@ -463,31 +462,13 @@ int build(spfe_handle h, const spfe_config *cfg) {
     // single-frame call's p50 0.357 -> 0.352 ms; but pipelined 7640 -> 7500 frames/s — a workgroup needs a whole CU (148 KB
     // of LDS, 380 registers), so beside the next batch's convolutions it only starts where one of theirs has ended, and
     // then holds that CU for its ~6 tiles.  So: synchronous calls only.
-    if (const char *e = getenv("SPFE_SPARSE_DA")) h->sparse_da_mode = atoi(e);
+    if (h->sparse_da_env >= 0) h->sparse_da_mode = h->sparse_da_env;
     h->sparse_da = h->sparse_da && h->sparse_da_mode != 0;
     if (h->sparse_da && (rc = dev_alloc(h, &h->act7_alt, (size_t)B * C * 128))) return rc;
   }
-  if (!h->bf16 && h->kc_mask != 0) {   // the K-chain kernel's weight tables (conv_f32_kc.hip): conv3a, conv4a, conv4b, convPa | convDa
-    const int kl[4] = {3, 5, 6, 7};
-    for (int q = 0; q < 4; ++q) {
-      const int i = kl[q];
-      const int l0 = specs[i].l0, l1 = specs[i].l1, nl = specs[i].nl;
-      const spfe_layer_t &La = SPFE_LAYERS[l0];
-      const int cout = La.cout + (nl == 2 ? SPFE_LAYERS[l1].cout : 0);
-      if (!spfe::conv_f32_kc_supports(h->layers[i].H, h->layers[i].W, La.cin, cout)) continue;
-      std::vector<float> wsrc((size_t)cout * La.cin * 9), wdst((size_t)cout * La.cin * 9);
-      memcpy(wsrc.data(), blob.data() + blob_weight_offset(l0), (size_t)La.cout * La.cin * 9 * 4);
-      if (nl == 2) memcpy(wsrc.data() + (size_t)La.cout * La.cin * 9, blob.data() + blob_weight_offset(l1), (size_t)SPFE_LAYERS[l1].cout * La.cin * 9 * 4);
-      spfe::conv_f32_kc_pack_weights(wsrc.data(), La.cin, cout, wdst.data());
-      if ((rc = dev_alloc(h, &h->d_wkc[i], wdst.size()))) return rc;
-      HIP_TRY(hipMemcpy(h->d_wkc[i], wdst.data(), wdst.size() * 4, hipMemcpyHostToDevice));
-    }
-  }
   if (!h->bf16) {  // f32 heads with register-resident weights (head_f32.hip), bit-identical to the generic kernel — opt-in:
     // measured 63 + 38.5 us per eight 752x480 frames against 72 + 35.5 for the generic kernel (matrix-bound: 47 us at the peak)
-    const char *fe = getenv("SPFE_F32_HEADS");
-    if (fe) h->f32_heads = atoi(fe) != 0;
-    if (const char *e = getenv("SPFE_PBTAIL")) h->pbtail = atoi(e) != 0;
+    h->pbtail = h->pbtail_env != 0;
     if (h->f32_heads) h->pbtail = false;
     if (h->pbtail) {
       const float *Wp = blob.data() + blob_weight_offset(9);   // layer 9 = convPb, [65][256]
@@ -509,7 +490,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
     // frames/s, a single-frame call's p50 -1.4 %
     h->sparse_da_mode = 2;
     h->sparse_da = h->sparse_db && (size_t)B * C * 2048 < ((size_t)1 << 31);
-    if (const char *e = getenv("SPFE_SPARSE_DA")) h->sparse_da_mode = atoi(e);
+    if (h->sparse_da_env >= 0) h->sparse_da_mode = h->sparse_da_env;
     h->sparse_da = h->sparse_da && h->sparse_da_mode != 0;
     if (h->sparse_da) {
       std::vector<float> w(spfe::da_gather_f32_weight_bytes() / 4);
@@ -520,7 +501,7 @@ int build(spfe_handle h, const spfe_config *cfg) {
     }
   }
   if (h->bf16) {  // both heads in bf16: convPa | convDa write bf16, convPb and convDb are head_bf16.hip's GEMMs
-    if (const char *e = getenv("SPFE_PBTAIL")) h->pbtail = atoi(e) != 0;   // (convPb inside the tail's launch: pbtail_bf16.hip)
+    h->pbtail = h->pbtail_env != 0;   // (convPb inside the tail's launch: pbtail_bf16.hip)
     if ((rc = dev_alloc(h, &h->d_hd, (size_t)B * C * 512))) return rc;
     for (int which = 0; which < 2; ++which) {
       const int lid = which ? 9 : 11;

@@ -11,14 +11,11 @@ namespace spfe_host {
 // finished long ago: one hipEventQuery on the host replaces the packet.  (Not under stream capture: a query is illegal there,
 // and a captured wait is a graph edge, not a packet.)
 hipError_t wait_if_pending(hipStream_t s, hipEvent_t ev) {
-  static const bool always = getenv("SPFE_ALWAYS_WAIT") && atoi(getenv("SPFE_ALWAYS_WAIT")) != 0;   // A/B knob
-  if (!always) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
-      const hipError_t q = hipEventQuery(ev);
-      if (q == hipSuccess) return hipSuccess;
-      if (q != hipErrorNotReady) (void)hipGetLastError();   // (e.g. an event never recorded: fall through to the wait)
-    }
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
+    const hipError_t q = hipEventQuery(ev);
+    if (q == hipSuccess) return hipSuccess;
+    if (q != hipErrorNotReady) (void)hipGetLastError();   // (e.g. an event never recorded: fall through to the wait)
   }
   return hipStreamWaitEvent(s, ev, 0);
 }
@@ -42,7 +39,8 @@ __global__ void copy_records_kernel(uint4 *dst, const uint4 *src, size_t n16) {
 // turns the +2 % of the split into -3 %.  The runtime offers no query, so the library measures — on the DEVICE clock: two
 // 150 us spin kernels, one per stream, each writing the wall_clock64 (100 MHz, one counter for the whole device) of its first
 // and last instruction.  On different queues the two intervals overlap; on one queue the second starts when the first has
-// ended.  No host timer is involved, so a preempted host thread cannot change the answer; the outcome is
+// ended (within microseconds: a larger gap is a late launch, not a shared queue, and counts as "not measurable").  No host
+// timer is involved; the outcome is
 // readable through spfe_debug_read("split_streams").  Once per launch stream (the first call that brings it synchronises that
 // stream), up to four candidates; without a free queue — or when the stream is being captured — the split stays off.
 __global__ void queue_probe_spin_kernel(long long ticks, long long *stamp) {
@@ -55,10 +53,11 @@ __global__ void zero_tile_counters_kernel(int *p, int n) {
 }
 }  // namespace spfe
 namespace spfe_host {
-// 1 = the two streams share a hardware queue, 0 = they do not, -1 = could not be measured (error / ambiguous twice)
+// 1 = the two streams share a hardware queue, 0 = they do not, -1 = could not be measured (error / ambiguous)
 int streams_share_a_queue(hipStream_t a, hipStream_t b, long long *h_stamp /* pinned, 4 entries */) {
   constexpr long long kTicks = 15000;   // 150 us
   if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return -1;
+  int shared_votes = 0;
   for (int rep = 0; rep < 3; ++rep) {   // (rep 0 includes the kernel's code load: its stamps are not used)
     for (int i = 0; i < 4; ++i) h_stamp[i] = 0;
     hipLaunchKernelGGL(spfe::queue_probe_spin_kernel, dim3(1), dim3(64), 0, a, kTicks, h_stamp);
@@ -67,12 +66,16 @@ int streams_share_a_queue(hipStream_t a, hipStream_t b, long long *h_stamp /* pi
     if (rep == 0) continue;
     const long long a0 = h_stamp[0], a1 = h_stamp[1], b0 = h_stamp[2], b1 = h_stamp[3];
     if (a1 <= a0 || b1 <= b0) continue;   // (a stamp did not arrive: try once more)
-    // overlap of the two intervals against the spin length: none = one queue; more than half = two queues
+    // overlap of the two intervals against the spin length: more than half = two queues.  None at all has two causes that
+    // look alike from the overlap alone: ONE queue — the second spin starts right where the first ended, a few us
+    // apart — or a host thread that was held up for > 150 us between the two launches — the second spin then starts whenever
+    // it was launched.  The gap tells them apart; "shared" is only returned when both measured repetitions say so.
     const long long ov = std::min(a1, b1) - std::max(a0, b0);
-    if (ov <= kTicks / 10) return 1;
     if (ov >= kTicks / 2) return 0;
+    const long long gap = b0 >= a1 ? b0 - a1 : a0 - b1;   // between the end of one spin and the start of the other
+    if (ov <= kTicks / 10 && gap >= 0 && gap <= 3000) ++shared_votes;   // (<= 30 us: back to back on one queue)
   }
-  return -1;
+  return shared_votes == 2 ? 1 : -1;
 }
 int pick_conv2(spfe_handle h, hipStream_t s) {
   for (const auto &k : h->conv2_known)
@@ -93,14 +96,6 @@ int pick_conv2(spfe_handle h, hipStream_t s) {
     h->host_allocs.push_back(q);
     h->probe_stamp = reinterpret_cast<long long *>(q);
   }
-  if (const char *e = getenv("SPFE_F32_SPLIT_PROBE"))   // 0: trust the first candidate (no measurement, no synchronisation)
-    if (atoi(e) == 0) {
-      if (h->conv2_pool.empty()) { hipStream_t c; HIP_TRY(hipStreamCreateWithFlags(&c, hipStreamNonBlocking)); h->conv2_pool.push_back(c); }
-      h->conv2 = h->conv2_pool[0];
-      h->conv2_ok = true;
-      h->split_probe = 2;
-      return SPFE_OK;
-    }
   h->split_probe = 0;
   for (int k = 0; k < 4; ++k) {
     if ((int)h->conv2_pool.size() <= k) {
@@ -160,8 +155,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   // Predicted from the last call's schedule; a wrong guess only repeats the (satisfied) waits later.  SPFE_EARLY_WAITS=0: off
   bool early_waits = false;
   {
-    static const bool ew_env = !(getenv("SPFE_EARLY_WAITS") && atoi(getenv("SPFE_EARLY_WAITS")) == 0);
-    if (ew_env && h->split_last && h->pbtail && n >= 2 && ((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode) && !(h->timing && h->timing_all)) {
+    if (h->early_waits && h->split_last && h->pbtail && n >= 2 && ((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode) && !(h->timing && h->timing_all)) {
       const int rcw = tail_waits(h, d_records, s);
       if (rcw) return rcw;
       early_waits = true;
@@ -228,14 +222,10 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
         p.wpack = reinterpret_cast<const float *>(h->d_wws[i]);
         p.tile_ctr = h->d_tile_ctr + 64 * i + 32 * part;
         if (i == 0 && fused16) { p.img = d_images; p.w1a = reinterpret_cast<const float *>(h->d_w1a_tab); p.b1a = h->d_b1a; }
-        // (experiment knobs, pipelined calls: conv1b / all Cin = 64 layers on fewer workgroups than CUs, so that the previous
-        // batch's selection — 143 KB of LDS per workgroup, nothing fits beside this kernel's 158 KB — starts beside conv1b
-        // instead of behind it.  1280x720 x 8: conv1b on 224 workgroups +0.3 ... 2 % whole path with conv1b at 0.51 - 0.53 of
-        // peak instead of 0.57; 240 / 208 / 192: -2 / -1 / -3 %.  Not taken: HISTORY.md "Round 4")
-        static const int ws_grid0 = getenv("SPFE_BF16_CONV1B_GRID") ? atoi(getenv("SPFE_BF16_CONV1B_GRID")) : 0;
-        static const int ws_grid = getenv("SPFE_BF16_WS_GRID") ? atoi(getenv("SPFE_BF16_WS_GRID")) : 0;
-        if (((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode) && (i == 0 && ws_grid0 ? ws_grid0 : ws_grid) > 0)
-          p.num_cus = i == 0 && ws_grid0 ? ws_grid0 : ws_grid;
+        // (measured and not kept: conv1b / all Cin = 64 layers on fewer workgroups than CUs in pipelined calls, so that the
+        // previous batch's selection — 143 KB of LDS, nothing fits beside this kernel's 158 KB — starts beside conv1b: 1280x720
+        // x 8 on 224 workgroups +0.3 ... 2 % with conv1b at 0.51 - 0.53 of peak instead of 0.57; 248 / 240 / 208 / 192: -1 / -2
+        // / -1 / -3 %.  HISTORY.md "Round 4"; re-measured in round 5)
         HIP_TRY(spfe::launch_conv_bf16_ws(p, L.pool, i == 0 ? (fused16 ? 2 : 1) : 0, s));
         STAGE_MARK(2 + i);
         return SPFE_OK;
@@ -294,7 +284,8 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
           const spfe::FrameBufs fb = frame_bufs(h, d_records, sparse);
           // (each half clears ITS tile-queue counters [layer][part][32] for the next call: the other half's may be in use)
           HIP_TRY(spfe::launch_pbtail_bf16(h->d_hd, h->d_wpb, h->layers[8].d_b, h->d_semi, fb, h->rl, n, H, W, s, f0,
-                                           h->d_tile_ctr ? h->d_tile_ctr + 32 * part : nullptr, h->d_tile_ctr ? 8 * 32 : 0, 64));
+                                           h->d_tile_ctr ? h->d_tile_ctr + 32 * part : nullptr, h->d_tile_ctr ? 8 * 32 : 0, 64,
+                                           h->pbtail_env > 1 ? h->pbtail_env : 0));
           if (h->d_tile_ctr) h->tile_ctr_clean = true;
         }
       }
@@ -314,18 +305,6 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     if (!h->bf16 && i >= 8 && h->f32_heads) {  // convPb / convDb in f32: head_f32.hip (weights in registers)
       if (i == 8) HIP_TRY(spfe::launch_head1x1_f32(h->d_head, h->d_wpb32, L.d_b, h->d_semi, n * h->C, 65, s));
       else HIP_TRY(spfe::launch_head1x1_f32(h->d_head, h->d_wdb32, L.d_b, h->d_coarse, n * h->C, 256, s));
-      STAGE_MARK(2 + i);
-      return SPFE_OK;
-    }
-    if (!h->bf16 && L.ks == 3 && !L.pool && L.relu && i < 8 && h->d_wkc[i] && n_all == 1 && !(i == 0 && fused) &&
-        (h->kc_mask > 0 ? ((h->kc_mask >> i) & 1) != 0 : h->kc_mask < 0 && ((kKcAuto >> i) & 1) &&
-         // ... where at least two of its workgroups share a CU (they fill each other's staging stalls: convPa of a 752x480
-         // frame, 480 workgroups, 45 -> 41 us; conv4a, 240 workgroups = one per CU, 27 -> 29 us: not taken)
-         (long)((L.H + (2 * ((L.W + 15) / 16) <= 12 ? 2 : 1) - 1) / (2 * ((L.W + 15) / 16) <= 12 ? 2 : 1)) *
-                 ((i == 7 && sparse_da ? L.cout_real / 2 : L.cout_real) / 16) * 2 >= 3L * (h->num_cus > 0 ? h->num_cus : 256))) {
-      const int cout = i == 7 && sparse_da ? L.cout_real / 2 : L.cout_real;   // (convPa alone when convDa runs gathered)
-      p.B = n; p.H = L.H; p.W = L.W;
-      HIP_TRY(spfe::launch_conv_f32_kc(p, L.cin, cout, h->d_wkc[i], L.d_b, s));
       STAGE_MARK(2 + i);
       return SPFE_OK;
     }
@@ -371,7 +350,6 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     }
     if (i == 0 && fused) small_tile = false;  // the fused first layer exists for 8-row tiles only
     int tile_mode = small_tile ? 1 : 0;
-    if (L.ks == 3 && !(i == 0 && fused) && ((h->tile16_mask >> i) & 1)) tile_mode = 2;
     // conv1b: 16-row tiles of 4 wavefronts x 4 rows x 64 channels (6 operand reads per 8 MFMAs instead of 8; bit-identical):
     // measured on conv1b 2.2 ... 2.5 % per tile (640x480: 0.863 -> 0.882 of peak; 752x480: the coarser list costs 45 -> 46
     // round equivalents and it still gains 0.3 %; whole path +0.6 ... 0.8 %) — taken when its rounds are not more than 2.5 %
@@ -436,7 +414,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   // f32, >= 2 frames: conv1b for the whole batch (its work list divides evenly over the CUs), then everything behind it as
   // two half batches on two streams: a layer's work list is 5.6 / 11.25 / 2.8 items per workgroup at 8 frames of 752x480, its
   // last round leaves most CUs idle, and the other half's kernel — independent frames — starts on exactly those CUs
-  bool split = (h->bf16 ? (h->bf16_split >= 1 || (h->bf16_split < 0 && h->C < 10000)) : (h->f32_split >= 1 && !h->f32_heads)) && n >= 2 && !(h->timing && h->timing_all) && !defer_db;
+  bool split = (h->split_mode >= 0 ? h->split_mode >= 1 : (!h->bf16 || h->C < 10000)) && !(!h->bf16 && h->f32_heads) && n >= 2 && !(h->timing && h->timing_all) && !defer_db;
   if (split) {
     const int rcp = pick_conv2(h, s);
     if (rcp) return rcp;
@@ -447,8 +425,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     // The detector tail rides in convPb's launch, and with the halves on two streams each half's tail can run right behind its
     // convPa instead of behind the join (SPFE_TAIL_PER_HALF=0: behind the join) — what it must wait for (the side chain two
     // tickets back) is waited for HERE, on the launch stream in front of conv1b; the second stream forks behind conv1b
-    static const bool tph_env = !(getenv("SPFE_TAIL_PER_HALF") && atoi(getenv("SPFE_TAIL_PER_HALF")) == 0);
-    tail_per_half = h->pbtail && tph_env;
+    tail_per_half = h->pbtail && h->tail_per_half;
     if (tail_per_half && !early_waits) {
       const int rcw = tail_waits(h, d_records, s);
       if (rcw) return rcw;
@@ -457,7 +434,6 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     if (rc) return rc;
     HIP_TRY(hipEventRecord(h->ev_fork, s));
     HIP_TRY(hipStreamWaitEvent(h->conv2, h->ev_fork, 0));
-    // (SPFE_F32_SPLIT = number of parts, alternating between the two streams; 2 = halves)
     const int parts = 2;
     for (int q = 0; q < parts; q += 2)
       for (int i = 1; i < nlayers; ++i)
@@ -543,8 +519,7 @@ int tail_waits(spfe_handle h, uint8_t *d_records, hipStream_t s) {
     const int NT = spfe_handle_s::NTICKET;
     if (h->ticket >= 2) HIP_TRY(wait_if_pending(s, h->ev_cov[(h->ticket - 2) % NT]));
     const int prev = (int)((h->ticket + NT - 1) % NT);
-    static const bool old_order = getenv("SPFE_TAIL_WAITS_PREV") && atoi(getenv("SPFE_TAIL_WAITS_PREV"));   // A/B knob
-    if (h->rec_of[prev] == d_records || old_order) HIP_TRY(wait_if_pending(s, h->ev_cov[prev]));
+    if (h->rec_of[prev] == d_records) HIP_TRY(wait_if_pending(s, h->ev_cov[prev]));
   }
   return SPFE_OK;
 }
@@ -566,14 +541,13 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
   h->rec_of[slot] = d_records;
   if (tail_done) {}
   else if (fused_pb && h->bf16) {
-    HIP_TRY(spfe::launch_pbtail_bf16(h->d_hd, h->d_wpb, h->layers[8].d_b, h->d_semi, f, h->rl, n, H, W, s, 0, h->d_tile_ctr, h->d_tile_ctr ? 8 * 64 : 0));
-    static const bool zit = !(getenv("SPFE_ZERO_IN_TAIL") && atoi(getenv("SPFE_ZERO_IN_TAIL")) == 0);   // A/B knob
-    if (h->d_tile_ctr && zit) h->tile_ctr_clean = true;
+    HIP_TRY(spfe::launch_pbtail_bf16(h->d_hd, h->d_wpb, h->layers[8].d_b, h->d_semi, f, h->rl, n, H, W, s, 0, h->d_tile_ctr, h->d_tile_ctr ? 8 * 64 : 0, 32,
+                                     h->pbtail_env > 1 ? h->pbtail_env : 0));
+    if (h->d_tile_ctr && h->zero_in_tail) h->tile_ctr_clean = true;
   } else if (fused_pb) HIP_TRY(spfe::launch_pbtail_f32(h->d_head, h->d_wpb32, h->d_wpb_dust, h->layers[8].d_b, h->d_semi, f, h->rl, n, H, W, s));
   else {
     HIP_TRY(spfe::launch_tail(f, h->rl, n, H, W, s, h->d_tile_ctr, h->d_tile_ctr ? 8 * 64 : 0));
-    static const bool zit = !(getenv("SPFE_ZERO_IN_TAIL") && atoi(getenv("SPFE_ZERO_IN_TAIL")) == 0);   // A/B knob
-    if (h->d_tile_ctr && zit) h->tile_ctr_clean = true;
+    if (h->d_tile_ctr && h->zero_in_tail) h->tile_ctr_clean = true;
   }
   STAGE_MARK(12);
   // Synchronous calls with the gathered descriptor branch (a single frame's operator(): BASELINE configs[1]): the detector
@@ -584,8 +558,7 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
   // covariance chain) takes the side stream: one hop at its start, beside the covariance kernels, and a join at the end that
   // has long been signalled.  (Round 3 ran it the other way round and let the replay launch carry the sampling: the replay
   // then waited for the gathered head — 28 us of a 0.80 ms call.)  SPFE_INLINE_CHAIN=0 restores that order.
-  static const bool inline_env = !(getenv("SPFE_INLINE_CHAIN") && atoi(getenv("SPFE_INLINE_CHAIN")) == 0);
-  if (inline_env && sparse && !conv_db && !((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode) && !(h->timing && h->timing_all)) {
+  if (h->inline_chain && sparse && !conv_db && !((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode) && !(h->timing && h->timing_all)) {
     if (h->cov_inflight) {   // (a pipelined call's chain still on the side stream — it owns heat_inv and the covariance scratch)
       HIP_TRY(hipStreamWaitEvent(s, h->ev_cov[(h->ticket + spfe_handle_s::NTICKET - 1) % spfe_handle_s::NTICKET], 0));
       h->cov_inflight = false;
@@ -593,12 +566,11 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
     STAGE_MARK(13);
     // (the event the side stream waits for is the selection's own completion signal: a hipEventRecord here put a marker
     // packet between the selection and the covariance walk — 7.6 us on the chain; SPFE_SEL_EXT_EVENT=0: that record)
-    static const bool sel_ext_env = !(getenv("SPFE_SEL_EXT_EVENT") && atoi(getenv("SPFE_SEL_EXT_EVENT")) == 0);
     // (under stream capture the record it is: the stop event of an extended launch is not a capture node, the side stream
     // would not join the capture and its kernels would run once, at capture time)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    const bool sel_ext = sel_ext_env && hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
-    HIP_TRY(spfe::launch_select(f, h->rl, n, H, W, h->cfg.num_features, s, &h->cov, h->rl.kmax, h->select_lean == 1,
+    const bool sel_ext = h->sel_ext_event && hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
+    HIP_TRY(spfe::launch_select(f, h->rl, n, H, W, h->cfg.num_features, s, &h->cov, h->rl.kmax, false,
                                 sel_ext ? h->ev_sel : nullptr));
     if (!sel_ext) HIP_TRY(hipEventRecord(h->ev_sel, s));
     HIP_TRY(hipStreamWaitEvent(h->side, h->ev_sel, 0));
@@ -625,20 +597,14 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
   if (h->join_pending) HIP_TRY(hipStreamWaitEvent(h->side, h->ev_join, 0));   // (the other half batch: its tail ran on the second stream)
   STAGE_MARK(13);   // ("select" reads 0 on the launch stream: it is part of post_side)
   // (the heat normalisation rides in the selection's first launch: both depend on the detector tail only)
-  {
-    const bool pipelined = (h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode;
-    HIP_TRY(spfe::launch_select(f, h->rl, n, H, W, h->cfg.num_features, h->side, &h->cov, h->rl.kmax,
-                                h->select_lean == 1 || (h->select_lean < 0 && pipelined)));
-  }
+  HIP_TRY(spfe::launch_select(f, h->rl, n, H, W, h->cfg.num_features, h->side, &h->cov, h->rl.kmax, false));
   // Synchronous calls: the descriptor sampling rides in the covariance replay launch (the chain's longest kernel) instead of
   // standing in front of the chain; pipelined calls keep it early — the NEXT call's convDb waits for it, and behind a replay
   // that shares the chip with that call's convolutions it would wait too long (0.5 ms steps in bf16 mode).
   const bool sync_call = !((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode);
   // pipelined calls, sparse: nothing on the launch stream waits for the sampling any more (the dense convDb of the NEXT call
   // did), so it may ride in the replay launch there too: bf16 1280x720 +0.2 %, f32 752x480 -0.7 % (kept early in f32 mode)
-  static const int sparse_dir_env = getenv("SPFE_SPARSE_DESC_IN_REPLAY") ? atoi(getenv("SPFE_SPARSE_DESC_IN_REPLAY")) : -1;
-  const bool sparse_dir = sparse_dir_env < 0 ? h->bf16 : sparse_dir_env != 0;
-  const bool desc_in_replay = h->desc_in_replay && (sync_call || (sparse && sparse_dir)) && !(h->timing && h->timing_all);
+  const bool desc_in_replay = (sync_call || (sparse && h->bf16)) && !(h->timing && h->timing_all);
   hipEvent_t before_replay = nullptr;
   if (conv_db) {   // the descriptor head, launched behind the detector tail (enqueue()): the sampling waits for it
     const int rc = (*conv_db)();
@@ -673,9 +639,8 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
     // bf16 pipelined calls: fat replay workgroups (8 components each), so that the previous batch's replay holds ~120 CUs
     // instead of a wavefront on nearly every CU — a register-resident-weights convolution workgroup of THIS batch needs a
     // whole CU's registers (SPFE_REPLAY_WAVES=2|8 overrides)
-    static const int rw_env = getenv("SPFE_REPLAY_WAVES") ? atoi(getenv("SPFE_REPLAY_WAVES")) : 0;
     // (measured, same-box A/B, 8 frames per call: bf16 1280x720 +0.7 %, bf16 752x480 -1.8 %, f32 -1 %: large bf16 frames only)
-    const int rwv = rw_env ? rw_env : (h->bf16 && !sync_call && h->C >= 10000 ? 8 : 2);
+    const int rwv = h->replay_waves ? h->replay_waves : (h->bf16 && !sync_call && h->C >= 10000 ? 8 : 2);
     HIP_TRY(spfe::launch_cov(f, h->rl, h->cov, n, H, W, h->side, desc_in_replay, before_replay, rwv));
   }
   if (desc_in_replay) {

@@ -577,7 +577,7 @@ hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H
     hipLaunchKernelGGL(nms_mask_kernel, dim3(((H / 8) * (W / 8) + 255) / 256, B), dim3(256), 0, s, f, H / 8, W / 8);
   }
   // `done`: the event rides on the selection's own dispatch packet (its completion signal) instead of a marker packet behind
-  // it — a hipEventRecord between two kernels of a latency chain costs the stream ~7 us (spfe_api.hip, enqueue_post)
+  // it — a hipEventRecord between two kernels of a latency chain costs the stream ~7 us (spfe_schedule.hip, enqueue_post)
   if (done) {
     if (big) hipExtLaunchKernelGGL(select_kernel<true>, dim3(B), dim3(1024), (unsigned)lds, s, nullptr, done, 0, f, r, H, W, num_features);
     else hipExtLaunchKernelGGL(select_kernel<false>, dim3(B), dim3(1024), (unsigned)lds, s, nullptr, done, 0, f, r, H, W, num_features);

@@ -38,7 +38,7 @@ def _align(v, a):
 
 
 class RecordLayout:
-    """Python mirror of make_layout() in csrc/spfe_api.hip (checked against the
+    """Python mirror of make_layout() in csrc/spfe_pack.hip (checked against the
     library by tests): byte offsets inside one per-frame record."""
 
     def __init__(self, height, width, num_features, desc_bf16=False):
@@ -272,7 +272,12 @@ class ShardedExtractor:
 
     def step(self, d_images, stream):
         """d_images: torch uint8 [frames_per_rank, H, W] on this rank's GPU; `stream`: torch.cuda.Stream
-        the compute is enqueued on (a non-default stream when world > 1)."""
+        the compute is enqueued on (a non-default stream when world > 1).
+
+        What `self.gathered` holds afterwards is COMPLETE ONLY AFTER sync() / decode() / flush(): with one rank and
+        pipelined calls nothing is put on `stream` per step (no wait, no event record: ~20 us of idle compute queue per
+        step otherwise), so a consumer that reads `gathered` on `stream` right after step() races with the side chain —
+        call sync(stream) first (it orders `stream` behind the batch), or set SPFE_LAZY_ORDER=0 for the per-step ordering."""
         k = self._calls % len(self.local)
         self._calls += 1
         if self._local_free[k] is not None:      # (long done: it was issued len(local) steps ago)

@@ -108,3 +108,17 @@ def test_a_rank_failing_inside_a_leg_does_not_cost_the_line():
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["parity_gathered"] is True and d["allgather_ms"] > 0
     assert "host_alt" in d["legs_incomplete"] and "host_alt" not in d
     assert "leg host_alt failed" in out.stderr
+
+
+def test_strict_legs_put_a_failed_leg_into_the_exit_status():
+    """SPFE_BENCH_STRICT_LEGS=1: the same injected failure — the line is still printed once, complete as far as it got,
+    and the job's exit status is non-zero (the failing rank leaves with 3, two seconds after rank 0 has printed)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, cwd=ROOT,
+                         env=_clean_env(SPFE_BENCH_BACKEND="gloo", SPFE_BENCH_FAIL_LEG="host_alt:1", SPFE_LEGS_TIMEOUT="40",
+                                        SPFE_BENCH_STRICT_LEGS="1"),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "host_alt" in d["legs_incomplete"]

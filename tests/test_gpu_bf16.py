@@ -120,9 +120,8 @@ def test_bf16_ws_kernel_equals_single_role_kernel(monkeypatch):
     imgs = [synth.make_image(80 + i, H, W) for i in range(3)]
     out = {}
     for mask, items, fuse in (("0", "11", "0"), ("15", "0", "0"), ("5", "0", "0"), ("15f", "0", "1")):
-        monkeypatch.setenv("SPFE_BF16_WS_MASK", mask.rstrip("f"))
-        monkeypatch.setenv("SPFE_BF16_WS_MIN_ITEMS", items)
-        monkeypatch.setenv("SPFE_BF16_FUSE_CONV1A", fuse)   # "15f": conv1a computed by conv1b's producer waves
+        monkeypatch.setenv("SPFE_BF16_WS", "%s,%s" % (mask.rstrip("f"), items))   # "mask,min_items"
+        monkeypatch.setenv("SPFE_FUSE_CONV1A", fuse)   # "15f": conv1a computed by conv1b's producer waves
         ext = SPExtractor(nf, H, W, blob, max_batch=3, precision="bf16", with_heat=False)
         frs = ext.extract_batch(imgs)
         out[mask] = (frs, [ext.debug_read("semi", i) for i in range(3)], [ext.debug_read("act%d" % k, 1) for k in (1, 2, 3, 4)])
@@ -177,15 +176,14 @@ def test_bf16_queue_order_equals_static_order(monkeypatch):
 
 
 def test_bf16_tile_heights_of_the_streamed_weight_layers_are_bit_identical(monkeypatch):
-    """conv_bf16.hip runs the Cin = 128 layers with 8-, 12- (no pool) or 16-row tiles (SPFE_BF16_TILE_ROWS,
-    SPFE_BF16_TILE16_MIN_ITEMS): a tile's height decides who computes a pixel, not how."""
+    """conv_bf16.hip runs the Cin = 128 layers with 8-, 12- (no pool) or 16-row tiles (SPFE_BF16_TILE_ROWS =
+    "rows,min_items"): a tile's height decides who computes a pixel, not how."""
     H, W, nf = 240, 376, 400
     blob = weights.synthetic(7, "dense")
     imgs = [synth.make_image(90 + i, H, W) for i in range(3)]
     out = {}
     for rows, mn in (("8", "0"), ("12", "1"), ("16", "1")):
-        monkeypatch.setenv("SPFE_BF16_TILE_ROWS", rows)
-        monkeypatch.setenv("SPFE_BF16_TILE16_MIN_ITEMS", mn)
+        monkeypatch.setenv("SPFE_BF16_TILE_ROWS", "%s,%s" % (rows, mn))
         ext = SPExtractor(nf, H, W, blob, max_batch=3, precision="bf16", with_heat=False)
         frs = ext.extract_batch(imgs)
         out[rows] = (frs, [ext.debug_read("semi", i) for i in range(3)], [ext.debug_read("coarse", i) for i in range(3)])
@@ -199,7 +197,7 @@ def test_bf16_tile_heights_of_the_streamed_weight_layers_are_bit_identical(monke
 
 @pytest.mark.parametrize("H,W,B", [(480, 752, 2), (256, 384, 3), (720, 1280, 2), (264, 400, 1)])
 def test_bf16_rw_kernel_equals_streamed_weight_kernel(monkeypatch, H, W, B):
-    """conv_bf16_rw.hip (Cin = 128 layers, weights resident in registers, 4- or 2-row tiles, SPFE_BF16_RW / _MIN4 / _MIN2)
+    """conv_bf16_rw.hip (Cin = 128 layers, weights resident in registers, 4- or 2-row tiles, SPFE_BF16_RW = "on,min4,min2,rows3")
     against conv_bf16.hip (weights streamed through LDS): same K order, same epilogue arithmetic -> the same bits in every
     activation, logit and record, whichever kernel a launch size selects.  Ragged widths (188 / 94 columns at 752x480, 100 /
     50 at 264x400), ragged heights (90 rows in 4-row tiles at 1280x720, 33 at 264x400), pooled and unpooled layers."""
@@ -209,10 +207,7 @@ def test_bf16_rw_kernel_equals_streamed_weight_kernel(monkeypatch, H, W, B):
     out = {}
     for key, rw, m4, m2, r3 in (("ref", "0", "0", "0", "0"), ("rows4", "1", "0", "0", "0"), ("rows2", "1", "1000000", "0", "0"),
                                ("rows3", "1", "0", "0", "1")):
-        monkeypatch.setenv("SPFE_BF16_RW", rw)
-        monkeypatch.setenv("SPFE_BF16_RW_MIN4", m4)
-        monkeypatch.setenv("SPFE_BF16_RW_MIN2", m2)
-        monkeypatch.setenv("SPFE_BF16_RW_ROWS3", r3)
+        monkeypatch.setenv("SPFE_BF16_RW", "%s,%s,%s,%s" % (rw, m4, m2, r3))
         ext = SPExtractor(nf, H, W, blob, max_batch=B, precision="bf16", with_heat=False)
         frs = ext.extract_batch(imgs)
         out[key] = (frs, [ext.debug_read(nm, B - 1) for nm in ("act5", "act6", "act7", "semi", "coarse")])
@@ -224,25 +219,8 @@ def test_bf16_rw_kernel_equals_streamed_weight_kernel(monkeypatch, H, W, B):
             assert a.K == b.K and np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.descriptors, b.descriptors)
 
 
-def test_side_stream_on_a_cu_mask(monkeypatch):
-    """SPFE_SIDE_CUS: the side stream (selection, descriptors, covariance) confined to 32 CUs gives the same records."""
-    H, W, nf = 240, 320, 300
-    blob = weights.synthetic(7, "dense")
-    img = synth.make_image(33, H, W)
-    res = []
-    for n in ("0", "32"):
-        monkeypatch.setenv("SPFE_SIDE_CUS", n)
-        ext = SPExtractor(nf, H, W, blob, precision="bf16", with_heat=False)
-        ext(img, None)
-        res.append(ext.last)
-        ext.close()
-    a, b = res
-    assert a.K == b.K and np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.descriptors, b.descriptors)
-    assert np.array_equal(a.cov2, b.cov2)
-
-
 def test_two_stream_half_batches_are_bit_identical(monkeypatch):
-    """SPFE_F32_SPLIT / SPFE_BF16_SPLIT: the layers behind conv1b issued as two half batches on two streams (one half's
+    """SPFE_SPLIT: the layers behind conv1b issued as two half batches on two streams (one half's
     workgroups fill the CUs the other half's kernel leaves idle in its last partial round) — same kernels on other frame
     ranges, so every record is bit-identical to the single-launch order, in both precisions, pipelined driver, odd batch."""
     import torch
@@ -251,9 +229,9 @@ def test_two_stream_half_batches_are_bit_identical(monkeypatch):
     blob = weights.synthetic(7, "dense")
     imgs = np.stack([synth.make_image(60 + i, H, W) for i in range(B)])
     d_img = torch.from_numpy(imgs).cuda()
-    for prec, var in (("f32", "SPFE_F32_SPLIT"), ("bf16", "SPFE_BF16_SPLIT")):
+    for prec, var in (("f32", "SPFE_SPLIT"), ("bf16", "SPFE_SPLIT")):
         out = {}
-        for val in ("0", "2"):
+        for val in ("0", "1"):
             monkeypatch.setenv(var, val)
             ext = SPExtractor(nf, H, W, blob, max_batch=B, precision=prec, with_heat=False, async_cov=True)
             sh = parallel.ShardedExtractor(ext, 1, 0, B)
@@ -263,7 +241,7 @@ def test_two_stream_half_batches_are_bit_identical(monkeypatch):
             sh.flush(stream)
             out[val] = [sh.decode(i) for i in range(B)]
             ext.close()
-        for a, b in zip(out["0"], out["2"]):
+        for a, b in zip(out["0"], out["1"]):
             assert a.status == 0 and b.status == 0 and a.K == b.K and np.array_equal(a.kp_xy, b.kp_xy)
             assert np.array_equal(a.descriptors.view(np.uint32), b.descriptors.view(np.uint32))
             assert np.array_equal(a.cov2.view(np.uint32), b.cov2.view(np.uint32)) and np.array_equal(a.occ_grid, b.occ_grid)
@@ -281,8 +259,7 @@ def test_bf16_convPb_inside_the_tail_launch_is_bit_identical(monkeypatch, H, W, 
     imgs = [synth.make_image(270 + i, H, W) for i in range(B)]
     out = {}
     for flag in ("0", "2", "4"):
-        monkeypatch.setenv("SPFE_PBTAIL", "0" if flag == "0" else "1")
-        monkeypatch.setenv("SPFE_PBTAIL_WAVES", flag)
+        monkeypatch.setenv("SPFE_PBTAIL", flag)   # 0: two launches; 2 / 4: the fused launch on that many wavefronts
         ext = SPExtractor(nf, H, W, blob, max_batch=B, precision="bf16", with_heat=True)
         ext.extract_batch(imgs[::-1])
         frs = ext.extract_batch(imgs)

@@ -122,7 +122,7 @@ def test_fused_first_layer_equals_separate_conv1a(H, W, B, monkeypatch):
     tiles per workgroup (the image patch double buffer) and batches."""
     blob = weights.synthetic(7, "dense")
     imgs = [synth.make_image(40 + i, H, W) for i in range(B)]
-    outs = []
+    out = {}
     for fuse in ("1", "0"):
         monkeypatch.setenv("SPFE_FUSE_CONV1A", fuse)
         ext = SPExtractor(100, H, W, blob, max_batch=B, with_heat=False)
@@ -676,15 +676,17 @@ def test_f32_heads_with_register_resident_weights_are_bit_identical(monkeypatch)
 @pytest.mark.parametrize("H,W,B", [(240, 376, 1), (120, 168, 3), (480, 752, 1)])
 def test_f32_two_row_tiles_are_bit_identical(monkeypatch, H, W, B):
     """2-row tiles of conv_f32_kernel (chosen by the cost model for single frames; forced here on every layer without a
-    pool) against the 4 / 8-row tiles (SPFE_TILE2_AUTO=0): the tile shape does not touch an output's K order, so semi,
+    pool, SPFE_TILE2_MASK=0xEA) against the 4 / 8-row tiles (SPFE_TILE2_MASK=0: never) and the cost model (unset): the tile shape does not touch an output's K order, so semi,
     coarse and the intermediate activations are the same bits — ragged heights (120 / 8 = 15 rows) included."""
     nf = 300
     blob = weights.synthetic(7, "dense")
     imgs = [synth.make_image(70 + i, H, W) for i in range(B)]
     out = {}
-    for name, auto, mask in (("tall", "0", "0"), ("two", "1", "0xEA"), ("auto", "1", "0")):
-        monkeypatch.setenv("SPFE_TILE2_AUTO", auto)
-        monkeypatch.setenv("SPFE_TILE2_MASK", mask)
+    for name, mask in (("tall", "0"), ("two", "0xEA"), ("auto", None)):
+        if mask is None:
+            monkeypatch.delenv("SPFE_TILE2_MASK", raising=False)
+        else:
+            monkeypatch.setenv("SPFE_TILE2_MASK", mask)
         ext = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=False)
         frs = ext.extract_batch(imgs)
         out[name] = (frs, [ext.debug_read(nm, i) for i in range(B) for nm in ("semi", "coarse", "feat")])
@@ -813,29 +815,6 @@ def test_f32_pooled_layer_as_unpooled_two_row_tiles_plus_a_pool_pass_is_bit_iden
         a, b = out["0"][0], out[flag][0]
         assert a.K == b.K and np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.descriptors, b.descriptors)
         assert np.array_equal(a.cov2, b.cov2)
-
-
-@pytest.mark.parametrize("H,W", [(480, 752), (480, 640), (136, 200), (64, 96), (720, 1280), (24, 40)])
-def test_f32_k_chain_kernel_on_mfma_16x16x4_is_bit_identical(monkeypatch, H, W):
-    """conv_f32_kc.hip (round 4): a single frame's conv3a / conv4a / conv4b / convPa on v_mfma_f32_16x16x4_f32 — 16 x 16 output
-    chains, 4 k per MFMA in ascending order — against conv_f32.hip's v_mfma_f32_32x32x2_f32 tiles (SPFE_KC=0): the K order per
-    output is the arithmetic contract's either way, so every activation, logit and record is the same bits.  Widths that are
-    not multiples of 16 (94, 25, 12, 5), odd heights (17, 3), one and two rows per strip, and a frame whose conv3a is too wide
-    for the kernel (1280x720: it keeps the other kernel there) included."""
-    blob = weights.synthetic(7, "dense")
-    img = synth.make_image(230, H, W)
-    out = {}
-    for flag in ("0", "0xE8"):
-        monkeypatch.setenv("SPFE_KC", flag)
-        ext = SPExtractor(300, H, W, blob, max_batch=1, with_heat=False)
-        ext(img, None)
-        out[flag] = (ext.last, [ext.debug_read(nm, 0) for nm in ("act4", "act6", "feat", "semi", "coarse")])
-        ext.close()
-    for a, b in zip(out["0"][1], out["0xE8"][1]):
-        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
-    a, b = out["0"][0], out["0xE8"][0]
-    assert a.K == b.K and np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.descriptors, b.descriptors)
-    assert np.array_equal(a.cov2, b.cov2)
 
 
 @pytest.mark.parametrize("cfg", ["f32 1", "f32 4", "bf16 1", "bf16 3", "bf16 2 720 1280"])

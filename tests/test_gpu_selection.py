@@ -179,13 +179,12 @@ def test_overlapping_covariance_regions_exact(H, W, sigma, nh, seed):
 
 
 def test_covariance_queue_overflow_is_handled_on_the_device(monkeypatch):
-    """Walks that outgrow the regular per-keypoint FIFO (forced here: SPFE_COV_QCAP=24) redo themselves in an
+    """Walks that outgrow the regular per-keypoint FIFO (forced here: SPFE_COV_CAPS = "qcap,ovf_slots,ovf_cap,fallback_cap,ecap" with qcap = 24) redo themselves in an
     overflow slot ON THE DEVICE: the record is complete and exact, status stays 0, no host fallback involved."""
     H, W = 128, 160
     semi = _hills(H, W, 1, 10.0, 12)
     coarse = _coarse(H, W, 1)
-    monkeypatch.setenv("SPFE_COV_QCAP", "24")
-    monkeypatch.setenv("SPFE_COV_OVF_SLOTS", "1024")
+    monkeypatch.setenv("SPFE_COV_CAPS", "24,1024")
     ext = SPExtractor(1000, H, W, _blob())
     fr = ext.postprocess(semi, coarse)[0]
     ext.close()
@@ -205,9 +204,7 @@ def test_covariance_overflow_beyond_the_slots_is_redone_on_the_device(monkeypatc
     coarse = _coarse(H, W, 1)
     ref = oracle.postprocess(semi, coarse, H, W, 1000)
     for slots, cap in (("0", "16384"), ("2", "40")):
-        monkeypatch.setenv("SPFE_COV_QCAP", "24")
-        monkeypatch.setenv("SPFE_COV_OVF_SLOTS", slots)
-        monkeypatch.setenv("SPFE_COV_OVF_CAP", cap)
+        monkeypatch.setenv("SPFE_COV_CAPS", "24,%s,%s" % (slots, cap))
         ext = SPExtractor(1000, H, W, _blob())
         fr = ext.postprocess(semi, coarse)[0]
         assert fr.status == 0
@@ -217,14 +214,12 @@ def test_covariance_overflow_beyond_the_slots_is_redone_on_the_device(monkeypatc
 
 
 def test_covariance_last_resort_capacity_is_the_only_reported_failure(monkeypatch):
-    """SPFE_COV_FALLBACK_CAP forced tiny: a region with more pops than the last-resort list holds is the one case that
+    """The last resort's list (SPFE_COV_CAPS field 4) forced tiny: a region with more pops than the last-resort list holds is the one case that
     leaves SPFE_STATUS_COV_OVERFLOW in the record (reported, not guessed); keypoints and descriptors are unaffected."""
     H, W = 128, 160
     semi = _hills(H, W, 1, 10.0, 12)
     coarse = _coarse(H, W, 1)
-    monkeypatch.setenv("SPFE_COV_QCAP", "24")
-    monkeypatch.setenv("SPFE_COV_OVF_SLOTS", "0")
-    monkeypatch.setenv("SPFE_COV_FALLBACK_CAP", "1024")
+    monkeypatch.setenv("SPFE_COV_CAPS", "24,0,,1024")
     ext = SPExtractor(1000, H, W, _blob())
     fr = ext.postprocess(semi, coarse)[0]
     ext.close()
@@ -244,9 +239,7 @@ def test_covariance_overflow_on_the_pipelined_host_path_without_heat_maps(monkey
     from sp_orb_slam_amd import synth, weights
     H, W, nf, B = 120, 160, 150, 2
     blob = weights.synthetic(7, "dense")
-    monkeypatch.setenv("SPFE_COV_QCAP", "16")
-    monkeypatch.setenv("SPFE_COV_OVF_SLOTS", "1")
-    monkeypatch.setenv("SPFE_COV_OVF_CAP", "32")
+    monkeypatch.setenv("SPFE_COV_CAPS", "16,1,32")
     batches = [[synth.make_image(900 + 10 * s + i, H, W) for i in range(B)] for s in range(4)]
     ext = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=False)
     tk = [ext.submit_batch(b) for b in batches[:3]]
@@ -333,11 +326,11 @@ def test_frames_beyond_65535_cells_are_refused():
         SPExtractor(1000, 2160, 3840, _blob())
 
 
-@pytest.mark.parametrize("env", [{"SPFE_COV_EDGES": "0"}, {"SPFE_COV_ECAP": "40"}, {}])
+@pytest.mark.parametrize("env", [{"SPFE_COV_CAPS": ",,,,0"}, {"SPFE_COV_CAPS": ",,,,40"}, {}])
 def test_covariance_link_from_the_classifications_edge_list_equals_the_pop_list_walk(monkeypatch, env):
     """Round 4: the classification lists the claim edges (lower claimant, dirty keypoint) while it has the claims in registers,
     and the link kernel unites from that list (one global round trip) and builds the chains by an all-pairs scan instead of a
-    bitonic sort.  Against the pop-list walk (SPFE_COV_EDGES=0), and with a list too short for the frame (SPFE_COV_ECAP=40:
+    bitonic sort.  Against the pop-list walk (SPFE_COV_CAPS field 5, ecap = 0), and with a list too short for the frame (ecap = 40:
     the link kernel must notice and walk the pop lists): covariances bitwise equal to the sequential oracle's either way."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)

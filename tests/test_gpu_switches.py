@@ -1,0 +1,144 @@
+"""GPU: one bit-identity test per environment switch of libspfe.so that no other test file exercises (README.md
+"Environment switches"): the handle is created with the NON-default value, driven the way the switch matters (synchronous
+single-frame calls, or twelve pipelined steps on changing frames into separate record buffers), and every record must equal
+the one a default synchronous handle computes for the same frames — every field, bit for bit.
+
+The switches are read once per handle by spfe_create (read_switches, csrc/spfe_pack.hip), so monkeypatch.setenv before the
+constructor is all it takes; the reference handle is made with the variable unset."""
+import numpy as np
+import pytest
+
+from sp_orb_slam_amd import parallel, synth, weights
+from sp_orb_slam_amd.extractor import SPExtractor
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("kp_xy", "response", "descriptors", "cov2", "cov2_inv", "occ_grid", "dense_dust", "semi_dust")
+ALL = ("SPFE_INLINE_CHAIN", "SPFE_DEFER_JOIN", "SPFE_TAIL_PER_HALF", "SPFE_EARLY_WAITS", "SPFE_SEL_EXT_EVENT", "SPFE_REPLAY_WAVES",
+       "SPFE_ZERO_IN_TAIL", "SPFE_SPARSE_DA", "SPFE_PIPE_COPY_KERNEL", "SPFE_COMM_OWN_STREAM")
+
+
+def _reference(torch, prec, H, W, B, nf, blob, sets):
+    ext = SPExtractor(nf, H, W, blob, max_batch=B, precision=prec, with_heat=False)
+    rb = ext.record_bytes()
+    ref = []
+    for d in sets:
+        rec = torch.zeros(B * rb, dtype=torch.uint8, device="cuda")
+        ext.extract_batch_device(d.data_ptr(), B, rec.data_ptr())
+        torch.cuda.synchronize()
+        ref.append([ext.view_record(rec.cpu().numpy()[i * rb:(i + 1) * rb]) for i in range(B)])
+    ext.close()
+    return ref, rb
+
+
+def _same(a, b, where):
+    assert a.status == 0 and a.K == b.K and a.K > 0, where
+    for name in FIELDS:
+        assert np.array_equal(getattr(a, name), getattr(b, name)), (where, name)
+
+
+# (switch, value, precision, pipelined): pipelined switches act on steps that run as two half batches (f32, and bf16 frames
+# of fewer than 10,000 cells) or on the side chain; synchronous ones on the single call's order
+CASES = [
+    ("SPFE_INLINE_CHAIN", "0", "f32", False), ("SPFE_INLINE_CHAIN", "0", "bf16", False),
+    ("SPFE_SEL_EXT_EVENT", "0", "f32", False),
+    ("SPFE_DEFER_JOIN", "0", "f32", True), ("SPFE_DEFER_JOIN", "0", "bf16", True),
+    ("SPFE_TAIL_PER_HALF", "0", "f32", True), ("SPFE_TAIL_PER_HALF", "0", "bf16", True),
+    ("SPFE_EARLY_WAITS", "0", "f32", True), ("SPFE_EARLY_WAITS", "0", "bf16", True),
+    ("SPFE_REPLAY_WAVES", "8", "f32", True), ("SPFE_REPLAY_WAVES", "2", "bf16", True), ("SPFE_REPLAY_WAVES", "8", "f32", False),
+    ("SPFE_ZERO_IN_TAIL", "0", "bf16", True), ("SPFE_ZERO_IN_TAIL", "0", "bf16", False),
+    ("SPFE_SPARSE_DA", "2", "bf16", True), ("SPFE_SPARSE_DA", "0", "f32", True), ("SPFE_SPARSE_DA", "1", "f32", True),
+]
+
+
+@pytest.mark.parametrize("var,val,prec,pipelined", CASES)
+def test_switch_gives_the_same_records(monkeypatch, var, val, prec, pipelined):
+    import torch
+    for v in ALL:
+        monkeypatch.delenv(v, raising=False)
+    H, W, B, nf, steps = 240, 376, 5, 300, 12
+    blob = weights.synthetic(7, "dense")
+    sets = [torch.from_numpy(np.stack([synth.make_image(640 + 7 * r + i, H, W) for i in range(B)])).cuda() for r in range(3)]
+    ref, rb = _reference(torch, prec, H, W, B, nf, blob, sets)
+    monkeypatch.setenv(var, val)
+    ext = SPExtractor(nf, H, W, blob, max_batch=B, precision=prec, with_heat=False, async_cov=pipelined)
+    recs = [torch.zeros(B * rb, dtype=torch.uint8, device="cuda") for _ in range(steps)]
+    stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for k in range(steps):
+        ext.extract_batch_device(sets[k % 3].data_ptr(), B, recs[k].data_ptr(), stream.cuda_stream)
+    if pipelined:
+        ext.wait_records(ext.last_ticket(), stream.cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(steps):
+        host = recs[k].cpu().numpy()
+        for i in range(B):
+            _same(ext.view_record(host[i * rb:(i + 1) * rb]), ref[k % 3][i], (var, val, k, i))
+    # single frames through the same handle (the inline chain / the selection's event act there)
+    one = torch.zeros(rb, dtype=torch.uint8, device="cuda")
+    for r in range(3):
+        ext.extract_batch_device(sets[r].data_ptr(), 1, one.data_ptr(), stream.cuda_stream)
+        if pipelined:
+            ext.wait_records(ext.last_ticket(), stream.cuda_stream)
+        torch.cuda.synchronize()
+        _same(ext.view_record(one.cpu().numpy()), ref[r][0], (var, val, "single", r))
+    ext.close()
+
+
+@pytest.mark.parametrize("val,prec", [("0", "f32"), ("1", "bf16")])
+def test_pipelined_host_path_copy_switch(monkeypatch, val, prec):
+    """SPFE_PIPE_COPY_KERNEL: the D2H of a pipelined batch by the runtime's copy engine (0; the f32 default is the kernel) / by
+    the library's copy kernel (1; the bf16 default for large frames is the engine): the same records reach the host."""
+    monkeypatch.delenv("SPFE_PIPE_COPY_KERNEL", raising=False)
+    H, W, B, nf = 120, 160, 2, 150
+    blob = weights.synthetic(7, "dense")
+    batches = [[synth.make_image(1200 + 10 * s + i, H, W) for i in range(B)] for s in range(4)]
+    ref_ext = SPExtractor(nf, H, W, blob, max_batch=B, precision=prec, with_heat=False)
+    ref = [ref_ext.extract_batch(b) for b in batches]
+    ref_ext.close()
+    monkeypatch.setenv("SPFE_PIPE_COPY_KERNEL", val)
+    ext = SPExtractor(nf, H, W, blob, max_batch=B, precision=prec, with_heat=False)
+    tk = [ext.submit_batch(b) for b in batches[:3]]
+    got = []
+    for k in range(4):
+        got.append(ext.collect_batch(tk.pop(0)))
+        if k == 0:
+            tk.append(ext.submit_batch(batches[3]))
+    ext.close()
+    for k, (g, e) in enumerate(zip(got, ref)):
+        for i in range(B):
+            _same(g[i], e[i], ("copy", val, k, i))
+
+
+def test_gather_on_a_communication_stream_of_its_own(monkeypatch):
+    """SPFE_COMM_OWN_STREAM=1 (read by spfe_comm_init): the all-gather on a stream of its own that waits for the batch's
+    covariance event instead of riding on the side stream — 1-rank RCCL communicator, pipelined driver, records equal the
+    host call's.  The same handle then re-makes its communicator without the switch (bench.py's comm_stream_ab does that)."""
+    import torch
+    H, W, nf, B = 120, 160, 150, 3
+    blob = weights.synthetic(7, "dense")
+    batches = [np.stack([synth.make_image(1500 + 10 * s + i, H, W) for i in range(B)]) for s in range(3)]
+    host = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=False)
+    expect = [host.extract_batch(list(b)) for b in batches]
+    host.close()
+    d_batches = [torch.from_numpy(b).cuda() for b in batches]
+    ext = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=False, async_cov=True)
+    streams = []
+    for own in ("1", "0"):
+        monkeypatch.setenv("SPFE_COMM_OWN_STREAM", own)
+        sh = parallel.ShardedExtractor(ext, 1, 0, B, native_comm=True)
+        streams.append(ext.comm_stream())
+        comp = torch.cuda.Stream()
+        done = []
+        for k in range(6):
+            sh.step(d_batches[k % 3], comp)
+            if k >= 1:
+                done.append((k - 1, [sh.decode(i) for i in range(B)]))
+        sh.flush(comp)
+        done.append((5, [sh.decode(i) for i in range(B)]))
+        for k, got in done:
+            for i, (g, e) in enumerate(zip(got, expect[k % 3])):
+                _same(g, e, ("own_stream", own, k, i))
+        ext.comm_destroy()
+    assert streams[0] != streams[1]   # the own-stream communicator did not use the side stream
+    ext.close()

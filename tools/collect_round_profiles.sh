@@ -5,7 +5,7 @@
 set -e
 tag=$1; pre=$2
 R=gpurun_out/round_$tag
-declare -A ARGS=([f32_async]="" [f32_sync]="--sync-cov" [f32_sync_nosplit]="--sync-cov  (SPFE_F32_SPLIT=0: one launch per layer)" [bf16_720p_async]="--precision bf16 --height 720 --width 1280" [bf16_720p_sync]="--precision bf16 --height 720 --width 1280 --sync-cov" [bf16_752_async]="--precision bf16")
+declare -A ARGS=([f32_async]="" [f32_sync]="--sync-cov" [f32_sync_nosplit]="--sync-cov  (SPFE_SPLIT=0: one launch per layer)" [bf16_720p_async]="--precision bf16 --height 720 --width 1280" [bf16_720p_sync]="--precision bf16 --height 720 --width 1280 --sync-cov" [bf16_752_async]="--precision bf16")
 for f in f32_async f32_sync f32_sync_nosplit bf16_720p_async bf16_720p_sync bf16_752_async; do
   {
     echo "# profiles/${pre}_kernel_stats_$f.txt — rocprofv3 --kernel-trace --stats of: python bench.py --no-cpu-baseline --no-bf16-leg --no-host-path --no-match --no-latency --no-stage-table --steps 100 --warmup 10 ${ARGS[$f]}  (tools/profile_round.sh)"

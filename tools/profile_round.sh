@@ -16,7 +16,7 @@ trace() {   # name, bench args
 trace f32_async
 trace f32_sync --sync-cov
 # one launch per layer (no two-stream half batches), synchronous: the trace per-layer fractions are recomputed from
-SPFE_F32_SPLIT=0 trace f32_sync_nosplit --sync-cov
+SPFE_SPLIT=0 trace f32_sync_nosplit --sync-cov
 # a single frame per call (BASELINE configs[1] as written): per-kernel durations and one call's timeline
 rocprofv3 --kernel-trace --stats -d $out/kt_b1 -o trace -- python tools/latency_stages.py --calls 200 > $out/kt_b1.log 2>&1
 python tools/rocpd_summary.py $out/kt_b1/*.db > $out/kernel_stats_f32_batch1.txt 2>&1
