@@ -122,7 +122,7 @@ def test_fused_first_layer_equals_separate_conv1a(H, W, B, monkeypatch):
     tiles per workgroup (the image patch double buffer) and batches."""
     blob = weights.synthetic(7, "dense")
     imgs = [synth.make_image(40 + i, H, W) for i in range(B)]
-    out = {}
+    outs = []
     for fuse in ("1", "0"):
         monkeypatch.setenv("SPFE_FUSE_CONV1A", fuse)
         ext = SPExtractor(100, H, W, blob, max_batch=B, with_heat=False)
