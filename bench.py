@@ -120,6 +120,32 @@ class SclkSampler:
         return {"min": min(s), "avg": round(sum(s) / len(s), 1), "max": max(s), "samples": len(s), "source": self.paths[0]}
 
 
+def bind_to_gpu_numa(torch, device):
+    """N > 1: this rank's host threads onto the cores of its GPU's NUMA node (/sys/bus/pci/devices/<addr>/numa_node ->
+    /sys/devices/system/node/nodeK/cpulist, intersected with the affinity the launcher left).  Eight ranks that all run on
+    the launcher's cores submit their kernels across the socket interconnect and share one node's memory bandwidth for the
+    pinned buffers; VERDICT r4 item 8.  Returns what was done (for the line's config), never raises."""
+    try:
+        pr = torch.cuda.get_device_properties(device)
+        addr = "%04x:%02x:%02x.0" % (int(getattr(pr, "pci_domain_id", 0)), int(pr.pci_bus_id), int(pr.pci_device_id))
+        with open("/sys/bus/pci/devices/%s/numa_node" % addr) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return {"pci": addr, "numa_node": node, "bound": False, "why": "the platform reports no NUMA node for this device"}
+        cpus = set()
+        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+            for part in f.read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = os.sched_getaffinity(0) & cpus
+        if not allowed:
+            return {"pci": addr, "numa_node": node, "bound": False, "why": "none of the node's cores is in this process's affinity mask"}
+        os.sched_setaffinity(0, allowed)
+        return {"pci": addr, "numa_node": node, "bound": True, "cores": len(allowed)}
+    except Exception as e:   # noqa: BLE001 — sysfs layouts differ; an unbound rank still measures
+        return {"bound": False, "why": "%s: %s" % (type(e).__name__, e)}
+
+
 def conv1b_flop(H, W):
     return 2 * H * W * 64 * 64 * 9
 
@@ -260,12 +286,14 @@ def parity_of(rec, ref, bf16):
         a = {(int(x), int(y)) for x, y in rec.kp_xy}
         b = {(int(x), int(y)) for x, y in ref["kp_xy"]}
         idx = {(int(x), int(y)): i for i, (x, y) in enumerate(ref["kp_xy"])}
-        cos = [float(np.dot(rec.descriptors[i], ref["desc"][idx[k]]))
-               for i, k in enumerate((int(x), int(y)) for x, y in rec.kp_xy) if k in idx]
+        pairs = [(i, idx[k]) for i, k in enumerate((int(x), int(y)) for x, y in rec.kp_xy) if k in idx]
+        cos = [float(np.dot(rec.descriptors[i], ref["desc"][j])) for i, j in pairs]
+        mabs = max((float(np.abs(rec.descriptors[i] - ref["desc"][j]).max()) for i, j in pairs), default=0.0)
         jac = len(a & b) / max(1, len(a | b))
-        return bool(jac >= 0.8 and (not cos or min(cos) >= 0.999)), {
-            "rule": "bf16 mode vs the f32 oracle: keypoint-set Jaccard >= 0.8, descriptor cosine of common keypoints >= 0.999",
-            "jaccard": round(jac, 4), "desc_cos_min": round(min(cos), 6) if cos else None}
+        return bool(jac >= 0.87 and (not cos or min(cos) >= 0.999) and mabs <= 2e-2), {
+            "rule": "bf16 mode vs the f32 oracle (SURVEY 8c; tests/golden/flip_report_bf16.json: 256 frames, Jaccard >= 0.890): keypoint-set "
+                    "Jaccard >= 0.87, descriptors of common keypoints: cosine >= 0.999, max-abs <= 2e-2",
+            "jaccard": round(jac, 4), "desc_cos_min": round(min(cos), 6) if cos else None, "desc_max_abs": round(mabs, 6)}
     desc_bits = kp_ok and np.array_equal(rec.descriptors.view(np.uint32), ref["desc"].view(np.uint32))
     cov_bits = kp_ok and np.array_equal(rec.cov2.view(np.uint32), ref["cov2"].view(np.uint32)) and \
         np.array_equal(rec.cov2_inv.view(np.uint32), ref["cov2_inv"].view(np.uint32))
@@ -739,6 +767,7 @@ def main():
         die("--gpus %d but only %d device(s) visible: one rank per GPU is the contract (SPFE_BENCH_BACKEND=gloo is the "
             "shared-GPU dry run)" % (world, ndev))
     torch.cuda.set_device(local)
+    numa = bind_to_gpu_numa(torch, local) if world > 1 else None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -806,6 +835,7 @@ def main():
                                       "covariance of step i overlapped with the convolutions of step i+1 (depth-2 pipeline)"),
                        "frames_per_gpu": B, "height": H, "width": W, "num_features": nf,
                        "parallelism": "dp%d" % world,
+                       "rank0_numa_binding": numa,   # N > 1: every rank binds itself to its GPU's NUMA node (bind_to_gpu_numa)
                        "gather": ("none (1 GPU)" if world == 1 else
                                   "ncclAllGather inside libspfe (spfe_allgather_records)" if getattr(sharded, "_native", False)
                                   else "torch.distributed all_gather_into_tensor")},

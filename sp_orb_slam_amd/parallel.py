@@ -139,6 +139,39 @@ def gather_records(local_records, world, group=None):
     return out
 
 
+def init_native_comm(extractor, world, rank, device="cuda"):
+    """The library's RCCL communicator on `extractor` (spfe_comm_unique_id on rank 0, broadcast of the 128-byte id through
+    torch.distributed, spfe_comm_init on every rank) — and the AGREEMENT that follows: a rank whose spfe_comm_init failed
+    (librccl missing, ncclCommInitRank refused) and a rank where it succeeded must not part ways, one calling ncclAllGather
+    and the other torch's all-gather.  So the outcome is min-reduced over the ranks; if any rank failed, EVERY rank destroys
+    its communicator and the caller falls back to torch.distributed's all-gather on all of them.  Returns (ok, error text
+    of this rank or None).  `device`: where the id / flag tensors live ("cuda" under RCCL; "cpu" in the gloo tests)."""
+    import torch
+
+    uid = torch.zeros(128, dtype=torch.uint8, device=device)
+    if rank == 0:
+        uid.copy_(torch.frombuffer(bytearray(extractor.comm_unique_id()), dtype=torch.uint8))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.broadcast(uid, 0)
+    ok, err = 1, None
+    try:
+        extractor.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+    except Exception as e:   # RCCL missing / init failure on this rank
+        ok, err = 0, str(e)
+    if world > 1:
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = int(flag.item())
+    if not ok:
+        try:
+            extractor.comm_destroy()
+        except Exception:
+            pass
+    return bool(ok), err
+
+
 class ShardedExtractor:
     """Per-rank driver of the batched path (BASELINE configs[2]): takes this rank's shard of
     device-resident frames, runs the HIP path, all-gathers the records.  One instance per
@@ -191,31 +224,9 @@ class ShardedExtractor:
         self.all = ([torch.zeros(world * nbytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
                     if self._collective else None)
         if self._native:
-            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                uid.copy_(torch.frombuffer(bytearray(extractor.comm_unique_id()), dtype=torch.uint8))
-            if world > 1:
-                import torch.distributed as dist
-
-                dist.broadcast(uid, 0)
-            ok = 1
-            try:
-                extractor.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
-            except Exception as e:   # RCCL missing / init failure on this rank
-                ok, self.native_comm_error = 0, str(e)
-            if world > 1:
-                # every rank takes the same path: one failed communicator sends all of them to torch's all-gather
-                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                ok = int(flag.item())
-            if not ok:
-                try:
-                    extractor.comm_destroy()
-                except Exception:
-                    pass
-                if world == 1:
-                    raise RuntimeError("spfe_comm_init failed: %s" % getattr(self, "native_comm_error", "?"))
-                self._native = False
+            self._native, self.native_comm_error = init_native_comm(extractor, world, rank, "cuda")
+            if not self._native and world == 1:
+                raise RuntimeError("spfe_comm_init failed: %s" % (self.native_comm_error or "?"))
         if self._native:
             # the library's communication stream, wrapped so torch events can be recorded on it
             self.comm = torch.cuda.ExternalStream(extractor.comm_stream())

@@ -37,3 +37,26 @@ def test_a_rendezvous_that_disagrees_with_gpus_is_refused():
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
     out = _run(["--gpus", "0"], _env())
     assert out.returncode != 0
+
+
+def test_numa_binding_reports_and_never_raises():
+    """bench.py binds every rank of an N > 1 run to the cores of its GPU's NUMA node; whatever sysfs looks like on the box
+    (no such PCI device here), the call reports what it did instead of raising, and leaves the affinity alone when it cannot
+    bind."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class _Props:
+        pci_domain_id, pci_bus_id, pci_device_id = 0xffff, 0xfe, 0x1f
+
+    class _Torch:
+        class cuda:
+            @staticmethod
+            def get_device_properties(_):
+                return _Props()
+    before = os.sched_getaffinity(0)
+    out = bench.bind_to_gpu_numa(_Torch, 0)
+    assert out["bound"] is False and "why" in out
+    assert os.sched_getaffinity(0) == before

@@ -19,7 +19,18 @@ pytestmark = pytest.mark.gpu
 # kernel sits well inside the precision step it is allowed.  A wrong tap / channel / tile shows as >= 1e-1.
 LOGIT_ATOL = 1e-2
 LOGIT_MEAN = 3e-3
-DESC_COS_MIN = 0.999   # descriptors of keypoints found by both paths
+# bf16 mode against the f32 oracle, to the letter of SURVEY.md §8(c) ("descriptor max-abs <= 2e-2, cos >= 0.999; report
+# keypoint-set Jaccard") — and what 64 frames per configuration support (tests/golden/flip_report_bf16.json, made by
+# tools/flip_report_bf16.py from the oracle's bf16 emulation; tests/test_oracle_golden.py reads it): Jaccard 0.890 ... 0.938
+# (minimum over 256 frames: 0.890), descriptor max-abs <= 2.0e-3, L2 <= 7.8e-3 (2.6 % of the matcher's tightest threshold,
+# 0.3), cosine >= 0.99997.  The GPU's logits differ from the emulation's by the summation order inside a dot product, so the
+# asserted floors sit a step below the report's extremes.
+DESC_COS_MIN = 0.999
+DESC_COS_MEASURED = 0.9999
+DESC_MAX_ABS = 2e-2
+DESC_MAX_ABS_MEASURED = 5e-3
+DESC_L2_MAX = 0.03         # a tenth of sp_matcher.cpp:18's TH_LOW
+JACCARD_MIN = 0.87
 
 
 def _run(H, W, nf, seed, det):
@@ -64,12 +75,17 @@ def test_bf16_vs_f32_path_720p():
         b = {(int(x), int(y)) for x, y in ref["kp_xy"]}
         jacc = len(a & b) / max(1, len(a | b))
         idx = {(int(x), int(y)): i for i, (x, y) in enumerate(ref["kp_xy"])}
-        cos = [float(np.dot(fr.descriptors[i], ref["desc"][idx[(int(x), int(y))]]))
-               for i, (x, y) in enumerate(fr.kp_xy) if (int(x), int(y)) in idx]
-        print("bf16 vs f32: K %d vs %d, keypoint Jaccard %.3f, descriptor cosine min %.5f mean %.5f"
-              % (fr.K, ref["K"], jacc, min(cos), float(np.mean(cos))))
-        assert jacc >= 0.80          # reported, loosely asserted: near-threshold cells flip
-        assert min(cos) >= DESC_COS_MIN
+        pairs = [(i, idx[(int(x), int(y))]) for i, (x, y) in enumerate(fr.kp_xy) if (int(x), int(y)) in idx]
+        da = np.stack([fr.descriptors[i] for i, _ in pairs]).astype(np.float64)
+        db = np.stack([ref["desc"][j] for _, j in pairs]).astype(np.float64)
+        cos = (da * db).sum(1)
+        max_abs, l2 = float(np.abs(da - db).max()), float(np.sqrt(((da - db) ** 2).sum(1)).max())
+        print("bf16 vs f32: K %d vs %d, keypoint Jaccard %.3f, descriptor cosine min %.5f mean %.5f, max-abs %.2e, L2 max %.2e"
+              % (fr.K, ref["K"], jacc, cos.min(), cos.mean(), max_abs, l2))
+        assert jacc >= JACCARD_MIN
+        assert cos.min() >= DESC_COS_MIN and cos.min() >= DESC_COS_MEASURED
+        assert max_abs <= DESC_MAX_ABS and max_abs <= DESC_MAX_ABS_MEASURED
+        assert l2 <= DESC_L2_MAX
         assert np.abs(np.linalg.norm(fr.descriptors, axis=1) - 1).max() < 1e-6
         # selection invariants hold exactly in either precision
         x, y = fr.kp_xy[:, 0].astype(int), fr.kp_xy[:, 1].astype(int)

@@ -4,6 +4,8 @@ Integer outputs (keypoints, occ_grid, candidate count, sort order) must be
 exact; float outputs within the tolerances of SURVEY.md §8c: descriptors
 max-abs <= 2e-5, heat abs <= 1e-5, cov2 rel <= 1e-5, logits rel 1e-5.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -112,3 +114,35 @@ def test_flip_report_is_committed_and_says_what_survey_8c_expects(golden_dir):
         assert all(g < 1e-5 for g in c["flipped_cells_top2_gaps"] + c["flipped_cells_threshold_gaps"]), key
         assert c["keypoints_on_one_side_only_total"] <= c["keypoints_total"] * 1e-4, key
         assert c["logit_max_abs_diff"] < 5e-5, key
+
+
+def test_bf16_flip_report_supports_the_bf16_bounds():
+    """tests/golden/flip_report_bf16.json (tools/flip_report_bf16.py: the oracle's bf16 emulation against the f32 oracle, 64
+    seeded frames x {1280x720, 752x480} x {dense, sparse}) is what the bf16 tolerances of tests/test_gpu_bf16.py and of
+    bench.py's parity rule stand on: SURVEY.md §8(c)'s "descriptor max-abs <= 2e-2, cos >= 0.999" hold with a wide margin, the
+    descriptor of a keypoint moves by at most a few percent of the matcher's tightest threshold (0.3, sp_matcher.cpp:18), and
+    the keypoint-set Jaccard over 256 frames never falls below the asserted floor."""
+    import json
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "flip_report_bf16.json")))
+    assert set(d["configs"]) == {"1280x720_dense", "1280x720_sparse", "752x480_dense", "752x480_sparse"}
+    for name, c in d["configs"].items():
+        assert c["frames"] == 64, name
+        assert c["desc_max_abs_max"] <= 2e-2 and c["desc_max_abs_max"] <= 5e-3, name
+        assert c["desc_cos_min"] >= 0.999 and c["desc_cos_min"] >= 0.9999, name
+        assert c["desc_l2_of_common_keypoints"]["max"] <= 0.03 and c["desc_l2_rows_above"]["0.03"] == 0, name
+        assert c["jaccard_min"] >= 0.87 + 0.015, name          # the GPU test's floor sits below every frame of the report
+        assert 0.0 < c["arg_flips_per_cell"] < 0.05, name      # bf16 logits DO flip near-ties: ~2 % of the cells
+        assert c["keypoints_common_total"] >= 0.95 * min(c["keypoints_f32_total"], c["keypoints_bf16_total"]), name
+
+
+def test_bf16_flip_report_tool_runs_on_a_small_frame():
+    """The report's per-frame function on one 64x96 frame (CPU, a second): same fields, same invariants."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from tools import flip_report_bf16
+    from sp_orb_slam_amd import synth, weights
+    r = flip_report_bf16.one_frame(oracle, weights.synthetic(7, "dense"), synth.make_image(300, 64, 96), 50)
+    assert r["cells"] == 96 and 0.0 <= r["jaccard"] <= 1.0 and r["common"] <= min(r["K_f32"], r["K_bf16"])
+    if r["common"]:
+        assert r["desc_cos"].min() >= 0.999 and r["desc_max_abs"] <= 2e-2

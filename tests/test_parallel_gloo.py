@@ -99,3 +99,58 @@ def test_two_rank_gloo_gather_matches_single_process():
                        o["cov2_inv"].tobytes()))
     for r in range(WORLD):
         assert results[r] == expect      # every rank holds every frame, in global order
+
+
+class _StubExtractor:
+    """What init_native_comm touches of an SPExtractor: the id, the init (failing on the ranks listed), the teardown."""
+
+    def __init__(self, rank, fail_ranks):
+        self.rank, self.fail_ranks, self.inited, self.destroyed, self.uid_seen = rank, fail_ranks, False, 0, None
+
+    def comm_unique_id(self):
+        return bytes(range(128))
+
+    def comm_init(self, uid, rank, world):
+        self.uid_seen = uid
+        if rank in self.fail_ranks:
+            raise RuntimeError("ncclCommInitRank refused (injected)")
+        self.inited = True
+
+    def comm_destroy(self):
+        self.destroyed += 1
+        self.inited = False
+
+
+def _comm_worker(rank, world, port, q, fail_ranks):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ext = _StubExtractor(rank, fail_ranks)
+        ok, err = parallel.init_native_comm(ext, world, rank, device="cpu")
+        q.put((rank, ok, err, ext.inited, ext.destroyed, ext.uid_seen == bytes(range(128))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_ranks", [(1,), (0,), ()])
+def test_one_rank_failing_comm_init_sends_every_rank_to_the_same_fallback(fail_ranks):
+    """spfe_comm_init fails on ONE rank (injected) -> the min-reduce makes EVERY rank report "no native
+    communicator", the ranks whose init had succeeded destroy theirs, and all of them take torch's all-gather; with no
+    failure every rank keeps its communicator.  The 128-byte id reaches rank 1 through the broadcast either way."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_comm_worker, args=(r, WORLD, port, q, tuple(fail_ranks))) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r[1:] for r in (q.get(timeout=120) for _ in range(WORLD))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect_ok = not fail_ranks
+    for r in range(WORLD):
+        ok, err, inited, destroyed, uid_ok = res[r]
+        assert ok == expect_ok and uid_ok
+        assert (err is not None) == (r in fail_ranks)
+        assert inited == expect_ok                       # nobody is left holding a communicator the others do not have
+        assert destroyed == (0 if expect_ok else 1)
