@@ -31,7 +31,9 @@ class SPExtractor : public BaseExtractor, public spfe::ExtractorCV {
   SPExtractor(int nfeatures);
   SPExtractor(int nfeatures, int height, int width, const std::string &model_path, int device = 0)
       : BaseExtractor(nfeatures, 1.0f, 1, 1, 1),   // one level, scale 1: sp_extractor.cpp:343
-        spfe::ExtractorCV(nfeatures, height, width, model_path, device, /*with_heat=*/true) {}
+        // heat_ is cloned by Frame::ExtractORB (frame.cpp:304); heat_inv_ is read by nobody outside computeCovariance
+        // (sp_extractor.cpp:508), which runs on the device here: it stays there unless heatInv() asks for it
+        spfe::ExtractorCV(nfeatures, height, width, model_path, device, /*with_heat=*/true, /*lazy_heat_inv=*/true) {}
   virtual ~SPExtractor() = default;
 
   void operator()(cv::InputArray image, cv::InputArray mask, std::vector<cv::KeyPoint> &keypoints,
@@ -43,7 +45,8 @@ class SPExtractor : public BaseExtractor, public spfe::ExtractorCV {
   const std::vector<Eigen::Vector2f> getCov() { return toEigen(spfe::ExtractorCV::getCov()); }
   const std::vector<Eigen::Vector2f> getCov2Inv() { return toEigen(spfe::ExtractorCV::getCov2Inv()); }
   // getMask(), getHeatMap(), semi_dust_, dense_dust_, mask_, heat_, heat_inv_, occ_grid_: inherited from
-  // spfe::ExtractorCV with the reference's names and cv::Mat types (sp_extractor.h:61-73)
+  // spfe::ExtractorCV with the reference's names and cv::Mat types (sp_extractor.h:61-73).  heat_inv_ is empty after
+  // operator() (nobody reads it) and filled by heatInv() on demand.
 
  private:
   static std::vector<Eigen::Vector2f> toEigen(const std::vector<spfe::Vec2f> &v) {

@@ -65,6 +65,13 @@ extern "C" {
                                   spfe_track_dust_record_device) widen the rows on load: distances are the f32 arithmetic
                                   of the reference on those rounded values. */
 
+#define SPFE_FLAG_LAZY_HEAT_INV 8u /* with SPFE_FLAG_HEAT: the host calls (spfe_extract*, spfe_submit_batch) bring back
+                                     `heat` only; spfe_result.heat_inv is NULL and spfe_fetch_heat_inv() copies a frame's
+                                     map on demand.  In the reference heat_inv_ is read by computeCovariance alone
+                                     (sp_extractor.cpp:508) — which runs on the device here — and by no caller (SURVEY.md
+                                     §8b "public but unread elsewhere"), so its 4 H W bytes per frame need not cross PCIe
+                                     on every call (752x480: 1.44 MB of the 4.0 MB a call with heat maps brings back). */
+
 /* spfe_result.status / record header word 2 */
 #define SPFE_STATUS_COV_OVERFLOW 1 /* Set only when ONE covariance region has more pops than the device's last-resort list
                                       holds (SPFE_COV_FALLBACK_CAP, 4 M by default — the reference's own loop would spend
@@ -79,7 +86,7 @@ extern "C" {
  * (4: spfe_result.desc_bf16, spfe_record_layout.desc_elem_bytes — round 3 — and this check).  A caller built against an older
  * header would hand the library arrays of the wrong stride; spfe_check_abi(SPFE_ABI_VERSION, sizeof(spfe_config),
  * sizeof(spfe_result), sizeof(spfe_record_layout)) refuses that up front (the C++ adaptor and the Python loader call it). */
-#define SPFE_ABI_VERSION 4
+#define SPFE_ABI_VERSION 5
 
 #define SPFE_DESC_DIM 256
 #define SPFE_NUM_PARAMS 1300865 /* sp_extractor.cpp:16-43; order = register_module order :46-62 */
@@ -126,7 +133,7 @@ typedef struct {
   const float *dense_dust;  /* [H/8][W/8] softmax dustbin (:107,450) */
   const float *semi_dust;   /* [H/8][W/8] raw dustbin logit (:106,448) */
   const float *heat;        /* [H][W] or NULL without SPFE_FLAG_HEAT (:467) */
-  const float *heat_inv;    /* [H][W] or NULL without SPFE_FLAG_HEAT (:468) */
+  const float *heat_inv;    /* [H][W] or NULL without SPFE_FLAG_HEAT / with SPFE_FLAG_LAZY_HEAT_INV (:468) */
   const uint16_t *desc_bf16; /* [K][256] bf16 bit patterns with SPFE_FLAG_DESC_BF16 (then desc is NULL), else NULL */
 } spfe_result;
 
@@ -391,6 +398,12 @@ SPFE_API int spfe_stage_batch_device(spfe_handle h, const void *d_src, int n, vo
 SPFE_API int spfe_stage_times(spfe_handle h, float *ms, int cap);
 SPFE_API int spfe_stage_reset(spfe_handle h);
 SPFE_API const char *spfe_stage_name(int i);
+
+/* heat_inv (sp_extractor.cpp:468) of frame `frame` of the LAST synchronous host call (spfe_extract, spfe_extract_batch,
+ * spfe_extract_staged) on this handle, copied to the library's pinned buffer on demand: *out is a view valid until the next
+ * call on the handle.  Meant for handles created with SPFE_FLAG_LAZY_HEAT_INV (without it the map is in spfe_result already;
+ * the call works all the same).  SPFE_EINVAL without SPFE_FLAG_HEAT, before the first call, or for a frame the call did not hold. */
+SPFE_API int spfe_fetch_heat_inv(spfe_handle h, int frame, const float **out);
 
 /* Test hook: evaluates the device forms of spfe_expf(x) and spfe_logf(|x|)
  * (include/spfe_exact_math.h) on n host floats, so tests can compare GPU bits

@@ -35,8 +35,10 @@ class ExtractorCV {
  public:
   // Reference ctor: SPExtractor(int nfeatures) reading camera::height/width and
   // common::model_path from globals (sp_extractor.cpp:342-359).
+  // lazy_heat_inv: heat_inv_ — which no caller of the reference reads — is not copied back by operator();
+  // heatInv() fetches it on demand (SPFE_FLAG_LAZY_HEAT_INV: 1.44 MB less D2H per 752x480 call)
   ExtractorCV(int nfeatures, int height, int width, const std::string &weights_path, int device = 0,
-              bool with_heat = true)
+              bool with_heat = true, bool lazy_heat_inv = false)
       : height_(height), width_(width) {
     // this translation unit's view of spfe.h against the library's (struct strides, entry points)
     if (spfe_check_abi(SPFE_ABI_VERSION, sizeof(spfe_config), sizeof(spfe_result), sizeof(spfe_record_layout)) != SPFE_OK)
@@ -48,7 +50,7 @@ class ExtractorCV {
     cfg.max_batch = 1;
     cfg.device = device;
     cfg.precision = SPFE_PRECISION_F32;
-    cfg.flags = with_heat ? SPFE_FLAG_HEAT : 0u;
+    cfg.flags = with_heat ? (SPFE_FLAG_HEAT | (lazy_heat_inv ? SPFE_FLAG_LAZY_HEAT_INV : 0u)) : 0u;
     cfg.weights = nullptr;
     cfg.weights_path = weights_path.c_str();
     if (spfe_create(&cfg, &h_) != SPFE_OK) throw std::runtime_error(std::string("spfe_create: ") + spfe_last_error());
@@ -130,6 +132,7 @@ class ExtractorCV {
     cv::Mat(hc, wc, CV_16SC1, const_cast<int16_t *>(r.occ_grid)).copyTo(occ_grid_);
     if (r.heat) cv::Mat(height_, width_, CV_32FC1, const_cast<float *>(r.heat)).copyTo(heat_);
     if (r.heat_inv) cv::Mat(height_, width_, CV_32FC1, const_cast<float *>(r.heat_inv)).copyTo(heat_inv_);
+    else heat_inv_ = cv::Mat();   // (lazy: heatInv() fetches this call's map; a stale one must not be mistaken for it)
     status_ = r.status;
   }
 
@@ -237,6 +240,15 @@ class ExtractorCV {
 
   cv::Mat getMask() { return mask_; }
   cv::Mat getHeatMap() { return heat_; }
+  // heat_inv_ of the last call (sp_extractor.cpp:468): the member when operator() brought it back, else fetched now
+  const cv::Mat &heatInv() {
+    if (heat_inv_.empty()) {
+      const float *p = nullptr;
+      if (spfe_fetch_heat_inv(h_, 0, &p) != SPFE_OK) throw std::runtime_error(std::string("spfe_fetch_heat_inv: ") + spfe_last_error());
+      cv::Mat(height_, width_, CV_32FC1, const_cast<float *>(p)).copyTo(heat_inv_);
+    }
+    return heat_inv_;
+  }
   const std::vector<Vec2f> &getCov() const { return cov2_; }
   const std::vector<Vec2f> &getCov2Inv() const { return cov2_inv_; }
   int status() const { return status_; }

@@ -521,19 +521,39 @@ __global__ __launch_bounds__(LINK_THREADS) void cov_link_kernel(FrameBufs f, Rec
       key[tid] = (myroot << 15) | myj;
     }
     __syncthreads();
+    // The workers go on the list LONGEST CHAIN FIRST (ties: lower keypoint first): a replay workgroup takes WV consecutive
+    // workers and lives as long as its longest chain, so with chains of similar length side by side most workgroups are gone
+    // after a member or two and only the first few — launched first — stay for the long chains.  (In arrival order of an
+    // atomic counter nearly every fat workgroup of a 1280x720 frame held one long chain, and in pipelined bf16 calls each of
+    // them keeps a register-resident-weights convolution workgroup off its CU for that long.)  The order changes no result:
+    // components are independent.
+    int *wkey = key + nd;                 // [<= nd] (chain length << 15 | 0x7fff - first member) of the workers
+    __shared__ int s_nw;
+    if (tid == 0) s_nw = 0;
+    int jn = 0x7fff, first = 1, len = 0;
     if (tid < nd) {
-      int jn = 0x7fff, first = 1;
       for (int e = 0; e < nd; ++e) {
         const int ke = key[e], je = ke & 0x7fff;
         const bool same = (ke >> 15) == myroot;
         jn = same && je > myj && je < jn ? je : jn;
         first &= !(same && je < myj);
+        len += same;
       }
       jn = jn == 0x7fff ? -1 : jn;
       c.nxt[myj] = jn;
       if (jn >= 0) { c.nxy[2 * myj] = c.kp_xy[2 * jn]; c.nxy[2 * myj + 1] = c.kp_xy[2 * jn + 1]; }
-      if (first) c.workers[atomicAdd(c.nworkers, 1)] = myj;
     }
+    __syncthreads();
+    const int mykey = (len << 15) | (0x7fff - myj);
+    if (tid < nd && first) wkey[atomicAdd(&s_nw, 1)] = mykey;
+    __syncthreads();
+    const int nw = s_nw;
+    if (tid < nd && first) {
+      int rank = 0;
+      for (int e = 0; e < nw; ++e) rank += wkey[e] > mykey;
+      c.workers[rank] = myj;
+    }
+    if (tid == 0) *c.nworkers = nw;
     return;
   }
   int P = 1;

@@ -47,7 +47,7 @@ using namespace spfe_host;
 extern "C" {
 
 const char *spfe_last_error(void) { return g_err.c_str(); }
-const char *spfe_version(void) { return "spfe 0.4 abi 4 (gfx950, f32-mfma + bf16-mfma)"; }
+const char *spfe_version(void) { return "spfe 0.5 abi 5 (gfx950, f32-mfma + bf16-mfma)"; }
 int spfe_abi_version(void) { return SPFE_ABI_VERSION; }
 int spfe_check_abi(int abi_version, size_t sizeof_config, size_t sizeof_result, size_t sizeof_record_layout) {
   if (abi_version != SPFE_ABI_VERSION)
@@ -208,16 +208,31 @@ int finish_host(spfe_handle h, int n, spfe_result *outs) {
   // (the synchronous path keeps the runtime's copy: a copy kernel as in spfe_submit_batch measured +4 % in f32 and -4 % in
   // bf16 mode here, nothing for a single frame)
   HIP_TRY(hipMemcpyAsync(h->h_records, h->d_records, (size_t)n * h->rl.bytes, hipMemcpyDeviceToHost, s));
+  const bool want_inv = want && !(h->cfg.flags & SPFE_FLAG_LAZY_HEAT_INV);   // (lazy: spfe_fetch_heat_inv on demand)
   if (want) {
-    HIP_TRY(hipMemcpyAsync(h->h_heat_inv, h->d_heat_inv, (size_t)n * H * W * 4, hipMemcpyDeviceToHost, s));
+    if (want_inv) HIP_TRY(hipMemcpyAsync(h->h_heat_inv, h->d_heat_inv, (size_t)n * H * W * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(h->h_heat, h->d_heat, (size_t)n * H * W * 4, hipMemcpyDeviceToHost, s));
   }
   HIP_TRY(hipStreamSynchronize(s));
   for (int i = 0; i < n; ++i) {
     uint8_t *rec = h->h_records + (size_t)i * h->rl.bytes;
     float *hinv = h->h_heat_inv + (size_t)i * H * W;
-    view_record(h, rec, want ? h->h_heat + (size_t)i * H * W : nullptr, want ? hinv : nullptr, &outs[i]);
+    view_record(h, rec, want ? h->h_heat + (size_t)i * H * W : nullptr, want_inv ? hinv : nullptr, &outs[i]);
   }
+  h->host_sync_n = n;
+  return SPFE_OK;
+}
+
+int spfe_fetch_heat_inv(spfe_handle h, int frame, const float **out) {
+  if (!h || !out) return fail(SPFE_EINVAL, "null argument");
+  if (!(h->cfg.flags & SPFE_FLAG_HEAT)) return fail(SPFE_EINVAL, "the handle was created without SPFE_FLAG_HEAT");
+  if (frame < 0 || frame >= h->host_sync_n) return fail(SPFE_EINVAL, "frame %d was not part of the last synchronous host call (%d frames)", frame, h->host_sync_n);
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const size_t HW = (size_t)h->H * h->W;
+  // (the stream of the call: its covariance — the only device reader / the writer's successor — has finished, finish_host synchronised)
+  HIP_TRY(hipMemcpyAsync(h->h_heat_inv + (size_t)frame * HW, h->d_heat_inv + (size_t)frame * HW, HW * 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *out = h->h_heat_inv + (size_t)frame * HW;
   return SPFE_OK;
 }
 
@@ -455,8 +470,9 @@ int spfe_submit_batch(spfe_handle h, const uint8_t *const *images, int stride, i
   }
   if (want) {
     const size_t m16 = (size_t)n * H * W * 4 / 16;   // (H, W multiples of 8)
-    hipLaunchKernelGGL(spfe::copy_records_kernel, dim3(64), dim3(256), 0, sc, reinterpret_cast<uint4 *>(ps.h_heat_inv),
-                       reinterpret_cast<const uint4 *>(h->d_heat_inv), m16);
+    if (!(h->cfg.flags & SPFE_FLAG_LAZY_HEAT_INV))
+      hipLaunchKernelGGL(spfe::copy_records_kernel, dim3(64), dim3(256), 0, sc, reinterpret_cast<uint4 *>(ps.h_heat_inv),
+                         reinterpret_cast<const uint4 *>(h->d_heat_inv), m16);
     hipLaunchKernelGGL(spfe::copy_records_kernel, dim3(64), dim3(256), 0, sc, reinterpret_cast<uint4 *>(ps.h_heat),
                        reinterpret_cast<const uint4 *>(h->d_heat), m16);
     HIP_TRY(hipGetLastError());
@@ -481,8 +497,8 @@ int spfe_collect_batch(spfe_handle h, long ticket, spfe_result *outs) {
   const bool want = (h->cfg.flags & SPFE_FLAG_HEAT) != 0;
   for (int i = 0; i < ps->n; ++i) {
     uint8_t *rec = ps->h_rec + (size_t)i * h->rl.bytes;
-    view_record(h, rec, want ? ps->h_heat + (size_t)i * H * W : nullptr, want ? ps->h_heat_inv + (size_t)i * H * W : nullptr,
-                &outs[i]);
+    view_record(h, rec, want ? ps->h_heat + (size_t)i * H * W : nullptr,
+                want && !(h->cfg.flags & SPFE_FLAG_LAZY_HEAT_INV) ? ps->h_heat_inv + (size_t)i * H * W : nullptr, &outs[i]);
   }
   ps->ticket = -1;   // the views stay valid until NPIPE further submits reuse the slot
   return SPFE_OK;

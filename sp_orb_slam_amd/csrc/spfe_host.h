@@ -173,6 +173,7 @@ struct spfe_handle_s {
   uint8_t *h_img = nullptr, *h_records = nullptr;
   float *h_heat = nullptr, *h_heat_inv = nullptr;
   int last_n = 0;
+  int host_sync_n = 0;   // frames of the last synchronous host call (spfe_fetch_heat_inv)
   int num_cus = 256;
   int small_maxh = -1;
   // input staging (spfe_set_staging)

@@ -131,6 +131,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   const int H = h->H, W = h->W;
   if (h->timing) h->ev = h->evpool.data() + (size_t)(h->calls % spfe_handle_s::EVSETS) * (NSTAGE + 1);
   h->calls++;
+  h->host_sync_n = 0;   // (heat_inv is about to be rewritten: finish_host() says when a synchronous host call's maps are complete)
   STAGE_MARK(0);
   // (a kernel of our own, not hipMemsetAsync: the runtime's fill is a blit that queues behind its other blits — the
   // pipelined host path's D2H copy of the PREVIOUS batch — and held the whole next batch back by 0.6 ms at 752x480 bf16)

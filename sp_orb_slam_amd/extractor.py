@@ -21,10 +21,11 @@ LIB_PATH = os.path.join(_PKG, "libspfe.so")
 SPFE_FLAG_HEAT = 1
 SPFE_FLAG_ASYNC_COV = 2
 SPFE_FLAG_DESC_BF16 = 4   # records / results carry bf16 descriptors (RNE of the f32 ones)
+SPFE_FLAG_LAZY_HEAT_INV = 8   # with SPFE_FLAG_HEAT: host calls bring back `heat` only; fetch_heat_inv() on demand
 SPFE_PRECISION_F32 = 0
 SPFE_PRECISION_BF16 = 1
 NUM_PARAMS = 1300865
-ABI_VERSION = 4           # SPFE_ABI_VERSION of include/spfe.h these ctypes structures mirror
+ABI_VERSION = 5           # SPFE_ABI_VERSION of include/spfe.h these ctypes structures mirror
 _ERRORS = {-1: "SPFE_EINVAL", -2: "SPFE_EEMPTY", -3: "SPFE_EHIP", -4: "SPFE_EWEIGHTS"}
 
 # every symbol include/spfe.h declares (tests check that the library exports all)
@@ -41,7 +42,7 @@ ABI_SYMBOLS = [
     "spfe_comm_unique_id", "spfe_comm_init", "spfe_comm_destroy", "spfe_allgather_records", "spfe_comm_wait",
     "spfe_comm_stream", "spfe_comm_count", "spfe_submit_batch", "spfe_collect_batch",
     "spfe_align_dust", "spfe_align_dust_record_device", "spfe_align_dust_batch_device", "spfe_match_knn2",
-    "spfe_track_dust_record_device",
+    "spfe_track_dust_record_device", "spfe_fetch_heat_inv",
 ]
 
 
@@ -294,7 +295,7 @@ class SPExtractor:
     """
 
     def __init__(self, nfeatures, height, width, weights, max_batch=1, device=0, with_heat=True,
-                 async_cov=False, precision="f32", desc_bf16=False):
+                 async_cov=False, precision="f32", desc_bf16=False, lazy_heat_inv=False):
         self._h = C.c_void_p()
         self._lib = load_library()
         self.nfeatures, self.height, self.width = int(nfeatures), int(height), int(width)
@@ -307,7 +308,7 @@ class SPExtractor:
         cfg.max_batch, cfg.device = self.max_batch, int(device)
         cfg.precision = SPFE_PRECISION_BF16 if precision == "bf16" else SPFE_PRECISION_F32
         cfg.flags = (SPFE_FLAG_HEAT if with_heat else 0) | (SPFE_FLAG_ASYNC_COV if async_cov else 0) | \
-            (SPFE_FLAG_DESC_BF16 if desc_bf16 else 0)
+            (SPFE_FLAG_DESC_BF16 if desc_bf16 else 0) | (SPFE_FLAG_LAZY_HEAT_INV if lazy_heat_inv and with_heat else 0)
         self.desc_bf16 = bool(desc_bf16)
         self.async_cov = bool(async_cov)
         keep = None
@@ -697,6 +698,15 @@ class SPExtractor:
         dist = b[kmax * 4:kmax * 8].view(np.float32)
         n = kmax if n_query is None else n_query
         return idx[:n].copy(), dist[:n].copy()
+
+    def fetch_heat_inv(self, frame=0):
+        """heat_inv (sp_extractor.cpp:468) of a frame of the last synchronous host call, copied back on demand
+        (spfe_fetch_heat_inv; the companion of lazy_heat_inv=True)."""
+        p = C.c_void_p()
+        self._lib.spfe_fetch_heat_inv.restype = C.c_int
+        self._lib.spfe_fetch_heat_inv.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        _check(self._lib.spfe_fetch_heat_inv(self._h, int(frame), C.byref(p)))
+        return _as_np(p.value, (self.height, self.width), np.float32)
 
     def debug_read(self, name, frame=0):
         shapes = {"semi": (self.height // 8, self.width // 8, 65),

@@ -61,6 +61,10 @@ int main(int argc, char **argv) {
     if (dynamic_cast<SPExtractor *>(mpORBextractorLeft) == nullptr) return 13;
     if ((int)cov2_inv_.size() != (int)mvKeys.size()) return 14;
     if (dynamic_cast<SPExtractor *>(mpORBextractorLeft)->getCov().size() != mvKeys.size()) return 15;
+    // heat_inv_ (sp_extractor.h:73; read by nobody) is not copied back by operator(); heatInv() fetches it
+    if (!dynamic_cast<SPExtractor *>(mpORBextractorLeft)->heat_inv_.empty()) return 16;
+    cv::Mat heat_inv = dynamic_cast<SPExtractor *>(mpORBextractorLeft)->heatInv().clone();
+    if (heat_inv.rows != H || heat_inv.cols != W || dynamic_cast<SPExtractor *>(mpORBextractorLeft)->heat_inv_.empty()) return 17;
 
     // the empty-image error of sp_extractor.cpp:364-365 through the base pointer
     bool threw = false;
@@ -86,6 +90,7 @@ int main(int argc, char **argv) {
     fwrite(occ_grid.data, 2, (size_t)grid_rows * grid_cols, o);
     fwrite(dust_.data, 4, (size_t)grid_rows * grid_cols, o);
     fwrite(heat_.data, 4, (size_t)H * W, o);
+    fwrite(heat_inv.data, 4, (size_t)H * W, o);
     fclose(o);
     delete mpORBextractorLeft;   // virtual destructor of the base
   } catch (const std::exception &e) {

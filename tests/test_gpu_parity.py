@@ -367,13 +367,44 @@ def test_cpp_dropin_through_base_pointer_matches_python_path(tmp_path):
     C = (H // 8) * (W // 8)
     occ = raw[off:off + C * 2].view(np.int16).reshape(H // 8, W // 8); off += C * 2
     dust = raw[off:off + C * 4].view(np.float32).reshape(H // 8, W // 8); off += C * 4
-    heat = raw[off:off + H * W * 4].view(np.float32).reshape(H, W)
+    heat = raw[off:off + H * W * 4].view(np.float32).reshape(H, W); off += H * W * 4
+    heat_inv = raw[off:off + H * W * 4].view(np.float32).reshape(H, W)   # (fetched on demand: heatInv())
     ref = oracle.extract(blob, img, nf)
+    assert np.array_equal(heat_inv, ref["heat_inv"])
     assert K == ref["K"] and np.array_equal(kp[:, :2], ref["kp_xy"])
     assert np.array_equal(kp[:, 3:].view(np.uint32), ref["cov2_inv"].view(np.uint32))
     assert np.array_equal(desc.view(np.uint32), ref["desc"].view(np.uint32))
     assert np.array_equal(occ, ref["occ_grid"]) and np.array_equal(dust, ref["dense_dust"])
     assert np.array_equal(heat, ref["heat"]) and np.array_equal(kp[:, 2], ref["response"])
+
+
+def test_lazy_heat_inv_is_fetched_on_demand():
+    """SPFE_FLAG_LAZY_HEAT_INV: the host calls bring back `heat` only (spfe_result.heat_inv NULL) and spfe_fetch_heat_inv
+    copies a frame's map on demand — the bits of the eager handle's; refused before the first call, for a frame the call did not
+    hold, and on a handle without SPFE_FLAG_HEAT."""
+    H, W, nf, B = 120, 160, 100, 3
+    blob = weights.synthetic(7, "dense")
+    imgs = [synth.make_image(60 + i, H, W) for i in range(B)]
+    eager = SPExtractor(nf, H, W, blob, max_batch=B)
+    lazy = SPExtractor(nf, H, W, blob, max_batch=B, lazy_heat_inv=True)
+    with pytest.raises(SpfeError):
+        lazy.fetch_heat_inv(0)
+    fe, fl = eager.extract_batch(imgs), lazy.extract_batch(imgs)
+    for i in range(B):
+        assert fl[i].heat_inv is None and np.array_equal(fl[i].heat, fe[i].heat)
+        assert np.array_equal(lazy.fetch_heat_inv(i).view(np.uint32), fe[i].heat_inv.view(np.uint32))
+        assert np.array_equal(fl[i].cov2, fe[i].cov2) and np.array_equal(fl[i].response, fe[i].response)
+    lazy(imgs[1], None)
+    assert np.array_equal(lazy.fetch_heat_inv(0), fe[1].heat_inv)
+    with pytest.raises(SpfeError):
+        lazy.fetch_heat_inv(1)       # the last call held one frame
+    assert np.array_equal(eager.fetch_heat_inv(2), fe[2].heat_inv)   # works on an eager handle too
+    noheat = SPExtractor(nf, H, W, blob, with_heat=False)
+    noheat(imgs[0], None)
+    with pytest.raises(SpfeError):
+        noheat.fetch_heat_inv(0)
+    for e in (eager, lazy, noheat):
+        e.close()
 
 
 def test_python_record_layout_matches_library():

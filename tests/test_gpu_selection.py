@@ -347,3 +347,33 @@ def test_covariance_link_from_the_classifications_edge_list_equals_the_pop_list_
     nd = np.frombuffer(ext.debug_read("cov_counters", 0).tobytes(), np.int32)
     assert nd[0] > 10          # the frame has dirty keypoints: the link stage did work
     ext.close()
+
+
+@pytest.mark.gpu
+def test_replay_workers_are_listed_longest_chain_first():
+    """cov_link_kernel lists the replay workers (first dirty member of each component) longest chain first, ties by lower
+    keypoint: a replay workgroup takes consecutive workers and lives as long as its longest chain (cov.hip).  The order is
+    deterministic and changes no result (the covariances are compared with the sequential oracle)."""
+    H, W, nf = 480, 752, 1000
+    blob = weights.synthetic(7, "dense")
+    img = synth.make_image(200, H, W)
+    ext = SPExtractor(nf, H, W, blob, with_heat=False)
+    runs = []
+    for _ in range(2):
+        ext(img, None)
+        cnt, nxt, workers = (ext.debug_read(n).copy() for n in ("cov_counters", "cov_nxt", "cov_workers"))
+        runs.append(workers[:cnt[1]].copy())
+        lens = []
+        for w in workers[:cnt[1]]:
+            j, n = int(w), 0
+            while j >= 0:
+                n += 1
+                j = int(nxt[j])
+            lens.append(n)
+        assert cnt[1] > 20 and max(lens) >= 4, (cnt, lens[:8])
+        assert all(a > b or (a == b and wa < wb) for a, b, wa, wb in zip(lens, lens[1:], workers, workers[1:])), lens
+        assert sum(lens) == cnt[0]
+    assert np.array_equal(runs[0], runs[1])
+    ref = oracle.extract(blob, img, nf)
+    assert np.array_equal(ext.last.cov2.view(np.uint32), ref["cov2"].view(np.uint32))
+    ext.close()
