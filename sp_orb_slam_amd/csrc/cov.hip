@@ -45,17 +45,20 @@ namespace spfe {
 #define COV_INF 0x7f7f7f7f
 #define COV_LCAP 128     // FIFO entries kept in LDS per wavefront
 #define COV_WIN 16       // the window covers dx,dy in [-16, 15] around the keypoint
-#define COV_WAVES 2      // wavefronts (= walks) per workgroup: 21 KB of LDS, fits beside a conv workgroup (127 KB)
+#define COV_WAVES 2      // wavefronts (= walks) per workgroup: 12.5 KB of LDS for lone walks (21 KB for replays, which stage `done` too)
 #define COV_OW 256       // popped pixels OUTSIDE the window a walk can remember (its visited set out there)
 
 struct WaveMem {         // LDS of one wavefront
   float hv[32 * 32];     // heat_inv window
-  int dn[32 * 32];       // done window (replay only)
   int lq[COV_LCAP];
   float lqv[COV_LCAP];
   uint32_t bm[32];       // own-visited bitmap
   int ow[COV_OW];        // popped pixels outside the window (visited set there), now = count
-};
+  int dn[32 * 32];       // done window — REPLAY ONLY, and last: the lone walks' workgroups allocate the struct up to here
+};                       // (6.1 KB a walk instead of 10.1: 24 walks fit a CU instead of 14, and three walk workgroups fit beside an
+                         // f32 convolution workgroup's 120 KB instead of one)
+constexpr size_t COV_WALK_LDS = offsetof(WaveMem, dn);
+static_assert(COV_WALK_LDS % 16 == 0, "the float4 reads of hv / lqv need 16-byte aligned wave blocks");
 
 struct Walk {
   WaveMem *m;
@@ -358,13 +361,13 @@ __device__ __forceinline__ void pop_list(const CovFrame &c, const CovScratch &cs
 // ---- A: lone walks, one wavefront per keypoint ----
 __global__ __launch_bounds__(64 * COV_WAVES) void cov_walk_kernel(FrameBufs f, RecordLayout rl, CovScratch cs,
                                                                   int H, int W) {
-  __shared__ WaveMem s_mem[COV_WAVES];
+  __shared__ __attribute__((aligned(16))) char s_raw[COV_WAVES * COV_WALK_LDS];   // (WaveMem without its `dn` tail)
   const int b = blockIdx.y, lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = blockIdx.x * COV_WAVES + wv;
   const CovFrame c = cov_frame(f, rl, cs, b, H, W);
   if (j >= c.K) return;
-  Walk w{&s_mem[wv], c.hinv, nullptr, c.queues + (size_t)j * cs.qcap, c.qvals + (size_t)j * cs.qcap, cs.qcap, W, H,
+  Walk w{reinterpret_cast<WaveMem *>(s_raw + wv * COV_WALK_LDS), c.hinv, nullptr, c.queues + (size_t)j * cs.qcap, c.qvals + (size_t)j * cs.qcap, cs.qcap, W, H,
          (int)c.kp_xy[2 * j], (int)c.kp_xy[2 * j + 1], j, w_magic(W)};
   stage_window<false>(w, lane);
   int n = walk<false>(w, lane);

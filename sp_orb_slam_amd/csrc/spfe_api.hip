@@ -73,10 +73,21 @@ int spfe_create(const spfe_config *cfg, spfe_handle *out) {
   if (cfg->max_batch < 1) return fail(SPFE_EINVAL, "max_batch must be >= 1");
   if (cfg->precision != SPFE_PRECISION_F32 && cfg->precision != SPFE_PRECISION_BF16)
     return fail(SPFE_EINVAL, "unsupported precision %d", cfg->precision);
-  if ((size_t)(cfg->height / 8) * (cfg->width / 8) > spfe::select_max_cells() ||
-      spfe::select_lds_bytes(cfg->height, cfg->width) > 160 * 1024)
-    return fail(SPFE_EINVAL, "image %dx%d has more than 65,535 cells (e.g. 2560x1632): too large for the selection stage "
-                             "(16-bit cell indices; 1920x1080 and 2560x1440 fit)", cfg->width, cfg->height);
+  {
+    // Frame size limits.  The convolutions address a frame's activations with 32-bit byte offsets below 2^31 (0x80000000 and
+    // above mean "outside the image": conv_f32.hip SPFE_OOB; the bf16 kernels alike), and the largest activation is conv1a's
+    // output, 64 channels a pixel: H W 256 bytes in f32 mode (3840x2160 = 2,123,366,400 fits; 4096x2304 does not), H W 128 in
+    // bf16 mode.  The selection handles 65,535 cells as select_kernel and 262,143 as select_huge_kernel (f32 mode: that form
+    // is tested against the oracle at 3840x2160; the bf16 path stays at 65,535 cells, where its parity reports end).
+    const size_t cells = (size_t)(cfg->height / 8) * (cfg->width / 8);
+    const size_t act0_bytes = (size_t)cfg->height * cfg->width * 64 * (cfg->precision == SPFE_PRECISION_BF16 ? 2 : 4);
+    const size_t max_cells = cfg->precision == SPFE_PRECISION_BF16 ? spfe::select_max_cells() : spfe::select_huge_max_cells();
+    if (cells > max_cells || act0_bytes >= 0x80000000ull ||
+        (cells <= spfe::select_max_cells() ? spfe::select_lds_bytes(cfg->height, cfg->width) : spfe::select_huge_lds_bytes(cfg->height, cfg->width)) > 160 * 1024)
+      return fail(SPFE_EINVAL, "image %dx%d is too large: %zu cells (limit %zu in this precision) / %zu bytes of first-layer "
+                               "activations per frame (limit 2^31: 32-bit buffer offsets); 3840x2160 f32 and 2560x1440 bf16 fit",
+                  cfg->width, cfg->height, cells, max_cells, act0_bytes);
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(SPFE_EHIP, "no HIP device available (libspfe has no CPU path)");
@@ -272,6 +283,11 @@ long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size
   if (std::string(name) == "conv1b_tile_rows") {   // f32: which conv1b instantiation the last call launched (8 or 16 rows per tile)
     if (cap < sizeof(int)) return fail(SPFE_EINVAL, "buffer 'conv1b_tile_rows' needs 4 bytes");
     *reinterpret_cast<int *>(dst) = h->conv1b_tile_rows;
+    return (long)sizeof(int);
+  }
+  if (std::string(name) == "select_huge") {   // 1: this handle's selection runs as select_huge_kernel (> 65,535 cells, or SPFE_SELECT_HUGE=1)
+    if (cap < sizeof(int)) return fail(SPFE_EINVAL, "buffer 'select_huge' needs 4 bytes");
+    *reinterpret_cast<int *>(dst) = h->select_huge ? 1 : 0;
     return (long)sizeof(int);
   }
   if (std::string(name) == "split_streams") {   // [2] int: outcome of the queue probe (see spfe_handle_s::split_probe), and whether the last call ran as two half batches

@@ -165,6 +165,11 @@ struct spfe_handle_s {
   // 752x480 2107 / 2116 -> 2085 / 2082 frames/s, conv1b 0.87 -> 0.83 of peak: HISTORY.md "Round 4" — the switch is gone)
   int *d_sel_slot = nullptr;          // frames of more than 16,384 cells: select_kernel's global scratch (tail_select.hip)
   uint16_t *d_sel_list = nullptr;
+  // frames of more than 65,535 cells (3840x2160), or SPFE_SELECT_HUGE=1: select_huge_kernel, everything per cell in global scratch
+  bool select_huge = false;
+  int select_huge_env = 0;
+  uint8_t *d_sel_state = nullptr;
+  int *d_sel_list32 = nullptr;
   uint8_t *d_records = nullptr;
   spfe::CovScratch cov{};
   ConvLayer layers[10];

@@ -114,6 +114,9 @@ struct FrameBufs {
   int *kp_cell;         // [B][kmax] cell index of emitted keypoint
   int *sel_slot;        // [B][C] frames of more than 16,384 cells: select_kernel's per-cell slot / index hand-off (else null)
   uint16_t *sel_list;   // [B][C] ... and its tie / layout list
+  uint8_t *sel_state;   // [B][C] frames of more than 65,535 cells (select_huge_kernel): the cell states ...
+  int *sel_list32;      // [B][C] ... and the tie / layout list with 32-bit cell indices (else null)
+  int sel_huge;         // 1: the selection runs as select_huge_kernel
   int *db_list;         // [B * min(4 kmax, C)] global cell indices (b * C + cell) some emitted keypoint's descriptor taps read,
   int *db_total;        // [1] ... and how many: written by select_kernel for the gathered descriptor head (or both null)
   uint8_t *records;     // [B][record_bytes]
@@ -184,7 +187,9 @@ hipError_t launch_heat_norm(const FrameBufs &f, const CovScratch &cs, int kmax, 
 hipError_t launch_desc(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s);
 size_t select_lds_bytes(int H, int W, bool lean = false);
 bool select_big(int H, int W);     // more than 16,384 cells: per-cell private data in global scratch (FrameBufs::sel_slot / sel_list)
-size_t select_max_cells();         // 65,535
+size_t select_max_cells();         // 65,535: select_kernel
+size_t select_huge_max_cells();    // 262,143: select_huge_kernel (frames beyond select_kernel's)
+size_t select_huge_lds_bytes(int H, int W);
 
 // ---------------------------------------------------------------------------
 // brute-force descriptor matching (match.hip)

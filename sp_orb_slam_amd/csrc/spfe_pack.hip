@@ -241,6 +241,7 @@ static void read_switches(spfe_handle h) {
     h->tile2_auto = m < 0;
     h->tile2_mask = m > 0 ? (unsigned)m : 0u;
   }
+  h->select_huge_env = env_int("SPFE_SELECT_HUGE", 0);       // 1: the selection of frames of any size on select_huge_kernel (the form for > 65,535 cells)
   h->pool_split = env_int("SPFE_POOL_SPLIT", -1);            // pooled layer as un-pooled 2-row tiles + pool pass: -1 model, 0 never, 1 wherever possible
   // bf16 kernel selection (bit-identical kernels; which one takes a launch is a size decision)
   h->ws_mask = (unsigned)env_field("SPFE_BF16_WS", 0, 15) & 0xfu;   // "mask[,min_items]": Cin = 64 layers that may take conv_bf16_ws.hip
@@ -377,9 +378,14 @@ int build(spfe_handle h, const spfe_config *cfg) {
     if ((rc = dev_alloc(h, &h->d_db_total, 16))) return rc;
     HIP_TRY(hipMemset(h->d_db_total, 0, 16 * sizeof(int)));
   }
-  {   // select_kernel's global scratch: frames of more than 16,384 cells, and the lean form of pipelined calls
+  {   // select_kernel's global scratch: frames of more than 16,384 cells
     if ((rc = dev_alloc(h, &h->d_sel_slot, (size_t)B * C))) return rc;
     if ((rc = dev_alloc(h, &h->d_sel_list, (size_t)B * C))) return rc;
+  }
+  h->select_huge = (size_t)C > spfe::select_max_cells() || h->select_huge_env != 0;
+  if (h->select_huge) {   // select_huge_kernel's: states and a 32-bit list
+    if ((rc = dev_alloc(h, &h->d_sel_state, (size_t)B * C))) return rc;
+    if ((rc = dev_alloc(h, &h->d_sel_list32, (size_t)B * C))) return rc;
   }
   {
     if ((rc = dev_alloc(h, &h->cov.claim, (size_t)B * H * W))) return rc;

@@ -507,6 +507,7 @@ spfe::FrameBufs frame_bufs(spfe_handle h, uint8_t *d_records, bool sparse) {
   f.minmax = reinterpret_cast<uint32_t *>(h->d_minmax[par]);
   f.cell_score = h->d_cell_score[par]; f.cell_k = h->d_cell_k[par]; f.cell_mask = h->d_cell_mask; f.kp_cell = h->d_kp_cell;
   f.sel_slot = h->d_sel_slot; f.sel_list = h->d_sel_list;
+  f.sel_state = h->d_sel_state; f.sel_list32 = h->d_sel_list32; f.sel_huge = h->select_huge ? 1 : 0;
   f.records = d_records; f.heat_consts = h->d_heat_consts;
   return f;
 }

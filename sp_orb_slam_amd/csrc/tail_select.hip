@@ -556,9 +556,326 @@ __global__ __launch_bounds__(1024) void select_kernel(FrameBufs f, RecordLayout 
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// Frames of more than 65,535 cells (3840x2160 = 129,600; the reference accepts any multiple of 8, sp_extractor.cpp:70).
+// select_kernel's 16-bit cell indices, its 64 cells per thread and its 2 bytes of LDS a cell end there.  This form is the same
+// algorithm — parallel rounds to the greedy NMS's fixed point, radix cut at the (num_features + 1)-th best survivor with the
+// lowest-index tie rule, border reject, raster numbering by (cell row, dy, cx), occ_grid, the descriptor head's cell list —
+// with EVERYTHING per cell in global scratch (state, slot, list: FrameBufs::sel_state / sel_slot / sel_list32; the
+// neighbour masks are read where nms_mask_kernel wrote them) and 64 NW cells per thread.  One workgroup per frame reads its
+// own writes back through its CU's L1 (workgroup scope), with the same barriers as select_kernel.  Built for coverage, not
+// for speed: a 3840x2160 frame's convolutions take ~10 ms, this kernel a fraction of one.  SPFE_SELECT_HUGE=1 runs it on
+// frames of any size (tests).
+// (The reference's `inds` are 16 bit (:177,187,229): a candidate of sorted rank >= 65,536 would be emitted with the position
+// and descriptor of the candidate 65,536 ranks above it.  It cannot happen for num_features <= 10,000: a survivor's 9x9 window
+// touches at most 2 x 2 cells, so the first 4 (num_features + 1) <= 40,004 candidates in sorted order hold num_features + 1
+// survivors and the loop breaks (:211-213) before rank 65,536 is reached.)
+// ---------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(1024) void select_huge_kernel(FrameBufs f, RecordLayout rl, int H, int W, int num_features) {
+  const int wc = W >> 3, hc = H >> 3, C = hc * wc;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  int *sRow = reinterpret_cast<int *>(smem);          // [hc + 16] kept cells per cell row
+  int *sRowBase = sRow + (hc + 16);                    // [hc + 16] exclusive prefix
+  int *sCnt = sRowBase + (hc + 16);                    // [16]
+  int *sHist = sCnt + 16;                              // [1024] + [16] wave totals
+  unsigned *sBits = reinterpret_cast<unsigned *>(sHist + 1024 + 16);   // [nwords] cells the descriptor head must compute, + [17] scan scratch
+  const int nwords = (C + 31) >> 5;
+
+  const float *gscore = f.cell_score + (size_t)b * C;
+  const uint8_t *gk = f.cell_k + (size_t)b * C;
+  const uint8_t *gmask = f.cell_mask + (size_t)b * C;
+  uint8_t *gstate = f.sel_state + (size_t)b * C;
+  int *slotp = f.sel_slot + (size_t)b * C;
+  int *gList = f.sel_list32 + (size_t)b * C;
+  uint8_t *rec = f.records + (size_t)b * rl.bytes;
+  int *hdr = reinterpret_cast<int *>(rec + rl.off_hdr);
+  float *kp_xy = reinterpret_cast<float *>(rec + rl.off_xy);
+  int16_t *occ = reinterpret_cast<int16_t *>(rec + rl.off_occ);
+  int *kp_cell = f.kp_cell + (size_t)b * rl.kmax;
+  // cell of bit j of word w of this thread's masks
+  auto cell_of = [&](int w, int j) -> int { return tid + (w * 64 + j) * 1024; };
+
+  if (tid < 16) sCnt[tid] = 0;
+  for (int i = tid; i < hc + 1; i += 1024) sRow[i] = 0;
+  if (f.db_list)
+    for (int i = tid; i < nwords + 17; i += 1024) sBits[i] = 0;
+  __syncthreads();
+  uint64_t und[NW], alive[NW], kept[NW];
+  int ncand = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    und[w] = alive[w] = kept[w] = 0;
+    for (int j = 0; j < 64; ++j) {
+      const int c = cell_of(w, j);
+      if (c >= C) break;
+      const float sc = gscore[c];
+      const uint8_t m = gmask[c];
+      gstate[c] = sc > 0.0f ? (m ? ST_UNDEC : ST_ALIVE) : ST_NONE;
+      und[w] |= (uint64_t)(sc > 0.0f && m) << j;
+      alive[w] |= (uint64_t)(sc > 0.0f && !m) << j;
+      ncand += sc > 0.0f;
+    }
+  }
+  if (ncand) atomicAdd(&sCnt[2], ncand);
+  __syncthreads();
+  // ---- NMS fixed point (select_kernel's rounds; the states live in global memory) ----
+  int *sFlag = sCnt + 8;   // [4]
+  for (int round = 0; round < C; ++round) {
+    if (tid == 0) sFlag[(round + 2) & 3] = 0;
+    bool pending = false;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      for (uint64_t rest = und[w]; rest;) {
+        const int j = __ffsll((long long)rest) - 1;
+        rest &= rest - 1;
+        const int c = cell_of(w, j);
+        const unsigned m = gmask[c];
+        bool dead = false, blocked = false;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int off = (q < 3 ? -wc : (q < 5 ? 0 : wc)) + (q < 3 ? q - 1 : (q == 3 ? -1 : (q == 4 ? 1 : q - 6)));
+          const bool on = (m >> q) & 1u;
+          const uint8_t st = __atomic_load_n(&gstate[on ? c + off : c], __ATOMIC_RELAXED);
+          dead |= on && st == ST_ALIVE;
+          blocked |= on && st == ST_UNDEC;
+        }
+        if (dead) __atomic_store_n(&gstate[c], (uint8_t)ST_DEAD, __ATOMIC_RELAXED);
+        else if (!blocked) __atomic_store_n(&gstate[c], (uint8_t)ST_ALIVE, __ATOMIC_RELAXED);
+        if (dead || !blocked) und[w] &= ~(1ull << j);
+        if (!dead && !blocked) alive[w] |= 1ull << j;
+      }
+      pending |= und[w] != 0;
+    }
+    if (pending) sFlag[round & 3] = 1;
+    __syncthreads();
+    if (sFlag[round & 3] == 0) break;
+  }
+  __syncthreads();
+  // ---- keep the num_features + 1 best-ranked survivors (:211-213): radix select over the keys' range, as select_kernel ----
+  int ns = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) ns += __popcll(alive[w]);
+  if (ns) atomicAdd(&sCnt[1], ns);
+  __syncthreads();
+  const int S = sCnt[1];
+  uint32_t prefix = 0;
+  int need = num_features + 1;
+  const bool cut = S > need;
+  if (cut) {
+    uint32_t kmin = 0xffffffffu, kmax = 0u;
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+      for (uint64_t rest = alive[w]; rest; rest &= rest - 1) {
+        const uint32_t k = __float_as_uint(gscore[cell_of(w, __ffsll((long long)rest) - 1)]);
+        kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax;
+      }
+    int *sAcc = sCnt + 4;
+    if (tid == 0) { sAcc[0] = 0x7fffffff; sAcc[1] = 0; }
+    __syncthreads();
+    if (kmax) { atomicMin(&sAcc[0], (int)kmin); atomicMax(&sAcc[1], (int)kmax); }
+    __syncthreads();
+    const uint32_t lo0 = (uint32_t)sAcc[0], range = (uint32_t)sAcc[1] - lo0;
+    int ub = 32 - __clz((int)(range | 1u));
+    uint32_t base = 0;
+    int *sWaveTot = sHist + 1024;
+    while (ub > 0) {
+      const int sh = ub > 10 ? ub - 10 : 0;
+      sHist[tid] = 0;
+      __syncthreads();
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+        for (uint64_t rest = alive[w]; rest; rest &= rest - 1) {
+          const uint32_t r = __float_as_uint(gscore[cell_of(w, __ffsll((long long)rest) - 1)]) - lo0 - base;
+          if ((r >> ub) == 0) atomicAdd(&sHist[r >> sh], 1);
+        }
+      __syncthreads();
+      const int mine = sHist[tid];
+      int suffix = mine;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_down(suffix, off, 64);
+        if (lane + off < 64) suffix += o;
+      }
+      if (lane == 0) sWaveTot[wave] = suffix;
+      __syncthreads();
+      int above = suffix - mine;
+      for (int w2 = wave + 1; w2 < 16; ++w2) above += sWaveTot[w2];
+      if (above < need && above + mine >= need) { sCnt[4] = tid; sCnt[5] = need - above; }
+      __syncthreads();
+      base += (uint32_t)sCnt[4] << sh;
+      need = sCnt[5];
+      ub = sh;
+      __syncthreads();   // (sCnt[4..5] are read above and rewritten by the next pass)
+    }
+    prefix = lo0 + base;
+    __syncthreads();
+    if (tid == 0) sCnt[6] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+      for (uint64_t rest = alive[w]; rest; rest &= rest - 1) {
+        const int c = cell_of(w, __ffsll((long long)rest) - 1);
+        if (__float_as_uint(gscore[c]) == prefix) gList[atomicAdd(&sCnt[6], 1)] = c;
+      }
+    __syncthreads();
+  }
+  const int nties = cut ? sCnt[6] : 0;
+  // keep / border reject; a kept cell takes the next slot of its cell row
+#pragma unroll
+  for (int w = 0; w < NW; ++w)
+    for (uint64_t rest = alive[w]; rest; rest &= rest - 1) {
+      const int j = __ffsll((long long)rest) - 1;
+      const int c = cell_of(w, j);
+      bool keep = true;
+      if (cut) {
+        const uint32_t key = __float_as_uint(gscore[c]);
+        if (key < prefix) keep = false;
+        else if (key == prefix && nties > need) {
+          int lower = 0;
+          for (int t = 0; t < nties; ++t) lower += gList[t] < c;
+          keep = lower < need;
+        }
+      }
+      if (!keep) continue;
+      const int cy = c / wc, cx = c - cy * wc;
+      const int k = gk[c];
+      const int x = cx * 8 + (k & 7), y = cy * 8 + (k >> 3);
+      if (!(x < SPFE_NMS_BORDER || x >= W - SPFE_NMS_BORDER || y < SPFE_NMS_BORDER || y >= H - SPFE_NMS_BORDER)) {   // :222-224
+        gstate[c] = ST_KEPT;
+        slotp[c] = atomicAdd(&sRow[cy], 1);
+        kept[w] |= 1ull << j;
+      }
+    }
+  __syncthreads();   // (also: every thread is done with the tie list before the layout below reuses gList)
+  // ---- raster order (y outer, x inner) (:220-238) and occ_grid (:227-228): (cell row, dy, cx) ----
+  if (wave == 0) {
+    int carry = 0;
+    for (int r0 = 0; r0 < hc; r0 += 64) {
+      const int r = r0 + lane;
+      const int v = r < hc ? sRow[r] : 0;
+      int incl = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+      }
+      if (r < hc) sRowBase[r] = carry + incl - v;
+      carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) {
+      sCnt[3] = carry;
+      hdr[0] = carry;     // K
+      hdr[1] = sCnt[2];   // n_candidates
+      hdr[2] = 0;         // status
+      hdr[3] = S;         // NMS survivors before the cut (diagnostic)
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < NW; ++w)
+    for (uint64_t rest = kept[w]; rest; rest &= rest - 1) {
+      const int c = cell_of(w, __ffsll((long long)rest) - 1);
+      gList[sRowBase[c / wc] + slotp[c]] = c;
+    }
+  __syncthreads();
+  const int K = sCnt[3];
+  for (int t = tid; t < K; t += 1024) {
+    const int c = gList[t];
+    const int cy = c / wc, cx = c - cy * wc;
+    const int k = gk[c];
+    const int mykey = ((k >> 3) << 20) | cx;
+    const int g0 = sRowBase[cy], g1 = g0 + sRow[cy];
+    int idx = g0;
+    for (int u = g0; u < g1; ++u) {
+      const int cu = gList[u];
+      idx += ((((int)gk[cu] >> 3) << 20) | (cu - cy * wc)) < mykey;
+    }
+    kp_xy[2 * idx] = (float)(cx * 8 + (k & 7));
+    kp_xy[2 * idx + 1] = (float)(cy * 8 + (k >> 3));
+    kp_cell[idx] = c;
+    slotp[c] = idx;   // (only this thread reads or writes slotp[c] from here on: each kept cell is one list entry)
+    if (f.db_list) {
+      const DescTaps tp = desc_taps((float)(cx * 8 + (k & 7)), (float)(cy * 8 + (k >> 3)), H, W);
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) {
+        const int txx = tp.x0 + (t4 & 1), tyy = tp.y0 + (t4 >> 1);
+        if (txx < 0 || txx >= wc || tyy < 0 || tyy >= hc) continue;
+        const int cell = tyy * wc + txx;
+        atomicOr(&sBits[cell >> 5], 1u << (cell & 31));
+      }
+    }
+  }
+  __syncthreads();
+  if (f.db_list) {
+    // the marked cells, in cell order, appended to the batch's list: thread t owns words [t wpt, (t + 1) wpt)
+    const int wpt = (nwords + 1023) >> 10;
+    int cnt = 0;
+    for (int i = 0; i < wpt; ++i) {
+      const int wi = tid * wpt + i;
+      cnt += wi < nwords ? __popc(sBits[wi]) : 0;
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    int *sTot = reinterpret_cast<int *>(sBits + nwords);
+    if (lane == 63) sTot[wave] = incl;
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < 16; ++w2) {
+      const int v = sTot[w2];
+      wbase += w2 < wave ? v : 0;
+      total += v;
+    }
+    if (tid == 0) sTot[16] = atomicAdd(f.db_total, total);
+    __syncthreads();
+    int pos = sTot[16] + wbase + incl - cnt;
+    for (int i = 0; i < wpt; ++i) {
+      const int wi = tid * wpt + i;
+      if (wi >= nwords) break;
+      for (unsigned rest = sBits[wi]; rest; rest &= rest - 1) f.db_list[pos++] = b * C + 32 * wi + (__ffs((int)rest) - 1);
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 1024)
+    occ[c] = gstate[c] == ST_KEPT ? (int16_t)slotp[c] : (int16_t)-1;
+}
+constexpr int SELECT_HUGE_NW = 4;   // 64 x 4 cells per thread: 262,144 cells
+size_t select_huge_lds_bytes(int H, int W) {
+  const size_t C = (size_t)(H / 8) * (W / 8);
+  return ((size_t)(H / 8) + 16) * 4 * 2 + 16 * 4 + (1024 + 16) * 4 + ((C + 31) / 32 + 17) * 4;
+}
+size_t select_huge_max_cells() { return (size_t)64 * SELECT_HUGE_NW * 1024 - 1; }
+
 hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H, int W,
                          int num_features, hipStream_t s, const CovScratch *with_heat_norm, int kmax_hn, bool lean,
                          hipEvent_t done) {
+  if (f.sel_huge) {   // frames of more than 65,535 cells (or SPFE_SELECT_HUGE=1): everything per cell in global scratch
+    const size_t lds = select_huge_lds_bytes(H, W);
+    if (lds > 160 * 1024 || (size_t)(H / 8) * (W / 8) > select_huge_max_cells() || !f.sel_state || !f.sel_slot || !f.sel_list32)
+      return hipErrorInvalidValue;
+    auto k = select_huge_kernel<SELECT_HUGE_NW>;
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    if (with_heat_norm) {
+      const int nmask = ((H / 8) * (W / 8) + 255) / 256, hb = (int)(((size_t)H * W / 4 + 255) / 256);
+      hipLaunchKernelGGL(mask_and_heat_norm_kernel, dim3(nmask + (hb < 128 ? hb : 128), B), dim3(256), 0, s, f, H, W, tail_parts(H, W),
+                         *with_heat_norm, kmax_hn, nmask);
+    } else {
+      hipLaunchKernelGGL(nms_mask_kernel, dim3(((H / 8) * (W / 8) + 255) / 256, B), dim3(256), 0, s, f, H / 8, W / 8);
+    }
+    if (done) hipExtLaunchKernelGGL(k, dim3(B), dim3(1024), (unsigned)lds, s, nullptr, done, 0, f, r, H, W, num_features);
+    else hipLaunchKernelGGL(k, dim3(B), dim3(1024), lds, s, f, r, H, W, num_features);
+    return hipGetLastError();
+  }
   const bool big = select_big(H, W) || (lean && f.sel_slot && f.sel_list);
   const size_t lds = select_lds_bytes(H, W, big);
   if (lds > 160 * 1024 || (size_t)(H / 8) * (W / 8) > select_max_cells()) return hipErrorInvalidValue;

@@ -321,9 +321,82 @@ def test_full_extraction_1080p_matches_oracle():
     assert np.array_equal(_bits(fr.cov2_inv), _bits(ref["cov2_inv"]))
 
 
-def test_frames_beyond_65535_cells_are_refused():
-    with pytest.raises(Exception):
-        SPExtractor(1000, 2160, 3840, _blob())
+def test_frame_size_limits():
+    """f32: up to 262,143 cells and 2^31 bytes of first-layer activations per frame (3840x2160 fits, 4096x2304 = 2.4 GB does
+    not); bf16: select_kernel's 65,535 cells (2560x1440 fits, 3840x2160 does not).  Refused at spfe_create with a message."""
+    with pytest.raises(Exception, match="too large"):
+        SPExtractor(1000, 2304, 4096, _blob())
+    with pytest.raises(Exception, match="too large"):
+        SPExtractor(1000, 2160, 3840, _blob(), precision="bf16")
+
+
+@pytest.mark.parametrize("H,W,nf,scale,seed", [(2160, 3840, 1000, 1.5, 0), (2160, 3840, 10000, 0.2, 1), (2160, 3840, 3000, 0.0, 2)])
+def test_selection_beyond_65535_cells(H, W, nf, scale, seed):
+    """3840x2160 = 129,600 cells: select_huge_kernel (tail_select.hip — everything per cell in global scratch, 32-bit cell
+    indices, 256 cells per thread) against the literal oracle on random logits: the cut among crowded scores (scale 0.2), by
+    the index tie rule alone (scale 0: all scores equal), border, raster order, occ_grid, descriptors, covariance."""
+    rng = np.random.default_rng(seed)
+    semi = (rng.standard_normal((H // 8, W // 8, 65)) * scale).astype(f32)
+    coarse = rng.standard_normal((H // 8, W // 8, 256)).astype(f32)
+    fr, ref = _run(semi, coarse, H, W, nf)
+    _check_exact(fr, ref)
+    assert fr.K > 0.5 * min(nf, ref["n_candidates"] // 9)
+
+
+def test_full_extraction_2160p_matches_oracle():
+    """3840x2160 through the whole f32 path (the reference accepts any multiple of 8, sp_extractor.cpp:70): conv1a's output is
+    2,123,366,400 bytes a frame — the largest the convolutions' 32-bit buffer offsets address — and the selection runs as
+    select_huge_kernel.  Bitwise vs the oracle."""
+    from sp_orb_slam_amd import synth
+    H, W, nf = 2160, 3840, 1000
+    blob = weights.synthetic(7, "sparse")
+    img = synth.make_image(78, H, W)
+    ext = SPExtractor(nf, H, W, blob, with_heat=False)
+    kps, desc = ext(img, None)
+    fr = ext.last
+    assert ext.debug_read("select_huge")[0] == 1
+    ext.close()
+    ref = oracle.extract(blob, img, nf)
+    assert fr.status == 0 and fr.K == ref["K"] and np.array_equal(fr.kp_xy, ref["kp_xy"])
+    assert np.array_equal(fr.occ_grid, ref["occ_grid"])
+    assert np.array_equal(_bits(fr.descriptors), _bits(ref["desc"]))
+    assert np.array_equal(_bits(fr.cov2_inv), _bits(ref["cov2_inv"]))
+
+
+def test_select_huge_form_on_frames_of_any_size(monkeypatch):
+    """SPFE_SELECT_HUGE=1 runs the selection of every frame on select_huge_kernel: the crafted cases of this file (border,
+    distance 4 / 5, cell corners, the cut before the border reject, ties by cell index, the threshold compare, cuts through
+    groups of equal scores), random logits at five sizes and 1920x1080 / 2560x1440 — all exact against the literal oracle —
+    and a batch of whole extractions equal to the default form's records."""
+    monkeypatch.setenv("SPFE_SELECT_HUGE", "1")
+    ext = SPExtractor(50, 64, 96, _blob())
+    ext.postprocess(np.zeros((8, 12, 65), f32), _coarse(64, 96))
+    assert ext.debug_read("select_huge")[0] == 1
+    ext.close()
+    test_handmade_nms_cases()
+    test_threshold_boundary_and_argmax_ties()
+    for args in [(64, 96, 30, 1.0, 0), (120, 160, 1000, 2.0, 1), (240, 320, 100, 0.5, 2), (480, 752, 1000, 1.5, 3), (480, 752, 200, 3.0, 4)]:
+        test_random_logits_exact(*args)
+    for nf, levels in [(10, (4.0,)), (37, (4.0,)), (25, (5.0, 4.0)), (60, (5.0, 4.0, 4.0, 3.0))]:
+        test_cut_through_a_group_of_equal_scores(nf, levels)
+    test_selection_with_more_cells_than_the_register_path_holds()
+    test_selection_beyond_16k_cells(1080, 1920, 10000, 0.2, 1)
+    test_selection_beyond_16k_cells(1088, 1920, 1000, 0.0, 3)
+    test_postprocess_batch()
+    from sp_orb_slam_amd import synth
+    H, W, nf, B = 240, 376, 300, 3
+    imgs = [synth.make_image(40 + i, H, W) for i in range(B)]
+    ext = SPExtractor(nf, H, W, _blob(), max_batch=B)
+    huge = ext.extract_batch(imgs)
+    ext.close()
+    monkeypatch.delenv("SPFE_SELECT_HUGE")
+    ext = SPExtractor(nf, H, W, _blob(), max_batch=B)
+    dflt = ext.extract_batch(imgs)
+    assert ext.debug_read("select_huge")[0] == 0
+    ext.close()
+    for a, b in zip(huge, dflt):
+        assert a.K == b.K and np.array_equal(a.kp_xy, b.kp_xy) and np.array_equal(a.occ_grid, b.occ_grid)
+        assert np.array_equal(_bits(a.descriptors), _bits(b.descriptors)) and np.array_equal(_bits(a.cov2), _bits(b.cov2))
 
 
 @pytest.mark.parametrize("env", [{"SPFE_COV_CAPS": ",,,,0"}, {"SPFE_COV_CAPS": ",,,,40"}, {}])
