@@ -140,7 +140,7 @@ struct spfe_handle_s {
   // ... and convDa with it (bf16 mode, da_gather_bf16.hip): the dense launch computes convPa only, the descriptor branch
   // runs on the listed cells from conv4b's output on.  SPFE_SPARSE_DA=0: convPa|Da dense, only convDb gathered.
   bool sparse_da = false;
-  int sparse_da_mode = 1;        // SPFE_SPARSE_DA: 0 never, 1 synchronous calls only (default), 2 pipelined calls too
+  int sparse_da_mode = 1;        // SPFE_SPARSE_DA: 0 never, 1 synchronous calls only, 2 pipelined calls too (the default of both precisions since round 5)
   bool sparse_da_call = false;   // ... this / the last call
   int *d_db_list = nullptr, *d_db_total = nullptr;
   int db_cap = 0;                // list entries per frame: min(4 kmax, C)

@@ -467,7 +467,10 @@ int build(spfe_handle h, const spfe_config *cfg) {
     // Measured at 1280x720 x 8 (da_gather_bf16.hip): 25 us alone against the 43 us the dense launch loses without convDa, a
     // single-frame call's p50 0.357 -> 0.352 ms; but pipelined 7640 -> 7500 frames/s — a workgroup needs a whole CU (148 KB
     // of LDS, 380 registers), so beside the next batch's convolutions it only starts where one of theirs has ended, and
-    // then holds that CU for its ~6 tiles.  So: synchronous calls only.
+    // then holds that CU for its ~6 tiles.  So: synchronous calls only — until round 5: with the replay workers listed
+    // longest chain first and the lone walks at 6 KB of LDS (cov.hip) the same A/B reads 7796 / 7830 -> 8159 / 8180 frames/s
+    // (+4.5 %): pipelined calls take it too (mode 2; it only ever applies where the gathered convDb does: frames of >= 10,000 cells)
+    h->sparse_da_mode = 2;
     if (h->sparse_da_env >= 0) h->sparse_da_mode = h->sparse_da_env;
     h->sparse_da = h->sparse_da && h->sparse_da_mode != 0;
     if (h->sparse_da && (rc = dev_alloc(h, &h->act7_alt, (size_t)B * C * 128))) return rc;
