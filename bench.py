@@ -725,6 +725,7 @@ def main():
     ap.add_argument("--no-stage-table", action="store_true", help="skip the separate per-stage timing pass")
     ap.add_argument("--no-match", action="store_true", help="skip the matching, dust-alignment, staging and front-end legs (SURVEY 8f)")
     ap.add_argument("--no-bf16-leg", action="store_true", help="skip the other-resolution / other-dtype legs (incl. configs[3])")
+    ap.add_argument("--no-uhd-leg", action="store_true", help="skip the 3840x2160 leg (4 GB of activations, ~6 s: synthetic frame + handle)")
     ap.add_argument("--no-aten", action="store_true", help="skip the ATen-CPU baseline")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host-path legs")
     ap.add_argument("--no-parity", action="store_true", help="N > 1: skip the oracle check of the gathered records")
@@ -902,6 +903,12 @@ def main():
             if (prec, h2, w2, 8) == (args.precision, H, W, B):
                 continue
             out[name] = device_leg(ctx, prec, h2, w2, 8, seed0, max(k2, args.steps), max(wu2, args.warmup), what)
+        # The largest frame the path takes (the reference accepts any multiple of 8, sp_extractor.cpp:70): 3840x2160, one frame
+        # per step — 129,600 cells (select_huge_kernel), conv1a's output 2.12 GB a frame (the end of the convolutions' 32-bit
+        # buffer offsets).  f32 only; exact against the oracle in tests/test_gpu_selection.py::test_full_extraction_2160p_matches_oracle
+        if args.precision == "f32" and not args.no_uhd_leg:
+            out["f32_3840x2160_b1"] = device_leg(ctx, "f32", 2160, 3840, 1, 500, 30, 3,
+                                                 "3840x2160, one frame per step, f32 MFMA, 1 GPU (select_huge_kernel: 129,600 cells)")
         # The headline workload with the SPARSE synthetic detector (~1-2 k candidates per frame in isolated peaks — what a trained
         # SuperPoint produces — instead of a candidate in every cell): the headline's cells_computed_frac, selection and
         # covariance costs are properties of the dense detector; this is the other end
