@@ -95,6 +95,12 @@ int spfe_create(const spfe_config *cfg, spfe_handle *out) {
     return fail(SPFE_EINVAL, "device %d out of range (%d devices)", cfg->device, ndev);
   spfe_handle h = new spfe_handle_s();
   int rc = build(h, cfg);
+  if (!rc && (cfg->flags & SPFE_FLAG_ASYNC_COV) &&
+      (h->two_chains_env >= 0 ? h->two_chains_env > 0 : (h->bf16 && h->C >= 10000))) {   // two side chains in flight (spfe_host.h)
+    h->twin = new spfe_handle_s();
+    h->twin->is_twin = true;
+    rc = build(h->twin, cfg);
+  }
   if (rc) {
     std::string keep = g_err;
     spfe_destroy(h);
@@ -107,6 +113,7 @@ int spfe_create(const spfe_config *cfg, spfe_handle *out) {
 
 void spfe_destroy(spfe_handle h) {
   if (!h) return;
+  if (h->twin) { spfe_destroy(h->twin); h->twin = nullptr; }
   (void)hipSetDevice(h->cfg.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->side) (void)hipStreamSynchronize(h->side);
@@ -165,6 +172,14 @@ int spfe_extract_batch_device(spfe_handle h, const void *d_images, int n, void *
   HIP_TRY(hipSetDevice(h->cfg.device));
   hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
   uint8_t *rec = d_records ? reinterpret_cast<uint8_t *>(d_records) : h->d_records;
+  if (h->twin) {   // two side chains in flight: even tickets on this handle, odd ones on its twin (own buffers, own side stream)
+    spfe_handle t = (h->g_ticket & 1) ? h->twin : h;
+    const int rc = enqueue(t, reinterpret_cast<const uint8_t *>(d_images), n, rec, s);
+    if (rc) return rc;
+    h->tmap[h->g_ticket % 8] = {t, t->ticket - 1};
+    h->g_ticket++;
+    return SPFE_OK;
+  }
   return enqueue(h, reinterpret_cast<const uint8_t *>(d_images), n, rec, s);
 }
 
@@ -253,15 +268,21 @@ int spfe_extract(spfe_handle h, const uint8_t *image, int stride, spfe_result *o
   return spfe_extract_batch(h, imgs, stride, 1, out);
 }
 
-long spfe_last_ticket(spfe_handle h) { return h ? h->ticket - 1 : -1; }
+long spfe_last_ticket(spfe_handle h) { return h ? api_tickets(h) - 1 : -1; }
 
 int spfe_wait_records(spfe_handle h, long ticket, void *stream) {
   if (!h) return fail(SPFE_EINVAL, "null handle");
-  if (ticket < 0 || ticket >= h->ticket || ticket + spfe_handle_s::NTICKET <= h->ticket)
+  if (ticket < 0 || ticket >= api_tickets(h) || ticket + spfe_handle_s::NTICKET <= api_tickets(h))
     return fail(SPFE_EINVAL, "ticket %ld is not one of the last %d calls", ticket, spfe_handle_s::NTICKET);
   HIP_TRY(hipSetDevice(h->cfg.device));
   hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
-  HIP_TRY(hipStreamWaitEvent(s, h->ev_cov[ticket % spfe_handle_s::NTICKET], 0));
+  const spfe_handle_s::TicketRef r = ticket_ref(h, ticket);   // (a handle with a twin: whichever of the two ran that call)
+  HIP_TRY(hipStreamWaitEvent(s, r.who->ev_cov[r.local % spfe_handle_s::NTICKET], 0));
+  if (h->twin && ticket > 0) {   // one side stream used to make "ticket t is done" mean "and every earlier one": keep that — the call before ran on the other of the pair
+    const spfe_handle_s::TicketRef p = ticket_ref(h, ticket - 1);
+    if (p.who && ticket - 1 + spfe_handle_s::NTICKET > api_tickets(h) - 1)
+      HIP_TRY(hipStreamWaitEvent(s, p.who->ev_cov[p.local % spfe_handle_s::NTICKET], 0));
+  }
   return SPFE_OK;
 }
 
@@ -273,6 +294,17 @@ int spfe_view_record(spfe_handle h, const void *host_record, spfe_result *out) {
 
 long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size_t cap) {
   if (!h || !name || !dst) return fail(SPFE_EINVAL, "null argument");
+  if (std::string(name) == "two_chains") {   // 1: pipelined device calls alternate between this handle and its twin
+    if (cap < sizeof(int)) return fail(SPFE_EINVAL, "buffer 'two_chains' needs 4 bytes");
+    *reinterpret_cast<int *>(dst) = h->twin ? 1 : 0;
+    return (long)sizeof(int);
+  }
+  if (h->twin) {   // the intermediates of the last call live in whichever of the two ran it; neither has work in flight afterwards
+    if (hipSetDevice(h->cfg.device) != hipSuccess) return fail(SPFE_EHIP, "hipSetDevice failed");
+    for (spfe_handle q : {h, h->twin})
+      if (hipStreamSynchronize(q->stream) != hipSuccess || hipStreamSynchronize(q->side) != hipSuccess) return fail(SPFE_EHIP, "debug read of '%s' failed", name);
+    h = last_caller(h);
+  }
   if (frame < 0 || frame >= h->B) return fail(SPFE_EINVAL, "frame %d out of range", frame);
   const size_t C = h->C, HW = (size_t)h->H * h->W;
   if (std::string(name) == "conv1b_split_rows") {
@@ -367,6 +399,7 @@ long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size
 int spfe_stage_reset(spfe_handle h) {
   if (!h) return fail(SPFE_EINVAL, "null handle");
   h->calls_at_reset = h->calls;
+  if (h->twin) h->twin->calls_at_reset = h->twin->calls;
   return SPFE_OK;
 }
 
@@ -374,6 +407,19 @@ int spfe_stage_reset(spfe_handle h) {
 // the last EVSETS calls).  Needs SPFE_STAGE_TIMING=1 at spfe_create.
 int spfe_stage_times(spfe_handle h, float *ms, int cap) {
   if (!h || !ms) return fail(SPFE_EINVAL, "null argument");
+  if (h->twin && h->timing && cap > 0) {   // the calls since the reset ran on both of the pair: the call-weighted mean of the two
+    float a[NSTAGE] = {}, b[NSTAGE] = {};
+    spfe_handle tw = h->twin;
+    h->twin = nullptr;
+    const long ca = h->calls - h->calls_at_reset, cb = tw->calls - tw->calls_at_reset;
+    const int na = spfe_stage_times(h, a, NSTAGE), nb = spfe_stage_times(tw, b, NSTAGE);
+    h->twin = tw;
+    if (na < 0 || nb < 0) return na < 0 ? na : nb;
+    if (na == 0 && nb == 0) return 0;
+    const int nst = cap < NSTAGE ? cap : NSTAGE;
+    for (int i = 0; i < nst; ++i) ms[i] = (float)((a[i] * (na ? ca : 0) + b[i] * (nb ? cb : 0)) / (double)((na ? ca : 0) + (nb ? cb : 0)));
+    return nst;
+  }
   if (!h->timing || h->calls == h->calls_at_reset) return 0;
   if (hipSetDevice(h->cfg.device) != hipSuccess) return fail(SPFE_EHIP, "hipSetDevice failed");
   long first = h->calls_at_reset;

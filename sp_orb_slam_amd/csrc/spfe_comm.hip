@@ -102,7 +102,7 @@ int spfe_allgather_records(spfe_handle h, long ticket, const void *d_local, void
   if (!h || !d_local || !d_all) return fail(SPFE_EINVAL, "null argument");
   if (!h->comm) return fail(SPFE_EINVAL, "spfe_comm_init has not been called");
   if (frames_per_rank < 1) return fail(SPFE_EINVAL, "frames_per_rank %d", frames_per_rank);
-  if (ticket < 0 || ticket >= h->ticket || ticket + spfe_handle_s::NTICKET <= h->ticket)
+  if (ticket < 0 || ticket >= api_tickets(h) || ticket + spfe_handle_s::NTICKET <= api_tickets(h))
     return fail(SPFE_EINVAL, "ticket %ld is not one of the last %d calls", ticket, spfe_handle_s::NTICKET);
   HIP_TRY(hipSetDevice(h->cfg.device));
   // on the side stream the gather simply follows the batch's covariance kernels (and everything enqueued there since:
@@ -111,7 +111,8 @@ int spfe_allgather_records(spfe_handle h, long ticket, const void *d_local, void
   // (always: in pipelined calls the covariance kernels sit on the side stream in front of the gather and the event has been
   // recorded there — a wait that is satisfied when it is reached; in synchronous calls the chain runs on the launch stream
   // (round 4) and this wait is what orders the gather behind it)
-  HIP_TRY(hipStreamWaitEvent(h->comm_stream, h->ev_cov[ticket % spfe_handle_s::NTICKET], 0));
+  const spfe_handle_s::TicketRef tr = ticket_ref(h, ticket);   // (a handle with a twin: whichever of the two ran that call)
+  HIP_TRY(hipStreamWaitEvent(h->comm_stream, tr.who->ev_cov[tr.local % spfe_handle_s::NTICKET], 0));
   const size_t count = (size_t)frames_per_rank * h->rl.bytes;   // bytes as ncclUint8; RCCL counts are size_t
   const ncclResult_t r = h->p_ncclAllGather(d_local, d_all, count, ncclUint8, h->comm, h->comm_stream);
   if (r != ncclSuccess) return fail(SPFE_EHIP, "ncclAllGather(%zu bytes per rank): %s", count, h->p_ncclGetErrorString(r));

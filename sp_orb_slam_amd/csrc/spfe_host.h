@@ -110,6 +110,22 @@ struct spfe_handle_s {
   int split_mode = -1;      // SPFE_SPLIT: -1 = f32 always, bf16 frames of fewer than 10,000 cells (752x480: +2 %; 1280x720: +-0); 0 never; 1 always
   // the other schedule switches (read_switches(), spfe_pack.hip; README "Environment switches"), defaults = the product's order
   bool inline_chain = true, tail_per_half = true, early_waits = true, sel_ext_event = true, zero_in_tail = true;
+  // TWO SIDE CHAINS IN FLIGHT (round 5).  The side chain of a batch is a serial string of latency-bound kernels on one stream,
+  // and what it hands over internally (heat_inv, the covariance scratch, the cell lists, the coarse map) exists once — so
+  // chain i + 1 starts when chain i has ended, and on large bf16 frames a chain (0.7 - 1.0 ms beside the convolutions of a
+  // 1.0 ms step; its selection cannot even start before conv1b ends: LDS) is as long as the step: the side stream, not the
+  // convolutions, then sets the step (1280x720 x 8: 7,530 - 8,290 frames/s depending on how many long replay chains the frames
+  // hold).  With a second, complete set of buffers and a second side stream the chains of consecutive batches overlap: the
+  // handle owns a TWIN — a whole second handle built from the same configuration — and pipelined device calls alternate
+  // between the two (measured first with two handles in one process, tools/microbench/two_chains.py: 7,530 -> 8,115 and
+  // 7,745 -> 8,125 frames/s at 1280x720 bf16; 752x480: -3 % bf16, -2 % f32: there the chain is short and a step runs as two
+  // half batches).  Tickets stay one sequence: tmap says which of the two ran a ticket, and under which ticket of its own.
+  // SPFE_TWO_CHAINS: -1 by workload (bf16 frames of >= 10,000 cells, SPFE_FLAG_ASYNC_COV handles), 0 never, 1 always.
+  spfe_handle twin = nullptr;
+  bool is_twin = false;
+  int two_chains_env = -1;
+  long g_ticket = 0;                         // tickets handed out by this handle when it has a twin
+  struct TicketRef { spfe_handle who; long local; } tmap[8] = {};
   int replay_waves = 0;     // SPFE_REPLAY_WAVES: 0 = by workload
   int sparse_db_env = -1, sparse_da_env = -1, pbtail_env = 1, fuse1a_env = -1, pipe_copy_kernel = -1, cov_ecap_env = -1;
   bool desc_recorded = false;
@@ -282,6 +298,16 @@ int host_alloc(spfe_handle h, T **p, size_t count) {
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// tickets as the caller of the C ABI sees them (one sequence per handle, twin or not)
+inline long api_tickets(const spfe_handle h) { return h->twin ? h->g_ticket : h->ticket; }
+inline spfe_handle_s::TicketRef ticket_ref(spfe_handle h, long t) {
+  if (!h->twin) return {h, t};
+  return h->tmap[t % 8];
+}
+inline spfe_handle last_caller(spfe_handle h) {   // the one of the pair whose buffers hold the last call's intermediates
+  return h->twin && h->g_ticket > 0 && h->tmap[(h->g_ticket - 1) % 8].who ? h->tmap[(h->g_ticket - 1) % 8].who : h;
+}
 
 hipError_t wait_if_pending(hipStream_t s, hipEvent_t ev);
 void make_layout(int kmax, int C, bool desc_bf16, spfe::RecordLayout *r);

@@ -220,7 +220,7 @@ static void read_switches(spfe_handle h) {
   h->inline_chain = env_int("SPFE_INLINE_CHAIN", 1) != 0;    // synchronous calls: detector chain on the launch stream
   h->defer_join = env_int("SPFE_DEFER_JOIN", 1) != 0;        // pipelined two-half steps: the join in front of the NEXT conv1b
   h->tail_per_half = env_int("SPFE_TAIL_PER_HALF", 1) != 0;  // ... each half's tail right behind its convPa
-  h->early_waits = env_int("SPFE_EARLY_WAITS", 1) != 0;      // ... the tails' waits in front of conv1a
+  h->two_chains_env = env_int("SPFE_TWO_CHAINS", -1);        // a twin handle, pipelined device calls alternate: -1 by workload, 0 never, 1 always
   h->sel_ext_event = env_int("SPFE_SEL_EXT_EVENT", 1) != 0;  // the selection's completion signal as the descriptor branch's event
   h->replay_waves = env_int("SPFE_REPLAY_WAVES", 0);         // components per replay workgroup: 0 by workload, 2 | 8
   h->zero_in_tail = env_int("SPFE_ZERO_IN_TAIL", 1) != 0;    // bf16 tile-queue counters cleared by the previous call's tail

@@ -153,7 +153,7 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
   // Pipelined two-half-batch steps: what the tails wait for (the side chain two tickets back: long finished, but the host
   // runs many steps ahead of the device, so these are real wait packets) is waited for in FRONT of conv1a — the packets are
   // then processed while the other half batch of the last step still runs, not between conv1a and conv1b with the chip idle.
-  // Predicted from the last call's schedule; a wrong guess only repeats the (satisfied) waits later.  SPFE_EARLY_WAITS=0: off
+  // Predicted from the last call's schedule; a wrong guess only repeats the (satisfied) waits later.
   bool early_waits = false;
   {
     if (h->early_waits && h->split_last && h->pbtail && n >= 2 && ((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode) && !(h->timing && h->timing_all)) {

@@ -14,7 +14,7 @@ from sp_orb_slam_amd.extractor import SPExtractor
 pytestmark = pytest.mark.gpu
 
 FIELDS = ("kp_xy", "response", "descriptors", "cov2", "cov2_inv", "occ_grid", "dense_dust", "semi_dust")
-ALL = ("SPFE_INLINE_CHAIN", "SPFE_DEFER_JOIN", "SPFE_TAIL_PER_HALF", "SPFE_EARLY_WAITS", "SPFE_SEL_EXT_EVENT", "SPFE_REPLAY_WAVES",
+ALL = ("SPFE_INLINE_CHAIN", "SPFE_DEFER_JOIN", "SPFE_TAIL_PER_HALF", "SPFE_TWO_CHAINS", "SPFE_SEL_EXT_EVENT", "SPFE_REPLAY_WAVES",
        "SPFE_ZERO_IN_TAIL", "SPFE_SPARSE_DA", "SPFE_PIPE_COPY_KERNEL", "SPFE_COMM_OWN_STREAM")
 
 
@@ -44,7 +44,7 @@ CASES = [
     ("SPFE_SEL_EXT_EVENT", "0", "f32", False),
     ("SPFE_DEFER_JOIN", "0", "f32", True), ("SPFE_DEFER_JOIN", "0", "bf16", True),
     ("SPFE_TAIL_PER_HALF", "0", "f32", True), ("SPFE_TAIL_PER_HALF", "0", "bf16", True),
-    ("SPFE_EARLY_WAITS", "0", "f32", True), ("SPFE_EARLY_WAITS", "0", "bf16", True),
+    ("SPFE_TWO_CHAINS", "1", "f32", True), ("SPFE_TWO_CHAINS", "1", "bf16", True),
     ("SPFE_REPLAY_WAVES", "8", "f32", True), ("SPFE_REPLAY_WAVES", "2", "bf16", True), ("SPFE_REPLAY_WAVES", "8", "f32", False),
     ("SPFE_ZERO_IN_TAIL", "0", "bf16", True), ("SPFE_ZERO_IN_TAIL", "0", "bf16", False),
     ("SPFE_SPARSE_DA", "2", "bf16", True), ("SPFE_SPARSE_DA", "0", "f32", True), ("SPFE_SPARSE_DA", "1", "f32", True),
@@ -142,3 +142,48 @@ def test_gather_on_a_communication_stream_of_its_own(monkeypatch):
         ext.comm_destroy()
     assert streams[0] != streams[1]   # the own-stream communicator did not use the side stream
     ext.close()
+
+
+def test_two_side_chains_in_flight_on_large_bf16_frames(monkeypatch):
+    """bf16 frames of >= 10,000 cells, SPFE_FLAG_ASYNC_COV: the handle owns a twin (a second set of buffers and a second side
+    stream) and pipelined device calls alternate between the two, so that the side chains of consecutive batches overlap
+    (spfe_host.h).  Tickets stay one sequence; spfe_wait_records(t) still means "t and every earlier call" — checked WITHOUT a
+    device-wide synchronisation: the stream that waited copies the record buffers out; records equal a synchronous handle's;
+    debug reads come from whichever of the pair ran the last call; SPFE_TWO_CHAINS=0 gives the single chain."""
+    import torch
+    for v in ALL:
+        monkeypatch.delenv(v, raising=False)
+    H, W, B, nf, steps = 720, 1280, 3, 500, 7
+    blob = weights.synthetic(7, "dense")
+    sets = [torch.from_numpy(np.stack([synth.make_image(900 + 5 * r + i, H, W) for i in range(B)])).cuda() for r in range(3)]
+    ref, rb = _reference(torch, "bf16", H, W, B, nf, blob, sets)
+    for env, want in ((None, 1), ("0", 0)):
+        if env is not None:
+            monkeypatch.setenv("SPFE_TWO_CHAINS", env)
+        ext = SPExtractor(nf, H, W, blob, max_batch=B, precision="bf16", with_heat=False, async_cov=True)
+        assert int(ext.debug_read("two_chains")[0]) == want
+        recs = [torch.zeros(B * rb, dtype=torch.uint8, device="cuda") for _ in range(steps)]
+        stream = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        tickets = []
+        for k in range(steps):
+            tickets.append(ext.extract_batch_device(sets[k % 3].data_ptr(), B, recs[k].data_ptr(), stream.cuda_stream))
+        assert tickets == list(range(steps))
+        ext.wait_records(tickets[-1], stream.cuda_stream)
+        with torch.cuda.stream(stream):
+            host = [r.to("cpu", non_blocking=False) for r in recs]    # (ordered on `stream` only)
+        for k in range(steps):
+            hk = host[k].numpy()
+            for i in range(B):
+                _same(ext.view_record(hk[i * rb:(i + 1) * rb]), ref[k % 3][i], ("two chains", env, k, i))
+        # the last call's intermediates: semi of frame 0 equals a synchronous handle's
+        semi = ext.debug_read("semi", 0)
+        sref = SPExtractor(nf, H, W, blob, max_batch=B, precision="bf16", with_heat=False)
+        one = torch.zeros(B * rb, dtype=torch.uint8, device="cuda")
+        sref.extract_batch_device(sets[(steps - 1) % 3].data_ptr(), B, one.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(semi.view(np.uint32), sref.debug_read("semi", 0).view(np.uint32))
+        sref.close()
+        with pytest.raises(Exception):
+            ext.wait_records(tickets[0], stream.cuda_stream)      # out of the window of the last four calls
+        ext.close()

@@ -12,8 +12,10 @@ from sp_orb_slam_amd.extractor import SPExtractor  # noqa: E402
 
 H, W, nf = (int(a) for a in (sys.argv[1:4] or (480, 752, 1000)))
 det = sys.argv[4] if len(sys.argv) > 4 else "dense"
-ext = SPExtractor(nf, H, W, weights.synthetic(7, det), with_heat=False)
-for seed in (200, 201, 202):
+seeds = [int(a) for a in sys.argv[5].split(",")] if len(sys.argv) > 5 else [200, 201, 202]
+prec = sys.argv[6] if len(sys.argv) > 6 else "f32"
+ext = SPExtractor(nf, H, W, weights.synthetic(7, det), with_heat=False, precision=prec)
+for seed in seeds:
     ext(synth.make_image(seed, H, W), None)
     cnt, nxt, workers, npop = (ext.debug_read(n) for n in ("cov_counters", "cov_nxt", "cov_workers", "cov_npop"))
     K = ext.last.K
