@@ -59,6 +59,19 @@ int spfe_check_abi(int abi_version, size_t sizeof_config, size_t sizeof_result, 
 }
 const char *spfe_stage_name(int i) { return (i >= 0 && i < NSTAGE) ? kStageNames[i] : ""; }
 
+// The twin of a handle whose pipelined calls are to alternate between two sets of buffers (spfe_host.h: two side chains in
+// flight) — where the workload (or SPFE_TWO_CHAINS) says so.  spfe_create for SPFE_FLAG_ASYNC_COV handles, the first
+// spfe_submit_batch for the others.
+static int make_twin(spfe_handle h) {
+  if (h->twin || h->is_twin) return SPFE_OK;
+  if (!(h->two_chains_env >= 0 ? h->two_chains_env > 0 : (h->bf16 && h->C >= 10000))) return SPFE_OK;
+  h->twin = new spfe_handle_s();
+  h->twin->is_twin = true;
+  const int rc = build(h->twin, &h->cfg);
+  if (rc) { std::string keep = g_err; spfe_destroy(h->twin); h->twin = nullptr; g_err = keep; }
+  return rc;
+}
+
 int spfe_create(const spfe_config *cfg, spfe_handle *out) {
   if (!cfg || !out) return fail(SPFE_EINVAL, "spfe_create: null argument");
   *out = nullptr;
@@ -95,12 +108,7 @@ int spfe_create(const spfe_config *cfg, spfe_handle *out) {
     return fail(SPFE_EINVAL, "device %d out of range (%d devices)", cfg->device, ndev);
   spfe_handle h = new spfe_handle_s();
   int rc = build(h, cfg);
-  if (!rc && (cfg->flags & SPFE_FLAG_ASYNC_COV) &&
-      (h->two_chains_env >= 0 ? h->two_chains_env > 0 : (h->bf16 && h->C >= 10000))) {   // two side chains in flight (spfe_host.h)
-    h->twin = new spfe_handle_s();
-    h->twin->is_twin = true;
-    rc = build(h->twin, cfg);
-  }
+  if (!rc && (cfg->flags & SPFE_FLAG_ASYNC_COV)) rc = make_twin(h);   // two side chains in flight (spfe_host.h)
   if (rc) {
     std::string keep = g_err;
     spfe_destroy(h);
@@ -454,6 +462,7 @@ int spfe_stage_times(spfe_handle h, float *ms, int cap) {
 namespace {
 int pipe_setup(spfe_handle h) {
   if (h->pipe_ready) return SPFE_OK;
+  { const int rct = make_twin(h); if (rct) return rct; }
   const size_t img = (size_t)h->B * h->H * h->W, rec = (size_t)h->B * h->rl.bytes;
   const bool want = (h->cfg.flags & SPFE_FLAG_HEAT) != 0;
   int rc;
@@ -499,22 +508,29 @@ int spfe_submit_batch(spfe_handle h, const uint8_t *const *images, int stride, i
   hipStream_t s = h->stream;
   HIP_TRY(hipStreamWaitEvent(s, ps.ev_h2d, 0));
   const bool want = (h->cfg.flags & SPFE_FLAG_HEAT) != 0;
-  if (want && h->pipe_submitted > 0) {
-    // the heat maps are single buffers: this batch's heat_norm (side stream) must not overwrite them
-    // before the previous batch's copy has left
-    const spfe_handle_s::PipeSlot &pp = h->pipe[(h->pipe_submitted - 1) % spfe_handle_s::NPIPE];
-    if (pp.ticket >= 0) HIP_TRY(hipStreamWaitEvent(h->side, pp.ev_done, 0));
+  // two side chains in flight: even submissions on this handle, odd ones on its twin (own buffers, own side stream)
+  spfe_handle hc = h->twin && (h->g_ticket & 1) ? h->twin : h;
+  const long back = h->twin ? 2 : 1;   // the previous batch that went through hc's buffers
+  if (want && h->pipe_submitted >= back) {
+    // the heat maps are single buffers (per handle of the pair): this batch's heat_norm (side stream) must not overwrite them
+    // before that batch's copy has left
+    const spfe_handle_s::PipeSlot &pp = h->pipe[(h->pipe_submitted - back) % spfe_handle_s::NPIPE];
+    if (pp.ticket >= 0) HIP_TRY(hipStreamWaitEvent(hc->side, pp.ev_done, 0));
   }
-  h->pipe_mode = true;
-  rc = enqueue(h, ps.d_img, n, ps.d_rec, s);
-  h->pipe_mode = false;
+  hc->pipe_mode = true;
+  rc = enqueue(hc, ps.d_img, n, ps.d_rec, s);
+  hc->pipe_mode = false;
   if (rc) return rc;
-  const long t = h->ticket - 1;
+  long t = h->ticket - 1;
+  if (h->twin) {
+    h->tmap[h->g_ticket % 8] = {hc, hc->ticket - 1};
+    t = h->g_ticket++;
+  }
   // D2H on the SIDE stream, behind the covariance kernels it has to follow anyway.  (A copy stream of its own, waiting
   // for the covariance event, looked cleaner and cost half the throughput in bf16 mode: HIP maps streams onto a few
   // hardware queues, the waiting copy stream shared one with the compute stream, and its barrier packet held the NEXT
   // batch's convolutions until the previous batch's covariance had finished — tools/microbench/run_hosttrace.sh.)
-  hipStream_t sc = h->side;
+  hipStream_t sc = hc->side;
   {
     // f32 mode: a copy kernel of our own (2038 against 2000 ... 2028 frames/s with the runtime's copy at 752x480 x 8).  bf16
     // mode: the runtime's copy engine — the kernel's 64 workgroups sit on the chip for the 0.2 ms the PCIe transfer takes,
@@ -534,9 +550,9 @@ int spfe_submit_batch(spfe_handle h, const uint8_t *const *images, int stride, i
     const size_t m16 = (size_t)n * H * W * 4 / 16;   // (H, W multiples of 8)
     if (!(h->cfg.flags & SPFE_FLAG_LAZY_HEAT_INV))
       hipLaunchKernelGGL(spfe::copy_records_kernel, dim3(64), dim3(256), 0, sc, reinterpret_cast<uint4 *>(ps.h_heat_inv),
-                         reinterpret_cast<const uint4 *>(h->d_heat_inv), m16);
+                         reinterpret_cast<const uint4 *>(hc->d_heat_inv), m16);
     hipLaunchKernelGGL(spfe::copy_records_kernel, dim3(64), dim3(256), 0, sc, reinterpret_cast<uint4 *>(ps.h_heat),
-                       reinterpret_cast<const uint4 *>(h->d_heat), m16);
+                       reinterpret_cast<const uint4 *>(hc->d_heat), m16);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(ps.ev_done, sc));

@@ -187,3 +187,29 @@ def test_two_side_chains_in_flight_on_large_bf16_frames(monkeypatch):
         with pytest.raises(Exception):
             ext.wait_records(tickets[0], stream.cuda_stream)      # out of the window of the last four calls
         ext.close()
+
+
+def test_two_side_chains_on_the_pipelined_host_path():
+    """spfe_submit_batch / spfe_collect_batch on large bf16 frames: the twin is made at the first submission (the handle was
+    created without SPFE_FLAG_ASYNC_COV), submissions alternate between the pair, each D2H copy rides the side stream of the
+    handle that ran the batch, heat maps included; records and maps equal the synchronous calls'."""
+    H, W, B, nf = 720, 1280, 2, 400
+    blob = weights.synthetic(7, "dense")
+    batches = [[synth.make_image(1500 + 10 * s + i, H, W) for i in range(B)] for s in range(6)]
+    ref_ext = SPExtractor(nf, H, W, blob, max_batch=B, precision="bf16", with_heat=True)
+    ref = [ref_ext.extract_batch(b) for b in batches]
+    ref_ext.close()
+    ext = SPExtractor(nf, H, W, blob, max_batch=B, precision="bf16", with_heat=True)
+    assert int(ext.debug_read("two_chains")[0]) == 0
+    tk = [ext.submit_batch(b) for b in batches[:3]]
+    assert int(ext.debug_read("two_chains")[0]) == 1 and tk == [0, 1, 2]
+    got = []
+    for k in range(6):
+        got.append(ext.collect_batch(tk.pop(0)))
+        if k + 3 < 6:
+            tk.append(ext.submit_batch(batches[k + 3]))
+    ext.close()
+    for k, (g, e) in enumerate(zip(got, ref)):
+        for i in range(B):
+            _same(g[i], e[i], ("pipe", k, i))
+            assert np.array_equal(g[i].heat, e[i].heat) and np.array_equal(g[i].heat_inv, e[i].heat_inv), ("pipe heat", k, i)
