@@ -99,7 +99,9 @@ typedef struct spfe_handle_s *spfe_handle;
  * common::model_path (:354-355) from globals.
  */
 typedef struct {
-  int height;               /* camera::height, multiple of 8 (:70) */
+  int height;               /* camera::height, multiple of 8 (:70); height x width: up to 262,143 cells of 8x8 and 2^31 bytes of
+                               first-layer activations (64 channels a pixel) per frame in f32 mode — 3840x2160 fits —, 65,535
+                               cells in bf16 mode */
   int width;                /* camera::width, multiple of 8 */
   int num_features;         /* tracking::num_features; up to num_features+1 keypoints (:211-213); 1 .. 10000 (the
                                covariance link stage keeps 16 bytes per keypoint in one workgroup's LDS; the
@@ -205,8 +207,9 @@ SPFE_API int spfe_extract_batch_device(spfe_handle h, const void *d_images, int 
  * outcome.  SPFE_F32_SPLIT=0 / SPFE_F32_SPLIT_PROBE=0 switch the split / the measurement off.) */
 /* Ticket of the most recent spfe_extract_batch_device call on this handle (0, 1, 2, ...), and the
  * ordering point for SPFE_FLAG_ASYNC_COV: makes `stream` (NULL = the handle's stream) wait until the
- * records of call `ticket` (one of the last 4 calls) are complete.  Without the flag the call itself
- * does this and spfe_wait_records is a no-op dependency. */
+ * records of call `ticket` (one of the last 4 calls) AND OF EVERY EARLIER CALL are complete (also where the handle runs two
+ * side chains on two sets of buffers — large bf16 frames, DESIGN.md 5.1: tickets stay one sequence).  Without the flag the
+ * call itself does this and spfe_wait_records is a no-op dependency. */
 SPFE_API long spfe_last_ticket(spfe_handle h);
 SPFE_API int spfe_wait_records(spfe_handle h, long ticket, void *stream);
 
