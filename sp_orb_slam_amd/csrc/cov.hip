@@ -43,6 +43,8 @@
 namespace spfe {
 
 #define COV_INF 0x7f7f7f7f
+// map entries: this batch's generation code in the upper half, the keypoint index in the lower (CovScratch::gen)
+__device__ __forceinline__ int cov_untag(int gen, int v) { return (v & (int)0xffff0000) == gen ? (v & 0xffff) : COV_INF; }
 #define COV_LCAP 128     // FIFO entries kept in LDS per wavefront
 #define COV_WIN 16       // the window covers dx,dy in [-16, 15] around the keypoint
 #define COV_WAVES 2      // wavefronts (= walks) per workgroup: 12.5 KB of LDS for lone walks (21 KB for replays, which stage `done` too)
@@ -68,6 +70,7 @@ struct Walk {
   float *gqv;
   int qcap, W, H, x0, y0, j;
   unsigned wmagic;       // floor((2^32 - 1) / W): row_of()
+  int gen = 0;           // CovScratch::gen (replay: the done map's entries are tagged)
 };
 
 // id / W for any id < 2^32 without the 40-instruction division (it sits on the walk's dependent chain): the
@@ -101,7 +104,7 @@ struct WinRegs {
 };
 template <bool REPLAY>
 __device__ __forceinline__ void load_window(const float *hinv, const int *done, int W, int H, int x0, int y0, int lane,
-                                            WinRegs &r) {
+                                            WinRegs &r, int gen) {
   const int wx0 = x0 - COV_WIN, wy0 = y0 - COV_WIN;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {  // all 16 (32) loads in flight together: one round trip
@@ -111,7 +114,7 @@ __device__ __forceinline__ void load_window(const float *hinv, const int *done, 
     const bool in = (unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H;
     const size_t g = in ? (size_t)y * W + x : 0;
     r.hv[k] = hinv[g];
-    if (REPLAY) r.dn[k] = done[g];
+    if (REPLAY) r.dn[k] = cov_untag(gen, done[g]);
     if (!in) { r.hv[k] = 0.0f; r.dn[k] = COV_INF; }
   }
 }
@@ -127,7 +130,7 @@ __device__ __forceinline__ void store_window(WaveMem *m, int lane, const WinRegs
 template <bool REPLAY>
 __device__ __forceinline__ void stage_window(const Walk &w, int lane) {
   WinRegs r;
-  load_window<REPLAY>(w.hinv, w.done, w.W, w.H, w.x0, w.y0, lane, r);
+  load_window<REPLAY>(w.hinv, w.done, w.W, w.H, w.x0, w.y0, lane, r, w.gen);
   store_window<REPLAY>(w.m, lane, r);
 }
 
@@ -194,7 +197,7 @@ __device__ int walk(const Walk &w, int lane) {
       if (inb && !inwin) {                                       // global lookups, search of the outside list
         v = slow_ld_f(w.hinv, nid);
         take = v > 0.0f && v < here;
-        if (take && REPLAY) take = !(slow_ld_i(w.done, nid) < w.j);
+        if (take && REPLAY) take = !(cov_untag(w.gen, slow_ld_i(w.done, nid)) < w.j);
         if (take) take = !ow_seen(m, now, nid);
       }
     }
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(64 * COV_WAVES) void cov_walk_kernel(FrameBufs f, R
   moments(w, n, lane, c.cov2 + 2 * j, c.cinv + 2 * j);  // final if the keypoint turns out clean
   const int k = n < COV_LCAP ? n : COV_LCAP;
   for (int i = lane; i < k; i += 64) { w.gq[i] = w.m->lq[i]; w.gqv[i] = w.m->lqv[i]; }  // publish the pop list
-  for (int i = lane; i < n; i += 64) atomicMin(&c.claim[fifo_id(w, i)], j);
+  for (int i = lane; i < n; i += 64) atomicMin(&c.claim[fifo_id(w, i)], cs.gen | j);
 }
 
 // ---- B: clean keypoints are final (their moments are already in the record);
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(64 * COV_WAVES) void cov_classify_kernel(FrameBufs 
   int bad = 0;
   for (int i0 = 1; i0 < n; i0 += 64) {   // claims were made by the previous kernel  (uniform trip count: ballots inside)
     const int i = i0 + lane;
-    const int a = i < n ? c.claim[q[i]] : COV_INF;
+    const int a = i < n ? cov_untag(cs.gen, c.claim[q[i]]) : COV_INF;
     bad |= a < j;
     // the link kernel's input, while the claim is in a register: (lower claimant, this keypoint).  One entry per pixel
     // (duplicates are harmless for a union); a frame with more edges than the list holds makes the link kernel walk the pop
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(64 * COV_WAVES) void cov_classify_kernel(FrameBufs 
     }
   }
   if (__ballot(bad) == 0) {
-    for (int i = lane; i < n; i += 64) atomicMin(&c.done[q[i]], j);
+    for (int i = lane; i < n; i += 64) atomicMin(&c.done[q[i]], cs.gen | j);
   } else if (lane == 0) {
     c.dirty[atomicAdd(c.ndirty, 1)] = j;
   }
@@ -490,7 +493,7 @@ __global__ __launch_bounds__(LINK_THREADS) void cov_link_kernel(FrameBufs f, Rec
     pop_list(c, cs, j, q, qv, cap);
     const int n = c.npop[j];
     for (int i = 1 + gl; i < n; i += GL) {
-      int a = c.claim[q[i]];
+      int a = cov_untag(cs.gen, c.claim[q[i]]);
       int bb = j;
       if (a >= j) continue;
       while (true) {  // hook the larger root under the smaller one
@@ -621,7 +624,7 @@ __global__ __launch_bounds__(64 * WV) void cov_replay_kernel(FrameBufs f, Record
   int jn = c.nxt[j];
   float nfx = c.nxy[2 * j], nfy = c.nxy[2 * j + 1];   // (garbage when jn < 0: never used)
   WinRegs win;
-  load_window<true>(c.hinv, c.done, W, H, (int)fx, (int)fy, lane, win);
+  load_window<true>(c.hinv, c.done, W, H, (int)fx, (int)fy, lane, win, cs.gen);
   int n_prev = 0, j_prev = -1;
   const unsigned wmagic = w_magic(W);
 #ifdef SPFE_REPLAY_PROBE   // phase cycles of the long chains (printf from chains of >= 8 members; tools/microbench/README.md)
@@ -648,13 +651,13 @@ __global__ __launch_bounds__(64 * WV) void cov_replay_kernel(FrameBufs f, Record
     }
     int *q; float *qv; int cap;
     pop_list(c, cs, j, q, qv, cap);
-    Walk w{m, c.hinv, c.done, q, qv, cap, W, H, x0, y0, j, wmagic};
+    Walk w{m, c.hinv, c.done, q, qv, cap, W, H, x0, y0, j, wmagic, cs.gen};
     // the next member's window and the member after it (index + position): all addresses are known, so the
     // requests go out now and their round trips pass under this member's walk
     int jnn = -1;
     float nnfx = 0.0f, nnfy = 0.0f;
     if (jn >= 0) {
-      load_window<true>(c.hinv, c.done, W, H, (int)nfx, (int)nfy, lane, win);
+      load_window<true>(c.hinv, c.done, W, H, (int)nfx, (int)nfy, lane, win, cs.gen);
       jnn = c.nxt[jn];
       nnfx = c.nxy[2 * jn];
       nnfy = c.nxy[2 * jn + 1];
@@ -668,7 +671,7 @@ __global__ __launch_bounds__(64 * WV) void cov_replay_kernel(FrameBufs f, Record
     RP(tp_mom);
     // stamp before the next member starts: this wavefront is the only writer and
     // the only reader of these pixels during the kernel
-    for (int i = lane; i < n; i += 64) c.done[fifo_id(w, i)] = j;  // popped => its stamp was >= j
+    for (int i = lane; i < n; i += 64) c.done[fifo_id(w, i)] = cs.gen | j;  // popped => its stamp was >= j
     __threadfence_block();  // same wavefront, same CU: L1 is coherent for it
     RP(tp_stamp);
 #ifdef SPFE_REPLAY_PROBE
@@ -772,6 +775,10 @@ __global__ __launch_bounds__(256) void cov_fallback_kernel(FrameBufs f, RecordLa
       }
       if (ok && lane == 0) atomicAnd(&c.hdr[2], ~1);
     }
+    __syncthreads();
+    // the claim map served as the visited mask (0 / 1): back to "nobody" — entries below every generation's would win all of
+    // the next batches' atomicMin
+    for (int i = tid; i < H * W; i += 256) c.claim[i] = COV_RESET;
     __syncthreads();
   }
 }

@@ -188,6 +188,9 @@ struct spfe_handle_s {
   int *d_sel_list32 = nullptr;
   uint8_t *d_records = nullptr;
   spfe::CovScratch cov{};
+  int cov_gen_code = 0;        // generation code of the last chain (CovScratch::gen = code << 16); 0: none yet
+  int cov_gen_start = 32766;   // SPFE_COV_CAPS field 6 (tests reach the wrap)
+  int cov_frames_clean = 0;    // leading frames whose claim / done maps hold tagged (or reset) entries
   ConvLayer layers[10];
   spfe::RecordLayout rl{};
   // host side

@@ -155,7 +155,14 @@ struct CovScratch {
   int *fb_q;
   float *fb_v;
   int fb_cap;
+  // claim / done entries carry the batch's GENERATION in their upper 16 bits (gen = code << 16, the code counts DOWN from
+  // 32,766 per chain): an entry of an earlier batch reads as "nobody" and loses every atomicMin against this batch's, so the
+  // maps are not cleared per batch (2 x 4 H W bytes per frame: half of what the heat normalisation moved) — only before a
+  // frame's first use and when the code wraps (reset_maps; COV_RESET, code 32,767, is never a batch's)
+  int gen;
+  int reset_maps;
 };
+#define COV_RESET 0x7fffffff
 size_t cov_link_lds(int kmax);
 // with_desc: the descriptor sampling (launch_desc) as extra wavefronts of the replay launch, behind `before_replay` if given
 // replay_waves: components per replay workgroup, 2 (default) or 8 (bf16 pipelined calls: see cov.hip)

@@ -259,6 +259,7 @@ static void read_switches(spfe_handle h) {
   h->cov.ovf_slots = std::max(0, env_field("SPFE_COV_CAPS", 1, 16));
   h->cov.ovf_cap = std::max(h->cov.qcap, env_field("SPFE_COV_CAPS", 2, 16384));
   h->cov.fb_cap = std::max(1024, env_field("SPFE_COV_CAPS", 3, 1 << 22));
+  h->cov_gen_start = std::min(32766, std::max(2, env_field("SPFE_COV_CAPS", 5, 32766)));   // first generation code of the claim / done maps (counts down; a small one reaches the wrap)
   h->cov_ecap_env = env_field("SPFE_COV_CAPS", 4, -1);       // -1: 32 x kmax; 0: no edge list (the link kernel walks the pop lists)
 }
 

@@ -533,6 +533,24 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
   const int H = h->H, W = h->W;
   spfe::FrameBufs f = frame_bufs(h, d_records, sparse);
   h->sparse_last = sparse;
+  {   // this chain's generation of the claim / done maps (cov.hip): one code per chain, counting down; a full reset of the maps
+      // only before a frame's first use and when the codes are used up
+    h->cov_gen_code = h->cov_gen_code > 1 ? h->cov_gen_code - 1 : 0;
+    h->cov.reset_maps = 0;
+    if (h->cov_gen_code == 0 || n > h->cov_frames_clean) {
+      // (after a wrap only the frames reset NOW are clean: a frame this call does not touch keeps entries of the old cycle,
+      // whose codes come round again — it is reset before its next use, like a frame never used)
+      if (h->cov_gen_code == 0) { h->cov_gen_code = h->cov_gen_start; h->cov_frames_clean = 0; }
+      h->cov.reset_maps = 1;
+      h->cov_frames_clean = std::max(h->cov_frames_clean, n);
+    }
+    h->cov.gen = h->cov_gen_code << 16;
+    // a captured call is replayed with the arguments of the capture — the same generation every time: it clears its maps
+    // itself, as every call did before round 5 (a later direct call's code is lower than the captured one: the replays' entries
+    // read as "nobody" there)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) h->cov.reset_maps = 1;
+  }
   const int par = (int)(h->ticket & 1);
   if (h->timing && !h->ev) return fail(SPFE_EINVAL, "internal: no event set");
   const int slot = (int)(h->ticket % spfe_handle_s::NTICKET);

@@ -120,14 +120,14 @@ __device__ __forceinline__ void heat_norm_body(const FrameBufs &f, int H, int W,
   float4 *hi4 = reinterpret_cast<float4 *>(f.heat_inv + (size_t)b * H * W);
   float4 *h4 = f.heat ? reinterpret_cast<float4 *>(f.heat + (size_t)b * H * W) : nullptr;
   int4 *cl4 = reinterpret_cast<int4 *>(cs.claim + (size_t)b * H * W), *dn4 = reinterpret_cast<int4 *>(cs.done + (size_t)b * H * W);
-  const int4 none = {0x7f7f7f7f, 0x7f7f7f7f, 0x7f7f7f7f, 0x7f7f7f7f};
+  const int4 none = {COV_RESET, COV_RESET, COV_RESET, COV_RESET};
+  const bool reset_maps = cs.reset_maps != 0;   // (else the entries' generation tags make earlier batches' read as "nobody": cov.hip)
   for (size_t i = (size_t)blk * 256 + threadIdx.x; i < n4; i += (size_t)nblk * 256) {
     const float4 L = L4[i];
     float4 o;
     o.x = L.x * a_i + b_i; o.y = L.y * a_i + b_i; o.z = L.z * a_i + b_i; o.w = L.w * a_i + b_i;
     hi4[i] = o;
-    cl4[i] = none;
-    dn4[i] = none;
+    if (reset_maps) { cl4[i] = none; dn4[i] = none; }
     if (h4) {
       o.x = L.x * a_h + b_h; o.y = L.y * a_h + b_h; o.z = L.z * a_h + b_h; o.w = L.w * a_h + b_h;
       h4[i] = o;

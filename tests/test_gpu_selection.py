@@ -450,3 +450,29 @@ def test_replay_workers_are_listed_longest_chain_first():
     ref = oracle.extract(blob, img, nf)
     assert np.array_equal(ext.last.cov2.view(np.uint32), ref["cov2"].view(np.uint32))
     ext.close()
+
+
+def test_covariance_maps_keep_their_entries_across_batches(monkeypatch):
+    """The claim / done maps are not cleared per batch: an entry carries its batch's generation code (counting down from
+    32,766) and an older batch's reads as "nobody" (cov.hip).  Forced here to start at code 3 (SPFE_COV_CAPS field 6): the codes
+    run out every third call, frames come and go between calls (a frame that sat out a wrap must be reset before its next use:
+    its old entries' codes come round again), and a frame is redone by the last resort in between (it uses the claim map as
+    its visited mask and must hand it back clean).  Every call's records equal a default handle's."""
+    H, W, nf, B = 240, 376, 300, 3
+    blob = _blob()
+    from sp_orb_slam_amd import synth
+    imgs = [synth.make_image(520 + i, H, W) for i in range(7)]
+    plan = [[0, 1, 2], [3], [4], [5], [6, 0, 1], [2, 3], [4, 5, 6], [0], [1, 2, 3], [4, 5, 6]]
+    ref_ext = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=False)
+    ref = [ref_ext.extract_batch([imgs[i] for i in p]) for p in plan]
+    ref_ext.close()
+    for caps in (",,,,,3", "24,0,,,,2"):      # (second: no overflow slots -> flagged frames go through cov_fallback_kernel; codes 2, 1, wrap)
+        monkeypatch.setenv("SPFE_COV_CAPS", caps)
+        ext = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=False)
+        for k, p in enumerate(plan):
+            got = ext.extract_batch([imgs[i] for i in p])
+            for g, e in zip(got, ref[k]):
+                assert g.status == 0 and g.K == e.K and np.array_equal(g.kp_xy, e.kp_xy), (caps, k)
+                assert np.array_equal(_bits(g.cov2), _bits(e.cov2)) and np.array_equal(_bits(g.cov2_inv), _bits(e.cov2_inv)), (caps, k)
+                assert np.array_equal(_bits(g.response), _bits(e.response)), (caps, k)
+        ext.close()
