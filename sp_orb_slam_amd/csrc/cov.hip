@@ -64,14 +64,19 @@ static_assert(COV_WALK_LDS % 16 == 0, "the float4 reads of hv / lqv need 16-byte
 
 struct Walk {
   WaveMem *m;
-  const float *hinv;     // frame's heat_inv
+  const float *hinv;     // frame's heat_log: heat_inv(p) = hinv[p] * ha + hb, formed where it is read (hinv_at)
   const int *done;       // frame's done map (replay) or null
   int *gq;               // global pop list of this keypoint [qcap]
   float *gqv;
   int qcap, W, H, x0, y0, j;
   unsigned wmagic;       // floor((2^32 - 1) / W): row_of()
   int gen = 0;           // CovScratch::gen (replay: the done map's entries are tagged)
+  float ha = 1.0f, hb = 0.0f;   // to_heat's scale / shift of heat_inv for this frame (FrameBufs::heat_consts[2..3])
 };
+// heat_inv of a pixel from the log heat map: one float multiply, then one float add (sp_extractor.cpp:461-474 as the oracle
+// fixes it; -ffp-contract=off) — the bits mask_and_heat_norm_kernel writes when the map is an output (SPFE_FLAG_HEAT).  Without
+// the flag the map is never materialised: 2 x 4 H W bytes per frame less for the normalisation to move beside conv1b.
+__device__ __forceinline__ float hinv_of(float L, float ha, float hb) { const float t = L * ha; return t + hb; }
 
 // id / W for any id < 2^32 without the 40-instruction division (it sits on the walk's dependent chain): the
 // multiply-high with floor(2^32 / W) is the quotient or one less
@@ -104,7 +109,7 @@ struct WinRegs {
 };
 template <bool REPLAY>
 __device__ __forceinline__ void load_window(const float *hinv, const int *done, int W, int H, int x0, int y0, int lane,
-                                            WinRegs &r, int gen) {
+                                            WinRegs &r, int gen, float ha, float hb) {
   const int wx0 = x0 - COV_WIN, wy0 = y0 - COV_WIN;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {  // all 16 (32) loads in flight together: one round trip
@@ -113,7 +118,7 @@ __device__ __forceinline__ void load_window(const float *hinv, const int *done, 
     const int x = wx0 + dx, y = wy0 + dy;
     const bool in = (unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H;
     const size_t g = in ? (size_t)y * W + x : 0;
-    r.hv[k] = hinv[g];
+    r.hv[k] = hinv_of(hinv[g], ha, hb);
     if (REPLAY) r.dn[k] = cov_untag(gen, done[g]);
     if (!in) { r.hv[k] = 0.0f; r.dn[k] = COV_INF; }
   }
@@ -130,7 +135,7 @@ __device__ __forceinline__ void store_window(WaveMem *m, int lane, const WinRegs
 template <bool REPLAY>
 __device__ __forceinline__ void stage_window(const Walk &w, int lane) {
   WinRegs r;
-  load_window<REPLAY>(w.hinv, w.done, w.W, w.H, w.x0, w.y0, lane, r, w.gen);
+  load_window<REPLAY>(w.hinv, w.done, w.W, w.H, w.x0, w.y0, lane, r, w.gen, w.ha, w.hb);
   store_window<REPLAY>(w.m, lane, r);
 }
 
@@ -195,7 +200,7 @@ __device__ int walk(const Walk &w, int lane) {
     bool take = inb & inwin & (hv > 0.0f) & (hv < here) & !(REPLAY & (dstamp < w.j)) & !((row >> dx) & 1u);
     if (__builtin_expect(__ballot(inb & !inwin) != 0ull, 0)) {   // (uniform, rare) a neighbour outside the staged window:
       if (inb && !inwin) {                                       // global lookups, search of the outside list
-        v = slow_ld_f(w.hinv, nid);
+        v = hinv_of(slow_ld_f(w.hinv, nid), w.ha, w.hb);
         take = v > 0.0f && v < here;
         if (take && REPLAY) take = !(cov_untag(w.gen, slow_ld_i(w.done, nid)) < w.j);
         if (take) take = !ow_seen(m, now, nid);
@@ -310,7 +315,8 @@ struct CovFrame {
   const float *kp_xy;
   float *cov2, *cinv;
   int *hdr;
-  const float *hinv;
+  const float *hinv;   // the frame's heat_log (see Walk::hinv)
+  float ha, hb;
   int *claim, *done, *queues, *npop, *dirty, *ndirty, *nxt, *workers, *nworkers;
   float *qvals;
   int *ovf_slot, *novf, *ovf_q;   // overflow slots: pop lists of the walks that outgrew qcap
@@ -330,7 +336,9 @@ __device__ __forceinline__ CovFrame cov_frame(const FrameBufs &f, const RecordLa
   c.kp_xy = reinterpret_cast<const float *>(rec + rl.off_xy);
   c.cov2 = reinterpret_cast<float *>(rec + rl.off_cov);
   c.cinv = reinterpret_cast<float *>(rec + rl.off_cinv);
-  c.hinv = f.heat_inv + (size_t)b * H * W;
+  c.hinv = f.heat_log + (size_t)b * H * W;
+  c.ha = f.heat_consts[(size_t)b * 4 + 2];
+  c.hb = f.heat_consts[(size_t)b * 4 + 3];
   c.claim = cs.claim + (size_t)b * H * W;
   c.done = cs.done + (size_t)b * H * W;
   c.queues = cs.queue + (size_t)b * rl.kmax * cs.qcap;
@@ -371,7 +379,7 @@ __global__ __launch_bounds__(64 * COV_WAVES) void cov_walk_kernel(FrameBufs f, R
   const CovFrame c = cov_frame(f, rl, cs, b, H, W);
   if (j >= c.K) return;
   Walk w{reinterpret_cast<WaveMem *>(s_raw + wv * COV_WALK_LDS), c.hinv, nullptr, c.queues + (size_t)j * cs.qcap, c.qvals + (size_t)j * cs.qcap, cs.qcap, W, H,
-         (int)c.kp_xy[2 * j], (int)c.kp_xy[2 * j + 1], j, w_magic(W)};
+         (int)c.kp_xy[2 * j], (int)c.kp_xy[2 * j + 1], j, w_magic(W), 0, c.ha, c.hb};
   stage_window<false>(w, lane);
   int n = walk<false>(w, lane);
   if (n == -1) {
@@ -624,7 +632,7 @@ __global__ __launch_bounds__(64 * WV) void cov_replay_kernel(FrameBufs f, Record
   int jn = c.nxt[j];
   float nfx = c.nxy[2 * j], nfy = c.nxy[2 * j + 1];   // (garbage when jn < 0: never used)
   WinRegs win;
-  load_window<true>(c.hinv, c.done, W, H, (int)fx, (int)fy, lane, win, cs.gen);
+  load_window<true>(c.hinv, c.done, W, H, (int)fx, (int)fy, lane, win, cs.gen, c.ha, c.hb);
   int n_prev = 0, j_prev = -1;
   const unsigned wmagic = w_magic(W);
 #ifdef SPFE_REPLAY_PROBE   // phase cycles of the long chains (printf from chains of >= 8 members; tools/microbench/README.md)
@@ -651,13 +659,13 @@ __global__ __launch_bounds__(64 * WV) void cov_replay_kernel(FrameBufs f, Record
     }
     int *q; float *qv; int cap;
     pop_list(c, cs, j, q, qv, cap);
-    Walk w{m, c.hinv, c.done, q, qv, cap, W, H, x0, y0, j, wmagic, cs.gen};
+    Walk w{m, c.hinv, c.done, q, qv, cap, W, H, x0, y0, j, wmagic, cs.gen, c.ha, c.hb};
     // the next member's window and the member after it (index + position): all addresses are known, so the
     // requests go out now and their round trips pass under this member's walk
     int jnn = -1;
     float nnfx = 0.0f, nnfy = 0.0f;
     if (jn >= 0) {
-      load_window<true>(c.hinv, c.done, W, H, (int)nfx, (int)nfy, lane, win, cs.gen);
+      load_window<true>(c.hinv, c.done, W, H, (int)nfx, (int)nfy, lane, win, cs.gen, c.ha, c.hb);
       jnn = c.nxt[jn];
       nnfx = c.nxy[2 * jn];
       nnfy = c.nxy[2 * jn + 1];
@@ -702,7 +710,7 @@ __device__ int walk_fallback(const Walk &w, int *visited, int lane) {
   const int W = w.W, H = w.H;
   if (lane == 0) {
     const int id0 = w.y0 * W + w.x0;
-    const float v0 = w.hinv[id0];
+    const float v0 = hinv_of(w.hinv[id0], w.ha, w.hb);
     m->lq[0] = id0; m->lqv[0] = v0;
     w.gq[0] = id0; w.gqv[0] = v0;
   }
@@ -725,7 +733,7 @@ __device__ int walk_fallback(const Walk &w, int *visited, int lane) {
     float v = 0.0f;
     bool take = false;
     if (inb) {
-      v = w.hinv[nid];
+      v = hinv_of(w.hinv[nid], w.ha, w.hb);
       take = v > 0.0f && v < here && visited[nid] == 0;
     }
 #define COV_CHK(k) take &= !((gi > (k)) & (nid == __builtin_amdgcn_readlane(id, 4 * (k))))
@@ -767,7 +775,7 @@ __global__ __launch_bounds__(256) void cov_fallback_kernel(FrameBufs f, RecordLa
       bool ok = true;
       for (int j = 0; j < c.K && ok; ++j) {
         Walk w{&s_mem, c.hinv, nullptr, cs.fb_q, cs.fb_v, cs.fb_cap, W, H, (int)c.kp_xy[2 * j], (int)c.kp_xy[2 * j + 1], j,
-               w_magic(W)};
+               w_magic(W), 0, c.ha, c.hb};
         const int n = walk_fallback(w, c.claim, lane);
         if (n < 0) { ok = false; break; }
         moments(w, n, lane, c.cov2 + 2 * j, c.cinv + 2 * j);

@@ -95,7 +95,9 @@ __device__ __forceinline__ void desc_keypoint(const FrameBufs &f, const RecordLa
   }
   if (lane == 0) {
     float *resp = reinterpret_cast<float *>(rec + rl.off_resp);
-    resp[i] = f.heat_inv[(size_t)b * H * W + (size_t)(int)y * W + (int)x];  // :271
+    // :271 response = heat_inv(y, x): the log heat through to_heat's multiply + add (cov.hip hinv_of: the bits of the map)
+    const float t = f.heat_log[(size_t)b * H * W + (size_t)(int)y * W + (int)x] * f.heat_consts[(size_t)b * 4 + 2];
+    resp[i] = t + f.heat_consts[(size_t)b * 4 + 3];
   }
 }
 

@@ -362,7 +362,10 @@ long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size
     src = h->d_head + frame * C * 512; bytes = C * 512 * 4;
   }
   else if (nm == "heat_log") { src = h->d_heat_log[(h->ticket + 1) & 1] + frame * HW; bytes = HW * 4; }
-  else if (nm == "heat_inv") { src = h->d_heat_inv + frame * HW; bytes = HW * 4; }
+  else if (nm == "heat_inv") {
+    if (!(h->cfg.flags & SPFE_FLAG_HEAT)) return fail(SPFE_EINVAL, "'heat_inv' is materialised with SPFE_FLAG_HEAT only");
+    src = h->d_heat_inv + frame * HW; bytes = HW * 4;
+  }
   else if (nm == "heat" && h->d_heat) { src = h->d_heat + frame * HW; bytes = HW * 4; }
   else if (nm == "image") { src = h->d_img + frame * HW; bytes = HW; }
   else if (nm == "cell_score") { src = h->d_cell_score[(h->ticket + 1) & 1] + frame * C; bytes = C * 4; }

@@ -503,7 +503,8 @@ spfe::FrameBufs frame_bufs(spfe_handle h, uint8_t *d_records, bool sparse) {
   f.semi = h->d_semi; f.coarse = h->d_coarse;
   if (sparse) { f.db_list = h->d_db_list; f.db_total = h->d_db_total; }
   const int par = (int)(h->ticket & 1);
-  f.heat_log = h->d_heat_log[par]; f.heat = h->d_heat; f.heat_inv = h->d_heat_inv;
+  f.heat_log = h->d_heat_log[par]; f.heat = h->d_heat;
+  f.heat_inv = (h->cfg.flags & SPFE_FLAG_HEAT) ? h->d_heat_inv : nullptr;   // materialised as an output only: the covariance kernels read heat_log
   f.minmax = reinterpret_cast<uint32_t *>(h->d_minmax[par]);
   f.cell_score = h->d_cell_score[par]; f.cell_k = h->d_cell_k[par]; f.cell_mask = h->d_cell_mask; f.kp_cell = h->d_kp_cell;
   f.sel_slot = h->d_sel_slot; f.sel_list = h->d_sel_list;

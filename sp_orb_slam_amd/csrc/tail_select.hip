@@ -117,17 +117,21 @@ __device__ __forceinline__ void heat_norm_body(const FrameBufs &f, int H, int W,
   const float a_h = sc[0], b_h = sc[1], a_i = sc[2], b_i = sc[3];
   const size_t n4 = (size_t)H * W / 4;
   const float4 *L4 = reinterpret_cast<const float4 *>(f.heat_log + (size_t)b * H * W);
-  float4 *hi4 = reinterpret_cast<float4 *>(f.heat_inv + (size_t)b * H * W);
+  float4 *hi4 = f.heat_inv ? reinterpret_cast<float4 *>(f.heat_inv + (size_t)b * H * W) : nullptr;   // (an output only: SPFE_FLAG_HEAT)
+  if (!hi4 && !cs.reset_maps && !f.heat) return;   // nothing to write per pixel: the covariance kernels form heat_inv where they read it
   float4 *h4 = f.heat ? reinterpret_cast<float4 *>(f.heat + (size_t)b * H * W) : nullptr;
   int4 *cl4 = reinterpret_cast<int4 *>(cs.claim + (size_t)b * H * W), *dn4 = reinterpret_cast<int4 *>(cs.done + (size_t)b * H * W);
   const int4 none = {COV_RESET, COV_RESET, COV_RESET, COV_RESET};
   const bool reset_maps = cs.reset_maps != 0;   // (else the entries' generation tags make earlier batches' read as "nobody": cov.hip)
   for (size_t i = (size_t)blk * 256 + threadIdx.x; i < n4; i += (size_t)nblk * 256) {
+    if (reset_maps) { cl4[i] = none; dn4[i] = none; }
+    if (!hi4 && !h4) continue;
     const float4 L = L4[i];
     float4 o;
-    o.x = L.x * a_i + b_i; o.y = L.y * a_i + b_i; o.z = L.z * a_i + b_i; o.w = L.w * a_i + b_i;
-    hi4[i] = o;
-    if (reset_maps) { cl4[i] = none; dn4[i] = none; }
+    if (hi4) {
+      o.x = L.x * a_i + b_i; o.y = L.y * a_i + b_i; o.z = L.z * a_i + b_i; o.w = L.w * a_i + b_i;
+      hi4[i] = o;
+    }
     if (h4) {
       o.x = L.x * a_h + b_h; o.y = L.y * a_h + b_h; o.z = L.z * a_h + b_h; o.w = L.w * a_h + b_h;
       h4[i] = o;
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(256) void heat_norm_kernel(FrameBufs f, int H, int 
 }
 
 hipError_t launch_heat_norm(const FrameBufs &f, const CovScratch &cs, int kmax, int B, int H, int W, hipStream_t s) {
-  const int blocks = (int)(((size_t)H * W / 4 + 255) / 256);
+  const int blocks = !f.heat_inv && !f.heat && !cs.reset_maps ? 1 : (int)(((size_t)H * W / 4 + 255) / 256);
   hipLaunchKernelGGL(heat_norm_kernel, dim3(blocks < 128 ? blocks : 128, B), dim3(256), 0, s, f, H, W, tail_parts(H, W), cs, kmax);
   return hipGetLastError();
 }
@@ -866,7 +870,8 @@ hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H
       if (e != hipSuccess) return e;
     }
     if (with_heat_norm) {
-      const int nmask = ((H / 8) * (W / 8) + 255) / 256, hb = (int)(((size_t)H * W / 4 + 255) / 256);
+      const int nmask = ((H / 8) * (W / 8) + 255) / 256;
+      const int hb = !f.heat_inv && !f.heat && !with_heat_norm->reset_maps ? 1 : (int)(((size_t)H * W / 4 + 255) / 256);   // (one block when there is nothing to write per pixel: the scale / shift only)
       hipLaunchKernelGGL(mask_and_heat_norm_kernel, dim3(nmask + (hb < 128 ? hb : 128), B), dim3(256), 0, s, f, H, W, tail_parts(H, W),
                          *with_heat_norm, kmax_hn, nmask);
     } else {
@@ -887,7 +892,8 @@ hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H
     if (e != hipSuccess) return e;
   }
   if (with_heat_norm) {
-    const int nmask = ((H / 8) * (W / 8) + 255) / 256, hb = (int)(((size_t)H * W / 4 + 255) / 256);
+    const int nmask = ((H / 8) * (W / 8) + 255) / 256;
+      const int hb = !f.heat_inv && !f.heat && !with_heat_norm->reset_maps ? 1 : (int)(((size_t)H * W / 4 + 255) / 256);   // (one block when there is nothing to write per pixel: the scale / shift only)
     hipLaunchKernelGGL(mask_and_heat_norm_kernel, dim3(nmask + (hb < 128 ? hb : 128), B), dim3(256), 0, s, f, H, W, tail_parts(H, W),
                        *with_heat_norm, kmax_hn, nmask);
   } else {
