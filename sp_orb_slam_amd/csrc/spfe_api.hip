@@ -181,7 +181,8 @@ int spfe_extract_batch_device(spfe_handle h, const void *d_images, int n, void *
   hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
   uint8_t *rec = d_records ? reinterpret_cast<uint8_t *>(d_records) : h->d_records;
   if (h->twin) {   // two side chains in flight: even tickets on this handle, odd ones on its twin (own buffers, own side stream)
-    spfe_handle t = (h->g_ticket & 1) ? h->twin : h;
+    // (a handle whose twin was made by the pipelined host path but whose device calls are synchronous stays on its own buffers)
+    spfe_handle t = (h->cfg.flags & SPFE_FLAG_ASYNC_COV) && (h->g_ticket & 1) ? h->twin : h;
     const int rc = enqueue(t, reinterpret_cast<const uint8_t *>(d_images), n, rec, s);
     if (rc) return rc;
     h->tmap[h->g_ticket % 8] = {t, t->ticket - 1};
@@ -286,10 +287,9 @@ int spfe_wait_records(spfe_handle h, long ticket, void *stream) {
   hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
   const spfe_handle_s::TicketRef r = ticket_ref(h, ticket);   // (a handle with a twin: whichever of the two ran that call)
   HIP_TRY(hipStreamWaitEvent(s, r.who->ev_cov[r.local % spfe_handle_s::NTICKET], 0));
-  if (h->twin && ticket > 0) {   // one side stream used to make "ticket t is done" mean "and every earlier one": keep that — the call before ran on the other of the pair
-    const spfe_handle_s::TicketRef p = ticket_ref(h, ticket - 1);
-    if (p.who && ticket - 1 + spfe_handle_s::NTICKET > api_tickets(h) - 1)
-      HIP_TRY(hipStreamWaitEvent(s, p.who->ev_cov[p.local % spfe_handle_s::NTICKET], 0));
+  if (h->twin && ticket > 0) {   // one side stream used to make "ticket t is done" mean "and every earlier one": keep that — the
+    const spfe_handle_s::TicketRef p = ticket_ref(h, ticket - 1);   // call before ran on the other of the pair (each side stream is serial)
+    if (p.who) HIP_TRY(hipStreamWaitEvent(s, p.who->ev_cov[p.local % spfe_handle_s::NTICKET], 0));
   }
   return SPFE_OK;
 }
@@ -416,21 +416,21 @@ int spfe_stage_reset(spfe_handle h) {
 
 // Average per-stage GPU time (ms) over the calls since spfe_stage_reset (at most
 // the last EVSETS calls).  Needs SPFE_STAGE_TIMING=1 at spfe_create.
+static int stage_times_one(spfe_handle h, float *ms, int cap);
 int spfe_stage_times(spfe_handle h, float *ms, int cap) {
   if (!h || !ms) return fail(SPFE_EINVAL, "null argument");
-  if (h->twin && h->timing && cap > 0) {   // the calls since the reset ran on both of the pair: the call-weighted mean of the two
-    float a[NSTAGE] = {}, b[NSTAGE] = {};
-    spfe_handle tw = h->twin;
-    h->twin = nullptr;
-    const long ca = h->calls - h->calls_at_reset, cb = tw->calls - tw->calls_at_reset;
-    const int na = spfe_stage_times(h, a, NSTAGE), nb = spfe_stage_times(tw, b, NSTAGE);
-    h->twin = tw;
-    if (na < 0 || nb < 0) return na < 0 ? na : nb;
-    if (na == 0 && nb == 0) return 0;
-    const int nst = cap < NSTAGE ? cap : NSTAGE;
-    for (int i = 0; i < nst; ++i) ms[i] = (float)((a[i] * (na ? ca : 0) + b[i] * (nb ? cb : 0)) / (double)((na ? ca : 0) + (nb ? cb : 0)));
-    return nst;
-  }
+  if (!h->twin) return stage_times_one(h, ms, cap);
+  // the calls since the reset ran on both of the pair: the call-weighted mean of the two
+  float a[NSTAGE] = {}, b[NSTAGE] = {};
+  const int na = stage_times_one(h, a, NSTAGE), nb = stage_times_one(h->twin, b, NSTAGE);
+  if (na < 0 || nb < 0) return na < 0 ? na : nb;
+  const double ca = na ? (double)(h->calls - h->calls_at_reset) : 0.0, cb = nb ? (double)(h->twin->calls - h->twin->calls_at_reset) : 0.0;
+  if (ca + cb == 0.0) return 0;
+  const int nst = cap < NSTAGE ? cap : NSTAGE;
+  for (int i = 0; i < nst; ++i) ms[i] = (float)((a[i] * ca + b[i] * cb) / (ca + cb));
+  return nst;
+}
+static int stage_times_one(spfe_handle h, float *ms, int cap) {
   if (!h->timing || h->calls == h->calls_at_reset) return 0;
   if (hipSetDevice(h->cfg.device) != hipSuccess) return fail(SPFE_EHIP, "hipSetDevice failed");
   long first = h->calls_at_reset;
