@@ -513,13 +513,11 @@ int spfe_submit_batch(spfe_handle h, const uint8_t *const *images, int stride, i
   const bool want = (h->cfg.flags & SPFE_FLAG_HEAT) != 0;
   // two side chains in flight: even submissions on this handle, odd ones on its twin (own buffers, own side stream)
   spfe_handle hc = h->twin && (h->g_ticket & 1) ? h->twin : h;
-  const long back = h->twin ? 2 : 1;   // the previous batch that went through hc's buffers
-  if (want && h->pipe_submitted >= back) {
+  if (want)
     // the heat maps are single buffers (per handle of the pair): this batch's heat_norm (side stream) must not overwrite them
-    // before that batch's copy has left
-    const spfe_handle_s::PipeSlot &pp = h->pipe[(h->pipe_submitted - back) % spfe_handle_s::NPIPE];
-    if (pp.ticket >= 0) HIP_TRY(hipStreamWaitEvent(hc->side, pp.ev_done, 0));
-  }
+    // before the copy of the batch that went through the same buffers has left
+    for (const auto &pp : h->pipe)
+      if (&pp != &ps && pp.ticket >= 0 && pp.who == hc) HIP_TRY(hipStreamWaitEvent(hc->side, pp.ev_done, 0));
   hc->pipe_mode = true;
   rc = enqueue(hc, ps.d_img, n, ps.d_rec, s);
   hc->pipe_mode = false;
@@ -561,6 +559,7 @@ int spfe_submit_batch(spfe_handle h, const uint8_t *const *images, int stride, i
   HIP_TRY(hipEventRecord(ps.ev_done, sc));
   ps.ticket = t;
   ps.n = n;
+  ps.who = hc;
   h->pipe_submitted++;
   *ticket = t;
   return SPFE_OK;

@@ -124,6 +124,8 @@ struct spfe_handle_s {
   spfe_handle twin = nullptr;
   bool is_twin = false;
   int two_chains_env = -1;
+  long last_seq = 0;                         // value of the process-wide call counter at this handle's last enqueue_post (debug reads
+                                             // of a pair come from the one that ran last)
   long g_ticket = 0;                         // tickets handed out by this handle when it has a twin
   struct TicketRef { spfe_handle who; long local; } tmap[8] = {};
   int replay_waves = 0;     // SPFE_REPLAY_WAVES: 0 = by workload
@@ -239,6 +241,7 @@ struct spfe_handle_s {
     hipEvent_t ev_h2d = nullptr, ev_done = nullptr;
     long ticket = -1;   // records ticket of the batch in this slot, -1 = free
     int n = 0;
+    spfe_handle who = nullptr;   // which of a twin pair ran the batch (its heat maps, its side stream)
   } pipe[NPIPE];
   bool pipe_ready = false, pipe_mode = false;
   hipStream_t s_h2d = nullptr, s_d2h = nullptr;
@@ -309,7 +312,7 @@ inline spfe_handle_s::TicketRef ticket_ref(spfe_handle h, long t) {
   return h->tmap[t % 8];
 }
 inline spfe_handle last_caller(spfe_handle h) {   // the one of the pair whose buffers hold the last call's intermediates
-  return h->twin && h->g_ticket > 0 && h->tmap[(h->g_ticket - 1) % 8].who ? h->tmap[(h->g_ticket - 1) % 8].who : h;
+  return h->twin && h->twin->last_seq > h->last_seq ? h->twin : h;
 }
 
 hipError_t wait_if_pending(hipStream_t s, hipEvent_t ev);

@@ -534,6 +534,7 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
   const int H = h->H, W = h->W;
   spfe::FrameBufs f = frame_bufs(h, d_records, sparse);
   h->sparse_last = sparse;
+  { static long g_call_seq = 0; h->last_seq = ++g_call_seq; }   // (handles are driven by one thread each; a pair by the same one)
   {   // this chain's generation of the claim / done maps (cov.hip): one code per chain, counting down; a full reset of the maps
       // only before a frame's first use and when the codes are used up
     h->cov_gen_code = h->cov_gen_code > 1 ? h->cov_gen_code - 1 : 0;

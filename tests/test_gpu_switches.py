@@ -183,6 +183,14 @@ def test_two_side_chains_in_flight_on_large_bf16_frames(monkeypatch):
         sref.extract_batch_device(sets[(steps - 1) % 3].data_ptr(), B, one.data_ptr())
         torch.cuda.synchronize()
         assert np.array_equal(semi.view(np.uint32), sref.debug_read("semi", 0).view(np.uint32))
+        # a synchronous host call in between runs on the handle itself: its intermediates are what a debug read returns then,
+        # whichever of the pair ran the last pipelined call
+        himgs = [synth.make_image(990 + i, H, W) for i in range(B)]
+        got = ext.extract_batch(himgs)
+        exp = sref.extract_batch(himgs)
+        for i in range(B):
+            _same(got[i], exp[i], ("two chains, host call", env, i))
+        assert np.array_equal(ext.debug_read("semi", 1).view(np.uint32), sref.debug_read("semi", 1).view(np.uint32))
         sref.close()
         with pytest.raises(Exception):
             ext.wait_records(tickets[0], stream.cuda_stream)      # out of the window of the last four calls
