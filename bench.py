@@ -909,6 +909,8 @@ def main():
         if args.precision == "f32" and not args.no_uhd_leg:
             out["f32_3840x2160_b1"] = device_leg(ctx, "f32", 2160, 3840, 1, 500, 30, 3,
                                                  "3840x2160, one frame per step, f32 MFMA, 1 GPU (select_huge_kernel: 129,600 cells)")
+            out["bf16_3840x2160_b1"] = device_leg(ctx, "bf16", 2160, 3840, 1, 500, 60, 5,
+                                                  "3840x2160, one frame per step, bf16 MFMA convolutions and heads, 1 GPU (select_huge_kernel, two side chains)")
         # The headline workload with the SPARSE synthetic detector (~1-2 k candidates per frame in isolated peaks — what a trained
         # SuperPoint produces — instead of a candidate in every cell): the headline's cells_computed_frac, selection and
         # covariance costs are properties of the dense detector; this is the other end

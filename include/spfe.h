@@ -100,8 +100,8 @@ typedef struct spfe_handle_s *spfe_handle;
  */
 typedef struct {
   int height;               /* camera::height, multiple of 8 (:70); height x width: up to 262,143 cells of 8x8 and 2^31 bytes of
-                               first-layer activations (64 channels a pixel) per frame in f32 mode — 3840x2160 fits —, 65,535
-                               cells in bf16 mode */
+                               first-layer activations (64 channels a pixel, 4 / 2 bytes each in f32 / bf16 mode) per frame:
+                               3840x2160 fits in both */
   int width;                /* camera::width, multiple of 8 */
   int num_features;         /* tracking::num_features; up to num_features+1 keypoints (:211-213); 1 .. 10000 (the
                                covariance link stage keeps 16 bytes per keypoint in one workgroup's LDS; the

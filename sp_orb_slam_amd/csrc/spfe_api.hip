@@ -90,15 +90,15 @@ int spfe_create(const spfe_config *cfg, spfe_handle *out) {
     // Frame size limits.  The convolutions address a frame's activations with 32-bit byte offsets below 2^31 (0x80000000 and
     // above mean "outside the image": conv_f32.hip SPFE_OOB; the bf16 kernels alike), and the largest activation is conv1a's
     // output, 64 channels a pixel: H W 256 bytes in f32 mode (3840x2160 = 2,123,366,400 fits; 4096x2304 does not), H W 128 in
-    // bf16 mode.  The selection handles 65,535 cells as select_kernel and 262,143 as select_huge_kernel (f32 mode: that form
-    // is tested against the oracle at 3840x2160; the bf16 path stays at 65,535 cells, where its parity reports end).
+    // bf16 mode.  The selection handles 65,535 cells as select_kernel and 262,143 as select_huge_kernel (tested against the
+    // oracle at 3840x2160 in both precisions; bf16: logits within tolerance, everything behind them exact given them).
     const size_t cells = (size_t)(cfg->height / 8) * (cfg->width / 8);
     const size_t act0_bytes = (size_t)cfg->height * cfg->width * 64 * (cfg->precision == SPFE_PRECISION_BF16 ? 2 : 4);
-    const size_t max_cells = cfg->precision == SPFE_PRECISION_BF16 ? spfe::select_max_cells() : spfe::select_huge_max_cells();
+    const size_t max_cells = spfe::select_huge_max_cells();
     if (cells > max_cells || act0_bytes >= 0x80000000ull ||
         (cells <= spfe::select_max_cells() ? spfe::select_lds_bytes(cfg->height, cfg->width) : spfe::select_huge_lds_bytes(cfg->height, cfg->width)) > 160 * 1024)
       return fail(SPFE_EINVAL, "image %dx%d is too large: %zu cells (limit %zu in this precision) / %zu bytes of first-layer "
-                               "activations per frame (limit 2^31: 32-bit buffer offsets); 3840x2160 f32 and 2560x1440 bf16 fit",
+                               "activations per frame (limit 2^31: 32-bit buffer offsets); 3840x2160 fits",
                   cfg->width, cfg->height, cells, max_cells, act0_bytes);
   }
   int ndev = 0;

@@ -327,3 +327,24 @@ def test_pipelined_steps_on_changing_frames_equal_synchronous_calls(prec, H, W, 
                 assert np.array_equal(getattr(a, name), getattr(b, name)), (k, i, name)
     ext.close()
     ref_ext.close()
+
+
+@pytest.mark.gpu
+def test_bf16_2160p_logits_and_everything_behind_them():
+    """3840x2160 in bf16 mode (129,600 cells: select_huge_kernel; the bf16 kernels' 32-bit offsets are half the f32 ones'):
+    logits within the bf16 tolerances of the oracle's bf16 emulation, everything behind the logits bit-exact given them."""
+    import time
+    H, W, nf = 2160, 3840, 1000
+    t0 = time.time()
+    blob, img, fr, semi, coarse = _run(H, W, nf, 79, "sparse")
+    rsemi, rcoarse = oracle.network_bf16(blob, img)
+    print("4K bf16: GPU + oracle emulation %.1f s" % (time.time() - t0))
+    d = np.abs(semi - rsemi)
+    assert d.max() <= LOGIT_ATOL * max(1.0, np.abs(rsemi).max()) and d.mean() <= LOGIT_MEAN * max(1.0, np.abs(rsemi).mean())
+    dc = np.abs(coarse - rcoarse)
+    assert dc.max() <= LOGIT_ATOL * max(1.0, np.abs(rcoarse).max()) and dc.mean() <= LOGIT_MEAN * max(1.0, np.abs(rcoarse).mean())
+    ref = oracle.postprocess(semi, coarse, H, W, nf)
+    assert fr.K == ref["K"] and np.array_equal(fr.kp_xy, ref["kp_xy"]) and np.array_equal(fr.occ_grid, ref["occ_grid"])
+    assert np.array_equal(fr.descriptors.view(np.uint32), ref["desc"].view(np.uint32))
+    assert np.array_equal(fr.cov2_inv.view(np.uint32), ref["cov2_inv"].view(np.uint32))
+    assert np.array_equal(fr.heat.view(np.uint32), ref["heat"].view(np.uint32))

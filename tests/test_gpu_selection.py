@@ -322,12 +322,12 @@ def test_full_extraction_1080p_matches_oracle():
 
 
 def test_frame_size_limits():
-    """f32: up to 262,143 cells and 2^31 bytes of first-layer activations per frame (3840x2160 fits, 4096x2304 = 2.4 GB does
-    not); bf16: select_kernel's 65,535 cells (2560x1440 fits, 3840x2160 does not).  Refused at spfe_create with a message."""
+    """Up to 262,143 cells and 2^31 bytes of first-layer activations per frame: f32 3840x2160 fits, 4096x2304 (2.4 GB) does not;
+    bf16 (half the bytes) ends at the cell limit (4096x4096 = 262,144 cells).  Refused at spfe_create with a message."""
     with pytest.raises(Exception, match="too large"):
         SPExtractor(1000, 2304, 4096, _blob())
     with pytest.raises(Exception, match="too large"):
-        SPExtractor(1000, 2160, 3840, _blob(), precision="bf16")
+        SPExtractor(1000, 4096, 4096, _blob(), precision="bf16")
 
 
 @pytest.mark.parametrize("H,W,nf,scale,seed", [(2160, 3840, 1000, 1.5, 0), (2160, 3840, 10000, 0.2, 1), (2160, 3840, 3000, 0.0, 2)])
