@@ -34,7 +34,18 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_FRAME = {(480, 752): 61221703680, (480, 640): 52103577600, (720, 1280): 156310732800}
+FLOP_PER_FRAME = {(480, 752): 61221703680, (480, 640): 52103577600, (720, 1280): 156310732800}   # SURVEY.md 8(d), exact
+
+
+def flop_per_frame(H, W):
+    """2 x sum over the twelve layers of (H / s)(W / s) Cin Cout k^2 (s = 1, 1, 2, 2, 4, 4, 8 ...); the three
+    sizes SURVEY quotes are kept as the table above and checked against this formula."""
+    layers = [(1, 1, 64, 3), (1, 64, 64, 3), (2, 64, 64, 3), (2, 64, 64, 3), (4, 64, 128, 3), (4, 128, 128, 3),
+              (8, 128, 128, 3), (8, 128, 128, 3), (8, 128, 256, 3), (8, 256, 65, 1), (8, 128, 256, 3), (8, 256, 256, 1)]
+    return 2 * sum((H // s) * (W // s) * cin * cout * k * k for s, cin, cout, k in layers)
+
+
+assert all(flop_per_frame(h, w) == v for (h, w), v in FLOP_PER_FRAME.items())
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 
@@ -155,9 +166,7 @@ def path_tflops(ext, fps, H, W, B, precision=None):
     cell) runs on the cells the emitted keypoints' bilinear taps read only (libspfe's gathered head, on by default in f32
     mode and for bf16 frames of >= 10,000 cells): the rows it skips are not counted.  `dense_graph` is the reference's dense
     graph over the same time, for comparison with earlier rounds."""
-    if (H, W) not in FLOP_PER_FRAME:
-        return {"whole_path_tflops": None}
-    nominal = FLOP_PER_FRAME[(H, W)]
+    nominal = FLOP_PER_FRAME.get((H, W)) or flop_per_frame(H, W)
     C = (H // 8) * (W // 8)
     try:
         da = bool(ext.debug_read("da_gathered")[0])                  # (read first: reading db_total does not change it)
