@@ -388,7 +388,7 @@ def host_path_leg(ctx, precision, H, W, B, frames, fps_device, steps):
     return out
 
 
-def dropin_leg(H, W, nf, blob, frame):
+def dropin_leg(H, W, nf, blob, frame, lazy=False):
     """The drop-in call AS THE BACK-END MAKES IT (VERDICT r3 item 3): the compiled orbslam::SPExtractor : BaseExtractor with heat
     maps on (its default), through the base pointer + dynamic_cast, with the copies Frame::ExtractORB makes (frame.cpp:296-311:
     getCov2Inv(), dense_dust_.clone(), heat_.clone(), occ_grid_.copyTo()) — host frame in, cv::KeyPoint / cv::Mat out.  A C++
@@ -404,7 +404,8 @@ def dropin_leg(H, W, nf, blob, frame):
         weights.save(wpath, blob)
         frame.tofile(ipath)
         try:
-            r = subprocess.run([exe, wpath, ipath, str(H), str(W), str(nf), "300", "30"], capture_output=True, text=True, timeout=120)
+            r = subprocess.run([exe, wpath, ipath, str(H), str(W), str(nf), "300", "30"] + (["lazy"] if lazy else []),
+                               capture_output=True, text=True, timeout=120)
         except Exception as e:
             return {"error": str(e)}
     if r.returncode != 0:
@@ -412,11 +413,12 @@ def dropin_leg(H, W, nf, blob, frame):
     d = json.loads(r.stdout.strip().splitlines()[-1])
     d["what"] = ("orbslam::SPExtractor::operator() through BaseExtractor* with heat maps on + Frame::ExtractORB's copies "
                  "(frame.cpp:296-311), host frame in -> cv::KeyPoint / cv::Mat / Eigen out, %dx%d f32, PCIe inclusive "
-                 "(record + 2 heat maps D2H)" % (W, H))
+                 "(record + %s D2H)" % (W, H, "heat_ only: the opt-in lazy form leaves heat_inv_ on the device until heatInv()" if lazy
+                                        else "both heat maps: the reference's post-call state, the drop-in's default"))
     return d
 
 
-def frontend_chain_leg(ctx, H, W, nframes):
+def frontend_chain_leg(ctx, H, W, nframes, precision="f32"):
     """The tracker's per-frame front end on records that never leave HBM (the C5 substitute): per frame
     spfe_stage_batch_device (raw BGR -> gray) -> spfe_extract_batch_device -> spfe_track_dust_record_device
     (PoseOptimizationDust + patch-wise association at the alignment's projections, tracker_dust.cpp:92-172); only the pose
@@ -428,7 +430,7 @@ def frontend_chain_leg(ctx, H, W, nframes):
     torch, SPExtractor, nf = ctx["torch"], ctx["SPExtractor"], ctx["nf"]
     blob = weights.synthetic(7, "trackable")
     world = ts.texture(21, *ts.world_size(H, W))
-    ext = SPExtractor(nf, H, W, blob, max_batch=1, device=ctx["local"], with_heat=False)
+    ext = SPExtractor(nf, H, W, blob, max_batch=1, device=ctx["local"], with_heat=False, precision=precision)
     ext.set_staging(H, W, 3, False)
     rb = ext.record_bytes()
     stream = torch.cuda.Stream()
@@ -461,6 +463,7 @@ def frontend_chain_leg(ctx, H, W, nframes):
     h_out = torch.zeros(DUST_OUT_BYTES, dtype=torch.uint8).pin_memory()
     h_kp = torch.zeros(512, dtype=torch.int32).pin_memory()
     keep = {}
+    poses = {}
     lat, assoc, correct, inl = [], 0, 0, []
     torch.cuda.synchronize()
     for rep in range(2):                                        # rep 0 warms up
@@ -485,6 +488,7 @@ def frontend_chain_leg(ctx, H, W, nframes):
                 gk = h_kp.numpy()[:n].copy()
                 m = gk >= 0
                 inl.append(g["n_inlier"])
+                poses[k] = g["Tcw"].astype(np.float64)
                 if k in (1, nframes // 2, nframes - 1):        # frames the CPU block re-does with the oracle chain
                     keep[k] = dict(raw=raws[k], pts=pts_all[k, :n], mpd=mpd_all[k, :n], T0=T_all[k].reshape(4, 4), g=g, gk=gk,
                                    rec=d_rec.cpu().numpy())
@@ -500,13 +504,16 @@ def frontend_chain_leg(ctx, H, W, nframes):
     out = {"what": "tracker front end per frame, device resident: spfe_stage_batch_device (BGR %dx%d -> gray) -> "
                    "spfe_extract_batch_device -> spfe_track_dust_record_device (PoseOptimizationDust + patch association, "
                    "tracker_dust.cpp:92-172); D2H = pose block + keypoint indices only; %d frames, <= %d map points, "
-                   "'trackable' synthetic weights (weights.py), f32" % (W, H, nframes - 1, NP),
+                   "'trackable' synthetic weights (weights.py), %s" % (W, H, nframes - 1, NP, precision),
            "frontend_ms_per_frame": {"p50": round(lat[len(lat) // 2], 4), "p99": round(lat[int(len(lat) * 0.99) - 1], 4),
                                      "frames": len(lat)},
            "inliers_mean": round(float(np.mean(inl)), 1), "associations": assoc,
            "associations_consistent_with_camera_motion": round(correct / max(1, assoc), 4)}
     ext.close()
-    return out, dict(keep=keep, blob=blob, H=H, W=W)
+    # against the camera's true pose (tools/track_scene.pose): what the alignment recovers, whatever the precision
+    err = [float(np.abs(poses[k][:3, 3] - ts.pose(*ts.offsets(k)).astype(np.float64)[:3, 3]).max()) for k in poses]
+    out["pose_translation_err_vs_true"] = {"max": round(max(err), 6), "mean": round(float(np.mean(err)), 6)}
+    return out, dict(keep=keep, blob=blob, H=H, W=W, poses=poses)
 
 
 def frontend_chain_parity(fc, nf):
@@ -595,7 +602,9 @@ def multi_gpu_legs(ctx, args, ext, sharded, d_img, stream, frames_lo, B, H, W, e
             oracle.set_num_threads(min(32, os.cpu_count() or 1))
             det = {}
             ok = True
-            for g in (B, 0, world * B - 1):                      # rank 1's first frame, our own, the last rank's last
+            # the first frame of EVERY rank's shard (rank 0's is our own) and the last rank's last: each rank's contribution, as
+            # it arrived through the gather, and both ends of the gathered buffer (world 8: 9 frames of the 64)
+            for g in sorted({r * B for r in range(world)} | {world * B - 1}):
                 ref = oracle.extract(ctx["blob"], synth.make_image(200 + g, H, W), nf)
                 p, d = parity_of(sharded.decode(g), ref, bf16)
                 det["frame_%d_from_rank_%d" % (g, g // B)] = d
@@ -689,6 +698,156 @@ def multi_gpu_legs(ctx, args, ext, sharded, d_img, stream, frames_lo, B, H, W, e
     return res, ranks_headline["library"]
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# The printed line.  The driver keeps the last 8 KB of the line it records (a 14 KB line lost BASELINE's own
+# configs[3] leg to that window), so the DEFAULT line is compact — every leg reduced to its figures, no prose — and ENDS with
+# a `configs` object that carries BASELINE.json's configurations in a fixed form; `--verbose-line` prints the full objects
+# (the "what" strings, rules, details) instead, and the full line is always written to gpurun_out/bench_full.json when that
+# directory exists.  tests/test_bench_line.py builds the line from canned leg objects and holds its length (<= 7500
+# characters) and the position of `configs` (last key).
+LINE_LIMIT = 7500
+_DROP_KEYS = ("what", "rule", "stage_ms_note", "parity_detail", "source", "samples")
+
+
+def _leg_summary(leg):
+    """A device leg (device_leg() / the headline) -> the figures the `configs` object and the compact legs carry."""
+    if not isinstance(leg, dict) or "value" not in leg:
+        return leg
+    rf = leg.get("roofline") or {}
+    sc = leg.get("sclk_mhz") or {}
+    out = {"value": leg.get("value"), "ms_per_step": leg.get("ms_per_step"), "kernel_ms": rf.get("kernel_ms"),
+           "frac": rf.get("frac"), "frac_of_sustained": rf.get("frac_of_sustained"),
+           "whole_path_frac_of_peak": leg.get("whole_path_frac_of_peak"),
+           "whole_path_frac_of_sustained": leg.get("whole_path_frac_of_sustained"),
+           "whole_path_tflops": leg.get("whole_path_tflops"), "whole_path_tflops_dense_graph": leg.get("whole_path_tflops_dense_graph"),
+           "cells_computed_frac": (leg.get("descriptor_head") or {}).get("cells_computed_frac"),
+           "mfma_sustained_tflops": rf.get("mfma_sustained_tflops"), "sclk_avg": sc.get("avg") if isinstance(sc, dict) else None}
+    if "records_ok" in leg:
+        out["records_ok"] = leg["records_ok"]
+    return {k: v for k, v in out.items() if v is not None}
+
+
+def _strip(v):
+    """Drop prose and bulky details, recursively; round floats to 4 significant decimals where they are long."""
+    if isinstance(v, dict):
+        return {k: _strip(x) for k, x in v.items() if k not in _DROP_KEYS}
+    if isinstance(v, list):
+        return [_strip(x) for x in v]
+    if isinstance(v, float):
+        return float("%.6g" % v)
+    return v
+
+
+# device legs that live in `configs` only (compact line): BASELINE configs[3] and the other resolutions / dtypes north_star lists
+_CONFIG_LEGS = (("bf16_1280x720_b8", "bf16_1280x720_b8 = configs[3]"), ("f32_640x480_b8", "f32_640x480_b8"),
+                ("f32_1280x720_b8", "f32_1280x720_b8"), ("bf16_752x480_b8", "bf16_752x480_b8"))
+
+
+def _configs_object(out):
+    """BASELINE.json's configurations, one entry each, in a fixed form (the LAST key of the line)."""
+    head = _leg_summary(dict(out, roofline=out.get("roofline"), sclk_mhz=out.get("sclk_mhz")))
+    cfg = out.get("config") or {}
+    hw = "%sx%s" % (cfg.get("width"), cfg.get("height"))
+    lat = out.get("latency_batch1_ms") or {}
+    drop = out.get("dropin_operator_call_ms") or {}
+    dropl = out.get("dropin_operator_call_lazy_ms") or {}
+    c = {}
+    c["configs[1] %s b1 %s" % (hw, out.get("dtype"))] = {
+        "latency_ms_p50": lat.get("p50"), "latency_ms_p99": lat.get("p99"), "calls": lat.get("calls"),
+        "dropin_operator_call_ms_p50": drop.get("p50"), "dropin_operator_call_lazy_ms_p50": dropl.get("p50")}
+    c["headline = configs[2] per-GPU shard %s b%s %s x %s GPU" % (hw, cfg.get("frames_per_gpu"), out.get("dtype"), out.get("n_gpus"))] = head
+    for name, label in _CONFIG_LEGS:
+        if name in out:
+            c[label] = _leg_summary(out[name])
+    fc = {}
+    for name in ("frontend_chain", "frontend_chain_bf16"):
+        f = out.get(name)
+        if isinstance(f, dict):
+            fc[name] = {"ms_p50": (f.get("frontend_ms_per_frame") or {}).get("p50"), "inliers_mean": f.get("inliers_mean"),
+                        "associations": f.get("associations"),
+                        "consistent_with_camera_motion": f.get("associations_consistent_with_camera_motion"),
+                        "final_pose_max_abs_diff_vs_f32": f.get("final_pose_max_abs_diff_vs_f32"),
+                        "parity_vs_oracle_chain": f.get("parity_vs_oracle_chain")}
+    if fc:
+        c["configs[4] substitute (blocked: no dataset / weights / back-end)"] = fc
+    return c
+
+
+def build_line(out, verbose=False):
+    """The dict bench.py prints: `out` (every leg's full object) -> the compact default line, `configs` last.  Legs that are
+    device legs shrink to _leg_summary(); prose goes; if the result still exceeds LINE_LIMIT the least important legs' objects
+    are replaced by their headline figure, in a fixed order, until it fits (named in `line_trimmed`)."""
+    if verbose:
+        line = dict(out)
+        line.pop("configs", None)
+        line["configs"] = _configs_object(out)
+        return line
+    line = {}
+    for k, v in out.items():
+        if k in _DROP_KEYS or k == "configs" or k in dict(_CONFIG_LEGS):   # (those legs: in `configs`, once)
+            continue
+        if k == "roofline" and isinstance(v, dict):
+            v = dict(v)
+            if isinstance(v.get("kernel"), str):
+                v["kernel"] = v["kernel"].split(" (")[0]
+            line[k] = _strip(v)
+        elif k == "config" and isinstance(v, dict):
+            v = dict(v)
+            if isinstance(v.get("workload"), str) and len(v["workload"]) > 150:
+                v["workload"] = v["workload"][:147] + "..."
+            line[k] = _strip(v)
+        elif k == "mfma_sustained" and isinstance(v, dict):
+            line[k] = {d: {"tflops": x.get("tflops"), "ghz": x.get("ghz")} for d, x in v.items() if isinstance(x, dict)} or _strip(v)
+        elif k == "sclk_mhz" and isinstance(v, dict):
+            line[k] = {"min": v.get("min"), "avg": v.get("avg"), "max": v.get("max")}
+        elif isinstance(v, dict) and "roofline" in v and "value" in v:   # an exploratory device leg: its brief form
+            line[k] = {x: y for x, y in _leg_summary(v).items() if x in ("value", "ms_per_step", "frac", "frac_of_sustained", "whole_path_frac_of_peak", "cells_computed_frac", "records_ok")}
+        elif k == "cpu_baseline_aten" and isinstance(v, dict):
+            line[k] = {x: v.get(x) for x in ("value", "unit", "cores", "host_cpus")}
+        else:
+            line[k] = _strip(v)
+    cfgs = _configs_object(out)
+    trimmed = []
+    order = ["f32_3840x2160_b1", "bf16_3840x2160_b1", "latency_batch1_stage_ms", "stage_ms", "dense_descriptor_branch_b8",
+             "f32_sparse_detector_b8", "bf16_sparse_detector_b8", "match_patches", "input_staging", "match_bruteforce",
+             "dust_alignment", "host_path_bf16", "host_path", "frontend_chain", "frontend_chain_bf16", "cpu_baseline_aten",
+             "latency_batch1_heat_maps_ms"]
+
+    def assemble():
+        full = dict(line)
+        if trimmed:
+            full["line_trimmed"] = trimmed
+        full["configs"] = cfgs
+        return full
+    keep = ("config", "roofline", "cpu_baseline", "latency_batch1_ms", "dropin_operator_call_ms", "dropin_operator_call_lazy_ms")
+    # (legs this list does not know: largest first, behind the known ones)
+    rest = sorted((k for k, v in line.items() if isinstance(v, dict) and k not in order and k not in keep),
+                  key=lambda k: -len(json.dumps(line[k])))
+    for k in order + rest:
+        if len(json.dumps(assemble())) <= LINE_LIMIT:
+            break
+        v = line.get(k)
+        if isinstance(v, dict):
+            small = {x: v[x] for x in ("value", "fps", "p50", "us_per_solve", "ms_per_batch", "us_per_call", "total") if x in v}
+            if not small and isinstance(v.get("frontend_ms_per_frame"), dict):
+                small = {"p50": v["frontend_ms_per_frame"].get("p50")}
+            line[k] = small
+            trimmed.append(k)
+    return assemble()
+
+
+def emit_line(out, args):
+    """Print THE line (compact unless --verbose-line) and leave the full objects in gpurun_out/bench_full.json."""
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(d):
+            with open(os.path.join(d, "bench_full.json"), "w") as f:
+                f.write(json.dumps(build_line(out, verbose=True)) + "\n")
+    except OSError:
+        pass
+    print(json.dumps(build_line(out, verbose=getattr(args, "verbose_line", False))), flush=True)
+
+
 def self_launch(args):
     """`--gpus N` (N > 1) without a rendezvous in the environment: re-execute under torch.distributed.run, one rank per GPU,
     exactly as the driver would have (same flags, 127.0.0.1 rendezvous, a free port).  Never returns."""
@@ -741,6 +900,9 @@ def main():
     ap.add_argument("--no-comm-ab", action="store_true", help="N > 1: skip the comm-stream A/B leg (gather on the library's side "
                     "stream vs on a stream of its own, SPFE_COMM_OWN_STREAM)")
     ap.add_argument("--latency-calls", type=int, default=1000)
+    ap.add_argument("--verbose-line", action="store_true",
+                    help="print every leg's full object (prose, rules, details): ~15 KB; the default line is compact (<= 7.5 KB, "
+                         "`configs` last) because the driver keeps the last 8 KB of what it records")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
                     help="f32: BASELINE configs[1]/[2] (bit-exact path, the headline); bf16: configs[3] (all twelve "
                          "convolutions, the two 1x1 heads included, as bf16 MFMA GEMMs with f32 accumulation; softmax, "
@@ -863,13 +1025,13 @@ def main():
         def emit_partial(part):
             line = dict(out)
             line.update(part)
-            print(json.dumps(line), flush=True)
+            emit_line(line, args)
         res, lib_ranks = multi_gpu_legs(ctx, args, ext, sharded, d_img, stream, lo, B, H, W, emit_partial)
         if lib_ranks is not None and lib_ranks != world:   # (every rank checks its own communicator: all leave together)
             die("the library's RCCL communicator reports %s ranks, --gpus %d" % (lib_ranks, world), dist)
         if rank == 0:
             out.update(res)
-            print(json.dumps(out), flush=True)
+            emit_line(out, args)
         torch.cuda.synchronize()
         dist.barrier()            # no rank destroys its communicator while another is still in a leg (or printing)
         ext.close()
@@ -995,6 +1157,7 @@ def main():
     if not args.no_host_path:
         out["host_path"] = host_path_leg(ctx, args.precision, H, W, B, frames, fps, args.steps)
         out["dropin_operator_call_ms"] = dropin_leg(H, W, nf, blob, frames[0]) if args.precision == "f32" else None
+        out["dropin_operator_call_lazy_ms"] = dropin_leg(H, W, nf, blob, frames[0], lazy=True) if args.precision == "f32" else None
         if not args.no_bf16_leg and not (bf16 and (H, W) == (720, 1280)):
             fr3 = synth.make_batch(300, 8, 720, 1280)
             dev3 = (out.get("bf16_1280x720_b8") or {}).get("value")
@@ -1170,6 +1333,18 @@ def main():
 
         # the tracker's front end chained on resident records (the C5 substitute)
         out["frontend_chain"], cpu_todo["frontend"] = frontend_chain_leg(ctx, H, W, 101)
+        # ... and the same sequence with the bf16 convolutions: the bf16 keypoint sets differ from the f32
+        # ones by 6 - 11 % (Jaccard 0.89 - 0.94) — what that does to what the tracker consumes: inliers of the alignment,
+        # associations, their consistency with the known camera motion, and the recovered pose against the f32 chain's
+        if args.precision == "f32":
+            fcb, keepb = frontend_chain_leg(ctx, H, W, 101, "bf16")
+            pf, pb = cpu_todo["frontend"]["poses"], keepb["poses"]
+            dif = [float(np.abs(pf[k] - pb[k]).max()) for k in pf if k in pb]
+            fcb["pose_max_abs_diff_vs_f32"] = {"max": round(max(dif), 6), "mean": round(float(np.mean(dif)), 6), "frames": len(dif)}
+            fcb["final_pose_max_abs_diff_vs_f32"] = round(float(np.abs(pf[max(pf)] - pb[max(pb)]).max()), 6)
+            fcb["consistency_vs_f32"] = round(fcb["associations_consistent_with_camera_motion"] -
+                                              out["frontend_chain"]["associations_consistent_with_camera_motion"], 4)
+            out["frontend_chain_bf16"] = fcb
 
     # ---------------------------------------------------------------- CPU legs (the oracle is the checker / the baseline)
     if not args.no_cpu_baseline:
@@ -1228,7 +1403,7 @@ def main():
                 "kind": "aten-cpu op sequence (torch %s, MKL-DNN), network + tail + descriptor sampling" % torch.__version__,
                 "sample": "%d frames of the same %dx%d workload, %.1f s, best of the thread sweep" % (best[2], W, H, best[3]),
                 "thread_sweep_fps": sweep, "host_cpus": ncpu}
-    print(json.dumps(out), flush=True)
+    emit_line(out, args)
     ext.close()
 
 

@@ -29,11 +29,14 @@ class SPExtractor : public BaseExtractor, public spfe::ExtractorCV {
   // camera::height / camera::width / common::model_path from config globals; its two-line
   // definition on top of the explicit one below is in INTEGRATION.md §2b.
   SPExtractor(int nfeatures);
-  SPExtractor(int nfeatures, int height, int width, const std::string &model_path, int device = 0)
+  // lazy_heat_inv = false (default): the reference's post-call state — heat_ AND heat_inv_ filled by operator()
+  // (sp_extractor.cpp:461-474).  true: heat_inv_ — which no caller of the reference reads
+  // (computeCovariance, its only reader, runs on the device here) — stays on the device, the member is empty
+  // after operator() and heatInv() fetches the last call's map on demand: 1.44 MB less D2H + one clone less per 752x480 call
+  // (bench.py: dropin_operator_call_ms / dropin_operator_call_lazy_ms).
+  SPExtractor(int nfeatures, int height, int width, const std::string &model_path, int device = 0, bool lazy_heat_inv = false)
       : BaseExtractor(nfeatures, 1.0f, 1, 1, 1),   // one level, scale 1: sp_extractor.cpp:343
-        // heat_ is cloned by Frame::ExtractORB (frame.cpp:304); heat_inv_ is read by nobody outside computeCovariance
-        // (sp_extractor.cpp:508), which runs on the device here: it stays there unless heatInv() asks for it
-        spfe::ExtractorCV(nfeatures, height, width, model_path, device, /*with_heat=*/true, /*lazy_heat_inv=*/true) {}
+        spfe::ExtractorCV(nfeatures, height, width, model_path, device, /*with_heat=*/true, lazy_heat_inv) {}
   virtual ~SPExtractor() = default;
 
   void operator()(cv::InputArray image, cv::InputArray mask, std::vector<cv::KeyPoint> &keypoints,
@@ -45,8 +48,8 @@ class SPExtractor : public BaseExtractor, public spfe::ExtractorCV {
   const std::vector<Eigen::Vector2f> getCov() { return toEigen(spfe::ExtractorCV::getCov()); }
   const std::vector<Eigen::Vector2f> getCov2Inv() { return toEigen(spfe::ExtractorCV::getCov2Inv()); }
   // getMask(), getHeatMap(), semi_dust_, dense_dust_, mask_, heat_, heat_inv_, occ_grid_: inherited from
-  // spfe::ExtractorCV with the reference's names and cv::Mat types (sp_extractor.h:61-73).  heat_inv_ is empty after
-  // operator() (nobody reads it) and filled by heatInv() on demand.
+  // spfe::ExtractorCV with the reference's names and cv::Mat types (sp_extractor.h:61-73), all filled by operator() as the
+  // reference fills them (heat_inv_ too, unless the integrator opted into lazy_heat_inv above).
 
  private:
   static std::vector<Eigen::Vector2f> toEigen(const std::vector<spfe::Vec2f> &v) {

@@ -62,14 +62,27 @@ const char *spfe_stage_name(int i) { return (i >= 0 && i < NSTAGE) ? kStageNames
 // The twin of a handle whose pipelined calls are to alternate between two sets of buffers (spfe_host.h: two side chains in
 // flight) — where the workload (or SPFE_TWO_CHAINS) says so.  spfe_create for SPFE_FLAG_ASYNC_COV handles, the first
 // spfe_submit_batch for the others.
+// The twin is an optimisation: when it cannot be built (a second full set of buffers — several GB for bf16 3840x2160) the
+// handle carries on with one side chain; spfe_debug_read("two_chains") says 0, ("twin_failed") 1, and the error text stays
+// readable through spfe_last_error() until the next failing call.  Built from the handle's OWN copy of the weight blob and
+// its own switches (spfe_host.h: blob), never from the caller's pointers.
 static int make_twin(spfe_handle h) {
-  if (h->twin || h->is_twin) return SPFE_OK;
-  if (!(h->two_chains_env >= 0 ? h->two_chains_env > 0 : (h->bf16 && h->C >= 10000))) return SPFE_OK;
+  if (h->twin || h->is_twin || h->twin_failed) return SPFE_OK;
+  if (!(h->two_chains_env >= 0 ? h->two_chains_env > 0 : (h->bf16 && h->C >= 10000))) { h->blob = std::vector<float>(); return SPFE_OK; }
   h->twin = new spfe_handle_s();
   h->twin->is_twin = true;
-  const int rc = build(h->twin, &h->cfg);
-  if (rc) { std::string keep = g_err; spfe_destroy(h->twin); h->twin = nullptr; g_err = keep; }
-  return rc;
+  // (SPFE_TWO_CHAINS=99, tests: a twin is wanted and its build fails — the failure path without exhausting 288 GB)
+  const int rc = h->two_chains_env == 99 ? fail(SPFE_EHIP, "twin build made to fail (SPFE_TWO_CHAINS=99)") : build(h->twin, &h->cfg, h);
+  if (rc) {
+    std::string keep = g_err;
+    spfe_destroy(h->twin);
+    h->twin = nullptr;
+    h->twin_failed = true;
+    (void)hipGetLastError();   // (an out-of-memory stays sticky otherwise)
+    g_err = "two side chains unavailable, continuing with one: " + keep;
+  }
+  h->blob = std::vector<float>();   // (no further use: a handle has at most one twin)
+  return SPFE_OK;
 }
 
 int spfe_create(const spfe_config *cfg, spfe_handle *out) {
@@ -183,6 +196,14 @@ int spfe_extract_batch_device(spfe_handle h, const void *d_images, int n, void *
   if (h->twin) {   // two side chains in flight: even tickets on this handle, odd ones on its twin (own buffers, own side stream)
     // (a handle whose twin was made by the pipelined host path but whose device calls are synchronous stays on its own buffers)
     spfe_handle t = (h->cfg.flags & SPFE_FLAG_ASYNC_COV) && (h->g_ticket & 1) ? h->twin : h;
+    {   // the same record buffer twice in a row: tail_waits() orders a call behind the previous chain of ITS handle only, and the
+        // previous call ran on the other of the pair — whose chain (its side stream) may still be writing this buffer
+      spfe_handle o = t == h ? h->twin : h;
+      if (o->cov_inflight && o->ticket > 0) {
+        const int prev = (int)((o->ticket - 1) % spfe_handle_s::NTICKET);
+        if (o->rec_of[prev] == rec) HIP_TRY(wait_if_pending(s, o->ev_cov[prev]));
+      }
+    }
     const int rc = enqueue(t, reinterpret_cast<const uint8_t *>(d_images), n, rec, s);
     if (rc) return rc;
     h->tmap[h->g_ticket % 8] = {t, t->ticket - 1};
@@ -302,9 +323,9 @@ int spfe_view_record(spfe_handle h, const void *host_record, spfe_result *out) {
 
 long spfe_debug_read(spfe_handle h, const char *name, int frame, void *dst, size_t cap) {
   if (!h || !name || !dst) return fail(SPFE_EINVAL, "null argument");
-  if (std::string(name) == "two_chains") {   // 1: pipelined device calls alternate between this handle and its twin
-    if (cap < sizeof(int)) return fail(SPFE_EINVAL, "buffer 'two_chains' needs 4 bytes");
-    *reinterpret_cast<int *>(dst) = h->twin ? 1 : 0;
+  if (std::string(name) == "two_chains" || std::string(name) == "twin_failed") {   // 1: pipelined device calls alternate between this handle and its twin / 1: the twin could not be built
+    if (cap < sizeof(int)) return fail(SPFE_EINVAL, "buffer '%s' needs 4 bytes", name);
+    *reinterpret_cast<int *>(dst) = std::string(name) == "two_chains" ? (h->twin ? 1 : 0) : (h->twin_failed ? 1 : 0);
     return (long)sizeof(int);
   }
   if (h->twin) {   // the intermediates of the last call live in whichever of the two ran it; neither has work in flight afterwards

@@ -123,7 +123,12 @@ struct spfe_handle_s {
   // SPFE_TWO_CHAINS: -1 by workload (bf16 frames of >= 10,000 cells, SPFE_FLAG_ASYNC_COV handles), 0 never, 1 always.
   spfe_handle twin = nullptr;
   bool is_twin = false;
+  bool twin_failed = false;                  // the twin could not be built (e.g. out of memory): one side chain, and no second attempt
   int two_chains_env = -1;
+  // The parsed weight blob (register_module order), kept for as long as a twin may still be built from it: spfe_config's
+  // weights / weights_path are the CALLER's memory and need not outlive spfe_create (the lazily built twin used to
+  // read them again at the first spfe_submit_batch) — the stored cfg carries neither.
+  std::vector<float> blob;
   long last_seq = 0;                         // value of the process-wide call counter at this handle's last enqueue_post (debug reads
                                              // of a pair come from the one that ran last)
   long g_ticket = 0;                         // tickets handed out by this handle when it has a twin
@@ -193,6 +198,7 @@ struct spfe_handle_s {
   int cov_gen_code = 0;        // generation code of the last chain (CovScratch::gen = code << 16); 0: none yet
   int cov_gen_start = 32766;   // SPFE_COV_CAPS field 6 (tests reach the wrap)
   int cov_frames_clean = 0;    // leading frames whose claim / done maps hold tagged (or reset) entries
+  int cov_captured_min = 0;    // lowest generation code a captured (hipGraph) call froze; 0: never captured (enqueue_post)
   ConvLayer layers[10];
   spfe::RecordLayout rl{};
   // host side
@@ -318,7 +324,9 @@ inline spfe_handle last_caller(spfe_handle h) {   // the one of the pair whose b
 hipError_t wait_if_pending(hipStream_t s, hipEvent_t ev);
 void make_layout(int kmax, int C, bool desc_bf16, spfe::RecordLayout *r);
 // spfe_pack.hip
-int build(spfe_handle h, const spfe_config *cfg);
+// (sibling: the handle whose twin `h` is to be — weights and environment switches are taken from it, not from the caller's
+// pointers or the environment of that later moment)
+int build(spfe_handle h, const spfe_config *cfg, spfe_handle sibling = nullptr);
 // spfe_schedule.hip
 int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, hipStream_t s);
 int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const std::function<int()> *conv_db = nullptr, bool sparse = false, bool fused_pb = false, bool tail_done = false);

@@ -220,7 +220,7 @@ static void read_switches(spfe_handle h) {
   h->inline_chain = env_int("SPFE_INLINE_CHAIN", 1) != 0;    // synchronous calls: detector chain on the launch stream
   h->defer_join = env_int("SPFE_DEFER_JOIN", 1) != 0;        // pipelined two-half steps: the join in front of the NEXT conv1b
   h->tail_per_half = env_int("SPFE_TAIL_PER_HALF", 1) != 0;  // ... each half's tail right behind its convPa
-  h->two_chains_env = env_int("SPFE_TWO_CHAINS", -1);        // a twin handle, pipelined device calls alternate: -1 by workload, 0 never, 1 always
+  h->two_chains_env = env_int("SPFE_TWO_CHAINS", -1);        // a twin handle, pipelined device calls alternate: -1 by workload, 0 never, 1 always, 99 wanted + its build fails (tests)
   h->sel_ext_event = env_int("SPFE_SEL_EXT_EVENT", 1) != 0;  // the selection's completion signal as the descriptor branch's event
   h->replay_waves = env_int("SPFE_REPLAY_WAVES", 0);         // components per replay workgroup: 0 by workload, 2 | 8
   h->zero_in_tail = env_int("SPFE_ZERO_IN_TAIL", 1) != 0;    // bf16 tile-queue counters cleared by the previous call's tail
@@ -263,9 +263,31 @@ static void read_switches(spfe_handle h) {
   h->cov_ecap_env = env_field("SPFE_COV_CAPS", 4, -1);       // -1: 32 x kmax; 0: no edge list (the link kernel walks the pop lists)
 }
 
-int build(spfe_handle h, const spfe_config *cfg) {
+// A twin runs its sibling's switches: they were read once, at the sibling's spfe_create (the environment may have changed
+// since — the twin of a handle that pipelines through spfe_submit_batch is built at the first submission).  Same list as
+// read_switches().
+static void copy_switches(spfe_handle h, const spfe_handle_s *o) {
+  h->timing = o->timing; h->timing_all = o->timing_all; h->split_mode = o->split_mode; h->inline_chain = o->inline_chain;
+  h->defer_join = o->defer_join; h->tail_per_half = o->tail_per_half; h->two_chains_env = o->two_chains_env;
+  h->sel_ext_event = o->sel_ext_event; h->replay_waves = o->replay_waves; h->zero_in_tail = o->zero_in_tail;
+  h->sparse_db_env = o->sparse_db_env; h->sparse_da_env = o->sparse_da_env; h->pbtail_env = o->pbtail_env;
+  h->f32_heads = o->f32_heads; h->fuse1a_env = o->fuse1a_env; h->pipe_copy_kernel = o->pipe_copy_kernel;
+  h->tile16x4 = o->tile16x4; h->tile2_auto = o->tile2_auto; h->tile2_mask = o->tile2_mask;
+  h->select_huge_env = o->select_huge_env; h->pool_split = o->pool_split;
+  h->ws_mask = o->ws_mask; h->ws_min_items = o->ws_min_items; h->ws_min_items_sync = o->ws_min_items_sync;
+  h->bf16_dyn = o->bf16_dyn; h->tile_rows_big = o->tile_rows_big; h->tile16_min_items = o->tile16_min_items;
+  h->bf16_rw = o->bf16_rw; h->rw_min4 = o->rw_min4; h->rw_min2 = o->rw_min2; h->rw_rows3 = o->rw_rows3;
+  h->cov.qcap = o->cov.qcap; h->cov.ovf_slots = o->cov.ovf_slots; h->cov.ovf_cap = o->cov.ovf_cap; h->cov.fb_cap = o->cov.fb_cap;
+  h->cov_gen_start = o->cov_gen_start; h->cov_ecap_env = o->cov_ecap_env;
+}
+
+int build(spfe_handle h, const spfe_config *cfg, spfe_handle sibling) {
   h->cfg = *cfg;
-  read_switches(h);
+  // the caller's weight memory is read HERE and never again: the stored configuration does not point into it
+  h->cfg.weights = nullptr;
+  h->cfg.weights_path = nullptr;
+  if (sibling) copy_switches(h, sibling);
+  else read_switches(h);
   h->H = cfg->height; h->W = cfg->width;
   h->hc = h->H / 8; h->wc = h->W / 8; h->C = h->hc * h->wc;
   h->kmax = cfg->num_features + 1;
@@ -319,9 +341,11 @@ int build(spfe_handle h, const spfe_config *cfg) {
     for (auto &e : h->evpool) HIP_TRY(hipEventCreate(&e));
   }
 
-  std::vector<float> blob;
-  int rc = load_blob(cfg, &blob);
-  if (rc) return rc;
+  int rc;
+  if (!sibling) {
+    if ((rc = load_blob(cfg, &h->blob))) return rc;
+  } else if (sibling->blob.size() != (size_t)SPFE_NUM_PARAMS) return fail(SPFE_EWEIGHTS, "internal: the sibling's weight blob is gone");
+  const std::vector<float> &blob = sibling ? sibling->blob : h->blob;
 
   // conv1a weights: [tap][64]
   {

@@ -547,11 +547,20 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
       h->cov_frames_clean = std::max(h->cov_frames_clean, n);
     }
     h->cov.gen = h->cov_gen_code << 16;
-    // a captured call is replayed with the arguments of the capture — the same generation every time: it clears its maps
-    // itself, as every call did before round 5 (a later direct call's code is lower than the captured one: the replays' entries
-    // read as "nobody" there)
+    // a captured call is replayed with the arguments of the capture — the same generation G every time: it clears its maps
+    // itself, as every call did before round 5, and every replay leaves entries tagged G behind.  A later direct call with a
+    // LOWER code reads them as "nobody" and wins every atomicMin against them.  Once the codes have wrapped (they restart at
+    // cov_gen_start > G) that is no longer true — a direct call behind a replay would lose its claims to the stale, lower
+    // G-tagged entries — so a handle that has been captured remembers the lowest code it was captured with, and
+    // direct calls clear the maps themselves while their code is not below it.
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) h->cov.reset_maps = 1;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+      h->cov.reset_maps = 1;
+      h->cov_captured_min = h->cov_captured_min ? std::min(h->cov_captured_min, h->cov_gen_code) : h->cov_gen_code;
+    } else if (h->cov_captured_min && h->cov_gen_code >= h->cov_captured_min) {
+      h->cov.reset_maps = 1;
+      h->cov_frames_clean = std::max(h->cov_frames_clean, n);
+    }
   }
   const int par = (int)(h->ticket & 1);
   if (h->timing && !h->ev) return fail(SPFE_EINVAL, "internal: no event set");

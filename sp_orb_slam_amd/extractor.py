@@ -723,7 +723,7 @@ class SPExtractor:
         shapes["coarse_sparse"] = shapes["coarse"]   # the descriptor map as the last call left it (only the rows it read)
         if name.startswith("cov_"):   # covariance scratch (int32): counters [4], nxt / workers / npop [kmax]
             out = np.empty(4 if name == "cov_counters" else self.nfeatures + 1, np.int32)
-        elif name in ("db_total", "da_gathered", "conv1b_tile_rows", "conv1b_split_rows", "select_huge", "two_chains"):   # gathered descriptor head: number of listed cells of the last call /
+        elif name in ("db_total", "da_gathered", "conv1b_tile_rows", "conv1b_split_rows", "select_huge", "two_chains", "twin_failed"):   # gathered descriptor head: number of listed cells of the last call /
             out = np.empty(1, np.int32)             # whether convDa ran on those cells only
         elif name == "db_list":       # ... and the list (global cell indices b * C + cell), max_batch * min(4 kmax, C) entries
             C_ = (self.height // 8) * (self.width // 8)

@@ -61,10 +61,20 @@ int main(int argc, char **argv) {
     if (dynamic_cast<SPExtractor *>(mpORBextractorLeft) == nullptr) return 13;
     if ((int)cov2_inv_.size() != (int)mvKeys.size()) return 14;
     if (dynamic_cast<SPExtractor *>(mpORBextractorLeft)->getCov().size() != mvKeys.size()) return 15;
-    // heat_inv_ (sp_extractor.h:73; read by nobody) is not copied back by operator(); heatInv() fetches it
-    if (!dynamic_cast<SPExtractor *>(mpORBextractorLeft)->heat_inv_.empty()) return 16;
-    cv::Mat heat_inv = dynamic_cast<SPExtractor *>(mpORBextractorLeft)->heatInv().clone();
-    if (heat_inv.rows != H || heat_inv.cols != W || dynamic_cast<SPExtractor *>(mpORBextractorLeft)->heat_inv_.empty()) return 17;
+    // heat_inv_ (sp_extractor.h:73): filled by operator() as the reference fills it (Appendix A item 18) ...
+    if (dynamic_cast<SPExtractor *>(mpORBextractorLeft)->heat_inv_.empty()) return 16;
+    cv::Mat heat_inv = dynamic_cast<SPExtractor *>(mpORBextractorLeft)->heat_inv_.clone();
+    if (heat_inv.rows != H || heat_inv.cols != W) return 17;
+    {   // ... unless the integrator opts into the lazy form: empty after operator(), the same map from heatInv() on demand
+      SPExtractor lazy(tracking::num_features, H, W, common::model_path, 0, /*lazy_heat_inv=*/true);
+      std::vector<cv::KeyPoint> k2;
+      cv::Mat d2;
+      lazy(im, cv::Mat(), k2, d2);
+      if (!lazy.heat_inv_.empty() || lazy.heat_.empty()) return 18;
+      cv::Mat hi2 = lazy.heatInv().clone();
+      if (lazy.heat_inv_.empty() || hi2.rows != H || hi2.cols != W || memcmp(hi2.data, heat_inv.data, (size_t)H * W * 4) != 0) return 19;
+      if (k2.size() != mvKeys.size()) return 20;
+    }
 
     // the empty-image error of sp_extractor.cpp:364-365 through the base pointer
     bool threw = false;

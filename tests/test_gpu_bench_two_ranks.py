@@ -80,18 +80,42 @@ def test_bench_two_ranks_one_gpu():
     assert "Traceback" not in out.stderr
 
 
+def test_bench_eight_ranks_one_gpu_configs2_dry_run():
+    """BASELINE configs[2] literally, as a dry run: `python bench.py --gpus 8` — 64 frames, 8 per rank, 8 ranks
+    that share the one GPU, the record all-gather through gloo — on small frames.  Rank 0 checks a gathered frame FROM EVERY RANK
+    (each rank's first, and rank 7's last = the end of the 64-record buffer) against the oracle, bit for bit."""
+    small8 = ["--steps", "2", "--warmup", "1", "--height", "128", "--width", "160", "--frames-per-gpu", "8", "--num-features", "100",
+              "--no-cpu-baseline", "--no-match", "--no-latency", "--no-stage-table"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"] + small8, cwd=ROOT,
+                         env=_clean_env(SPFE_BENCH_BACKEND="gloo", SPFE_LEGS_TIMEOUT="600"), capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["parallelism"] == "dp8" and d["config"]["frames_per_gpu"] == 8 and d["value"] > 0
+    assert d["parity_gathered"] is True
+    want = {"frame_%d_from_rank_%d" % (8 * r, r) for r in range(8)} | {"frame_63_from_rank_7"}
+    assert set(d["parity_gathered_detail"]) == want
+    assert all(v["keypoints_exact"] and v["desc_bitwise"] and v["cov2_bitwise"] for v in d["parity_gathered_detail"].values())
+    assert d["rccl_ranks"]["process_group"] == 8 and d["allgather"]["bytes_per_rank"] > 0 and d["host_alt"]["records_ok"]
+    assert "legs_incomplete" not in d and list(d)[-1] == "configs"
+
+
 def test_scale_sweep_script_dry_run(tmp_path):
-    """tools/scale_sweep.sh (the N = 1, 2, 4, 8 curve of SCALE_rNN.json) on one GPU: N = 1 and N = 2 (gloo dry run), small frames —
-    one JSON line per N in scale.jsonl, the N = 2 line from two ranks, the summary table printed."""
-    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "scale_sweep.sh"), str(tmp_path), "--height", "240", "--width", "320",
-                          "--frames-per-gpu", "3", "--num-features", "200", "--no-cpu-baseline", "--no-stage-table", "--no-comm-ab"],
-                         cwd=ROOT, env=_clean_env(SPFE_BENCH_BACKEND="gloo", MAXN="2", STEPS="3", WARMUP="1"), capture_output=True,
-                         text=True, timeout=900)
+    """tools/scale_sweep.sh (the N = 1, 2, 4, 8 curve of SCALE_rNN.json) on one GPU, MAXN = 8 (gloo dry run: the ranks share the
+    GPU), small frames, 8 frames per rank as configs[2] shards them — one JSON line per N in scale.jsonl, the N = 8 line from
+    eight ranks with a gathered frame of every rank checked, the summary table printed."""
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "scale_sweep.sh"), str(tmp_path), "--height", "128", "--width", "160",
+                          "--frames-per-gpu", "8", "--num-features", "100", "--no-cpu-baseline", "--no-stage-table", "--no-comm-ab"],
+                         cwd=ROOT, env=_clean_env(SPFE_BENCH_BACKEND="gloo", MAXN="8", STEPS="2", WARMUP="1", SPFE_LEGS_TIMEOUT="600"),
+                         capture_output=True, text=True, timeout=2400)
     assert out.returncode == 0, out.stderr[-2000:]
     rows = [json.loads(l) for l in open(tmp_path / "scale.jsonl")]
-    assert [r["n_gpus"] for r in rows] == [1, 2]
-    assert rows[1]["parity_gathered"] is True and rows[1]["config"]["parallelism"] == "dp2"
-    assert "N=1" in out.stdout and "N=2" in out.stdout
+    assert [r["n_gpus"] for r in rows] == [1, 2, 4, 8]
+    for r in rows[1:]:
+        assert r["parity_gathered"] is True and r["config"]["parallelism"] == "dp%d" % r["n_gpus"]
+        assert len(r["parity_gathered_detail"]) == r["n_gpus"] + 1
+    assert all("N=%d" % n in out.stdout for n in (1, 2, 4, 8))
 
 
 def test_a_rank_failing_inside_a_leg_does_not_cost_the_line():

@@ -368,7 +368,7 @@ def test_cpp_dropin_through_base_pointer_matches_python_path(tmp_path):
     occ = raw[off:off + C * 2].view(np.int16).reshape(H // 8, W // 8); off += C * 2
     dust = raw[off:off + C * 4].view(np.float32).reshape(H // 8, W // 8); off += C * 4
     heat = raw[off:off + H * W * 4].view(np.float32).reshape(H, W); off += H * W * 4
-    heat_inv = raw[off:off + H * W * 4].view(np.float32).reshape(H, W)   # (fetched on demand: heatInv())
+    heat_inv = raw[off:off + H * W * 4].view(np.float32).reshape(H, W)   # (heat_inv_ after operator(): filled by default; dropin_main also runs the lazy opt-in form)
     ref = oracle.extract(blob, img, nf)
     assert np.array_equal(heat_inv, ref["heat_inv"])
     assert K == ref["K"] and np.array_equal(kp[:, :2], ref["kp_xy"])
@@ -862,3 +862,19 @@ def test_a_synchronous_call_captured_into_a_hip_graph_replays_bit_identically(cf
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
     assert "bit-identical to direct calls: True" in out.stdout
+
+
+@pytest.mark.parametrize("cfg", ["f32 2", "bf16 2"])
+def test_direct_calls_behind_graph_replays_across_a_generation_wrap(cfg):
+    """tools/graph_capture_check.py wrap — the claim / done maps' generation codes start at 5
+    (SPFE_COV_CAPS field 6), a call is captured at code 2, direct calls run across the wrap, and direct calls follow replays
+    with codes above, at and below the captured one: every record equals a fresh default handle's (the stale, lower G-tagged
+    entries a replay leaves behind must not win a later direct call's claims)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SPFE_COV_CAPS=",,,,,5")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "graph_capture_check.py"), "wrap"] + cfg.split(), cwd=root,
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    assert "every call bit-identical to a fresh handle's: True" in out.stdout

@@ -221,3 +221,112 @@ def test_two_side_chains_on_the_pipelined_host_path():
         for i in range(B):
             _same(g[i], e[i], ("pipe", k, i))
             assert np.array_equal(g[i].heat, e[i].heat) and np.array_equal(g[i].heat_inv, e[i].heat_inv), ("pipe heat", k, i)
+
+
+def test_the_lazily_built_twin_does_not_read_the_callers_weight_memory(tmp_path, monkeypatch):
+    """a handle created without SPFE_FLAG_ASYNC_COV builds its twin at the FIRST spfe_submit_batch — long after
+    spfe_create returned and the caller's weight array / path string were released (SPExtractor drops both before __init__
+    returns).  The library keeps its own parsed blob for the twin and the stored configuration points nowhere; the twin also
+    runs its sibling's switches, not the environment of that later moment.  Weights from a path that is deleted and from a
+    temporary array that is overwritten and freed; odd tickets (the twin's) must equal the synchronous records."""
+    import gc
+    for v in ALL:
+        monkeypatch.delenv(v, raising=False)
+    H, W, B, nf = 720, 1280, 2, 300
+    blob = weights.synthetic(7, "dense")
+    batches = [[synth.make_image(1700 + 10 * s + i, H, W) for i in range(B)] for s in range(4)]
+    ref_ext = SPExtractor(nf, H, W, blob, max_batch=B, precision="bf16", with_heat=False)
+    ref = [ref_ext.extract_batch(b) for b in batches]
+    ref_ext.close()
+    path = tmp_path / "w.spfw"
+    weights.save(str(path), blob)
+    for how in ("path", "array"):
+        if how == "path":
+            ext = SPExtractor(nf, H, W, str(path), max_batch=B, precision="bf16", with_heat=False)
+            path.unlink()                                   # the file is gone before the twin is built
+        else:
+            tmp = blob.copy()
+            ext = SPExtractor(nf, H, W, tmp, max_batch=B, precision="bf16", with_heat=False)
+            tmp[:] = np.float32(np.nan)                     # the caller's memory is garbage, then released
+            del tmp
+            gc.collect()
+            junk = [np.full(blob.size, 7.0, np.float32) for _ in range(4)]   # (likely to land where the array was)
+            assert junk
+        monkeypatch.setenv("SPFE_SPARSE_DA", "0")           # an environment change behind spfe_create: the twin must not see it
+        monkeypatch.setenv("SPFE_TWO_CHAINS", "0")
+        assert int(ext.debug_read("two_chains")[0]) == 0
+        tk = [ext.submit_batch(b) for b in batches[:3]]
+        assert int(ext.debug_read("two_chains")[0]) == 1
+        got = [ext.collect_batch(t) for t in tk]
+        got.append(ext.collect_batch(ext.submit_batch(batches[3])))
+        assert int(ext.debug_read("da_gathered")[0]) == 1   # (ticket 3 ran on the twin: gathered convDa = the sibling's switch)
+        ext.close()
+        monkeypatch.delenv("SPFE_SPARSE_DA")
+        monkeypatch.delenv("SPFE_TWO_CHAINS")
+        for k, (g, e) in enumerate(zip(got, ref)):
+            for i in range(B):
+                _same(g[i], e[i], ("twin lifetime", how, k, i))
+
+
+def test_a_twin_that_cannot_be_built_is_not_fatal(monkeypatch):
+    """the twin is an optimisation — when its build fails (a second full set of buffers), spfe_create / the first
+    spfe_submit_batch carry on with one side chain.  SPFE_TWO_CHAINS=99 wants a twin and makes its build fail."""
+    import torch
+    for v in ALL:
+        monkeypatch.delenv(v, raising=False)
+    H, W, B, nf = 240, 376, 2, 200
+    blob = weights.synthetic(7, "dense")
+    sets = [torch.from_numpy(np.stack([synth.make_image(1800 + 5 * r + i, H, W) for i in range(B)])).cuda() for r in range(3)]
+    ref, rb = _reference(torch, "f32", H, W, B, nf, blob, sets)
+    monkeypatch.setenv("SPFE_TWO_CHAINS", "99")
+    ext = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=False, async_cov=True)      # spfe_create: twin wanted, fails, handle lives
+    assert int(ext.debug_read("two_chains")[0]) == 0 and int(ext.debug_read("twin_failed")[0]) == 1
+    recs = [torch.zeros(B * rb, dtype=torch.uint8, device="cuda") for _ in range(5)]
+    stream = torch.cuda.Stream()
+    for k in range(5):
+        t = ext.extract_batch_device(sets[k % 3].data_ptr(), B, recs[k].data_ptr(), stream.cuda_stream)
+    ext.wait_records(t, stream.cuda_stream)
+    stream.synchronize()
+    for k in range(5):
+        hk = recs[k].cpu().numpy()
+        for i in range(B):
+            _same(ext.view_record(hk[i * rb:(i + 1) * rb]), ref[k % 3][i], ("twin failed", k, i))
+    ext.close()
+    ext = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=False)                      # the lazy form: first spfe_submit_batch
+    himgs = [[synth.make_image(1800 + 5 * r + i, H, W) for i in range(B)] for r in range(3)]
+    got = [ext.collect_batch(ext.submit_batch(b)) for b in himgs]
+    assert int(ext.debug_read("two_chains")[0]) == 0 and int(ext.debug_read("twin_failed")[0]) == 1
+    ext.close()
+    for k in range(3):
+        for i in range(B):
+            _same(got[k][i], ref[k][i], ("twin failed, host path", k, i))
+
+
+def test_two_chains_into_one_record_buffer_stay_ordered(monkeypatch):
+    """with a twin, consecutive pipelined calls run on different handles; a caller that passes the SAME record
+    buffer call after call is still ordered — call i + 1's tail and chain do not write the buffer while chain i, on the
+    sibling's side stream, is still writing it.  30 calls into one buffer, frames alternating: the buffer holds the last
+    call's records, bit for bit."""
+    import torch
+    for v in ALL:
+        monkeypatch.delenv(v, raising=False)
+    H, W, B, nf = 240, 376, 3, 300
+    blob = weights.synthetic(7, "dense")
+    sets = [torch.from_numpy(np.stack([synth.make_image(1900 + 5 * r + i, H, W) for i in range(B)])).cuda() for r in range(2)]
+    for prec in ("f32", "bf16"):
+        ref, rb = _reference(torch, prec, H, W, B, nf, blob, sets)
+        monkeypatch.setenv("SPFE_TWO_CHAINS", "1")
+        ext = SPExtractor(nf, H, W, blob, max_batch=B, precision=prec, with_heat=False, async_cov=True)
+        monkeypatch.delenv("SPFE_TWO_CHAINS")
+        assert int(ext.debug_read("two_chains")[0]) == 1
+        rec = torch.zeros(B * rb, dtype=torch.uint8, device="cuda")
+        stream = torch.cuda.Stream()
+        for last in (29, 30):
+            for k in range(last + 1):
+                t = ext.extract_batch_device(sets[k & 1].data_ptr(), B, rec.data_ptr(), stream.cuda_stream)
+            ext.wait_records(t, stream.cuda_stream)
+            stream.synchronize()
+            hk = rec.cpu().numpy()
+            for i in range(B):
+                _same(ext.view_record(hk[i * rb:(i + 1) * rb]), ref[last & 1][i], ("one buffer", prec, last, i))
+        ext.close()

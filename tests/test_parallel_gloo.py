@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, NFRAMES=NFRAMES):
     from oracle import oracle
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -79,15 +79,19 @@ def test_record_codec_roundtrip():
         lay.unpack(bad)
 
 
-def test_two_rank_gloo_gather_matches_single_process():
+@pytest.mark.parametrize("NFRAMES,WORLD", [(5, 2), (64, 8), (67, 8)])
+def test_gloo_gather_matches_single_process(NFRAMES, WORLD):
+    """(5, 2): ragged shards on two ranks.  (64, 8): BASELINE configs[2] literally — 64 frames, 8 per rank, 8 ranks — as a dry
+    run on small frames: `shard_range` for 8, the 64-record gathered buffer, ALL 64 records on every rank (rank 7 included)
+    against the single-process result.  (67, 8): the same with ragged shards (9 / 8 frames)."""
     from oracle import oracle
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, q)) for r in range(WORLD)]
+    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, q, NFRAMES)) for r in range(WORLD)]
     for p in procs:
         p.start()
-    results = dict(q.get(timeout=240) for _ in range(WORLD))
+    results = dict(q.get(timeout=600) for _ in range(WORLD))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -97,7 +101,9 @@ def test_two_rank_gloo_gather_matches_single_process():
         o = oracle.extract(blob, synth.make_image(40 + fidx, H, W), NF)
         expect.append((fidx, o["K"], o["kp_xy"].tobytes(), o["desc"].tobytes(), o["occ_grid"].tobytes(),
                        o["cov2_inv"].tobytes()))
+    assert sorted(results) == list(range(WORLD))
     for r in range(WORLD):
+        assert len(results[r]) == NFRAMES
         assert results[r] == expect      # every rank holds every frame, in global order
 
 

@@ -5,7 +5,8 @@
 // cv::Mat / Eigen out: PCIe inclusive (0.36 MB up; record 1.1 MB + 2 x 1.44 MB of heat maps down at 752x480).
 // Built by __graft_entry__.build() against the interface stand-ins under tests/stubs (the GPU box has neither OpenCV nor the
 // reference tree); bench.py runs it and puts the line into `dropin_operator_call_ms`.
-// usage: dropin_latency <weights.spfw> <image.raw> <H> <W> <nfeatures> <calls> <warmup>   -> one JSON line
+// usage: dropin_latency <weights.spfw> <image.raw> <H> <W> <nfeatures> <calls> <warmup> [lazy]   -> one JSON line
+// (lazy: the opt-in form whose heat_inv_ stays on the device, orbslam_sp_extractor.hpp; default: the reference's post-call state)
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -25,7 +26,8 @@ SPExtractor::SPExtractor(int nfeatures) : SPExtractor(nfeatures, camera::height,
 using namespace orbslam;
 
 int main(int argc, char **argv) {
-  if (argc != 8) return 2;
+  if (argc != 8 && argc != 9) return 2;
+  const bool lazy = argc == 9 && std::string(argv[8]) == "lazy";
   camera::height = atoi(argv[3]);
   camera::width = atoi(argv[4]);
   tracking::num_features = atoi(argv[5]);
@@ -38,7 +40,8 @@ int main(int argc, char **argv) {
   if (!f || fread(pix.data(), 1, pix.size(), f) != pix.size()) return 3;
   fclose(f);
   try {
-    BaseExtractor *mpORBextractorLeft = new SPExtractor(tracking::num_features);   // tracker.cpp:131
+    BaseExtractor *mpORBextractorLeft = lazy ? new SPExtractor(tracking::num_features, H, W, common::model_path, 0, true)
+                                             : new SPExtractor(tracking::num_features);   // tracker.cpp:131
     cv::Mat im(H, W, CV_8UC1, pix.data());
     std::vector<double> ms;
     size_t K = 0;
@@ -56,10 +59,11 @@ int main(int argc, char **argv) {
       if (i >= warm) ms.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
       K = mvKeys.size();
       if (cov2_inv_.size() != K || heat_.rows != H || occ_grid.cols != W / 8) return 5;
+      if (dynamic_cast<SPExtractor *>(mpORBextractorLeft)->heat_inv_.empty() != lazy) return 6;
     }
     std::sort(ms.begin(), ms.end());
-    printf("{\"p50\": %.4f, \"p99\": %.4f, \"calls\": %d, \"K\": %zu, \"heat_maps\": true}\n", ms[ms.size() / 2],
-           ms[std::max<size_t>(1, (size_t)(ms.size() * 0.99)) - 1], (int)ms.size(), K);
+    printf("{\"p50\": %.4f, \"p99\": %.4f, \"calls\": %d, \"K\": %zu, \"heat_maps\": true, \"heat_inv_after_call\": %s}\n", ms[ms.size() / 2],
+           ms[std::max<size_t>(1, (size_t)(ms.size() * 0.99)) - 1], (int)ms.size(), K, lazy ? "false" : "true");
     delete mpORBextractorLeft;
   } catch (const std::exception &e) {
     fprintf(stderr, "dropin_latency: %s\n", e.what());
