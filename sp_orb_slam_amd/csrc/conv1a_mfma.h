@@ -14,11 +14,17 @@
 // matrix product it is 2 MFMAs per 32 pixels.
 //
 // Operands of one 32-pixel group (lane = (l31 = lane & 31, hi = lane >> 5)):
-//   A (weights, per channel tile j): row m = l31 <-> channel 32 j + l31, k = 8 hi + e <-> tap k (zero for k >= 9): the
-//     packed table `wtab` [2][64 lanes][8 bf16] built by the host;
+//   A (weights, per channel tile j): row m = l31 <-> channel 32 j + row_channel(m), k = 8 hi + e <-> tap k (zero for k >= 9):
+//     the packed table `wtab` [2][64 lanes][8 bf16] built by the host;
 //   B (pixels): column n = l31 <-> the group's pixel l31, k = 8 hi + e <-> its tap k, read from a bf16 patch in LDS;
-//   D[channel][pixel]: the lane owns one pixel, register r <-> channel 32 j + 8 (r >> 2) + 4 hi + (r & 3): four
-//     consecutive channels per (r >> 2) = 8 bytes of bf16 = half of a 16-byte piece of the NHWC activation.
+//   D[row][pixel]: the lane owns one pixel, register r <-> row 8 (r >> 2) + 4 hi + (r & 3).
+// Which channel a row computes is free (the rows are independent dot products), and round 6 chose it so that a lane ends up
+// with WHOLE 16-byte pieces of the NHWC activation: row_channel swaps bits 2 and 3 of the row index, so register r of lane
+// (l31, hi) holds channel 32 j + 16 (r >> 3) + 8 hi + (r & 7) — registers 8 rr .. 8 rr + 7 are the eight consecutive channels
+// of piece 4 j + 2 rr + hi of the lane's pixel.  (Before, a lane held the low or the high 8 bytes of every piece according to
+// hi; the 16 lanes of a ds_write_b64 group then all wrote the same half of their pieces: 2-way bank conflicts on every halo
+// write of the fused conv1b, 19 % of its LDS cycles.  Now the even pixels of a group write the low half of their piece while
+// the odd ones write the high half, and the other way round in a second store: conv_bf16_ws.hip, make_halo.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -61,29 +67,38 @@ __device__ __forceinline__ void product(const bf16x8 (&wA)[2], bf16x8 px, f32x16
   acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA[1], px, z, 0, 0, 0);
 }
 
-// epilogue of one (channel tile j, q = r >> 2): channels 32 j + 8 q + 4 hi + 0..3 of the lane's pixel, as 8 bytes of bf16
-__device__ __forceinline__ u32x2 finish4(const f32x16 &acc, int q, const float (&bias)[16]) {
-  float v[4];
+// row m of a channel tile <-> channel 32 j + row_channel(m): bits 2 and 3 of m swapped (host packing: spfe_pack.hip)
+__host__ __device__ constexpr int row_channel(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }
+
+// epilogue of one (channel tile j, rr = r >> 3): channels 32 j + 16 rr + 8 hi + 0..7 of the lane's pixel = piece 4 j + 2 rr + hi
+// of its 128-byte NHWC row, as 16 bytes of bf16
+// (scalar fmaf / max on purpose.  The packed forms — v_pk_fma_f32 on register pairs, the ReLU as one v_pk_max_i16 on the rounded
+// pair, bit-identical and half the VALU instructions — were measured in the producers of conv1b (round 6): 1280x720 x 8 392 ->
+// 448 us.  Packed f32 arithmetic beside a saturated MFMA stream costs the matrix pipe far more than the issue slots it saves.)
+__device__ __forceinline__ u32x4 finish8(const f32x16 &acc, int rr, const float (&bias)[16]) {
+  float v[8];
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    v[m] = __builtin_fmaf(acc[4 * q + m], 1.0f / 255.0f, bias[4 * q + m]);
+  for (int m = 0; m < 8; ++m) {
+    v[m] = __builtin_fmaf(acc[8 * rr + m], 1.0f / 255.0f, bias[8 * rr + m]);
     v[m] = __builtin_fmaxf(v[m], 0.0f);
   }
-  u32x2 o;
+  u32x4 o;
   o.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v[0], v[1]}, bf16x2));
   o.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v[2], v[3]}, bf16x2));
+  o.z = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v[4], v[5]}, bf16x2));
+  o.w = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v[6], v[7]}, bf16x2));
   return o;
 }
 
 // per-lane constants: A operands from the host table, the lane's 2 x 16 biases (register r of tile j <-> channel
-// 32 j + 8 (r >> 2) + 4 hi + (r & 3))
+// 32 j + 16 (r >> 3) + 8 hi + (r & 7))
 __device__ __forceinline__ void load_constants(const void *wtab, const float *b64, int lane, bf16x8 (&wA)[2], float (&bias)[2][16]) {
   const int hi = lane >> 5;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     wA[j] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4 *>(wtab)[j * 64 + lane]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bias[j][r] = b64[32 * j + 8 * (r >> 2) + 4 * hi + (r & 3)];
+    for (int r = 0; r < 16; ++r) bias[j][r] = b64[32 * j + 16 * (r >> 3) + 8 * hi + (r & 7)];
   }
 }
 

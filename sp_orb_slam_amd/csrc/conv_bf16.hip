@@ -684,13 +684,13 @@ __global__ __launch_bounds__(256) void conv1a_bf16_kernel(const uint8_t *__restr
     c1a::product(wA, px, acc);
     const int gy = ty0 + row, gx = tx0 + l31;
     if (gy < H && gx < W) {
-      unsigned short *o = out + (((size_t)b * H + gy) * W + gx) * 64 + 4 * hi;
+      unsigned short *o = out + (((size_t)b * H + gy) * W + gx) * 64 + 8 * hi;   // (the lane's pieces: 4 j + 2 rr + hi, conv1a_mfma.h)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const c1a::u32x2 v = c1a::finish4(acc[j], q, bias[j]);
-          *reinterpret_cast<uint2 *>(o + 32 * j + 8 * q) = make_uint2(v.x, v.y);
+        for (int rr = 0; rr < 2; ++rr) {
+          const c1a::u32x4 v = c1a::finish8(acc[j], rr, bias[j]);
+          *reinterpret_cast<uint4 *>(o + 32 * j + 16 * rr) = make_uint4(v.x, v.y, v.z, v.w);
         }
     }
   }

@@ -87,6 +87,9 @@ __device__ unsigned long long ws_dbg[10];
 #ifndef WS_EPI_GAP
 #define WS_EPI_GAP 2     // the gap (0..3) of a K step that carries the epilogue item
 #endif
+#ifndef WS_C1A_STORE
+#define WS_C1A_STORE 1   // TAG 2, how a producer lane stores its four 16-byte pieces of a halo pixel: 1 = ds_write_b128, 2 = two conflict-free ds_write_b64 (see make_halo)
+#endif
 #ifndef WS_ABLATE
 #define WS_ABLATE 0  // probe builds: 1 = producers issue no halo passes in the loop, 2 = consumers issue no MFMAs,
                      // 3 = every tile loads the same halo (cache hits only), 4 = no fragment reads, 5 = no stores
@@ -435,7 +438,8 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
     constexpr int NGRP = (ROWS * COLS + 31) / 32;   // 11
     [[maybe_unused]] bf16x8 wA[2];
     [[maybe_unused]] float bias1[2][16];
-    [[maybe_unused]] unsigned tap0[3], hdst[3][8], pdst[3];
+    [[maybe_unused]] unsigned tap0[3], hdst[3][4], pdst[3];
+    [[maybe_unused]] bool podd[3];
     [[maybe_unused]] int hrc[3], prel[3];
     if constexpr (TAG == 2) {
       c1a::load_constants(p.w1a, p.b1a, lane, wA, bias1);
@@ -445,8 +449,18 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
         const int g = pw + 4 * gi, P = 32 * g + l31, r = P / COLS, c = P % COLS, r0 = (32 * g) / COLS;
         tap0[gi] = (unsigned)(((r - r0) * c1a::PATCH_PITCH + c + 2) * 2);   // patch column 0 <-> image column x0 - 4
         hrc[gi] = (g < NGRP && P < ROWS * COLS) ? (int)(((unsigned)(r - 1) << 16) | ((unsigned)(c - 1) & 0xffffu)) : (int)0x80000000;
+        // the lane's four whole pieces of its pixel's 128-byte row (conv1a_mfma.h): piece 4 j + 2 rr + hi, at its swizzled slot,
+        // one ds_write_b128 each (WS_C1A_STORE 1, the default: half the store instructions of the 8-byte form and no selects).
+        // WS_C1A_STORE 2 = the bank-conflict-free form: two ds_write_b64 per piece — FIRST the low 8 bytes from the even pixels
+        // and the high 8 bytes from the odd ones, then the other halves (pixels c and c + 1 share a slot and sit 128 B apart, the
+        // same banks of a 32-bank store; with different halves the 16 lanes of a store group cover all 32 banks once).  Measured
+        // (round 6, 1280x720 x 8): SQ_LDS_BANK_CONFLICT 19 % -> 4.8 % of the LDS cycles, LDS-active cycles -16 %, and the kernel
+        // 1.6 % SLOWER (392.4 -> 398.7 us): its 16 selects + 4 address flips per group cost the producers' issue slots more than
+        // the conflicts cost the LDS.  hdst = the address of the (first) store.
+        podd[gi] = (c & 1) != 0;
 #pragma unroll
-        for (int pi = 0; pi < 8; ++pi) hdst[gi][pi] = (unsigned)(P * 128 + ((pi ^ ((c >> 1) & 7)) * 16) + 8 * hi);
+        for (int k = 0; k < 4; ++k)
+          hdst[gi][k] = (unsigned)(P * 128 + (((2 * k + hi) ^ ((c >> 1) & 7)) * 16) + (WS_C1A_STORE == 2 ? 8 * (c & 1) : 0));
         // the group's patch: 4 rows x 40 bytes starting at image column x0 - 4 (4-byte aligned; widths are multiples of
         // 8, so a dword is entirely inside the frame or entirely outside): lane < 40 loads one dword = 4 pixels
         const int prow = lane / 10, pdw = lane % 10;
@@ -493,21 +507,29 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
         f32x16 acc1[2];
         c1a::product(wA, pxop, acc1);
         if (hrc[gi] != (int)0x80000000) {
+          // conv1b's own zero padding (border tiles only): halo pixels outside the frame are zeros, not conv1a evaluated out there
+          bool outside = false;
+          if (border) {
+            const int hy = y0 + (hrc[gi] >> 16), hx = x0 + (int)(short)(hrc[gi] & 0xffff);
+            outside = !((unsigned)hy < (unsigned)p.H && (unsigned)hx < (unsigned)p.W);
+          }
+          [[maybe_unused]] const bool odd = podd[gi];
 #pragma unroll
           for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-              *reinterpret_cast<__attribute__((address_space(3))) u32x2 *>(lds + buf * HALO_BYTES + hdst[gi][4 * j + q]) =
-                  c1a::finish4(acc1[j], q, bias1[j]);
-          if (border) {
-            // conv1b's own zero padding: halo pixels outside the frame are zeros, not conv1a evaluated out there
-            const int hy = y0 + (hrc[gi] >> 16), hx = x0 + (int)(short)(hrc[gi] & 0xffff);
-            if (!((unsigned)hy < (unsigned)p.H && (unsigned)hx < (unsigned)p.W)) {
-#pragma unroll
-              for (int pi = 0; pi < 8; ++pi)
-                *reinterpret_cast<__attribute__((address_space(3))) u32x2 *>(lds + buf * HALO_BYTES + hdst[gi][pi]) = (u32x2){0u, 0u};
+            for (int rr = 0; rr < 2; ++rr) {
+              u32x4 v = c1a::finish8(acc1[j], rr, bias1[j]);
+              if (border) { if (outside) v = (u32x4){0u, 0u, 0u, 0u}; }   // (wave-uniform branch: interior tiles carry no select)
+              const unsigned a = hdst[gi][2 * j + rr];
+              if constexpr (WS_C1A_STORE == 2) {
+                *reinterpret_cast<__attribute__((address_space(3))) u32x2 *>(lds + buf * HALO_BYTES + a) =
+                    odd ? (u32x2){v.z, v.w} : (u32x2){v.x, v.y};
+                *reinterpret_cast<__attribute__((address_space(3))) u32x2 *>(lds + buf * HALO_BYTES + (a ^ 8u)) =
+                    odd ? (u32x2){v.x, v.y} : (u32x2){v.z, v.w};
+              } else {
+                *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(lds + buf * HALO_BYTES + a) = v;
+              }
             }
-          }
         }
       }
     };

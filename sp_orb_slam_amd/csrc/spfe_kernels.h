@@ -139,7 +139,9 @@ struct CovScratch {
   int *npop;      // [B][kmax]
   int *dirty;     // [B][kmax] keypoints whose lone region meets a lower keypoint's
   int *nxt;       // [B][kmax] next dirty member of the same component (ascending) or -1
-  float *nxy;     // [B][kmax][2] keypoint position of nxt
+  int *chain;     // [B][kmax] int4 {keypoint, x, y, overflow slot}: the dirty members, each component's chain contiguous and in
+                  // ascending keypoint order, the chains longest first (the replay reads a chain with ONE load)
+  int *wmeta;     // [B][kmax] int2 {first entry in `chain`, members} of worker (= chain) number w
   int *workers;   // [B][kmax] lowest dirty member of each component
   int *counters;  // [B][4] number of dirty keypoints, number of components, overflow slots taken, claim edges listed
   int *edges;     // [B][ecap] int2 (lower claimant, dirty keypoint): the union-find's input, written by the classification (or null)

@@ -360,12 +360,13 @@ int build(spfe_handle h, const spfe_config *cfg, spfe_handle sibling) {
     HIP_TRY(hipMemcpy(h->d_w1a, w.data(), w.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->d_b1a, bv.data(), bv.size() * 4, hipMemcpyHostToDevice));
     if (h->bf16) {
-      // conv1a_mfma.h: [j 2][lane 64][e 8] = bf16(w[channel 32 j + (lane & 31)][tap 8 (lane >> 5) + e]), 0 for taps >= 9
+      // conv1a_mfma.h: [j 2][lane 64][e 8] = bf16(w[channel 32 j + row_channel(lane & 31)][tap 8 (lane >> 5) + e]), 0 for taps >= 9
+      // (row_channel: bits 2 and 3 of the row swapped, so that a lane of the product holds whole 16-byte pieces)
       std::vector<unsigned short> tab(2 * 64 * 8, 0);
       for (int j = 0; j < 2; ++j)
         for (int ln = 0; ln < 64; ++ln)
           for (int e = 0; e < 8; ++e) {
-            const int t = 8 * (ln >> 5) + e, co = 32 * j + (ln & 31);
+            const int t = 8 * (ln >> 5) + e, m = ln & 31, co = 32 * j + ((m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1));
             if (t < 9) tab[(j * 64 + ln) * 8 + e] = host_bf16_rne(Wt[co * 9 + t]);
           }
       if ((rc = dev_alloc(h, &h->d_w1a_tab, tab.size()))) return rc;
@@ -420,7 +421,8 @@ int build(spfe_handle h, const spfe_config *cfg, spfe_handle sibling) {
     if ((rc = dev_alloc(h, &h->cov.npop, (size_t)B * h->kmax))) return rc;
     if ((rc = dev_alloc(h, &h->cov.dirty, (size_t)B * h->kmax))) return rc;
     if ((rc = dev_alloc(h, &h->cov.nxt, (size_t)B * h->kmax))) return rc;
-    if ((rc = dev_alloc(h, &h->cov.nxy, (size_t)B * h->kmax * 2))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.chain, (size_t)B * h->kmax * 4))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.wmeta, (size_t)B * h->kmax * 2))) return rc;
     if ((rc = dev_alloc(h, &h->cov.workers, (size_t)B * h->kmax))) return rc;
     if ((rc = dev_alloc(h, &h->cov.counters, (size_t)B * 4))) return rc;
     h->cov.ecap = h->cov_ecap_env >= 0 ? h->cov_ecap_env : 32 * h->kmax;   // (~24 pops per keypoint on the dense synthetic detector, a quarter of the keypoints dirty)

@@ -135,6 +135,22 @@ def test_bf16_flip_report_supports_the_bf16_bounds():
         assert c["keypoints_common_total"] >= 0.95 * min(c["keypoints_f32_total"], c["keypoints_bf16_total"]), name
 
 
+def test_bf16_flip_report_at_3840x2160():
+    """The same report at the largest frame the path takes (round 6; DESIGN §12.5 of round 5): tests/golden/flip_report_bf16_2160p.json,
+    4 seeded 3840x2160 frames x {dense, sparse} (129,600 cells each; 500 s of CPU) — the bf16 mode behaves there as at the sizes
+    above: ~2 % arg-max flips, Jaccard 0.90 - 0.92, descriptors within 2.6 % of the matcher's tightest threshold."""
+    import json
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "flip_report_bf16_2160p.json")))
+    assert set(d["configs"]) == {"3840x2160_dense", "3840x2160_sparse"}
+    for name, c in d["configs"].items():
+        assert c["frames"] == 4 and c["cells_per_frame"] == 129600, name
+        assert c["desc_max_abs_max"] <= 5e-3 and c["desc_cos_min"] >= 0.9999, name
+        assert c["desc_l2_of_common_keypoints"]["max"] <= 0.03 and c["desc_l2_rows_above"]["0.03"] == 0, name
+        assert c["jaccard_min"] >= 0.87 + 0.015, name
+        assert 0.0 < c["arg_flips_per_cell"] < 0.05, name
+        assert c["keypoints_common_total"] >= 0.95 * min(c["keypoints_f32_total"], c["keypoints_bf16_total"]), name
+
+
 def test_bf16_flip_report_tool_runs_on_a_small_frame():
     """The report's per-frame function on one 64x96 frame (CPU, a second): same fields, same invariants."""
     import sys

@@ -105,12 +105,12 @@ int main(int argc, char **argv) {
   if (fuse) {
     if (!pool || cout != 64) { printf("fuse needs pool = 1, cout = 64\n"); return 2; }
     CK(hipMalloc(&d_img, img.size()));
-    // conv1a_mfma.h operand table: [j][lane][e] = bf16(w[tap 8 (lane >> 5) + e][channel 32 j + (lane & 31)])  (w1a is [tap][64] here)
+    // conv1a_mfma.h operand table: [j][lane][e] = bf16(w[tap 8 (lane >> 5) + e][channel 32 j + row_channel(lane & 31)])  (w1a is [tap][64] here)
     std::vector<unsigned short> tab(2 * 64 * 8, 0);
     for (int j = 0; j < 2; ++j)
       for (int ln = 0; ln < 64; ++ln)
         for (int e = 0; e < 8; ++e) {
-          const int t = 8 * (ln >> 5) + e, co = 32 * j + (ln & 31);
+          const int t = 8 * (ln >> 5) + e, co = 32 * j + spfe::c1a::row_channel(ln & 31);
           if (t < 9) tab[(j * 64 + ln) * 8 + e] = bf16_rne(w1a[t * 64 + co]);
         }
     CK(hipMalloc(&d_w1a, tab.size() * 2));
