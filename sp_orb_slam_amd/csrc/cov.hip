@@ -49,8 +49,6 @@ __device__ __forceinline__ int cov_untag(int gen, int v) { return (v & (int)0xff
 #define COV_WIN 16       // the window covers dx,dy in [-16, 15] around the keypoint
 #define COV_WAVES 2      // wavefronts (= walks) per workgroup: 12.5 KB of LDS for lone walks (21 KB for replays, which stage `done` too)
 #define COV_OW 256       // popped pixels OUTSIDE the window a walk can remember (its visited set out there)
-#define COV_CL 1024      // replay: pops of the chain's earlier members kept in LDS (patches for windows loaded before their stamps)
-#define COV_AHEAD 4      // replay: windows of this many members in flight
 
 struct WaveMem {         // LDS of one wavefront
   float hv[32 * 32];     // heat_inv window
@@ -58,8 +56,7 @@ struct WaveMem {         // LDS of one wavefront
   float lqv[COV_LCAP];
   uint32_t bm[32];       // own-visited bitmap
   int ow[COV_OW];        // popped pixels outside the window (visited set there), now = count
-  int dn[32 * 32];       // done window — REPLAY ONLY, and behind everything the lone walks use: their workgroups allocate the struct up to here
-  int cl[COV_CL];        // REPLAY ONLY: pixels popped by the chain's earlier members (since the last fence), see cov_replay_kernel
+  int dn[32 * 32];       // done window — REPLAY ONLY, and last: the lone walks' workgroups allocate the struct up to here
 };                       // (6.1 KB a walk instead of 10.1: 24 walks fit a CU instead of 14, and three walk workgroups fit beside an
                          // f32 convolution workgroup's 120 KB instead of one)
 constexpr size_t COV_WALK_LDS = offsetof(WaveMem, dn);
@@ -75,7 +72,6 @@ struct Walk {
   unsigned wmagic;       // floor((2^32 - 1) / W): row_of()
   int gen = 0;           // CovScratch::gen (replay: the done map's entries are tagged)
   float ha = 1.0f, hb = 0.0f;   // to_heat's scale / shift of heat_inv for this frame (FrameBufs::heat_consts[2..3])
-  int ncl = 0;           // replay: entries of m->cl (pixels popped by earlier members of the chain whose stamps a global lookup may not see yet)
 };
 // heat_inv of a pixel from the log heat map: one float multiply, then one float add (sp_extractor.cpp:461-474 as the oracle
 // fixes it; -ffp-contract=off) — the bits mask_and_heat_norm_kernel writes when the map is an output (SPFE_FLAG_HEAT).  Without
@@ -148,11 +144,6 @@ __device__ __attribute__((noinline)) bool ow_seen(const WaveMem *m, int now, int
     if (m->ow[u] == id) return true;
   return false;
 }
-__device__ __attribute__((noinline)) bool cl_seen(const WaveMem *m, int ncl, int id) {
-  for (int u = 0; u < ncl; ++u)
-    if (m->cl[u] == id) return true;
-  return false;
-}
 
 // The FIFO walk, run by the whole wavefront in lock step, up to 16 pops at a time.  A group is the next
 // G = min(16, tail - head) FIFO entries; lane = 4 * g + t examines neighbour t (left, up, right, down —
@@ -212,7 +203,6 @@ __device__ int walk(const Walk &w, int lane) {
         v = hinv_of(slow_ld_f(w.hinv, nid), w.ha, w.hb);
         take = v > 0.0f && v < here;
         if (take && REPLAY) take = !(cov_untag(w.gen, slow_ld_i(w.done, nid)) < w.j);
-        if (take && REPLAY) take = !cl_seen(m, w.ncl, nid);   // (an earlier member of the chain whose stamp is not fenced yet)
         if (take) take = !ow_seen(m, now, nid);
       }
     }
@@ -331,8 +321,7 @@ struct CovFrame {
   float *qvals;
   int *ovf_slot, *novf, *ovf_q;   // overflow slots: pop lists of the walks that outgrew qcap
   float *ovf_v;
-  int4 *chain;                    // [kmax] {keypoint, x, y, overflow slot}: chains contiguous, members ascending (CovScratch::chain)
-  int2 *wmeta;                    // [kmax] {first chain entry, members} per worker
+  float *nxy;                     // [kmax][2] position of nxt[j] (so that one load yields the next member AND its window)
   int *nedges;                    // claim edges (lower claimant, dirty keypoint) found by the classification: count ...
   int2 *edges;                    // ... and list [ecap] (null: the link kernel walks the pop lists itself)
   int K;
@@ -364,8 +353,7 @@ __device__ __forceinline__ CovFrame cov_frame(const FrameBufs &f, const RecordLa
   c.ovf_slot = cs.ovf_slot + (size_t)b * rl.kmax;
   c.ovf_q = cs.ovf_q + (size_t)b * cs.ovf_slots * cs.ovf_cap;
   c.ovf_v = cs.ovf_v + (size_t)b * cs.ovf_slots * cs.ovf_cap;
-  c.chain = reinterpret_cast<int4 *>(cs.chain) + (size_t)b * rl.kmax;
-  c.wmeta = reinterpret_cast<int2 *>(cs.wmeta) + (size_t)b * rl.kmax;
+  c.nxy = cs.nxy + (size_t)b * rl.kmax * 2;
   c.nedges = cs.counters + 4 * b + 3;
   c.edges = cs.edges ? reinterpret_cast<int2 *>(cs.edges) + (size_t)b * cs.ecap : nullptr;
   return c;
@@ -389,12 +377,9 @@ __global__ __launch_bounds__(64 * COV_WAVES) void cov_walk_kernel(FrameBufs f, R
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = blockIdx.x * COV_WAVES + wv;
   const CovFrame c = cov_frame(f, rl, cs, b, H, W);
-  // (the keypoint's position is read beside the frame's K, not behind the test against it: the record holds kmax positions
-  // whatever K says, and every dependent global load of this latency chain is a ~2 us round trip)
-  const float kx = j < rl.kmax ? c.kp_xy[2 * j] : 0.0f, ky = j < rl.kmax ? c.kp_xy[2 * j + 1] : 0.0f;
   if (j >= c.K) return;
   Walk w{reinterpret_cast<WaveMem *>(s_raw + wv * COV_WALK_LDS), c.hinv, nullptr, c.queues + (size_t)j * cs.qcap, c.qvals + (size_t)j * cs.qcap, cs.qcap, W, H,
-         (int)kx, (int)ky, j, w_magic(W), 0, c.ha, c.hb};
+         (int)c.kp_xy[2 * j], (int)c.kp_xy[2 * j + 1], j, w_magic(W), 0, c.ha, c.hb};
   stage_window<false>(w, lane);
   int n = walk<false>(w, lane);
   if (n == -1) {
@@ -430,13 +415,10 @@ __global__ __launch_bounds__(64 * COV_WAVES) void cov_classify_kernel(FrameBufs 
   const int b = blockIdx.y, lane = threadIdx.x & 63;
   const int j = blockIdx.x * COV_WAVES + (threadIdx.x >> 6);
   const CovFrame c = cov_frame(f, rl, cs, b, H, W);
-  // (slot and pop count are read beside K and the status, not behind the test: see cov_walk_kernel)
-  const int slot = j < rl.kmax ? c.ovf_slot[j] : -1;
-  const int n = j < rl.kmax ? c.npop[j] : 0;
   if (j >= c.K || (c.hdr[2] & 1)) return;
-  int *q;
-  if (__builtin_expect(slot < 0, 1)) q = c.queues + (size_t)j * cs.qcap;
-  else q = c.ovf_q + (size_t)slot * cs.ovf_cap;
+  int *q; float *qv; int cap;
+  pop_list(c, cs, j, q, qv, cap);
+  const int n = c.npop[j];
   int bad = 0;
   for (int i0 = 1; i0 < n; i0 += 64) {   // claims were made by the previous kernel  (uniform trip count: ballots inside)
     const int i = i0 + lane;
@@ -479,28 +461,19 @@ __global__ __launch_bounds__(LINK_THREADS) void cov_link_kernel(FrameBufs f, Rec
                                                                 int H, int W) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const CovFrame c = cov_frame(f, rl, cs, b, H, W);
-  // Everything this kernel reads from global memory was written by the kernels in front of it (other XCDs: every load is a
-  // round trip of ~2 us), so the loads whose ADDRESSES do not depend on loaded values go out together, first: the counts, this
-  // thread's dirty keypoint and claim edge (speculative: the arrays hold kmax / ecap entries whatever the counts say).  The
-  // dependent chain count -> edge -> dirty keypoint -> its position was four round trips of a single frame's 22 us.
   const int nd = *c.ndirty;
-  const int st = c.hdr[2];
-  const int ne = c.edges ? *c.nedges : -1;
-  const int2 ed0 = (c.edges && tid < cs.ecap) ? c.edges[tid] : make_int2(0, 0);
-  const int dj0 = tid < rl.kmax ? c.dirty[tid] : 0;
   const int K = c.K;
-  if (nd == 0 || (st & 1)) return;
+  if (nd == 0 || (c.hdr[2] & 1)) return;
   extern __shared__ __attribute__((aligned(16))) int smem_i[];
   int *parent = smem_i;      // [K] union-find forest over keypoint indices
-  int *ckey = smem_i + K;    // [K] per dirty keypoint (small frames' path): its chain's key (length << 15 | 0x7fff - first member)
-  for (int j = tid; j < K; j += LINK_THREADS) parent[j] = j;
-  // this thread's dirty keypoint: position and overflow slot for the chain entry (addresses depend on dj0 only: in flight
-  // under the union phase)
-  float myx = 0.0f, myy = 0.0f;
-  int myslot = -1;
-  if (tid < nd) { myx = c.kp_xy[2 * dj0]; myy = c.kp_xy[2 * dj0 + 1]; myslot = c.ovf_slot[dj0]; }
+  int *leader = smem_i + K;  // [K] lowest DIRTY member of the component rooted here
+  for (int j = tid; j < K; j += LINK_THREADS) { parent[j] = j; leader[j] = COV_INF; }
   __syncthreads();
   // every pixel links its claimants to its lowest claimant: union(claim[p], j).
+  // (one wavefront per dirty keypoint, lanes over its pixels)
+  // (a quarter-wavefront per dirty keypoint, its 16 lanes over the pixels: the phase is two dependent global round trips
+  // per keypoint — pop list, then the claims of its pixels — and 64 groups keep four times as many of them in flight
+  // as 16 wavefronts did)
   auto unite = [&](int a, int bb) {   // hook the larger root under the smaller one
     while (true) {
       a = uf_find(parent, a);
@@ -513,17 +486,13 @@ __global__ __launch_bounds__(LINK_THREADS) void cov_link_kernel(FrameBufs f, Rec
       bb = lo;
     }
   };
+  const int ne = c.edges ? *c.nedges : -1;
   const bool from_edges = ne >= 0 && ne <= cs.ecap;   // the classification listed every claim edge: ONE global round trip
-  if (from_edges) {
-    if (tid < ne) unite(ed0.x, ed0.y);
-    for (int e = tid + LINK_THREADS; e < ne; e += LINK_THREADS) {
+  if (from_edges)
+    for (int e = tid; e < ne; e += LINK_THREADS) {
       const int2 ed = c.edges[e];
       unite(ed.x, ed.y);
     }
-  }
-  // (a quarter-wavefront per dirty keypoint, its 16 lanes over the pixels: the phase is two dependent global round trips
-  // per keypoint — pop list, then the claims of its pixels — and 64 groups keep four times as many of them in flight
-  // as 16 wavefronts did)
   constexpr int GL = 16;
   const int gl = tid & (GL - 1), grp = tid / GL;
   for (int d = grp; d < (from_edges ? 0 : nd); d += LINK_THREADS / GL) {
@@ -532,9 +501,19 @@ __global__ __launch_bounds__(LINK_THREADS) void cov_link_kernel(FrameBufs f, Rec
     pop_list(c, cs, j, q, qv, cap);
     const int n = c.npop[j];
     for (int i = 1 + gl; i < n; i += GL) {
-      const int a = cov_untag(cs.gen, c.claim[q[i]]);
+      int a = cov_untag(cs.gen, c.claim[q[i]]);
+      int bb = j;
       if (a >= j) continue;
-      unite(a, j);
+      while (true) {  // hook the larger root under the smaller one
+        a = uf_find(parent, a);
+        bb = uf_find(parent, bb);
+        if (a == bb) break;
+        const int hi = a > bb ? a : bb, lo = a > bb ? bb : a;
+        const int old = atomicMin(&parent[hi], lo);
+        if (old == hi) break;
+        a = old;
+        bb = lo;
+      }
     }
   }
   __syncthreads();
@@ -547,11 +526,11 @@ __global__ __launch_bounds__(LINK_THREADS) void cov_link_kernel(FrameBufs f, Rec
   if (nd <= LINK_THREADS) {
     // few dirty keypoints (a frame has a few hundred at most on the dense synthetic detector, none on a trained one): every
     // thread owns one and scans the others' (root, index) keys in LDS — broadcast reads, no barrier — for its successor in
-    // the component, its position in the chain and the chain's length and first member: the 36 barrier-separated passes of
-    // the bitonic sort below were most of this kernel's 25 us on a single frame
+    // the component and for "am I the first": the 36 barrier-separated passes of the bitonic sort below were most of this
+    // kernel's 25 us on a single frame
     int myj = -1, myroot = -1;
     if (tid < nd) {
-      myj = dj0;
+      myj = c.dirty[tid];
       myroot = parent[myj];
       key[tid] = (myroot << 15) | myj;
     }
@@ -562,44 +541,31 @@ __global__ __launch_bounds__(LINK_THREADS) void cov_link_kernel(FrameBufs f, Rec
     // atomic counter nearly every fat workgroup of a 1280x720 frame held one long chain, and in pipelined bf16 calls each of
     // them keeps a register-resident-weights convolution workgroup off its CU for that long.)  The order changes no result:
     // components are independent.
-    // ... and the CHAINS THEMSELVES are laid out in that order, contiguously, members ascending (round 6): entry = {keypoint, x, y,
-    // overflow slot}.  The replay wavefront reads its whole chain with one load and has the windows of the next COV_AHEAD
-    // members in flight; following nxt[] from member to member was a global round trip per member (~5 us of a member's ~0.6 us
-    // of work: a single frame's replay took 61 us for a longest chain of 9 members).
-    int *wkey = key + nd;                 // [<= nd] chain keys of the workers
+    int *wkey = key + nd;                 // [<= nd] (chain length << 15 | 0x7fff - first member) of the workers
     __shared__ int s_nw;
     if (tid == 0) s_nw = 0;
-    int jn = 0x7fff, jmin = 0x7fff, pos = 0, len = 0;
+    int jn = 0x7fff, first = 1, len = 0;
     if (tid < nd) {
       for (int e = 0; e < nd; ++e) {
         const int ke = key[e], je = ke & 0x7fff;
         const bool same = (ke >> 15) == myroot;
         jn = same && je > myj && je < jn ? je : jn;
-        jmin = same && je < jmin ? je : jmin;
-        pos += same && je < myj;
+        first &= !(same && je < myj);
         len += same;
       }
       jn = jn == 0x7fff ? -1 : jn;
       c.nxt[myj] = jn;
+      if (jn >= 0) { c.nxy[2 * myj] = c.kp_xy[2 * jn]; c.nxy[2 * myj + 1] = c.kp_xy[2 * jn + 1]; }
     }
-    const bool first = tid < nd && pos == 0;
-    const int mykey = (len << 15) | (0x7fff - jmin);   // the chain's key: the same for all its members
-    if (tid < nd) ckey[tid] = mykey;
     __syncthreads();
-    if (first) wkey[atomicAdd(&s_nw, 1)] = mykey;
-    // entries of the chains listed before this one = dirty keypoints whose chain key is larger
-    int base = 0;
-    if (tid < nd) {
-      for (int e = 0; e < nd; ++e) base += ckey[e] > mykey;
-      c.chain[base + pos] = make_int4(myj, (int)myx, (int)myy, myslot);
-    }
+    const int mykey = (len << 15) | (0x7fff - myj);
+    if (tid < nd && first) wkey[atomicAdd(&s_nw, 1)] = mykey;
     __syncthreads();
     const int nw = s_nw;
-    if (first) {
+    if (tid < nd && first) {
       int rank = 0;
       for (int e = 0; e < nw; ++e) rank += wkey[e] > mykey;
       c.workers[rank] = myj;
-      c.wmeta[rank] = make_int2(base, len);
     }
     if (tid == 0) *c.nworkers = nw;
     return;
@@ -627,20 +593,13 @@ __global__ __launch_bounds__(LINK_THREADS) void cov_link_kernel(FrameBufs f, Rec
       }
       __syncthreads();
     }
-  // the sorted list IS the chain layout: components contiguous, members ascending (in root order, not by length)
   for (int d = tid; d < nd; d += LINK_THREADS) {
     const int kd = key[d], j = kd & 0x7fff, root = kd >> 15;
     const int kn = d + 1 < nd ? key[d + 1] : COV_INF;
     const int jn = (kn != COV_INF && (kn >> 15) == root) ? (kn & 0x7fff) : -1;
     c.nxt[j] = jn;
-    c.chain[d] = make_int4(j, (int)c.kp_xy[2 * j], (int)c.kp_xy[2 * j + 1], c.ovf_slot[j]);
-    if (d == 0 || (key[d - 1] >> 15) != root) {
-      int len = 1;
-      while (d + len < nd && (key[d + len] >> 15) == root) ++len;
-      const int wi = atomicAdd(c.nworkers, 1);
-      c.workers[wi] = j;
-      c.wmeta[wi] = make_int2(d, len);
-    }
+    if (jn >= 0) { c.nxy[2 * j] = c.kp_xy[2 * jn]; c.nxy[2 * j + 1] = c.kp_xy[2 * jn + 1]; }
+    if (d == 0 || (key[d - 1] >> 15) != root) c.workers[atomicAdd(c.nworkers, 1)] = j;
   }
 }
 
@@ -665,36 +624,17 @@ __global__ __launch_bounds__(64 * WV) void cov_replay_kernel(FrameBufs f, Record
   }
   const int widx = blockIdx.x * WV + wv;
   const CovFrame c = cov_frame(f, rl, cs, b, H, W);
-  // (the worker's chain descriptor is read beside the counts, not behind them: widx < kmax, the entry exists either way)
-  const int2 wm = c.wmeta[widx];
   if ((c.hdr[2] & 1) || widx >= *c.nworkers) return;
-  const int cbase = wm.x, clen = wm.y;
+  int j = c.workers[widx];
   WaveMem *m = &s_mem[wv];
+  const int *prev_q = nullptr;
+  float fx = c.kp_xy[2 * j], fy = c.kp_xy[2 * j + 1];
+  int jn = c.nxt[j];
+  float nfx = c.nxy[2 * j], nfy = c.nxy[2 * j + 1];   // (garbage when jn < 0: never used)
+  WinRegs win;
+  load_window<true>(c.hinv, c.done, W, H, (int)fx, (int)fy, lane, win, cs.gen, c.ha, c.hb);
+  int n_prev = 0, j_prev = -1;
   const unsigned wmagic = w_magic(W);
-  // The chain, members in ascending keypoint order: lane i holds member k0 + i (one load; chains of more than 64 members
-  // reload every 64).  What a member needs from global memory is its 32 x 32 window of heat_log and of the `done` map AS THE
-  // CLASSIFICATION LEFT IT: components own disjoint pixel sets, so the only stamps that can change under this wavefront's feet
-  // are its own chain's — and those it applies itself, from the pops it keeps in LDS (WaveMem::cl), to every window it stores.
-  // So the windows of the next COV_AHEAD members are in flight while a member walks (a member is ~0.6 us of work, its window a
-  // ~3 us round trip; with one window ahead and the chain followed through nxt[] a member cost ~5 us).  The global stamps are
-  // still written (a later member's look OUTSIDE its window reads the map; the last resort and debug reads expect them).
-  // When the list is full: fence (the stamps so far are visible to loads issued from now on), empty it, and re-issue the
-  // windows already in flight — they were loaded before those stamps.
-  int4 me = make_int4(-1, 0, 0, -1);
-  int k0 = 0;
-  if (lane < clen) me = c.chain[cbase + lane];
-  WinRegs win[COV_AHEAD];
-  auto member = [&](int k) -> int4 {   // (k0 <= k < k0 + 64, wave-uniform k)
-    const int i = k - k0;
-    return make_int4(__builtin_amdgcn_readlane(me.x, i), __builtin_amdgcn_readlane(me.y, i), __builtin_amdgcn_readlane(me.z, i),
-                     __builtin_amdgcn_readlane(me.w, i));
-  };
-#pragma unroll
-  for (int u = 0; u < COV_AHEAD; ++u)
-    if (u < clen) { const int4 e = member(u); load_window<true>(c.hinv, c.done, W, H, e.y, e.z, lane, win[u], cs.gen, c.ha, c.hb); }
-  int ncl = 0;
-  const int j0 = __builtin_amdgcn_readlane(me.x, 0);   // the chain's first (lowest) member: the stamp the patches carry — any
-                                                       // value below the current member's index blocks, and that is all a stamp does
 #ifdef SPFE_REPLAY_PROBE   // phase cycles of the long chains (printf from chains of >= 8 members; tools/microbench/README.md)
   unsigned long long tp0 = 0, tp_store = 0, tp_walk = 0, tp_mom = 0, tp_stamp = 0, tp_all = __builtin_readcyclecounter();
   int members = 0, pops = 0;
@@ -702,68 +642,52 @@ __global__ __launch_bounds__(64 * WV) void cov_replay_kernel(FrameBufs f, Record
 #else
 #define RP(acc) do { } while (0)
 #endif
-  for (int k = 0; k < clen;) {
-#pragma unroll
-    for (int u = 0; u < COV_AHEAD; ++u) {
-      if (k >= clen) break;
+  while (j >= 0) {
 #ifdef SPFE_REPLAY_PROBE
-      tp0 = __builtin_readcyclecounter();
+    tp0 = __builtin_readcyclecounter();
 #endif
-      const int4 e = member(k);
-      const int j = e.x, x0 = e.y, y0 = e.z;
-      // this member's window goes to LDS; the pixels the chain's earlier members popped were (possibly) loaded before their
-      // stamps existed: patch them from the list
-      store_window<true>(m, lane, win[u]);
-      for (int i = lane; i < ncl; i += 64) {
-        const int id = m->cl[i];
-        const int py = row_of(id, W, wmagic), px = id - py * W;
-        const int dx = px - x0 + COV_WIN, dy = py - y0 + COV_WIN;
-        if ((unsigned)dx < 32u && (unsigned)dy < 32u) m->dn[dy * 32 + dx] = j0;
-      }
-      int *q; float *qv; int cap;
-      if (__builtin_expect(e.w < 0, 1)) { q = c.queues + (size_t)j * cs.qcap; qv = c.qvals + (size_t)j * cs.qcap; cap = cs.qcap; }
-      else { q = c.ovf_q + (size_t)e.w * cs.ovf_cap; qv = c.ovf_v + (size_t)e.w * cs.ovf_cap; cap = cs.ovf_cap; }
-      Walk w{m, c.hinv, c.done, q, qv, cap, W, H, x0, y0, j, wmagic, cs.gen, c.ha, c.hb, ncl};
-      RP(tp_store);
-      // a replay's pop list is a subsequence of the lone walk's: it cannot overflow
-      const int n = walk<true>(w, lane);
-      RP(tp_walk);
-      if (n < 0) { if (lane == 0) atomicOr(&c.hdr[2], 1); return; }
-      moments(w, n, lane, c.cov2 + 2 * j, c.cinv + 2 * j);
-      RP(tp_mom);
-      for (int i = lane; i < n; i += 64) c.done[fifo_id(w, i)] = cs.gen | j;  // popped => its stamp was >= j
-      ++k;
-      bool refill = false;
-      if (__builtin_expect(ncl + n <= COV_CL, 1)) {
-        for (int i = lane; i < n; i += 64) m->cl[ncl + i] = fifo_id(w, i);
-        ncl += n;
-      } else {   // (uniform, rare) the list is full: make every stamp so far visible, start the list again, reload what is in flight
-        __threadfence();
-        ncl = 0;
-        refill = true;
-      }
-      if (__builtin_expect(k - k0 + COV_AHEAD > 64 && k0 + 64 < clen, 0)) {
-        // (uniform, rare) the chain's next 64 members (the windows in flight belong to members k .. k + COV_AHEAD - 2: unaffected)
-        k0 = k;
-        me = k0 + lane < clen ? c.chain[cbase + k0 + lane] : make_int4(-1, 0, 0, -1);
-      }
-      if (__builtin_expect(refill, 0)) {
-#pragma unroll
-        for (int d = 1; d < COV_AHEAD; ++d)
-          if (k + d - 1 < clen) {
-            const int4 en = member(k + d - 1);
-            load_window<true>(c.hinv, c.done, W, H, en.y, en.z, lane, win[(u + d) % COV_AHEAD], cs.gen, c.ha, c.hb);
-          }
-      }
-      if (k + COV_AHEAD - 1 < clen) {   // the window of the member COV_AHEAD - 1 behind the next one takes this member's registers
-        const int4 en = member(k + COV_AHEAD - 1);
-        load_window<true>(c.hinv, c.done, W, H, en.y, en.z, lane, win[u], cs.gen, c.ha, c.hb);
-      }
-      RP(tp_stamp);
-#ifdef SPFE_REPLAY_PROBE
-      ++members; pops += n;
-#endif
+    const int x0 = (int)fx, y0 = (int)fy;
+    // this member's window goes to LDS; the pixels the previous member just stamped were loaded before its
+    // stamps existed: patch them from its pop list, which still sits in the LDS FIFO (no other wavefront
+    // writes this component's pixels)
+    store_window<true>(m, lane, win);
+    for (int i = lane; i < n_prev; i += 64) {
+      const int id = i < COV_LCAP ? m->lq[i] : slow_ld_i(prev_q, i);
+      const int py = row_of(id, W, wmagic), px = id - py * W;
+      const int dx = px - x0 + COV_WIN, dy = py - y0 + COV_WIN;
+      if ((unsigned)dx < 32u && (unsigned)dy < 32u) m->dn[dy * 32 + dx] = j_prev;
     }
+    int *q; float *qv; int cap;
+    pop_list(c, cs, j, q, qv, cap);
+    Walk w{m, c.hinv, c.done, q, qv, cap, W, H, x0, y0, j, wmagic, cs.gen, c.ha, c.hb};
+    // the next member's window and the member after it (index + position): all addresses are known, so the
+    // requests go out now and their round trips pass under this member's walk
+    int jnn = -1;
+    float nnfx = 0.0f, nnfy = 0.0f;
+    if (jn >= 0) {
+      load_window<true>(c.hinv, c.done, W, H, (int)nfx, (int)nfy, lane, win, cs.gen, c.ha, c.hb);
+      jnn = c.nxt[jn];
+      nnfx = c.nxy[2 * jn];
+      nnfy = c.nxy[2 * jn + 1];
+    }
+    RP(tp_store);
+    // a replay's pop list is a subsequence of the lone walk's: it cannot overflow
+    const int n = walk<true>(w, lane);
+    RP(tp_walk);
+    if (n < 0) { if (lane == 0) atomicOr(&c.hdr[2], 1); return; }
+    moments(w, n, lane, c.cov2 + 2 * j, c.cinv + 2 * j);
+    RP(tp_mom);
+    // stamp before the next member starts: this wavefront is the only writer and
+    // the only reader of these pixels during the kernel
+    for (int i = lane; i < n; i += 64) c.done[fifo_id(w, i)] = cs.gen | j;  // popped => its stamp was >= j
+    __threadfence_block();  // same wavefront, same CU: L1 is coherent for it
+    RP(tp_stamp);
+#ifdef SPFE_REPLAY_PROBE
+    ++members; pops += n;
+#endif
+    n_prev = n; j_prev = j; prev_q = q;
+    j = jn; fx = nfx; fy = nfy;
+    jn = jnn; nfx = nnfx; nfy = nnfy;
   }
 #ifdef SPFE_REPLAY_PROBE
   if (lane == 0 && members >= 8)

@@ -155,6 +155,9 @@ void spfe_destroy(spfe_handle h) {
     if (ps.ev_h2d) (void)hipEventDestroy(ps.ev_h2d);
     if (ps.ev_done) (void)hipEventDestroy(ps.ev_done);
   }
+  if (h->s_heat) { (void)hipStreamSynchronize(h->s_heat); (void)hipStreamDestroy(h->s_heat); }
+  if (h->ev_heat) (void)hipEventDestroy(h->ev_heat);
+  if (h->ev_heat_copied) (void)hipEventDestroy(h->ev_heat_copied);
   if (h->s_h2d) { (void)hipStreamSynchronize(h->s_h2d); (void)hipStreamDestroy(h->s_h2d); }
   if (h->s_d2h) { (void)hipStreamSynchronize(h->s_d2h); (void)hipStreamDestroy(h->s_d2h); }
   if (h->side) (void)hipStreamDestroy(h->side);
@@ -227,7 +230,9 @@ int spfe_postprocess(spfe_handle h, const float *semi, const float *coarse, int 
   if (h->timing) h->ev = h->evpool.data() + (size_t)(h->calls % spfe_handle_s::EVSETS) * (NSTAGE + 1);
   if (h->timing) for (int i = 0; i <= 11; ++i) HIP_TRY(hipEventRecord(h->ev[i], s));
   h->calls++;
+  h->host_sync_call = true;
   int rc = enqueue_post(h, n, h->d_records, s);
+  h->host_sync_call = false;
   if (rc) return rc;
   return finish_host(h, n, outs);
 }
@@ -246,7 +251,9 @@ int spfe_extract_batch(spfe_handle h, const uint8_t *const *images, int stride, 
   HIP_TRY(hipSetDevice(h->cfg.device));
   hipStream_t s = h->stream;
   HIP_TRY(hipMemcpyAsync(h->d_img, h->h_img, (size_t)n * H * W, hipMemcpyHostToDevice, s));
+  h->host_sync_call = true;   // (the heat maps may leave ahead of the record: spfe_host.h, s_heat)
   int rc = enqueue(h, h->d_img, n, h->d_records, s);
+  h->host_sync_call = false;
   if (rc) return rc;
   return finish_host(h, n, outs);
 }
@@ -265,11 +272,15 @@ int finish_host(spfe_handle h, int n, spfe_result *outs) {
   // bf16 mode here, nothing for a single frame)
   HIP_TRY(hipMemcpyAsync(h->h_records, h->d_records, (size_t)n * h->rl.bytes, hipMemcpyDeviceToHost, s));
   const bool want_inv = want && !(h->cfg.flags & SPFE_FLAG_LAZY_HEAT_INV);   // (lazy: spfe_fetch_heat_inv on demand)
-  if (want) {
+  if (want && !h->heat_early) {
     if (want_inv) HIP_TRY(hipMemcpyAsync(h->h_heat_inv, h->d_heat_inv, (size_t)n * H * W * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(h->h_heat, h->d_heat, (size_t)n * H * W * 4, hipMemcpyDeviceToHost, s));
   }
   HIP_TRY(hipStreamSynchronize(s));
+  if (h->heat_early) {   // the maps left behind the heat normalisation, on their own copy stream (spfe_host.h)
+    HIP_TRY(hipEventSynchronize(h->ev_heat_copied));
+    h->heat_early = false;
+  }
   for (int i = 0; i < n; ++i) {
     uint8_t *rec = h->h_records + (size_t)i * h->rl.bytes;
     float *hinv = h->h_heat_inv + (size_t)i * H * W;

@@ -206,6 +206,16 @@ struct spfe_handle_s {
   float *h_heat = nullptr, *h_heat_inv = nullptr;
   int last_n = 0;
   int host_sync_n = 0;   // frames of the last synchronous host call (spfe_fetch_heat_inv)
+  // Synchronous host calls with SPFE_FLAG_HEAT (the drop-in's operator(): Frame clones heat_, frame.cpp:304): the heat maps are
+  // final when the heat normalisation ends — ~150 us before a single frame's record is (selection + covariance behind it) — so
+  // their D2H (2 x 4 H W bytes: 2.9 MB at 752x480, ~100 us of PCIe) starts THERE, on a copy stream of its own behind the
+  // normalisation's completion signal, and runs beside the chain instead of behind it (round 6; SPFE_EARLY_HEAT_COPY=0: behind
+  // the record's copy, as before).
+  hipStream_t s_heat = nullptr;
+  hipEvent_t ev_heat = nullptr, ev_heat_copied = nullptr;
+  bool early_heat_copy = true;   // SPFE_EARLY_HEAT_COPY
+  bool host_sync_call = false;   // set by the synchronous host entry points around enqueue()
+  bool heat_early = false;       // this call's maps were sent ahead: finish_host waits for ev_heat_copied instead of copying
   int num_cus = 256;
   int small_maxh = -1;
   // input staging (spfe_set_staging)

@@ -139,9 +139,7 @@ struct CovScratch {
   int *npop;      // [B][kmax]
   int *dirty;     // [B][kmax] keypoints whose lone region meets a lower keypoint's
   int *nxt;       // [B][kmax] next dirty member of the same component (ascending) or -1
-  int *chain;     // [B][kmax] int4 {keypoint, x, y, overflow slot}: the dirty members, each component's chain contiguous and in
-                  // ascending keypoint order, the chains longest first (the replay reads a chain with ONE load)
-  int *wmeta;     // [B][kmax] int2 {first entry in `chain`, members} of worker (= chain) number w
+  float *nxy;     // [B][kmax][2] keypoint position of nxt
   int *workers;   // [B][kmax] lowest dirty member of each component
   int *counters;  // [B][4] number of dirty keypoints, number of components, overflow slots taken, claim edges listed
   int *edges;     // [B][ecap] int2 (lower claimant, dirty keypoint): the union-find's input, written by the classification (or null)
@@ -190,7 +188,9 @@ hipError_t launch_tail(const FrameBufs &f, const RecordLayout &r, int B, int H, 
 // at 1280x720 — a whole CU): a pipelined call's selection then starts beside a convolution workgroup instead of waiting for a CU
 hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H, int W,
                          int num_features, hipStream_t s, const CovScratch *with_heat_norm = nullptr, int kmax_hn = 0,
-                         bool lean = false, hipEvent_t done = nullptr);
+                         bool lean = false, hipEvent_t done = nullptr, hipEvent_t heat_done = nullptr);
+// (heat_done: an event that fires when the heat normalisation — the launch in FRONT of the selection — has completed: the heat
+// maps are final there, ~150 us before a single-frame call's record is, and a synchronous host call starts their D2H behind it)
 // (also resets the covariance scratch: launch_cov must follow it)
 hipError_t launch_heat_norm(const FrameBufs &f, const CovScratch &cs, int kmax, int B, int H, int W, hipStream_t s);
 hipError_t launch_desc(const FrameBufs &f, const RecordLayout &r, int B, int H, int W, hipStream_t s);

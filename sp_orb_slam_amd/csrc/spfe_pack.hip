@@ -231,6 +231,7 @@ static void read_switches(spfe_handle h) {
   h->f32_heads = env_int("SPFE_F32_HEADS", 0) != 0;          // dense f32 convPb / convDb on head_f32.hip
   h->fuse1a_env = env_int("SPFE_FUSE_CONV1A", -1);           // conv1a inside conv1b: f32 default 0, bf16 default 1
   // host path
+  h->early_heat_copy = env_int("SPFE_EARLY_HEAT_COPY", 1) != 0;   // synchronous host calls: the heat maps' D2H behind the normalisation, beside the chain
   h->pipe_copy_kernel = env_int("SPFE_PIPE_COPY_KERNEL", -1);   // D2H of a pipelined batch: -1 by precision, 0 runtime copy, 1 copy kernel
   // (SPFE_COMM_OWN_STREAM — the all-gather on a stream of its own instead of the side stream — belongs to the communicator: read
   // by spfe_comm_init, spfe_comm.hip, each time one is made)
@@ -272,6 +273,7 @@ static void copy_switches(spfe_handle h, const spfe_handle_s *o) {
   h->sel_ext_event = o->sel_ext_event; h->replay_waves = o->replay_waves; h->zero_in_tail = o->zero_in_tail;
   h->sparse_db_env = o->sparse_db_env; h->sparse_da_env = o->sparse_da_env; h->pbtail_env = o->pbtail_env;
   h->f32_heads = o->f32_heads; h->fuse1a_env = o->fuse1a_env; h->pipe_copy_kernel = o->pipe_copy_kernel;
+  h->early_heat_copy = o->early_heat_copy;
   h->tile16x4 = o->tile16x4; h->tile2_auto = o->tile2_auto; h->tile2_mask = o->tile2_mask;
   h->select_huge_env = o->select_huge_env; h->pool_split = o->pool_split;
   h->ws_mask = o->ws_mask; h->ws_min_items = o->ws_min_items; h->ws_min_items_sync = o->ws_min_items_sync;
@@ -421,8 +423,7 @@ int build(spfe_handle h, const spfe_config *cfg, spfe_handle sibling) {
     if ((rc = dev_alloc(h, &h->cov.npop, (size_t)B * h->kmax))) return rc;
     if ((rc = dev_alloc(h, &h->cov.dirty, (size_t)B * h->kmax))) return rc;
     if ((rc = dev_alloc(h, &h->cov.nxt, (size_t)B * h->kmax))) return rc;
-    if ((rc = dev_alloc(h, &h->cov.chain, (size_t)B * h->kmax * 4))) return rc;
-    if ((rc = dev_alloc(h, &h->cov.wmeta, (size_t)B * h->kmax * 2))) return rc;
+    if ((rc = dev_alloc(h, &h->cov.nxy, (size_t)B * h->kmax * 2))) return rc;
     if ((rc = dev_alloc(h, &h->cov.workers, (size_t)B * h->kmax))) return rc;
     if ((rc = dev_alloc(h, &h->cov.counters, (size_t)B * 4))) return rc;
     h->cov.ecap = h->cov_ecap_env >= 0 ? h->cov_ecap_env : 32 * h->kmax;   // (~24 pops per keypoint on the dense synthetic detector, a quarter of the keypoints dirty)

@@ -527,6 +527,32 @@ int tail_waits(spfe_handle h, uint8_t *d_records, hipStream_t s) {
   return SPFE_OK;
 }
 
+// Synchronous host calls with heat maps: `ev` fires when the heat normalisation has completed; the maps' D2H goes to a copy
+// stream of its own behind it (spfe_host.h: s_heat).  Returns the event to hand to launch_select, or null when this call does
+// not send its maps ahead.
+static hipEvent_t heat_event_for(spfe_handle h, hipStream_t s) {
+  h->heat_early = false;
+  if (!h->host_sync_call || !h->early_heat_copy || !(h->cfg.flags & SPFE_FLAG_HEAT) || (h->timing && h->timing_all)) return nullptr;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+  if (!h->s_heat) {
+    if (hipStreamCreateWithFlags(&h->s_heat, hipStreamNonBlocking) != hipSuccess) { h->s_heat = nullptr; return nullptr; }
+    if (hipEventCreateWithFlags(&h->ev_heat, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_heat_copied, hipEventDisableTiming) != hipSuccess) { h->early_heat_copy = false; return nullptr; }
+  }
+  return h->ev_heat;
+}
+static int send_heat_maps_ahead(spfe_handle h, int n) {
+  const size_t bytes = (size_t)n * h->H * h->W * 4;
+  HIP_TRY(hipStreamWaitEvent(h->s_heat, h->ev_heat, 0));
+  HIP_TRY(hipMemcpyAsync(h->h_heat, h->d_heat, bytes, hipMemcpyDeviceToHost, h->s_heat));
+  if (!(h->cfg.flags & SPFE_FLAG_LAZY_HEAT_INV))
+    HIP_TRY(hipMemcpyAsync(h->h_heat_inv, h->d_heat_inv, bytes, hipMemcpyDeviceToHost, h->s_heat));
+  HIP_TRY(hipEventRecord(h->ev_heat_copied, h->s_heat));
+  h->heat_early = true;
+  return SPFE_OK;
+}
+
 // Detector tail, selection, descriptors, covariance for n frames whose semi /
 // coarse maps are in the handle's buffers.  tail_done: the detector tail (inside pbtail_f32_kernel) was launched per half
 // batch by enqueue(), behind tail_waits().
@@ -601,8 +627,10 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
     // would not join the capture and its kernels would run once, at capture time)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool sel_ext = h->sel_ext_event && hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
+    hipEvent_t const heat_ev = heat_event_for(h, s);
     HIP_TRY(spfe::launch_select(f, h->rl, n, H, W, h->cfg.num_features, s, &h->cov, h->rl.kmax, false,
-                                sel_ext ? h->ev_sel : nullptr));
+                                sel_ext ? h->ev_sel : nullptr, heat_ev));
+    if (heat_ev) { const int rch = send_heat_maps_ahead(h, n); if (rch) return rch; }
     if (!sel_ext) HIP_TRY(hipEventRecord(h->ev_sel, s));
     HIP_TRY(hipStreamWaitEvent(h->side, h->ev_sel, 0));
     int rc = launch_db_gathered(h, n, h->side);
@@ -628,7 +656,11 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
   if (h->join_pending) HIP_TRY(hipStreamWaitEvent(h->side, h->ev_join, 0));   // (the other half batch: its tail ran on the second stream)
   STAGE_MARK(13);   // ("select" reads 0 on the launch stream: it is part of post_side)
   // (the heat normalisation rides in the selection's first launch: both depend on the detector tail only)
-  HIP_TRY(spfe::launch_select(f, h->rl, n, H, W, h->cfg.num_features, h->side, &h->cov, h->rl.kmax, false));
+  {
+    hipEvent_t const heat_ev = heat_event_for(h, h->side);
+    HIP_TRY(spfe::launch_select(f, h->rl, n, H, W, h->cfg.num_features, h->side, &h->cov, h->rl.kmax, false, nullptr, heat_ev));
+    if (heat_ev) { const int rch = send_heat_maps_ahead(h, n); if (rch) return rch; }
+  }
   // Synchronous calls: the descriptor sampling rides in the covariance replay launch (the chain's longest kernel) instead of
   // standing in front of the chain; pipelined calls keep it early — the NEXT call's convDb waits for it, and behind a replay
   // that shares the chip with that call's convolutions it would wait too long (0.5 ms steps in bf16 mode).

@@ -859,7 +859,7 @@ size_t select_huge_max_cells() { return (size_t)64 * SELECT_HUGE_NW * 1024 - 1; 
 
 hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H, int W,
                          int num_features, hipStream_t s, const CovScratch *with_heat_norm, int kmax_hn, bool lean,
-                         hipEvent_t done) {
+                         hipEvent_t done, hipEvent_t heat_done) {
   if (f.sel_huge) {   // frames of more than 65,535 cells (or SPFE_SELECT_HUGE=1): everything per cell in global scratch
     const size_t lds = select_huge_lds_bytes(H, W);
     if (lds > 160 * 1024 || (size_t)(H / 8) * (W / 8) > select_huge_max_cells() || !f.sel_state || !f.sel_slot || !f.sel_list32)
@@ -872,7 +872,9 @@ hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H
     if (with_heat_norm) {
       const int nmask = ((H / 8) * (W / 8) + 255) / 256;
       const int hb = !f.heat_inv && !f.heat && !with_heat_norm->reset_maps ? 1 : (int)(((size_t)H * W / 4 + 255) / 256);   // (one block when there is nothing to write per pixel: the scale / shift only)
-      hipLaunchKernelGGL(mask_and_heat_norm_kernel, dim3(nmask + (hb < 128 ? hb : 128), B), dim3(256), 0, s, f, H, W, tail_parts(H, W),
+      if (heat_done) hipExtLaunchKernelGGL(mask_and_heat_norm_kernel, dim3(nmask + (hb < 128 ? hb : 128), B), dim3(256), 0, s, nullptr, heat_done, 0, f, H, W,
+                                           tail_parts(H, W), *with_heat_norm, kmax_hn, nmask);
+      else hipLaunchKernelGGL(mask_and_heat_norm_kernel, dim3(nmask + (hb < 128 ? hb : 128), B), dim3(256), 0, s, f, H, W, tail_parts(H, W),
                          *with_heat_norm, kmax_hn, nmask);
     } else {
       hipLaunchKernelGGL(nms_mask_kernel, dim3(((H / 8) * (W / 8) + 255) / 256, B), dim3(256), 0, s, f, H / 8, W / 8);
@@ -894,7 +896,9 @@ hipError_t launch_select(const FrameBufs &f, const RecordLayout &r, int B, int H
   if (with_heat_norm) {
     const int nmask = ((H / 8) * (W / 8) + 255) / 256;
       const int hb = !f.heat_inv && !f.heat && !with_heat_norm->reset_maps ? 1 : (int)(((size_t)H * W / 4 + 255) / 256);   // (one block when there is nothing to write per pixel: the scale / shift only)
-    hipLaunchKernelGGL(mask_and_heat_norm_kernel, dim3(nmask + (hb < 128 ? hb : 128), B), dim3(256), 0, s, f, H, W, tail_parts(H, W),
+    if (heat_done) hipExtLaunchKernelGGL(mask_and_heat_norm_kernel, dim3(nmask + (hb < 128 ? hb : 128), B), dim3(256), 0, s, nullptr, heat_done, 0, f, H, W,
+                                         tail_parts(H, W), *with_heat_norm, kmax_hn, nmask);
+    else hipLaunchKernelGGL(mask_and_heat_norm_kernel, dim3(nmask + (hb < 128 ? hb : 128), B), dim3(256), 0, s, f, H, W, tail_parts(H, W),
                        *with_heat_norm, kmax_hn, nmask);
   } else {
     hipLaunchKernelGGL(nms_mask_kernel, dim3(((H / 8) * (W / 8) + 255) / 256, B), dim3(256), 0, s, f, H / 8, W / 8);

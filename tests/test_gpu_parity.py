@@ -878,3 +878,38 @@ def test_direct_calls_behind_graph_replays_across_a_generation_wrap(cfg):
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
     assert "every call bit-identical to a fresh handle's: True" in out.stdout
+
+
+def test_heat_maps_sent_ahead_of_the_record_are_the_same_maps(monkeypatch):
+    """Round 6: a synchronous host call with heat maps (the drop-in's operator(): Frame clones heat_, frame.cpp:304) starts the
+    maps' D2H behind the heat normalisation's completion signal, on a copy stream of its own, beside selection + covariance
+    instead of behind the record (SPFE_EARLY_HEAT_COPY=0: as before).  Same maps, same records, call after call on changing
+    frames — single frames, batches, the lazy heat_inv form and spfe_postprocess."""
+    H, W, nf, B = 240, 376, 300, 3
+    blob = weights.synthetic(7, "dense")
+    frames = [[synth.make_image(2100 + 7 * r + i, H, W) for i in range(B)] for r in range(4)]
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SPFE_EARLY_HEAT_COPY", flag)
+        ext = SPExtractor(nf, H, W, blob, max_batch=B)
+        lazy = SPExtractor(nf, H, W, blob, max_batch=B, lazy_heat_inv=True)
+        res = []
+        for r in range(4):
+            for fr in ext.extract_batch(frames[r]):
+                res.append((fr.K, fr.kp_xy.copy(), fr.descriptors.copy(), fr.cov2.copy(), fr.heat.copy(), fr.heat_inv.copy()))
+            ext(frames[r][0], None)
+            res.append((ext.last.K, ext.last.kp_xy.copy(), ext.last.descriptors.copy(), ext.last.cov2.copy(), ext.heat_.copy(), ext.heat_inv_.copy()))
+            fl = lazy.extract_batch(frames[r])
+            assert all(x.heat_inv is None for x in fl)
+            res.append((fl[1].K, fl[1].kp_xy.copy(), fl[1].descriptors.copy(), fl[1].cov2.copy(), fl[1].heat.copy(), lazy.fetch_heat_inv(1).copy()))
+        ext.close()
+        lazy.close()
+        out[flag] = res
+    monkeypatch.delenv("SPFE_EARLY_HEAT_COPY")
+    assert len(out["0"]) == len(out["1"]) == 4 * (B + 2)
+    for a, b in zip(out["0"], out["1"]):
+        assert a[0] == b[0] and a[0] > 0
+        for x, y in zip(a[1:], b[1:]):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    ref = oracle.extract(blob, frames[3][0], nf)       # ... and they are the oracle's maps
+    assert np.array_equal(out["1"][-2][4], ref["heat"]) and np.array_equal(out["1"][-2][5], ref["heat_inv"])
