@@ -72,22 +72,39 @@ __host__ __device__ constexpr int row_channel(int m) { return (m & ~12) | ((m & 
 
 // epilogue of one (channel tile j, rr = r >> 3): channels 32 j + 16 rr + 8 hi + 0..7 of the lane's pixel = piece 4 j + 2 rr + hi
 // of its 128-byte NHWC row, as 16 bytes of bf16
-// (scalar fmaf / max on purpose.  The packed forms — v_pk_fma_f32 on register pairs, the ReLU as one v_pk_max_i16 on the rounded
-// pair, bit-identical and half the VALU instructions — were measured in the producers of conv1b (round 6): 1280x720 x 8 392 ->
-// 448 us.  Packed f32 arithmetic beside a saturated MFMA stream costs the matrix pipe far more than the issue slots it saves.)
+// (scalar fmaf on purpose.  v_pk_fma_f32 on register pairs — half the instructions, bit-identical — was measured in the producers
+// of conv1b (round 6) together with the packed ReLU: 1280x720 x 8 392 -> 448 us.  Packed f32 arithmetic beside a saturated MFMA
+// stream costs the matrix pipe far more than the issue slots it saves.)
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+// fmaf(a, 1 / 255, b) as ONE scalar-form instruction the vectoriser cannot pair up (it turns two adjacent fmaf calls into a
+// v_pk_fma_f32, which is what must not run beside the MFMA stream, see above); 0x3b808081 = float(1 / 255)
+__device__ __forceinline__ float fma255(float a, float b) {
+  float r;
+  asm("v_fmamk_f32 %0, %1, 0x3b808081, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+#ifndef C1A_RELU_PACKED
+#define C1A_RELU_PACKED 1   // 1: the ReLU on the rounded pair (one v_pk_max_i16 per two values), 0: v_max_f32 per value in front of the rounding
+#endif
 __device__ __forceinline__ u32x4 finish8(const f32x16 &acc, int rr, const float (&bias)[16]) {
-  float v[8];
+  unsigned o[4];
 #pragma unroll
-  for (int m = 0; m < 8; ++m) {
-    v[m] = __builtin_fmaf(acc[8 * rr + m], 1.0f / 255.0f, bias[8 * rr + m]);
-    v[m] = __builtin_fmaxf(v[m], 0.0f);
+  for (int m = 0; m < 4; ++m) {
+    float v0 = fma255(acc[8 * rr + 2 * m], bias[8 * rr + 2 * m]);
+    float v1 = fma255(acc[8 * rr + 2 * m + 1], bias[8 * rr + 2 * m + 1]);
+    if constexpr (C1A_RELU_PACKED) {
+      // a negative float is a negative int16 in its upper half and rounds to a negative (or -0) bf16; RNE is monotonic and keeps
+      // the sign: max(bf16(v), +0) as 16-bit integers == bf16(max(v, 0)) bit for bit
+      const i16x2 r = __builtin_bit_cast(i16x2, __builtin_convertvector((f32x2){v0, v1}, bf16x2));
+      const i16x2 z = {0, 0};
+      o[m] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(r, z));
+    } else {
+      v0 = __builtin_fmaxf(v0, 0.0f);
+      v1 = __builtin_fmaxf(v1, 0.0f);
+      o[m] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v0, v1}, bf16x2));
+    }
   }
-  u32x4 o;
-  o.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v[0], v[1]}, bf16x2));
-  o.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v[2], v[3]}, bf16x2));
-  o.z = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v[4], v[5]}, bf16x2));
-  o.w = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v[6], v[7]}, bf16x2));
-  return o;
+  return (u32x4){o[0], o[1], o[2], o[3]};
 }
 
 // per-lane constants: A operands from the host table, the lane's 2 x 16 biases (register r of tile j <-> channel

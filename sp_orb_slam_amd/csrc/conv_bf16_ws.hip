@@ -17,7 +17,7 @@
 //     barrier and 144 MFMAs per consumer wave (4608 matrix cycles) — the time an HBM round trip of
 //     the next tile's loads gets to hide under, twice what a 32-channel stage offered.
 //   * no padding: pixels and weight rows are 128 B, XOR-swizzled in 16-byte pieces
-//     (piece j of halo column c sits in slot j ^ ((c >> 1) & 7); the swizzle is applied by the
+//     (piece j of halo column c sits in slot j ^ halo_swz(c), halo_swz(c) = ((c >> 1) & 7) ^ ((c & 1) << 2); the swizzle is applied by the
 //     producer's choice of source address — free with LDS-direct loads — and by the packed weight
 //     layout).  A halo row is 34 * 128 B = 17 * 256 B, so the bank slot of a fragment depends on the
 //     column only: the 16 lanes of a ds_read_b128 group read 16 distinct columns mod 16 = 16 distinct
@@ -59,7 +59,8 @@ constexpr int HALO_IT = (HALO_INSTR + 3) / 4;          // 11 per producer wave
 constexpr int W_BYTES = 9 * 64 * 128;                  // 73,728: [tap][cout][64 cin], swizzled
 [[maybe_unused]] constexpr int W_INSTR = W_BYTES / 1024;                // 72
 constexpr int LDS_W = 2 * HALO_BYTES;                  // 87,040
-constexpr int LDS_SLOT = LDS_W + W_BYTES;              // 160,768: 3 tile descriptors of 16 B
+constexpr int LDS_SLOT = LDS_W + W_BYTES;              // 160,768: NSLOT tile descriptors of 16 B
+constexpr int NSLOT = 4;                               // descriptors run three tiles ahead of the tile being multiplied (see the producers)
 constexpr int LDS_PATCH = LDS_SLOT + 64;               // TAG 2: per producer wave a 4 x 40 bf16 patch of the frame (320 B)
 constexpr int LDS_TOTAL = LDS_PATCH + 4 * 320;         // 162,112 of the 163,840 bytes
 constexpr int NSTEP = 36;                              // K steps per tile: 2 chunks x 9 taps x 2
@@ -90,6 +91,9 @@ __device__ unsigned long long ws_dbg[10];
 #ifndef WS_C1A_STORE
 #define WS_C1A_STORE 1   // TAG 2, how a producer lane stores its four 16-byte pieces of a halo pixel: 1 = ds_write_b128, 2 = two conflict-free ds_write_b64 (see make_halo)
 #endif
+#ifndef WS_CLAIM
+#define WS_CLAIM 1       // TAG 2: tiles a workgroup takes from its queue per atomic, asked for one tile ahead of their use
+#endif
 #ifndef WS_ABLATE
 #define WS_ABLATE 0  // probe builds: 1 = producers issue no halo passes in the loop, 2 = consumers issue no MFMAs,
                      // 3 = every tile loads the same halo (cache hits only), 4 = no fragment reads, 5 = no stores
@@ -102,6 +106,15 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "mem
 __device__ __forceinline__ bf16x8 lds_read(lds_char *p, int imm) {
   return *reinterpret_cast<lds_frag *>(p + imm);
 }
+
+// Slot of logical 16-byte piece j of halo column c inside the pixel's 128 bytes: j ^ halo_swz(c).  (c >> 1) & 7 is what makes
+// the consumers' ds_read_b128 conflict-free (the 16 lanes of a read group hold 8 even and 8 odd columns; a column pair shares
+// (c >> 1) and sits 128 B apart: the two parities use the two halves of the 64 read banks, and within a parity the 8 values
+// are distinct for every tap offset).  Round 6 adds the (c & 1) << 2 term, which keeps that property — within a parity it is
+// a constant xor — and makes the PRODUCERS' stores of whole pieces (TAG 2: ds_write_b128, 8 consecutive columns per store
+// group, 32 store banks = 128 B) hit 8 distinct slots instead of 4 slots twice: the fused conv1a's halo stores were 2-way
+// bank conflicts, 19 % of this kernel's LDS cycles in round 5 (profiles/r05_pmc_bf16_720p.txt).
+__device__ __forceinline__ constexpr int halo_swz(int c) { return ((c >> 1) & 7) ^ ((c & 1) << 2); }
 
 // left edge of tile column tx: the last column of a ragged row ends at the image edge instead of overhanging it
 __device__ __forceinline__ int tile_x0(int tx, int W) {
@@ -192,7 +205,7 @@ struct TileHooks {
   __device__ __forceinline__ void at() {
     if constexpr (S == 3 && M == 1) aim(dc, *eMine);
     if constexpr (S == 24 && M == 1)
-      raw = *reinterpret_cast<const __attribute__((address_space(3))) i32x4 *>(lds + LDS_SLOT + ((t + 1) % 3) * 16);
+      raw = *reinterpret_cast<const __attribute__((address_space(3))) i32x4 *>(lds + LDS_SLOT + ((t + 1) % NSLOT) * 16);
     if constexpr (S == 28 && M == 1) {
       dn.b = __builtin_amdgcn_readfirstlane(raw.x);
       dn.ty = __builtin_amdgcn_readfirstlane(raw.y);
@@ -385,10 +398,24 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
     // ------------------------------------------------------------------ producers
     const int pw = wave - 4;
     int *ctr = p.tile_ctr + nb * 8 + xcd;
-    auto fetch = [&]() -> int {  // next tile of this (XCD, block) queue, or -1
+    // The queue: one counter per (XCD, channel block), shared by the ~32 workgroups of that group; a workgroup takes WS_CLAIM
+    // consecutive tiles per atomic.  An atomic's round trip is ~2.5 us under load — as long as a tile: the probe's timing build
+    // (round 6) showed a tile of the fused kernel taking 2.86 us with the consumers issuing no MFMA at all, the queue wave
+    // waiting for its answer; with the request ONE TILE AHEAD of its use (TAG 2, below) the same build makes a tile in 1.6 us.
+    // Layers whose halo comes by LDS-direct loads (TAG 0 / 1) ask per tile, behind their loads: the answer comes back under
+    // the loads' own wait, and they are memory-bound — larger claims measured -2 % there (coarser balance).
+    int q_base = 0, q_left = 0;
+    [[maybe_unused]] int raw_pend = 0;
+    [[maybe_unused]] bool pend = false;
+    auto queue_index = [&](int k) -> int {   // tile number k (>= NSLOT - 1) of this workgroup -> the tile, or -1   (WS_ABLATE 6: no queue)
+      const int v = k * gsize + gi;
+      return v < t_cnt ? t_lo + v : -1;
+    };
+    (void)queue_index;
+    auto fetch = [&]() -> int {  // next tile of this (XCD, block) queue, or -1   (TAG 0 / 1: one atomic per tile)
       int v = 0;
       if (lane == 0) v = atomicAdd(ctr, 1);
-      v = __builtin_amdgcn_readfirstlane(v) + 2 * gsize;   // the first 2 * gsize tiles are pre-assigned
+      v = __builtin_amdgcn_readfirstlane(v) + (NSLOT - 1) * gsize;   // the first three tiles of every workgroup are pre-assigned
       return v < t_cnt ? t_lo + v : -1;
     };
     auto publish = [&](int k, int tile) {  // decode + write descriptor k (wave 4 only)
@@ -410,7 +437,7 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
       const int r = q / (COLS * 8), rem = q % (COLS * 8), c = rem >> 3, slot = rem & 7;
       prow[it] = q < HALO_PIECES ? r - 1 : (1 << 20);
       pcol[it] = c - 1;
-      pj16[it] = (unsigned)(slot ^ ((c >> 1) & 7)) * 16u;
+      pj16[it] = (unsigned)(slot ^ halo_swz(c)) * 16u;
     }
     auto load_halo = [&](const TileDesc &d, int buf) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -460,7 +487,7 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
         podd[gi] = (c & 1) != 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          hdst[gi][k] = (unsigned)(P * 128 + (((2 * k + hi) ^ ((c >> 1) & 7)) * 16) + (WS_C1A_STORE == 2 ? 8 * (c & 1) : 0));
+          hdst[gi][k] = (unsigned)(P * 128 + (((2 * k + hi) ^ halo_swz(c)) * 16) + (WS_C1A_STORE == 2 ? 8 * (c & 1) : 0));
         // the group's patch: 4 rows x 40 bytes starting at image column x0 - 4 (4-byte aligned; widths are multiples of
         // 8, so a dword is entirely inside the frame or entirely outside): lane < 40 loads one dword = 4 pixels
         const int prow = lane / 10, pdw = lane % 10;
@@ -468,30 +495,27 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
         prel[gi] = (g < NGRP && lane < 40) ? (int)(((unsigned)(r0 - 2 + prow) << 16) | ((unsigned)(4 * pdw - 4) & 0xffffu)) : (int)0x80000000;
       }
     }
-    // (fetch_next: the queue-keeping wave also asks the tile queue for the tile after this one — the atomic goes out behind
-    // the patch loads and returns while the matrix products run; the raw counter value comes back through *fetched)
-    auto make_halo = [&](const TileDesc &d, int buf, bool fetch_next, int *fetched) {
+    // The u8 pixels a tile's groups need (one dword = 4 pixels per lane and group): issued ONE TILE AHEAD of their use — the
+    // probe's timing build had shown the producers, not the MFMA stream, to be this kernel's critical path (round 6: 4,800
+    // cycles of a 6,170-cycle tile in make_halo at 1.66 GHz, and 2.86 us a tile even with the consumers issuing no MFMA at
+    // all): every tile began with this load's round trip — ~1 us from L2 / HBM — in front of the matrix products it feeds.
+    auto load_patch = [&](const TileDesc &d, unsigned (&px)[3]) {
       // the frame as a buffer: out-of-range offsets read 0 — conv1a's own zero padding — and nothing is conditional,
       // so the tile's patch bytes leave as ONE burst of loads
       const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<uint8_t *>(p.img) + (size_t)d.b * p.H * p.W, 0, (unsigned)(p.H * p.W), 0x00020000);
       const int y0 = d.ty * TH, x0 = tile_x0(d.tx, p.W);
-      lds_char *patch = lds + LDS_PATCH + pw * 320;
-      const int hi = lane >> 5;
-      unsigned px[3];
 #pragma unroll
       for (int gi = 0; gi < 3; ++gi) {
         const int gy = y0 + (prel[gi] >> 16), gx = x0 + (int)(short)(prel[gi] & 0xffff);
-        const bool in = prel[gi] != (int)0x80000000 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        const bool in = d.valid && prel[gi] != (int)0x80000000 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
         px[gi] = __builtin_amdgcn_raw_buffer_load_b32(rimg, in ? (unsigned)(gy * p.W + gx) : OOB, 0, 0);
       }
-      if (fetch_next) {
-        // (the compiler's atomic optimiser waits for the return right here — vmcnt(0) + readfirstlane — which is why this
-        // duty belongs to the wave with a group less to make: measured on wave 4, it added ~2000 cycles to the 3500 of its groups)
-        int v = 0;
-        if (lane == 0) v = atomicAdd(ctr, 1);
-        *fetched = v;
-      }
+    };
+    auto make_halo = [&](const TileDesc &d, int buf, const unsigned (&px)[3]) {
+      const int y0 = d.ty * TH, x0 = tile_x0(d.tx, p.W);
+      lds_char *patch = lds + LDS_PATCH + pw * 320;
+      const int hi = lane >> 5;
       // border tiles only: some halo pixel lies outside the frame (conv1b's zero padding)
       const bool border = y0 == 0 || x0 == 0 || y0 + TH + 1 > p.H || x0 + 33 > p.W;
 #pragma unroll
@@ -507,19 +531,12 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
         f32x16 acc1[2];
         c1a::product(wA, pxop, acc1);
         if (hrc[gi] != (int)0x80000000) {
-          // conv1b's own zero padding (border tiles only): halo pixels outside the frame are zeros, not conv1a evaluated out there
-          bool outside = false;
-          if (border) {
-            const int hy = y0 + (hrc[gi] >> 16), hx = x0 + (int)(short)(hrc[gi] & 0xffff);
-            outside = !((unsigned)hy < (unsigned)p.H && (unsigned)hx < (unsigned)p.W);
-          }
           [[maybe_unused]] const bool odd = podd[gi];
 #pragma unroll
           for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
-              u32x4 v = c1a::finish8(acc1[j], rr, bias1[j]);
-              if (border) { if (outside) v = (u32x4){0u, 0u, 0u, 0u}; }   // (wave-uniform branch: interior tiles carry no select)
+              const u32x4 v = c1a::finish8(acc1[j], rr, bias1[j]);
               const unsigned a = hdst[gi][2 * j + rr];
               if constexpr (WS_C1A_STORE == 2) {
                 *reinterpret_cast<__attribute__((address_space(3))) u32x2 *>(lds + buf * HALO_BYTES + a) =
@@ -530,14 +547,19 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
                 *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(lds + buf * HALO_BYTES + a) = v;
               }
             }
+          if (border) {   // (wave-uniform branch: interior tiles carry nothing of this)
+            // conv1b's own zero padding: halo pixels outside the frame are zeros, not conv1a evaluated out there — written over
+            // what the lane has just stored (LDS operations of a wave are in order)
+            const int hy = y0 + (hrc[gi] >> 16), hx = x0 + (int)(short)(hrc[gi] & 0xffff);
+            if (!((unsigned)hy < (unsigned)p.H && (unsigned)hx < (unsigned)p.W)) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(lds + buf * HALO_BYTES + (hdst[gi][k] & ~8u)) = (u32x4){0u, 0u, 0u, 0u};
+            }
+          }
         }
       }
     };
-    auto fill_halo = [&](const TileDesc &d, int buf) {
-      if constexpr (TAG == 2) { int unused = 0; make_halo(d, buf, false, &unused); }
-      else load_halo(d, buf);
-    };
-
     // The resident weight block first: nothing it needs has to be fetched or decided.
     {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -552,46 +574,71 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
       }
 #endif
     }
-    // the first two tiles of every workgroup are fixed (its index in the queue's group, and that + the group
-    // size): no atomic round trips before the first loads; the queue hands out the tiles after those
+    // the first three tiles of every workgroup are fixed (its index in the queue's group, + the group size, + twice that): no
+    // atomic round trips before the first loads; the queue hands out the tiles after those, THREE tiles ahead of the tile the
+    // consumers multiply (a ring of NSLOT descriptors): tile t + 1's halo is made while tile t is multiplied, tile t + 2's u8
+    // pixels are in flight meanwhile (TAG 2), and the queue's answer for tile t + 3 has that long to come back.
     // the wave that keeps the tile queue: with conv1a inside (TAG 2), wave 7 — it makes two groups of halo pixels per tile,
     // the others three, so the atomic's round trip (1-2 us under load) hides in its slack instead of adding to the
     // longest producer
     constexpr int QW = TAG == 2 ? 3 : 0;
     if (pw == QW) {
-      publish(0, gi < t_cnt ? t_lo + gi : -1);
-      publish(1, gi + gsize < t_cnt ? t_lo + gi + gsize : -1);
+#pragma unroll
+      for (int k = 0; k < NSLOT - 1; ++k) publish(k, gi + k * gsize < t_cnt ? t_lo + gi + k * gsize : -1);
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-    wg_barrier();                        // barrier #0: descriptors 0 and 1 are published
+    wg_barrier();                        // barrier #0: the first descriptors are published
     TileDesc cur = read_slot(0);
-    if (cur.valid) fill_halo(cur, 0);
+    [[maybe_unused]] unsigned pxA[3] = {0u, 0u, 0u}, pxB[3] = {0u, 0u, 0u};
+    if constexpr (TAG == 2) {
+      load_patch(cur, pxB);
+      load_patch(read_slot(1), pxA);     // (an invalid descriptor loads zeros nobody uses)
+      if (cur.valid) make_halo(cur, 0, pxB);
+    } else {
+      if (cur.valid) load_halo(cur, 0);
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): (TAG 2) the halo's LDS stores
     wg_barrier();                        // barrier #1: weights and tile 0 are in LDS
     int t = 0;
+    if constexpr (TAG == 2 && WS_ABLATE != 6) {   // the first claim (tile NSLOT - 1 ...), taken at the start of the first iteration
+      if (pw == QW && cur.valid) { if (lane == 0) raw_pend = atomicAdd(ctr, WS_CLAIM); pend = true; }
+    }
 #ifdef WS_PROBE_TIMING
     unsigned long long pt_issue = 0, pt_wait = 0, pt_bar = 0;
     WS_T(pt_begin);
 #endif
     while (cur.valid) {
       WS_T(p0);
-      const TileDesc nxt = read_slot((t + 1) % 3);
-      int i2 = -1;
+      const TileDesc nxt = read_slot((t + 1) % NSLOT);
+      const bool more = read_slot((t + 2) % NSLOT).valid != 0;   // the queue is asked as long as the last tile it gave was one
+      int i3 = -1;
       if constexpr (TAG == 2) {
-        int raw = 0;
-        if (nxt.valid) make_halo(nxt, (t + 1) & 1, pw == QW, &raw);
-        if (pw == QW && nxt.valid) {
-          raw = __builtin_amdgcn_readfirstlane(raw) + 2 * gsize;
-          i2 = raw < t_cnt ? t_lo + raw : -1;
+        // the claim asked for a tile ago has come back by now (taken BEFORE this tile's loads are issued: the wait for it must
+        // not cover them) ...
+        if (pw == QW && WS_ABLATE != 6 && q_left == 0 && pend) { q_base = __builtin_amdgcn_readfirstlane(raw_pend); q_left = WS_CLAIM; pend = false; }
+        load_patch(read_slot((t + 2) % NSLOT), pxB);   // tile t + 2's pixels: a whole tile to land
+        // ... and the next one goes out at once (one claim in flight)
+        if (pw == QW && WS_ABLATE != 6 && more && !pend && q_left <= 1) { if (lane == 0) raw_pend = atomicAdd(ctr, WS_CLAIM); pend = true; }
+        if (nxt.valid) make_halo(nxt, (t + 1) & 1, pxA);
+        if (pw == QW && more) {
+          if constexpr (WS_ABLATE == 6) i3 = queue_index(t + NSLOT - 1);
+          else if (q_left > 0) {
+            const int v = q_base + (WS_CLAIM - q_left) + (NSLOT - 1) * gsize;
+            --q_left;
+            i3 = v < t_cnt ? t_lo + v : -1;
+          }
         }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pxA[k] = pxB[k];
       } else if (WS_ABLATE != 1 && nxt.valid) {
-        fill_halo(nxt, (t + 1) & 1);
+        load_halo(nxt, (t + 1) & 1);
       }
       WS_T(p1);
-      if (TAG != 2 && pw == QW && nxt.valid) i2 = fetch();  // behind the passes: its round trip hides under theirs
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the next tile has landed
+      if (TAG != 2 && pw == QW && more) i3 = fetch();  // behind the passes: its round trip hides under theirs
+      if constexpr (TAG != 2) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the next tile has landed (TAG 2: its stores are LDS stores, below)
       WS_T(p2);
-      if (pw == QW) publish((t + 2) % 3, i2);
+      if (pw == QW) publish((t + NSLOT - 1) % NSLOT, i3);
       __builtin_amdgcn_s_waitcnt(0xC07F);
       wg_barrier();                      // end of tile t
       WS_T(p3);
@@ -619,7 +666,7 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int c = dx + l31;
-      aptr[dx][kk] = lds + (wm * 2) * ROW_BYTES + c * 128 + (((kk * 2 + hi) ^ ((c >> 1) & 7)) * 16);
+      aptr[dx][kk] = lds + (wm * 2) * ROW_BYTES + c * 128 + (((kk * 2 + hi) ^ halo_swz(c)) * 16);
     }
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {

@@ -270,7 +270,14 @@ int finish_host(spfe_handle h, int n, spfe_result *outs) {
   const bool want = (h->cfg.flags & SPFE_FLAG_HEAT) != 0;
   // (the synchronous path keeps the runtime's copy: a copy kernel as in spfe_submit_batch measured +4 % in f32 and -4 % in
   // bf16 mode here, nothing for a single frame)
-  HIP_TRY(hipMemcpyAsync(h->h_records, h->d_records, (size_t)n * h->rl.bytes, hipMemcpyDeviceToHost, s));
+  if (h->desc_early) {   // the descriptor rows left behind the sampling (spfe_host.h): the record's two ends remain
+    HIP_TRY(hipMemcpy2DAsync(h->h_records, h->rl.bytes, h->d_records, h->rl.bytes, h->rl.off_desc, (size_t)n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpy2DAsync(h->h_records + h->rl.off_occ, h->rl.bytes, h->d_records + h->rl.off_occ, h->rl.bytes,
+                             h->rl.bytes - h->rl.off_occ, (size_t)n, hipMemcpyDeviceToHost, s));
+    h->desc_early = false;
+  } else {
+    HIP_TRY(hipMemcpyAsync(h->h_records, h->d_records, (size_t)n * h->rl.bytes, hipMemcpyDeviceToHost, s));
+  }
   const bool want_inv = want && !(h->cfg.flags & SPFE_FLAG_LAZY_HEAT_INV);   // (lazy: spfe_fetch_heat_inv on demand)
   if (want && !h->heat_early) {
     if (want_inv) HIP_TRY(hipMemcpyAsync(h->h_heat_inv, h->d_heat_inv, (size_t)n * H * W * 4, hipMemcpyDeviceToHost, s));

@@ -216,6 +216,11 @@ struct spfe_handle_s {
   bool early_heat_copy = true;   // SPFE_EARLY_HEAT_COPY
   bool host_sync_call = false;   // set by the synchronous host entry points around enqueue()
   bool heat_early = false;       // this call's maps were sent ahead: finish_host waits for ev_heat_copied instead of copying
+  // ... and the descriptor rows of the record (kmax x 256 floats: 1.0 of a 752x480 record's 1.1 MB) leave right behind the
+  // descriptor sampling, on the side stream that ran it, beside the covariance replay (the chain's longest kernel) instead of
+  // behind it; finish_host then copies the record's two small ends only.  Inline-chain calls (a synchronous call with the
+  // gathered descriptor branch: the single-frame operator()); same switch.
+  bool desc_early = false;
   int num_cus = 256;
   int small_maxh = -1;
   // input staging (spfe_set_staging)

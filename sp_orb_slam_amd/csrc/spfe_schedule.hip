@@ -560,6 +560,7 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
   const int H = h->H, W = h->W;
   spfe::FrameBufs f = frame_bufs(h, d_records, sparse);
   h->sparse_last = sparse;
+  h->desc_early = false;   // (set below when this call sends its descriptor rows ahead)
   { static long g_call_seq = 0; h->last_seq = ++g_call_seq; }   // (handles are driven by one thread each; a pair by the same one)
   {   // this chain's generation of the claim / done maps (cov.hip): one code per chain, counting down; a full reset of the maps
       // only before a frame's first use and when the codes are used up
@@ -638,6 +639,15 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
     HIP_TRY(hipEventRecord(h->ev_dbs[par], h->side));
     h->dbs_recorded[par] = true;
     HIP_TRY(spfe::launch_desc(f, h->rl, n, H, W, h->side));
+    h->desc_early = false;
+    if (h->host_sync_call && h->early_heat_copy && d_records == h->d_records && cap == hipStreamCaptureStatusNone) {
+      // a synchronous host call: the descriptor rows are final here — their D2H rides the side stream beside the covariance
+      // chain (spfe_host.h: desc_early); rows of the n records, a 2-D copy with the record stride as pitch
+      const size_t seg = h->rl.off_occ - h->rl.off_desc;
+      HIP_TRY(hipMemcpy2DAsync(h->h_records + h->rl.off_desc, h->rl.bytes, h->d_records + h->rl.off_desc, h->rl.bytes, seg, (size_t)n,
+                               hipMemcpyDeviceToHost, h->side));
+      h->desc_early = true;
+    }
     HIP_TRY(hipEventRecord(h->ev_desc, h->side));
     h->desc_recorded = true;
     HIP_TRY(spfe::launch_cov(f, h->rl, h->cov, n, H, W, s, false, nullptr));

@@ -381,7 +381,7 @@ def test_cpp_dropin_through_base_pointer_matches_python_path(tmp_path):
 def test_lazy_heat_inv_is_fetched_on_demand():
     """SPFE_FLAG_LAZY_HEAT_INV: the host calls bring back `heat` only (spfe_result.heat_inv NULL) and spfe_fetch_heat_inv
     copies a frame's map on demand — the bits of the eager handle's; refused before the first call, for a frame the call did not
-    hold, and on a handle without SPFE_FLAG_HEAT."""
+    hold, behind a call that was not a synchronous host call, and on a handle without SPFE_FLAG_HEAT."""
     H, W, nf, B = 120, 160, 100, 3
     blob = weights.synthetic(7, "dense")
     imgs = [synth.make_image(60 + i, H, W) for i in range(B)]
@@ -399,6 +399,20 @@ def test_lazy_heat_inv_is_fetched_on_demand():
     with pytest.raises(SpfeError):
         lazy.fetch_heat_inv(1)       # the last call held one frame
     assert np.array_equal(eager.fetch_heat_inv(2), fe[2].heat_inv)   # works on an eager handle too
+    # a call that is not a synchronous host call overwrites the device map (a device-resident call, a pipelined submission):
+    # a fetch behind it is refused, not served from another call's map (enqueue() clears the host-call mark)
+    import torch
+    lazy.extract_batch(imgs)
+    d = torch.from_numpy(np.stack(imgs)).cuda()
+    lazy.extract_batch_device(d.data_ptr(), B)
+    torch.cuda.synchronize()
+    with pytest.raises(SpfeError):
+        lazy.fetch_heat_inv(0)
+    lazy.extract_batch(imgs)
+    assert np.array_equal(lazy.fetch_heat_inv(2), fe[2].heat_inv)
+    lazy.collect_batch(lazy.submit_batch(imgs))
+    with pytest.raises(SpfeError):
+        lazy.fetch_heat_inv(0)
     noheat = SPExtractor(nf, H, W, blob, with_heat=False)
     noheat(imgs[0], None)
     with pytest.raises(SpfeError):
