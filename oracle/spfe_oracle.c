@@ -185,22 +185,24 @@ EXPORT int oracle_network(const float *blob, const uint8_t *img, int H, int W, f
 }
 
 /*
- * The network in the build's bf16 mode: conv1a as conv1a_bf16() below (bf16 weights, exact u8 inputs, the 1/255
- * applied to the sum, output rounded to bf16);
+ * The network in the build's bf16 mode: conv1a as conv1a_bf16() below (bf16 weights with the 1/255 folded in, exact u8
+ * inputs, the bias as the accumulator's start, output rounded to bf16);
  * conv1b..conv4b with bf16 weights and activations (f32 accumulate, bias, ReLU, pool; outputs
  * rounded); convPa and convDa with bf16 weights and bf16 output; the 1x1 heads convPb (the detector
  * logits) and convDb with bf16 weights, f32 accumulate and f32 output; everything after the two
  * heads in f32.  (The MFMA's accumulation order differs from this loop's, so the GPU is
  * compared with a tolerance in this mode, not bitwise.)
  */
-/* conv1a of the bf16 mode (sp_orb_slam_amd/csrc/conv1a_mfma.h): the u8 pixels enter the product unscaled (exact
- * in bf16), the weights rounded to bf16, the 1/255 of convertTo (:388) applied to the f32 sum:
- *   a0[c] = bf16( max( fmaf( sum_t float(u8_t) * bf16(w[c][t]), 1/255, b[c] ), 0 ) ),  zero padding. */
+/* conv1a of the bf16 mode (sp_orb_slam_amd/csrc/conv1a_mfma.h, round 6 form): the u8 pixels enter the product unscaled (exact
+ * in bf16); the 1/255 of convertTo (:388) is folded into the weight before its rounding to bf16 (one f32 multiply by
+ * float(1/255), then RNE — the library's host packing does the same); the bias is the accumulator's initial value:
+ *   a0[c] = bf16( max( b[c] + sum_t float(u8_t) * bf16(w[c][t] * (1/255)), 0 ) ),  f32 accumulate, zero padding.
+ * (Rounds 2 - 5: bf16(w) and fmaf(sum, 1/255, b) per value.  Both are bf16 quantisations of the same f32 layer.) */
 static void conv1a_bf16(const float *blob, const uint8_t *img, int H, int W, float *out) {
   const float *w = blob + oracle_weight_offset(0); /* [64][1][3][3] */
   const float *b = blob + oracle_bias_offset(0);
   float wb[64 * 9];
-  for (int i = 0; i < 64 * 9; ++i) wb[i] = bf16_round(w[i]);
+  for (int i = 0; i < 64 * 9; ++i) wb[i] = bf16_round(w[i] * (1.0f / 255.0f));
 #pragma omp parallel for schedule(static)
   for (int y = 0; y < H; ++y)
     for (int x = 0; x < W; ++x) {
@@ -211,11 +213,10 @@ static void conv1a_bf16(const float *blob, const uint8_t *img, int H, int W, flo
       }
       float *o = out + ((size_t)y * W + x) * 64;
       for (int c = 0; c < 64; ++c) {
-        float s = 0.0f;
+        float s = b[c];
         for (int t = 0; t < 9; ++t) s = __builtin_fmaf(px[t], wb[c * 9 + t], s);
-        float v = __builtin_fmaf(s, 1.0f / 255.0f, b[c]);
-        v = v > 0.0f ? v : 0.0f;
-        o[c] = bf16_round(v);
+        s = s > 0.0f ? s : 0.0f;
+        o[c] = bf16_round(s);
       }
     }
 }

@@ -4,11 +4,16 @@
 //   * conv_bf16_ws.hip, TAG 2: the producer waves of conv1b make conv1b's halo tile instead of loading it;
 //   * conv_bf16.hip, conv1a_bf16_kernel: the stand-alone layer (launches too small for the wave-specialised kernel).
 //
-// Definition (the oracle's oracle_network_bf16 restates it):
-//   s[c]  = sum over the 9 taps of  float(u8 pixel) * bf16(w[c][tap])          (f32 accumulate; the products are exact)
-//   a0[c] = bf16( max( fmaf(s[c], 1/255, bias[c]), 0 ) )
-// i.e. the 1/255 of convertTo(CV_32F, 1.f/255.f) is applied to the sum, so the matrix operands are exact: u8 values are
-// integers below 2^8 (exact in bf16) and the weights are rounded to bf16 like every other layer's of this mode.
+// Definition (the oracle's conv1a_bf16 restates it; round 6 form):
+//   s[c]  = bias[c] + sum over the 9 taps of  float(u8 pixel) * bf16(w[c][tap] * (1/255))      (f32 accumulate; products exact)
+//   a0[c] = bf16( max( s[c], 0 ) )
+// i.e. the 1/255 of convertTo(CV_32F, 1.f/255.f) is folded into the weights BEFORE their rounding to bf16 (one f32 multiply by
+// float(1/255), then RNE: the host packing and the oracle do the same), the matrix operands stay exact — u8 values are
+// integers below 2^8 (exact in bf16), an 8-bit x 8-bit significand product is exact in f32 — and the bias is the MFMA's C
+// operand, the accumulator's initial value.  What is left per output value is the rounding and the ReLU.  (Rounds 2 - 5 rounded
+// w itself and applied fmaf(sum, 1/255, bias) per value: two more VALU instructions per pair of values in the producers of the
+// fused conv1b, whose issue slots are what that kernel is short of — conv_bf16_ws.hip.  Both are bf16 quantisations of the
+// same f32 layer with the same relative weight error; the mode's tolerances and its flip / margin reports were re-made.)
 // As VALU code (9 taps x 64 channels of f32 FMAs per pixel) this layer cost 0.27 ms per eight 1280x720 frames on its own,
 // and ~950 instructions per tile and wave when fused — more issue slots than the MFMA stream beside it leaves; as a
 // matrix product it is 2 MFMAs per 32 pixels.
@@ -58,13 +63,16 @@ __device__ __forceinline__ bf16x8 pixel_operand(lds_u16 *tap0, int hi) {
   return __builtin_bit_cast(bf16x8, d);
 }
 
-// the two accumulator tiles of a 32-pixel group
-__device__ __forceinline__ void product(const bf16x8 (&wA)[2], bf16x8 px, f32x16 (&acc)[2]) {
-  f32x16 z;
+// the two accumulator tiles of a 32-pixel group; `bias` = the accumulators' initial values (register r of tile j <-> the
+// lane's channel 32 j + 16 (r >> 3) + 8 hi + (r & 7), load_constants)
+__device__ __forceinline__ void product(const bf16x8 (&wA)[2], bf16x8 px, const float (&bias)[2][16], f32x16 (&acc)[2]) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-  acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA[0], px, z, 0, 0, 0);
-  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA[1], px, z, 0, 0, 0);
+  for (int j = 0; j < 2; ++j) {
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = bias[j][r];
+    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA[j], px, c, 0, 0, 0);
+  }
 }
 
 // row m of a channel tile <-> channel 32 j + row_channel(m): bits 2 and 3 of m swapped (host packing: spfe_pack.hip)
@@ -72,37 +80,18 @@ __host__ __device__ constexpr int row_channel(int m) { return (m & ~12) | ((m & 
 
 // epilogue of one (channel tile j, rr = r >> 3): channels 32 j + 16 rr + 8 hi + 0..7 of the lane's pixel = piece 4 j + 2 rr + hi
 // of its 128-byte NHWC row, as 16 bytes of bf16
-// (scalar fmaf on purpose.  v_pk_fma_f32 on register pairs — half the instructions, bit-identical — was measured in the producers
-// of conv1b (round 6) together with the packed ReLU: 1280x720 x 8 392 -> 448 us.  Packed f32 arithmetic beside a saturated MFMA
-// stream costs the matrix pipe far more than the issue slots it saves.)
 typedef short i16x2 __attribute__((ext_vector_type(2)));
-// fmaf(a, 1 / 255, b) as ONE scalar-form instruction the vectoriser cannot pair up (it turns two adjacent fmaf calls into a
-// v_pk_fma_f32, which is what must not run beside the MFMA stream, see above); 0x3b808081 = float(1 / 255)
-__device__ __forceinline__ float fma255(float a, float b) {
-  float r;
-  asm("v_fmamk_f32 %0, %1, 0x3b808081, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-#ifndef C1A_RELU_PACKED
-#define C1A_RELU_PACKED 1   // 1: the ReLU on the rounded pair (one v_pk_max_i16 per two values), 0: v_max_f32 per value in front of the rounding
-#endif
-__device__ __forceinline__ u32x4 finish8(const f32x16 &acc, int rr, const float (&bias)[16]) {
+// epilogue of one (channel tile j, rr = r >> 3): channels 32 j + 16 rr + 8 hi + 0..7 of the lane's pixel = piece 4 j + 2 rr + hi
+// of its 128-byte NHWC row, as 16 bytes of bf16: RNE, then the ReLU on the rounded pair as ONE v_pk_max_i16 against 0 — a
+// negative float is a negative int16 in its upper half and rounds to a negative (or -0) bf16, RNE is monotonic and keeps the
+// sign: max(bf16(v), +0) as 16-bit integers == bf16(max(v, 0)) bit for bit.
+__device__ __forceinline__ u32x4 finish8(const f32x16 &acc, int rr) {
   unsigned o[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
-    float v0 = fma255(acc[8 * rr + 2 * m], bias[8 * rr + 2 * m]);
-    float v1 = fma255(acc[8 * rr + 2 * m + 1], bias[8 * rr + 2 * m + 1]);
-    if constexpr (C1A_RELU_PACKED) {
-      // a negative float is a negative int16 in its upper half and rounds to a negative (or -0) bf16; RNE is monotonic and keeps
-      // the sign: max(bf16(v), +0) as 16-bit integers == bf16(max(v, 0)) bit for bit
-      const i16x2 r = __builtin_bit_cast(i16x2, __builtin_convertvector((f32x2){v0, v1}, bf16x2));
-      const i16x2 z = {0, 0};
-      o[m] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(r, z));
-    } else {
-      v0 = __builtin_fmaxf(v0, 0.0f);
-      v1 = __builtin_fmaxf(v1, 0.0f);
-      o[m] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v0, v1}, bf16x2));
-    }
+    const i16x2 r = __builtin_bit_cast(i16x2, __builtin_convertvector((f32x2){acc[8 * rr + 2 * m], acc[8 * rr + 2 * m + 1]}, bf16x2));
+    const i16x2 z = {0, 0};
+    o[m] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(r, z));
   }
   return (u32x4){o[0], o[1], o[2], o[3]};
 }

@@ -681,7 +681,7 @@ __global__ __launch_bounds__(256) void conv1a_bf16_kernel(const uint8_t *__restr
     const c1a::bf16x8 px = c1a::pixel_operand(
         (c1a::lds_u16 *)sP + row * c1a::PATCH_PITCH + l31, hi);
     c1a::f32x16 acc[2];
-    c1a::product(wA, px, acc);
+    c1a::product(wA, px, bias, acc);
     const int gy = ty0 + row, gx = tx0 + l31;
     if (gy < H && gx < W) {
       unsigned short *o = out + (((size_t)b * H + gy) * W + gx) * 64 + 8 * hi;   // (the lane's pieces: 4 j + 2 rr + hi, conv1a_mfma.h)
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(256) void conv1a_bf16_kernel(const uint8_t *__restr
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
-          const c1a::u32x4 v = c1a::finish8(acc[j], rr, bias[j]);
+          const c1a::u32x4 v = c1a::finish8(acc[j], rr);
           *reinterpret_cast<uint4 *>(o + 32 * j + 16 * rr) = make_uint4(v.x, v.y, v.z, v.w);
         }
     }

@@ -529,14 +529,14 @@ __global__ __launch_bounds__(512) void conv_bf16_ws_kernel(ConvParams p) {
         }
         const bf16x8 pxop = c1a::pixel_operand(reinterpret_cast<c1a::lds_u16 *>(patch + tap0[gi]), hi);
         f32x16 acc1[2];
-        c1a::product(wA, pxop, acc1);
+        c1a::product(wA, pxop, bias1, acc1);
         if (hrc[gi] != (int)0x80000000) {
           [[maybe_unused]] const bool odd = podd[gi];
 #pragma unroll
           for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
-              const u32x4 v = c1a::finish8(acc1[j], rr, bias1[j]);
+              const u32x4 v = c1a::finish8(acc1[j], rr);
               const unsigned a = hdst[gi][2 * j + rr];
               if constexpr (WS_C1A_STORE == 2) {
                 *reinterpret_cast<__attribute__((address_space(3))) u32x2 *>(lds + buf * HALO_BYTES + a) =

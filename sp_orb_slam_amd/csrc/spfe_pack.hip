@@ -369,7 +369,7 @@ int build(spfe_handle h, const spfe_config *cfg, spfe_handle sibling) {
         for (int ln = 0; ln < 64; ++ln)
           for (int e = 0; e < 8; ++e) {
             const int t = 8 * (ln >> 5) + e, m = ln & 31, co = 32 * j + ((m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1));
-            if (t < 9) tab[(j * 64 + ln) * 8 + e] = host_bf16_rne(Wt[co * 9 + t]);
+            if (t < 9) tab[(j * 64 + ln) * 8 + e] = host_bf16_rne(Wt[co * 9 + t] * (1.0f / 255.0f));   // the 1/255 of convertTo folded into the weight before its rounding (conv1a_mfma.h)
           }
       if ((rc = dev_alloc(h, &h->d_w1a_tab, tab.size()))) return rc;
       HIP_TRY(hipMemcpy(h->d_w1a_tab, tab.data(), tab.size() * 2, hipMemcpyHostToDevice));

@@ -111,7 +111,7 @@ int main(int argc, char **argv) {
       for (int ln = 0; ln < 64; ++ln)
         for (int e = 0; e < 8; ++e) {
           const int t = 8 * (ln >> 5) + e, co = 32 * j + spfe::c1a::row_channel(ln & 31);
-          if (t < 9) tab[(j * 64 + ln) * 8 + e] = bf16_rne(w1a[t * 64 + co]);
+          if (t < 9) tab[(j * 64 + ln) * 8 + e] = bf16_rne(w1a[t * 64 + co] * (1.0f / 255.0f));
         }
     CK(hipMalloc(&d_w1a, tab.size() * 2));
     CK(hipMalloc(&d_b1a, b1a.size() * 4));
