@@ -85,6 +85,10 @@ __device__ unsigned long long ws_dbg[10];
 #ifndef WS_READ_SPREAD
 #define WS_READ_SPREAD -1
 #endif
+#ifndef WS_EPI_PKRELU
+#define WS_EPI_PKRELU 1  // pool, burst form: the epilogue's ReLU on the rounded channel pair (one v_pk_max_i16) instead of one v_max_f32 per
+                         // value (round 6: +0.3 %; an item split into two half bursts over two K steps measured +-0 and is gone)
+#endif
 #ifndef WS_EPI_GAP
 #define WS_EPI_GAP 2     // the gap (0..3) of a K step that carries the epilogue item
 #endif
@@ -161,6 +165,13 @@ __device__ __forceinline__ float relu_nc(float a) {
 __device__ __forceinline__ unsigned pack2(float v0, float v1) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v0, v1}, bf16x2));
 }
+// RNE, then the ReLU on the rounded pair as 16-bit integers (max(bf16(v), +0) == bf16(max(v, 0)) bit for bit: conv1a_mfma.h)
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2_relu(float v0, float v1) {
+  const i16x2 r = __builtin_bit_cast(i16x2, __builtin_convertvector((f32x2){v0, v1}, bf16x2));
+  const i16x2 z = {0, 0};
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(r, z));
+}
 
 template <bool POOL, int G>
 __device__ __forceinline__ void epi_item_c(const Epi &e, const float (&bias)[2], const f32x16 (&acc)[2][2]) {
@@ -172,9 +183,9 @@ __device__ __forceinline__ void epi_item_c(const Epi &e, const float (&bias)[2],
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         v[j] = max3_nc(acc[0][j][r], acc[0][j][r + 1], max_nc(acc[1][j][r], acc[1][j][r + 1]));
-        v[j] = relu_nc(v[j] + bias[j]);
+        v[j] = WS_EPI_PKRELU ? v[j] + bias[j] : relu_nc(v[j] + bias[j]);
       }
-      __builtin_amdgcn_raw_buffer_store_b32(pack2(v[0], v[1]), e.rout, e.rowoff[0], (unsigned)(4 * g + h2) * e.pitch, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(WS_EPI_PKRELU ? pack2_relu(v[0], v[1]) : pack2(v[0], v[1]), e.rout, e.rowoff[0], (unsigned)(4 * g + h2) * e.pitch, 0);
     } else {
       constexpr int i = G / 8, g = (G / 2) % 4, mh = G % 2;
 #pragma unroll
@@ -307,7 +318,9 @@ __device__ __forceinline__ void k_steps(bf16x8 (&ah)[2][4], bf16x8 (&w)[3][2], f
       if constexpr (WS_ABLATE != 4) {
         // the operand fragments of step S + 2: one per gap where the epilogue is spread too (+1 %), else all behind the
         // first MFMA (probe builds: WS_READ_SPREAD forces either)
-        constexpr bool SPREAD = WS_READ_SPREAD >= 0 ? WS_READ_SPREAD != 0 : MICRO;
+        // (round 6: one fragment read per gap in the burst form too — with the producers at ~270 VALU instructions a tile the
+        // gaps have room again: conv1b with conv1a inside +1.0 %)
+        constexpr bool SPREAD = WS_READ_SPREAD >= 0 ? WS_READ_SPREAD != 0 : true;
         if constexpr (SPREAD) {
           if (m == 0) read_frags<S + 2, BUF, 0>(ah, w, aptr, wptr);
           if (m == 1) read_frags<S + 2, BUF, 1>(ah, w, aptr, wptr);
