@@ -215,8 +215,8 @@ def test_frontend_chain_with_bf16_convolutions_tracks_like_f32():
     assert b["tracked"] >= f["tracked"] - 1 >= 0.9 * (nframes - 1) - 1, (f["tracked"], b["tracked"])
     assert abs(np.mean(b["inliers"]) - np.mean(f["inliers"])) <= 0.03 * np.mean(f["inliers"]), (np.mean(f["inliers"]), np.mean(b["inliers"]))
     assert abs(b["assoc"] - f["assoc"]) <= 0.03 * f["assoc"], (f["assoc"], b["assoc"])
-    # the recovered pose: bf16 against f32 frame by frame (measured: mean 2.7e-3, max 1.45e-2 — metres / matrix entries, a camera
-    # 4 m from the plane: 0.3 / 1.7 px), and both against the camera's true pose, where the two precisions are equally far
+    # the recovered pose: bf16 against f32 frame by frame (measured: mean 1.5e-3, max 2.3e-3 with round 6's conv1a rounding point,
+    # 2.7e-3 / 1.45e-2 with round 5's — metres / matrix entries, a camera 4 m from the plane: 0.2 - 1.7 px), and both against the camera's true pose, where the two precisions are equally far
     # off (the alignment's own residual on this scene, 6.6e-2: the start pose is one cell off in y)
     dif = [float(np.abs(f["poses"][k] - b["poses"][k]).max()) for k in f["poses"]]
     assert np.mean(dif) <= 6e-3 and max(dif) <= 3e-2, (np.mean(dif), max(dif))
