@@ -56,7 +56,7 @@ struct WaveMem {         // LDS of one wavefront
   float lqv[COV_LCAP];
   uint32_t bm[32];       // own-visited bitmap
   int ow[COV_OW];        // popped pixels outside the window (visited set there), now = count
-  int dn[32 * 32];       // done window — REPLAY ONLY, and last: the lone walks' workgroups allocate the struct up to here
+  int dn[32 * 32];       // done window — REPLAY ONLY, and behind everything the lone walks use: their workgroups allocate the struct up to here
 };                       // (6.1 KB a walk instead of 10.1: 24 walks fit a CU instead of 14, and three walk workgroups fit beside an
                          // f32 convolution workgroup's 120 KB instead of one)
 constexpr size_t COV_WALK_LDS = offsetof(WaveMem, dn);
@@ -169,6 +169,11 @@ __device__ int walk(const Walk &w, int lane) {
   const int ox = t == 0 ? -1 : (t == 2 ? 1 : 0), oy = t == 1 ? -1 : (t == 3 ? 1 : 0);
   const unsigned long long below = (1ull << lane) - 1ull;
   while (head < tail) {
+    // (head and tail are wave-uniform by construction — ballots and popcounts — but the compiler carried them in vector
+    // registers and turned every test on them into an exec-mask branch: pinned to scalar registers here, the loop's control
+    // flow is s_cmp / s_cbranch and ~15 VALU instructions shorter per step)
+    head = __builtin_amdgcn_readfirstlane(head);
+    tail = __builtin_amdgcn_readfirstlane(tail);
     const int G = tail - head < 16 ? tail - head : 16;
     const bool act = gi < G;
     const int e = head + (act ? gi : 0);
@@ -604,6 +609,52 @@ __global__ __launch_bounds__(LINK_THREADS) void cov_link_kernel(FrameBufs f, Rec
 }
 
 // ---- C2: replay.  One wavefront per component, members in ascending order. ----
+// DEFERRED MOMENTS (round 6).  What one member hands to the next is its POP SET (stamps + the patch of the next window); its
+// second moments depend on nothing behind it and nothing behind it depends on them.  `-DSPFE_REPLAY_PROBE` puts a member at
+// 16.4 k cycles, 3.2 k of them moments() — a serial sum, a round of divisions, two more serial sums, two reciprocals, one
+// wavefront's instruction latency each.  So a chain's members park their pop lists (pixel, value) in LDS and the moments of
+// ALL parked members are formed at the end, one LANE per member, every lane running the reference's loops (:316-333) over its
+// own list: the same IEEE operations in the same order per member — same bits — in the time of the longest list instead of
+// the sum of all.  Single-member components (most of a frame's) and members whose list spilled past the LDS FIFO take
+// moments() as before; a full park area is drained where it fills.
+#define COV_DM 512        // parked pops per wavefront (a member of the dense synthetic detector pops ~35)
+#define COV_DM_MEMBERS 64 // parked members per drain (one lane each)
+struct ReplayMem {
+  WaveMem m;
+  int dm_xy[COV_DM];              // (y << 16) | x of a parked pop
+  float dm_v[COV_DM];             // its heat_inv value
+  int4 dm_meta[COV_DM_MEMBERS];   // {first parked pop, pops, keypoint, (y0 << 16) | x0}
+};
+
+// the moments of the parked members, lane m <-> member m: the loops of moments(), per lane
+__device__ void drain_moments(ReplayMem *rm, int nmem, int lane, float *cov2_base, float *cinv_base) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the parks were written by other lanes of this wavefront)
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (lane < nmem) {
+    const int4 me = rm->dm_meta[lane];
+    const int off = me.x, n = me.y, j = me.z;
+    const float x0 = (float)(me.w & 0xffff), y0 = (float)(me.w >> 16);
+    float sum = 0.0f;
+    for (int i = 0; i < n; ++i) sum += rm->dm_v[off + i];
+    float cx = 0.0f, cy = 0.0f;
+    for (int i = 0; i < n; ++i) {
+      const int xy = rm->dm_xy[off + i];
+      const float wgt = rm->dm_v[off + i] / sum;
+      const float dx = (float)(xy & 0xffff) - x0, dy = (float)(xy >> 16) - y0;
+      const float tx = wgt * (dx * dx), ty = wgt * (dy * dy);
+      cx += tx;
+      cy += ty;
+    }
+    cx = cx < 1.0f ? 1.0f : cx;
+    cy = cy < 1.0f ? 1.0f : cy;
+    cov2_base[2 * j] = cx;
+    cov2_base[2 * j + 1] = cy;
+    cinv_base[2 * j] = 1.0f / cx;
+    cinv_base[2 * j + 1] = 1.0f / cy;
+  }
+}
+
 // desc_first >= 0: blocks from that index on are not replay workers but the descriptor sampling of the frame's keypoints, one
 // wavefront each (desc_body.h) — synchronous calls: the sampling is needed by the finished record only, so it runs beside the
 // longest kernel of the chain instead of in front of the chain.
@@ -611,11 +662,15 @@ __global__ __launch_bounds__(LINK_THREADS) void cov_link_kernel(FrameBufs f, Rec
 // frame's ~120 live workers into ~15 workgroups, so that in bf16 pipelined calls — where a register-resident-weights
 // convolution workgroup needs every register of its CU and cannot start on a CU that hosts ONE side-chain wavefront — the
 // replay holds ~120 CUs' worth of nothing instead of a wavefront on nearly every CU (launch_cov).
-template <int WV>
+// DEFER: the moments of a chain's members at the end of the chain (ReplayMem, above) — synchronous calls, where the replay is on
+// a single call's critical path (a 9-member chain 147.7 k -> 128.2 k cycles, 21 members 437.7 k -> 349.9 k; a single frame's call
+// -5 us).  Pipelined calls keep the inline form: the park area is 5 KB more LDS per wavefront beside the next batch's
+// convolutions, and measured -0.6 % on the f32 headline for nothing (the replay is off their critical path).
+template <int WV, bool DEFER>
 __global__ __launch_bounds__(64 * WV) void cov_replay_kernel(FrameBufs f, RecordLayout rl, CovScratch cs,
                                                               int H, int W, int desc_first) {
   extern __shared__ __attribute__((aligned(16))) char s_replay_raw[];
-  WaveMem *const s_mem = reinterpret_cast<WaveMem *>(s_replay_raw);
+  constexpr size_t STRIDE = DEFER ? sizeof(ReplayMem) : sizeof(WaveMem);   // (ReplayMem begins with its WaveMem)
   const int b = blockIdx.y, lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (desc_first >= 0 && (int)blockIdx.x >= desc_first) {
@@ -626,7 +681,9 @@ __global__ __launch_bounds__(64 * WV) void cov_replay_kernel(FrameBufs f, Record
   const CovFrame c = cov_frame(f, rl, cs, b, H, W);
   if ((c.hdr[2] & 1) || widx >= *c.nworkers) return;
   int j = c.workers[widx];
-  WaveMem *m = &s_mem[wv];
+  ReplayMem *const rm = reinterpret_cast<ReplayMem *>(s_replay_raw + (size_t)wv * STRIDE);   // (its park arrays exist when DEFER)
+  WaveMem *m = &rm->m;
+  int dm_n = 0, dm_members = 0;   // parked pops / members (wave-uniform)
   const int *prev_q = nullptr;
   float fx = c.kp_xy[2 * j], fy = c.kp_xy[2 * j + 1];
   int jn = c.nxt[j];
@@ -675,12 +732,29 @@ __global__ __launch_bounds__(64 * WV) void cov_replay_kernel(FrameBufs f, Record
     const int n = walk<true>(w, lane);
     RP(tp_walk);
     if (n < 0) { if (lane == 0) atomicOr(&c.hdr[2], 1); return; }
-    moments(w, n, lane, c.cov2 + 2 * j, c.cinv + 2 * j);
+    if (!DEFER || (j_prev < 0 && jn < 0) || n > COV_LCAP || n > COV_DM) {
+      moments(w, n, lane, c.cov2 + 2 * j, c.cinv + 2 * j);   // a lone member, or a list that left the LDS FIFO: as before
+    } else {
+      if (dm_n + n > COV_DM || dm_members == COV_DM_MEMBERS) {   // (uniform) the park area is full: drain it
+        drain_moments(rm, dm_members, lane, c.cov2, c.cinv);
+        dm_n = 0; dm_members = 0;
+      }
+      for (int i = lane; i < n; i += 64) {
+        const int id = m->lq[i];
+        const int py = row_of(id, W, wmagic), px = id - py * W;
+        rm->dm_xy[dm_n + i] = (py << 16) | px;
+        rm->dm_v[dm_n + i] = m->lqv[i];
+      }
+      if (lane == 0) rm->dm_meta[dm_members] = make_int4(dm_n, n, j, (y0 << 16) | x0);
+      dm_n += n;
+      ++dm_members;
+    }
     RP(tp_mom);
     // stamp before the next member starts: this wavefront is the only writer and
     // the only reader of these pixels during the kernel
     for (int i = lane; i < n; i += 64) c.done[fifo_id(w, i)] = cs.gen | j;  // popped => its stamp was >= j
-    __threadfence_block();  // same wavefront, same CU: L1 is coherent for it
+    __threadfence_block();  // same wavefront, same CU: L1 is coherent for it   (round 6: patching from the last TWO members' lists
+                            // instead of this wait measured 132.0 k against 128.2 k cycles on the 9-member chain: the wait is not what a member costs)
     RP(tp_stamp);
 #ifdef SPFE_REPLAY_PROBE
     ++members; pops += n;
@@ -689,6 +763,7 @@ __global__ __launch_bounds__(64 * WV) void cov_replay_kernel(FrameBufs f, Record
     j = jn; fx = nfx; fy = nfy;
     jn = jnn; nfx = nnfx; nfy = nnfy;
   }
+  if (DEFER && dm_members) drain_moments(rm, dm_members, lane, c.cov2, c.cinv);   // (LDS operations of a wavefront are in order: the parks are visible)
 #ifdef SPFE_REPLAY_PROBE
   if (lane == 0 && members >= 8)
     printf("REPLAY chain %d members %d pops | store+patch %llu walk %llu moments %llu stamp %llu | total %llu\n", members, pops,
@@ -793,11 +868,11 @@ __global__ __launch_bounds__(256) void cov_fallback_kernel(FrameBufs f, RecordLa
 
 size_t cov_link_lds(int kmax) { return (size_t)kmax * 4 * sizeof(int); }   // parent, leader, 2 K sort keys
 
-template <int WV>
+template <int WV, bool DEFER>
 static hipError_t launch_replay(const FrameBufs &f, const RecordLayout &r, const CovScratch &cs, int B, int H, int W, hipStream_t s,
                                 bool with_desc) {
-  const size_t lds = sizeof(WaveMem) * WV;
-  auto k = cov_replay_kernel<WV>;
+  const size_t lds = (DEFER ? sizeof(ReplayMem) : sizeof(WaveMem)) * WV;
+  auto k = cov_replay_kernel<WV, DEFER>;
   if (lds > 64 * 1024) {
     static bool attr_done[64] = {};
     int dev = 0;
@@ -814,7 +889,7 @@ static hipError_t launch_replay(const FrameBufs &f, const RecordLayout &r, const
 }
 
 hipError_t launch_cov(const FrameBufs &f, const RecordLayout &r, const CovScratch &cs, int B, int H, int W,
-                      hipStream_t s, bool with_desc, hipEvent_t before_replay, int replay_waves) {
+                      hipStream_t s, bool with_desc, hipEvent_t before_replay, int replay_waves, bool defer_moments) {
   // claim / done / counters / ovf_slot were reset by heat_norm_kernel (the kernel in front of this stage)
   hipError_t e = hipSuccess;
   const dim3 grid((r.kmax + COV_WAVES - 1) / COV_WAVES, B), block(64 * COV_WAVES);
@@ -832,7 +907,8 @@ hipError_t launch_cov(const FrameBufs &f, const RecordLayout &r, const CovScratc
     e = hipStreamWaitEvent(s, before_replay, 0);
     if (e != hipSuccess) return e;
   }
-  e = replay_waves >= 8 ? launch_replay<8>(f, r, cs, B, H, W, s, with_desc) : launch_replay<COV_WAVES>(f, r, cs, B, H, W, s, with_desc);
+  if (defer_moments) e = replay_waves >= 8 ? launch_replay<8, true>(f, r, cs, B, H, W, s, with_desc) : launch_replay<COV_WAVES, true>(f, r, cs, B, H, W, s, with_desc);
+  else e = replay_waves >= 8 ? launch_replay<8, false>(f, r, cs, B, H, W, s, with_desc) : launch_replay<COV_WAVES, false>(f, r, cs, B, H, W, s, with_desc);
   if (e != hipSuccess) return e;
   // (one workgroup that returns at once unless a record carries the overflow bit: ~2 us at the end of the chain)
   if (cs.fb_q) hipLaunchKernelGGL(cov_fallback_kernel, dim3(1), dim3(256), 0, s, f, r, cs, B, H, W);

@@ -167,7 +167,8 @@ size_t cov_link_lds(int kmax);
 // with_desc: the descriptor sampling (launch_desc) as extra wavefronts of the replay launch, behind `before_replay` if given
 // replay_waves: components per replay workgroup, 2 (default) or 8 (bf16 pipelined calls: see cov.hip)
 hipError_t launch_cov(const FrameBufs &f, const RecordLayout &r, const CovScratch &cs, int B, int H, int W,
-                      hipStream_t s, bool with_desc = false, hipEvent_t before_replay = nullptr, int replay_waves = 2);
+                      hipStream_t s, bool with_desc = false, hipEvent_t before_replay = nullptr, int replay_waves = 2,
+                      bool defer_moments = false);   // defer_moments: synchronous calls (cov.hip, cov_replay_kernel)
 
 int tail_parts(int H, int W);  // min/max partials per frame written by the tail kernel
 // f32 mode: convPb (1x1, 256 -> 65) + the detector tail in one launch (pbtail_f32.hip), bit-identical to convPb through

@@ -650,7 +650,7 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
     }
     HIP_TRY(hipEventRecord(h->ev_desc, h->side));
     h->desc_recorded = true;
-    HIP_TRY(spfe::launch_cov(f, h->rl, h->cov, n, H, W, s, false, nullptr));
+    HIP_TRY(spfe::launch_cov(f, h->rl, h->cov, n, H, W, s, false, nullptr, 2, true));   // (a synchronous call: moments deferred, cov.hip)
     HIP_TRY(hipStreamWaitEvent(s, h->ev_desc, 0));    // the join: records complete in `s` order
     HIP_TRY(hipEventRecord(h->ev_cov[slot], s));
     h->cov_inflight = false;
@@ -714,7 +714,7 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
     // whole CU's registers (SPFE_REPLAY_WAVES=2|8 overrides)
     // (measured, same-box A/B, 8 frames per call: bf16 1280x720 +0.7 %, bf16 752x480 -1.8 %, f32 -1 %: large bf16 frames only)
     const int rwv = h->replay_waves ? h->replay_waves : (h->bf16 && !sync_call && h->C >= 10000 ? 8 : 2);
-    HIP_TRY(spfe::launch_cov(f, h->rl, h->cov, n, H, W, h->side, desc_in_replay, before_replay, rwv));
+    HIP_TRY(spfe::launch_cov(f, h->rl, h->cov, n, H, W, h->side, desc_in_replay, before_replay, rwv, sync_call));
   }
   if (desc_in_replay) {
     HIP_TRY(hipEventRecord(h->ev_desc, h->side));
