@@ -150,6 +150,22 @@ SPFE_API int spfe_extract(spfe_handle h, const uint8_t *image, int stride, spfe_
 SPFE_API int spfe_extract_batch(spfe_handle h, const uint8_t *const *images, int stride, int n,
                        spfe_result *outs);
 
+/* The synchronous call in three parts, for a caller that copies the outputs out of the library's buffers (the drop-in
+ * class does: the reference's members are deep cv::Mat copies, sp_extractor.cpp:436-474): the two H x W maps are complete
+ * after the network's tail, ~0.15 ms before the record (selection, sampling, covariance follow), and their D2H runs beside
+ * that work (SPFE_EARLY_HEAT_COPY) — so the caller's own copy of the maps can run beside it too.
+ *   spfe_extract_begin   what spfe_extract_batch does up to the end of its enqueueing; returns at once
+ *   spfe_extract_maps    blocks until the maps of the begun call are in host memory; *heat / *heat_inv = frame 0's map,
+ *                        frame i at + i * H * W floats (*heat_inv = NULL with SPFE_FLAG_LAZY_HEAT_INV).  Both NULL (and
+ *                        SPFE_OK) when the maps do not travel ahead of the record in this call (no SPFE_FLAG_HEAT,
+ *                        SPFE_EARLY_HEAT_COPY=0): spfe_extract_finish delivers them as spfe_extract_batch does.  Optional.
+ *   spfe_extract_finish  the rest of spfe_extract_batch: blocks, fills outs[0 .. n) (same pointers, same lifetime)
+ * begin + finish == spfe_extract_batch, bit for bit.  Between the two no other call on the handle (SPFE_EINVAL from begin
+ * while a call is open, from maps / finish when none is). */
+SPFE_API int spfe_extract_begin(spfe_handle h, const uint8_t *const *images, int stride, int n);
+SPFE_API int spfe_extract_maps(spfe_handle h, const float **heat, const float **heat_inv);
+SPFE_API int spfe_extract_finish(spfe_handle h, spfe_result *outs);
+
 /* Pipelined host path.  spfe_extract_batch is synchronous like the reference's operator() (upload
  * sp_extractor.cpp:379-390, blocking D2H :427-433).  A host that has the next frames while the current ones
  * are being processed (a dataset player, a multi-camera rig, the batch path) submits instead:

@@ -68,11 +68,22 @@ class ExtractorCV {
     if (image.type() != CV_8UC1) throw std::runtime_error("input image must be CV_8UC1");  // assert :368
     if (image.rows != height_ || image.cols != width_)
       throw std::runtime_error("input image size differs from the configured extractor size");
-    spfe_result r{};
-    const int rc = spfe_extract(h_, image.data, static_cast<int>(image.step), &r);
+    // the call in three parts (spfe.h): the two H x W maps are in host memory before selection, sampling and covariance have
+    // finished on the device, and their deep copies into the members (:461-474 fills heat_ / heat_inv_) run beside those
+    const uint8_t *one[1] = {image.data};
+    int rc = spfe_extract_begin(h_, one, static_cast<int>(image.step), 1);
     if (rc == SPFE_EEMPTY) throw std::runtime_error("input image is empty");
     if (rc != SPFE_OK) throw std::runtime_error(std::string("spfe_extract: ") + spfe_last_error());
-    publish(r, _keypoints, _descriptors);
+    const float *heat = nullptr, *heat_inv = nullptr;
+    rc = spfe_extract_maps(h_, &heat, &heat_inv);
+    if (rc == SPFE_OK) {
+      if (heat) cv::Mat(height_, width_, CV_32FC1, const_cast<float *>(heat)).copyTo(heat_);
+      if (heat_inv) cv::Mat(height_, width_, CV_32FC1, const_cast<float *>(heat_inv)).copyTo(heat_inv_);
+    }
+    spfe_result r{};
+    const int rcf = spfe_extract_finish(h_, &r);   // (always: it closes the call)
+    if (rc != SPFE_OK || rcf != SPFE_OK) throw std::runtime_error(std::string("spfe_extract: ") + spfe_last_error());
+    publish(r, _keypoints, _descriptors, heat != nullptr, heat_inv != nullptr);
   }
 
   // Input staging on the GPU.  setStaging() once, with the CV_32FC1 maps of
@@ -111,7 +122,9 @@ class ExtractorCV {
   }
 
  protected:
-  void publish(const spfe_result &r, std::vector<cv::KeyPoint> &_keypoints, cv::OutputArray _descriptors) {
+  // heat_done / heat_inv_done: that map of this call is in its member already (operator() copied it beside the device's work)
+  void publish(const spfe_result &r, std::vector<cv::KeyPoint> &_keypoints, cv::OutputArray _descriptors,
+               bool heat_done = false, bool heat_inv_done = false) {
     const int hc = height_ / 8, wc = width_ / 8;
     _keypoints.resize(r.K);
     cov2_.resize(r.K);
@@ -130,9 +143,9 @@ class ExtractorCV {
     cv::Mat(hc, wc, CV_32FC1, const_cast<float *>(r.semi_dust)).copyTo(semi_dust_);
     cv::Mat(hc, wc, CV_32FC1, const_cast<float *>(r.dense_dust)).copyTo(dense_dust_);
     cv::Mat(hc, wc, CV_16SC1, const_cast<int16_t *>(r.occ_grid)).copyTo(occ_grid_);
-    if (r.heat) cv::Mat(height_, width_, CV_32FC1, const_cast<float *>(r.heat)).copyTo(heat_);
-    if (r.heat_inv) cv::Mat(height_, width_, CV_32FC1, const_cast<float *>(r.heat_inv)).copyTo(heat_inv_);
-    else heat_inv_ = cv::Mat();   // (lazy: heatInv() fetches this call's map; a stale one must not be mistaken for it)
+    if (r.heat && !heat_done) cv::Mat(height_, width_, CV_32FC1, const_cast<float *>(r.heat)).copyTo(heat_);
+    if (r.heat_inv && !heat_inv_done) cv::Mat(height_, width_, CV_32FC1, const_cast<float *>(r.heat_inv)).copyTo(heat_inv_);
+    else if (!r.heat_inv) heat_inv_ = cv::Mat();   // (lazy: heatInv() fetches this call's map; a stale one must not be mistaken for it)
     status_ = r.status;
   }
 

@@ -191,6 +191,7 @@ size_t spfe_record_bytes(spfe_handle h) { return h ? h->rl.bytes : 0; }
 
 int spfe_extract_batch_device(spfe_handle h, const void *d_images, int n, void *d_records, void *stream) {
   if (!h) return fail(SPFE_EINVAL, "null handle");
+  if (h->open_n) return fail(SPFE_EINVAL, "a call begun by spfe_extract_begin is open: spfe_extract_finish first");
   if (!d_images) return fail(SPFE_EEMPTY, "input image is empty");
   if (n < 1 || n > h->B) return fail(SPFE_EINVAL, "batch %d not in [1, %d]", n, h->B);
   HIP_TRY(hipSetDevice(h->cfg.device));
@@ -237,8 +238,9 @@ int spfe_postprocess(spfe_handle h, const float *semi, const float *coarse, int 
   return finish_host(h, n, outs);
 }
 
-int spfe_extract_batch(spfe_handle h, const uint8_t *const *images, int stride, int n, spfe_result *outs) {
-  if (!h || !outs) return fail(SPFE_EINVAL, "null argument");
+int spfe_extract_begin(spfe_handle h, const uint8_t *const *images, int stride, int n) {
+  if (!h) return fail(SPFE_EINVAL, "null argument");
+  if (h->open_n) return fail(SPFE_EINVAL, "a call of %d frames is open: spfe_extract_finish first", h->open_n);
   if (!images) return fail(SPFE_EEMPTY, "input image is empty");
   if (n < 1 || n > h->B) return fail(SPFE_EINVAL, "batch %d not in [1, %d]", n, h->B);
   const int H = h->H, W = h->W;
@@ -255,7 +257,36 @@ int spfe_extract_batch(spfe_handle h, const uint8_t *const *images, int stride, 
   int rc = enqueue(h, h->d_img, n, h->d_records, s);
   h->host_sync_call = false;
   if (rc) return rc;
+  h->open_n = n;
+  return SPFE_OK;
+}
+
+int spfe_extract_maps(spfe_handle h, const float **heat, const float **heat_inv) {
+  if (!h || !heat || !heat_inv) return fail(SPFE_EINVAL, "null argument");
+  if (!h->open_n) return fail(SPFE_EINVAL, "no open call: spfe_extract_begin first");
+  *heat = *heat_inv = nullptr;
+  if (!h->heat_early) return SPFE_OK;   // the maps come with the record (spfe_extract_finish)
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  HIP_TRY(hipEventSynchronize(h->ev_heat_copied));
+  *heat = h->h_heat;
+  if (!(h->cfg.flags & SPFE_FLAG_LAZY_HEAT_INV)) *heat_inv = h->h_heat_inv;
+  return SPFE_OK;
+}
+
+int spfe_extract_finish(spfe_handle h, spfe_result *outs) {
+  if (!h || !outs) return fail(SPFE_EINVAL, "null argument");
+  if (!h->open_n) return fail(SPFE_EINVAL, "no open call: spfe_extract_begin first");
+  const int n = h->open_n;
+  h->open_n = 0;
+  HIP_TRY(hipSetDevice(h->cfg.device));
   return finish_host(h, n, outs);
+}
+
+int spfe_extract_batch(spfe_handle h, const uint8_t *const *images, int stride, int n, spfe_result *outs) {
+  if (!h || !outs) return fail(SPFE_EINVAL, "null argument");
+  const int rc = spfe_extract_begin(h, images, stride, n);
+  if (rc) return rc;
+  return spfe_extract_finish(h, outs);
 }
 
 // D2H of the records (+ maps), sync, host views.
@@ -529,6 +560,7 @@ int pipe_setup(spfe_handle h) {
 
 int spfe_submit_batch(spfe_handle h, const uint8_t *const *images, int stride, int n, long *ticket) {
   if (!h || !ticket) return fail(SPFE_EINVAL, "null argument");
+  if (h->open_n) return fail(SPFE_EINVAL, "a call begun by spfe_extract_begin is open: spfe_extract_finish first");
   if (!images) return fail(SPFE_EEMPTY, "input image is empty");
   if (n < 1 || n > h->B) return fail(SPFE_EINVAL, "batch %d not in [1, %d]", n, h->B);
   const int H = h->H, W = h->W;

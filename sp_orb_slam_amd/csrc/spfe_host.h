@@ -214,6 +214,7 @@ struct spfe_handle_s {
   hipStream_t s_heat = nullptr;
   hipEvent_t ev_heat = nullptr, ev_heat_copied = nullptr;
   bool early_heat_copy = true;   // SPFE_EARLY_HEAT_COPY
+  int open_n = 0;                // frames of a call begun by spfe_extract_begin and not yet finished
   bool host_sync_call = false;   // set by the synchronous host entry points around enqueue()
   bool heat_early = false;       // this call's maps were sent ahead: finish_host waits for ev_heat_copied instead of copying
   // ... and the descriptor rows of the record (kmax x 256 floats: 1.0 of a 752x480 record's 1.1 MB) leave right behind the

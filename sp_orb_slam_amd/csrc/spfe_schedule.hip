@@ -129,6 +129,7 @@ int settle_join(spfe_handle h, hipStream_t s) {
 
 int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, hipStream_t s) {
   const int H = h->H, W = h->W;
+  if (h->open_n) return fail(SPFE_EINVAL, "a call begun by spfe_extract_begin is open: spfe_extract_finish first");
   if (h->timing) h->ev = h->evpool.data() + (size_t)(h->calls % spfe_handle_s::EVSETS) * (NSTAGE + 1);
   h->calls++;
   h->host_sync_n = 0;   // (heat_inv is about to be rewritten: finish_host() says when a synchronous host call's maps are complete)
@@ -558,6 +559,7 @@ static int send_heat_maps_ahead(spfe_handle h, int n) {
 // batch by enqueue(), behind tail_waits().
 int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const std::function<int()> *conv_db, bool sparse, bool fused_pb, bool tail_done) {
   const int H = h->H, W = h->W;
+  if (h->open_n) return fail(SPFE_EINVAL, "a call begun by spfe_extract_begin is open: spfe_extract_finish first");
   spfe::FrameBufs f = frame_bufs(h, d_records, sparse);
   h->sparse_last = sparse;
   h->desc_early = false;   // (set below when this call sends its descriptor rows ahead)

@@ -43,6 +43,7 @@ ABI_SYMBOLS = [
     "spfe_comm_stream", "spfe_comm_count", "spfe_submit_batch", "spfe_collect_batch",
     "spfe_align_dust", "spfe_align_dust_record_device", "spfe_align_dust_batch_device", "spfe_match_knn2",
     "spfe_track_dust_record_device", "spfe_fetch_heat_inv",
+    "spfe_extract_begin", "spfe_extract_maps", "spfe_extract_finish",
 ]
 
 
@@ -137,6 +138,12 @@ def load_library():
                                      C.POINTER(_Result)]
     L.spfe_postprocess.restype = C.c_int
     L.spfe_postprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(_Result)]
+    L.spfe_extract_begin.restype = C.c_int
+    L.spfe_extract_begin.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int]
+    L.spfe_extract_maps.restype = C.c_int
+    L.spfe_extract_maps.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float))]
+    L.spfe_extract_finish.restype = C.c_int
+    L.spfe_extract_finish.argtypes = [C.c_void_p, C.POINTER(_Result)]
     L.spfe_get_record_layout.restype = C.c_int
     L.spfe_get_record_layout.argtypes = [C.c_void_p, C.POINTER(RecordLayout)]
     L.spfe_record_bytes.restype = C.c_size_t
@@ -400,6 +407,35 @@ class SPExtractor:
         ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
         res = (_Result * n)()
         _check(self._lib.spfe_extract_batch(self._h, ptrs, imgs[0].strides[0], n, res))
+        out = [FrameResult(res[i], self.height, self.width, self.with_heat) for i in range(n)]
+        self._publish(out[-1])
+        return out
+
+    # -- the synchronous call in three parts (spfe.h: spfe_extract_begin / _maps / _finish) --
+    def extract_begin(self, images):
+        """Enqueue what extract_batch(images) runs and return at once; extract_finish() delivers the results."""
+        imgs = [np.ascontiguousarray(self._check_image(im)) for im in images]
+        if not imgs:
+            raise RuntimeError("input image is empty")
+        ptrs = (C.c_void_p * len(imgs))(*[im.ctypes.data for im in imgs])
+        _check(self._lib.spfe_extract_begin(self._h, ptrs, imgs[0].strides[0], len(imgs)))
+        self._open_n = len(imgs)
+
+    def extract_maps(self):
+        """Block until the open call's H x W maps are in host memory: (heat [n,H,W], heat_inv [n,H,W] or None) as views of
+        the library's buffers — or (None, None) when the maps travel with the record in this call."""
+        ph, pi = C.POINTER(C.c_float)(), C.POINTER(C.c_float)()
+        _check(self._lib.spfe_extract_maps(self._h, C.byref(ph), C.byref(pi)))
+        n = getattr(self, "_open_n", 0)
+        view = lambda p: np.ctypeslib.as_array(p, shape=(n, self.height, self.width)) if p else None
+        return view(ph), view(pi)
+
+    def extract_finish(self):
+        """The rest of the call begun by extract_begin(); returns what extract_batch would have."""
+        n = max(getattr(self, "_open_n", 0), 1)
+        res = (_Result * n)()
+        self._open_n = 0
+        _check(self._lib.spfe_extract_finish(self._h, res))
         out = [FrameResult(res[i], self.height, self.width, self.with_heat) for i in range(n)]
         self._publish(out[-1])
         return out

@@ -927,3 +927,53 @@ def test_heat_maps_sent_ahead_of_the_record_are_the_same_maps(monkeypatch):
             assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
     ref = oracle.extract(blob, frames[3][0], nf)       # ... and they are the oracle's maps
     assert np.array_equal(out["1"][-2][4], ref["heat"]) and np.array_equal(out["1"][-2][5], ref["heat_inv"])
+
+
+def test_the_call_in_three_parts_is_the_call(monkeypatch):
+    """spfe_extract_begin / spfe_extract_maps / spfe_extract_finish (spfe.h; what the drop-in's operator() runs so that its deep
+    copies of heat_ / heat_inv_ go beside the device's selection + covariance): begin + finish is spfe_extract_batch bit for bit,
+    the maps handed out early are the maps of the result, with SPFE_EARLY_HEAT_COPY=0 / without SPFE_FLAG_HEAT none are handed
+    out early, and the handle refuses anything else while a call is open."""
+    H, W, nf, B = 240, 376, 300, 3
+    blob = weights.synthetic(7, "dense")
+    frames = [[synth.make_image(2300 + 5 * r + i, H, W) for i in range(B)] for r in range(3)]
+    same = lambda x, y: np.array_equal(np.ascontiguousarray(x).view(np.uint32), np.ascontiguousarray(y).view(np.uint32))
+    for flag, heat, lazy in (("1", True, False), ("1", True, True), ("0", True, False), ("1", False, False)):
+        monkeypatch.setenv("SPFE_EARLY_HEAT_COPY", flag)
+        ref = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=heat, lazy_heat_inv=lazy)
+        ext = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=heat, lazy_heat_inv=lazy)
+        for r in range(3):
+            batch = frames[r][: 1 + (r % B)] if r else frames[r]
+            want = ref.extract_batch(batch)
+            ext.extract_begin(batch)
+            with pytest.raises(Exception, match="open"):
+                ext.extract_begin(batch)
+            with pytest.raises(Exception, match="open"):
+                ext.extract_batch(batch)
+            hm, hi = ext.extract_maps()
+            early = heat and flag == "1"
+            assert (hm is not None) == early and (hi is not None) == (early and not lazy)
+            hm = hm.copy() if early else None
+            hi = hi.copy() if hi is not None else None
+            got = ext.extract_finish()
+            assert len(got) == len(want)
+            for i, (a, b) in enumerate(zip(got, want)):
+                assert a.K == b.K and a.K > 0
+                for f in ("kp_xy", "response", "descriptors", "cov2", "cov2_inv", "dense_dust", "semi_dust"):
+                    assert same(getattr(a, f), getattr(b, f)), f
+                assert np.array_equal(a.occ_grid, b.occ_grid)
+                if heat:
+                    assert same(a.heat, b.heat)
+                    if early:
+                        assert same(hm[i], b.heat)
+                    if not lazy:
+                        assert same(a.heat_inv, b.heat_inv)
+                        if early:
+                            assert same(hi[i], b.heat_inv)
+            with pytest.raises(Exception, match="no open call"):
+                ext.extract_maps()
+            with pytest.raises(Exception, match="no open call"):
+                ext.extract_finish()
+        ext.close()
+        ref.close()
+    monkeypatch.delenv("SPFE_EARLY_HEAT_COPY")
