@@ -155,10 +155,12 @@ SPFE_API int spfe_extract_batch(spfe_handle h, const uint8_t *const *images, int
  * after the network's tail, ~0.15 ms before the record (selection, sampling, covariance follow), and their D2H runs beside
  * that work (SPFE_EARLY_HEAT_COPY) — so the caller's own copy of the maps can run beside it too.
  *   spfe_extract_begin   what spfe_extract_batch does up to the end of its enqueueing; returns at once
- *   spfe_extract_maps    blocks until the maps of the begun call are in host memory; *heat / *heat_inv = frame 0's map,
- *                        frame i at + i * H * W floats (*heat_inv = NULL with SPFE_FLAG_LAZY_HEAT_INV).  Both NULL (and
- *                        SPFE_OK) when the maps do not travel ahead of the record in this call (no SPFE_FLAG_HEAT,
- *                        SPFE_EARLY_HEAT_COPY=0): spfe_extract_finish delivers them as spfe_extract_batch does.  Optional.
+ *   spfe_extract_maps    blocks until the maps asked for (either argument may be NULL: not asked for) are in host
+ *                        memory; *heat / *heat_inv = frame 0's map, frame i at + i * H * W floats (*heat_inv = NULL with
+ *                        SPFE_FLAG_LAZY_HEAT_INV).  `heat` arrives first, `heat_inv` behind it: a caller copying both asks
+ *                        for heat alone, copies it, then asks for heat_inv.  NULL results (and SPFE_OK) when the maps do not
+ *                        travel ahead of the record in this call (no SPFE_FLAG_HEAT, SPFE_EARLY_HEAT_COPY=0):
+ *                        spfe_extract_finish delivers them as spfe_extract_batch does.  Optional, any number of times.
  *   spfe_extract_finish  the rest of spfe_extract_batch: blocks, fills outs[0 .. n) (same pointers, same lifetime)
  * begin + finish == spfe_extract_batch, bit for bit.  Between the two no other call on the handle (SPFE_EINVAL from begin
  * while a call is open, from maps / finish when none is). */

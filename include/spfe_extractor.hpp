@@ -75,10 +75,11 @@ class ExtractorCV {
     if (rc == SPFE_EEMPTY) throw std::runtime_error("input image is empty");
     if (rc != SPFE_OK) throw std::runtime_error(std::string("spfe_extract: ") + spfe_last_error());
     const float *heat = nullptr, *heat_inv = nullptr;
-    rc = spfe_extract_maps(h_, &heat, &heat_inv);
-    if (rc == SPFE_OK) {
-      if (heat) cv::Mat(height_, width_, CV_32FC1, const_cast<float *>(heat)).copyTo(heat_);
-      if (heat_inv) cv::Mat(height_, width_, CV_32FC1, const_cast<float *>(heat_inv)).copyTo(heat_inv_);
+    rc = spfe_extract_maps(h_, &heat, nullptr);          // heat is the first to arrive; heat_inv travels while it is copied
+    if (rc == SPFE_OK && heat) {
+      cv::Mat(height_, width_, CV_32FC1, const_cast<float *>(heat)).copyTo(heat_);
+      rc = spfe_extract_maps(h_, nullptr, &heat_inv);
+      if (rc == SPFE_OK && heat_inv) cv::Mat(height_, width_, CV_32FC1, const_cast<float *>(heat_inv)).copyTo(heat_inv_);
     }
     spfe_result r{};
     const int rcf = spfe_extract_finish(h_, &r);   // (always: it closes the call)

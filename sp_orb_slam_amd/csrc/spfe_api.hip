@@ -158,6 +158,7 @@ void spfe_destroy(spfe_handle h) {
   if (h->s_heat) { (void)hipStreamSynchronize(h->s_heat); (void)hipStreamDestroy(h->s_heat); }
   if (h->ev_heat) (void)hipEventDestroy(h->ev_heat);
   if (h->ev_heat_copied) (void)hipEventDestroy(h->ev_heat_copied);
+  if (h->ev_heat_copied1) (void)hipEventDestroy(h->ev_heat_copied1);
   if (h->s_h2d) { (void)hipStreamSynchronize(h->s_h2d); (void)hipStreamDestroy(h->s_h2d); }
   if (h->s_d2h) { (void)hipStreamSynchronize(h->s_d2h); (void)hipStreamDestroy(h->s_d2h); }
   if (h->side) (void)hipStreamDestroy(h->side);
@@ -262,14 +263,16 @@ int spfe_extract_begin(spfe_handle h, const uint8_t *const *images, int stride, 
 }
 
 int spfe_extract_maps(spfe_handle h, const float **heat, const float **heat_inv) {
-  if (!h || !heat || !heat_inv) return fail(SPFE_EINVAL, "null argument");
+  if (!h || (!heat && !heat_inv)) return fail(SPFE_EINVAL, "null argument");
   if (!h->open_n) return fail(SPFE_EINVAL, "no open call: spfe_extract_begin first");
-  *heat = *heat_inv = nullptr;
+  if (heat) *heat = nullptr;
+  if (heat_inv) *heat_inv = nullptr;
   if (!h->heat_early) return SPFE_OK;   // the maps come with the record (spfe_extract_finish)
   HIP_TRY(hipSetDevice(h->cfg.device));
-  HIP_TRY(hipEventSynchronize(h->ev_heat_copied));
-  *heat = h->h_heat;
-  if (!(h->cfg.flags & SPFE_FLAG_LAZY_HEAT_INV)) *heat_inv = h->h_heat_inv;
+  const bool inv = heat_inv && !(h->cfg.flags & SPFE_FLAG_LAZY_HEAT_INV);
+  HIP_TRY(hipEventSynchronize(inv ? h->ev_heat_copied : h->ev_heat_copied1));   // (one copy stream: heat first, heat_inv behind it)
+  if (heat) *heat = h->h_heat;
+  if (inv) *heat_inv = h->h_heat_inv;
   return SPFE_OK;
 }
 

@@ -212,7 +212,7 @@ struct spfe_handle_s {
   // normalisation's completion signal, and runs beside the chain instead of behind it (round 6; SPFE_EARLY_HEAT_COPY=0: behind
   // the record's copy, as before).
   hipStream_t s_heat = nullptr;
-  hipEvent_t ev_heat = nullptr, ev_heat_copied = nullptr;
+  hipEvent_t ev_heat = nullptr, ev_heat_copied1 = nullptr, ev_heat_copied = nullptr;   // normalisation done / heat in host memory / both maps
   bool early_heat_copy = true;   // SPFE_EARLY_HEAT_COPY
   int open_n = 0;                // frames of a call begun by spfe_extract_begin and not yet finished
   bool host_sync_call = false;   // set by the synchronous host entry points around enqueue()

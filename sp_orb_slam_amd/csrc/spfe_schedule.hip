@@ -539,6 +539,7 @@ static hipEvent_t heat_event_for(spfe_handle h, hipStream_t s) {
   if (!h->s_heat) {
     if (hipStreamCreateWithFlags(&h->s_heat, hipStreamNonBlocking) != hipSuccess) { h->s_heat = nullptr; return nullptr; }
     if (hipEventCreateWithFlags(&h->ev_heat, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_heat_copied1, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_heat_copied, hipEventDisableTiming) != hipSuccess) { h->early_heat_copy = false; return nullptr; }
   }
   return h->ev_heat;
@@ -547,6 +548,7 @@ static int send_heat_maps_ahead(spfe_handle h, int n) {
   const size_t bytes = (size_t)n * h->H * h->W * 4;
   HIP_TRY(hipStreamWaitEvent(h->s_heat, h->ev_heat, 0));
   HIP_TRY(hipMemcpyAsync(h->h_heat, h->d_heat, bytes, hipMemcpyDeviceToHost, h->s_heat));
+  HIP_TRY(hipEventRecord(h->ev_heat_copied1, h->s_heat));   // (`heat` alone: spfe_extract_maps hands it out while heat_inv travels)
   if (!(h->cfg.flags & SPFE_FLAG_LAZY_HEAT_INV))
     HIP_TRY(hipMemcpyAsync(h->h_heat_inv, h->d_heat_inv, bytes, hipMemcpyDeviceToHost, h->s_heat));
   HIP_TRY(hipEventRecord(h->ev_heat_copied, h->s_heat));

@@ -425,7 +425,8 @@ class SPExtractor:
         """Block until the open call's H x W maps are in host memory: (heat [n,H,W], heat_inv [n,H,W] or None) as views of
         the library's buffers — or (None, None) when the maps travel with the record in this call."""
         ph, pi = C.POINTER(C.c_float)(), C.POINTER(C.c_float)()
-        _check(self._lib.spfe_extract_maps(self._h, C.byref(ph), C.byref(pi)))
+        _check(self._lib.spfe_extract_maps(self._h, C.byref(ph), None))      # heat arrives first ...
+        _check(self._lib.spfe_extract_maps(self._h, None, C.byref(pi)))      # ... heat_inv behind it
         n = getattr(self, "_open_n", 0)
         view = lambda p: np.ctypeslib.as_array(p, shape=(n, self.height, self.width)) if p else None
         return view(ph), view(pi)

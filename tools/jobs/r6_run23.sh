@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 6, job 22: the synchronous call in three parts (spfe_extract_begin / _maps / _finish): tests, and the drop-in's
+# round 6, job 23 (= 22 again, heat and heat_inv waited for separately): the synchronous call in three parts (spfe_extract_begin / _maps / _finish): tests, and the drop-in's
 # operator() with its map copies beside the device's chain against the binary built before the change
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/r22; mkdir -p $out
+out=gpurun_out/r23; mkdir -p $out
 B=tools/microbench/bin
 ( time timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_switches.py tests/test_abi.py -x -q -m gpu ) > $out/pytest.log 2>&1
 echo "pytest rc=$?" >> $out/pytest.log
