@@ -426,6 +426,16 @@ SPFE_API const char *spfe_stage_name(int i);
  * the call works all the same).  SPFE_EINVAL without SPFE_FLAG_HEAT, before the first call, or for a frame the call did not hold. */
 SPFE_API int spfe_fetch_heat_inv(spfe_handle h, int frame, const float **out);
 
+/* The H x W maps of the synchronous host calls (spfe_extract*, spfe_postprocess, the three-part call) straight into memory of
+ * the caller: heat / heat_inv = max_batch * H * W floats each, page-locked by the library for as long as they are set
+ * (hipHostRegister; the caller keeps them allocated until the next spfe_set_map_buffers or spfe_destroy), and what
+ * spfe_result.heat / .heat_inv (and spfe_extract_maps, spfe_fetch_heat_inv) point at from then on.  NULL = the library's own
+ * buffer for that map again.  For a caller whose outputs are deep copies anyway — the drop-in class keeps heat_ / heat_inv_ as
+ * cv::Mat members the reference fills per call (sp_extractor.cpp:461-474): with the members' own storage set here the maps
+ * land in them by DMA and the copies (2 x 1.44 MB at 752x480) disappear from the call.  The pipelined host path
+ * (spfe_submit_batch) keeps its own buffers.  SPFE_EINVAL without SPFE_FLAG_HEAT or while a call is open. */
+SPFE_API int spfe_set_map_buffers(spfe_handle h, float *heat, float *heat_inv);
+
 /* Test hook: evaluates the device forms of spfe_expf(x) and spfe_logf(|x|)
  * (include/spfe_exact_math.h) on n host floats, so tests can compare GPU bits
  * with host bits. */

@@ -39,7 +39,7 @@ class ExtractorCV {
   // heatInv() fetches it on demand (SPFE_FLAG_LAZY_HEAT_INV: 1.44 MB less D2H per 752x480 call)
   ExtractorCV(int nfeatures, int height, int width, const std::string &weights_path, int device = 0,
               bool with_heat = true, bool lazy_heat_inv = false)
-      : height_(height), width_(width) {
+      : height_(height), width_(width), with_heat_(with_heat), lazy_(lazy_heat_inv) {
     // this translation unit's view of spfe.h against the library's (struct strides, entry points)
     if (spfe_check_abi(SPFE_ABI_VERSION, sizeof(spfe_config), sizeof(spfe_result), sizeof(spfe_record_layout)) != SPFE_OK)
       throw std::runtime_error(std::string("libspfe: ") + spfe_last_error());
@@ -68,8 +68,17 @@ class ExtractorCV {
     if (image.type() != CV_8UC1) throw std::runtime_error("input image must be CV_8UC1");  // assert :368
     if (image.rows != height_ || image.cols != width_)
       throw std::runtime_error("input image size differs from the configured extractor size");
-    // the call in three parts (spfe.h): the two H x W maps are in host memory before selection, sampling and covariance have
-    // finished on the device, and their deep copies into the members (:461-474 fills heat_ / heat_inv_) run beside those
+    spfe_result r{};
+    if (aimMaps()) {   // heat_ / heat_inv_ are where the device writes the maps: nothing to copy
+      const int rc1 = spfe_extract(h_, image.data, static_cast<int>(image.step), &r);
+      if (rc1 == SPFE_EEMPTY) throw std::runtime_error("input image is empty");
+      if (rc1 != SPFE_OK) throw std::runtime_error(std::string("spfe_extract: ") + spfe_last_error());
+      publish(r, _keypoints, _descriptors);
+      return;
+    }
+    // (the members' storage could not be page-locked.)  The call in three parts (spfe.h): the two H x W maps are in host memory
+    // before selection, sampling and covariance have finished on the device, and their deep copies into the members (:461-474
+    // fills heat_ / heat_inv_) run beside those
     const uint8_t *one[1] = {image.data};
     int rc = spfe_extract_begin(h_, one, static_cast<int>(image.step), 1);
     if (rc == SPFE_EEMPTY) throw std::runtime_error("input image is empty");
@@ -81,7 +90,6 @@ class ExtractorCV {
       rc = spfe_extract_maps(h_, nullptr, &heat_inv);
       if (rc == SPFE_OK && heat_inv) cv::Mat(height_, width_, CV_32FC1, const_cast<float *>(heat_inv)).copyTo(heat_inv_);
     }
-    spfe_result r{};
     const int rcf = spfe_extract_finish(h_, &r);   // (always: it closes the call)
     if (rc != SPFE_OK || rcf != SPFE_OK) throw std::runtime_error(std::string("spfe_extract: ") + spfe_last_error());
     publish(r, _keypoints, _descriptors, heat != nullptr, heat_inv != nullptr);
@@ -116,6 +124,7 @@ class ExtractorCV {
     if (raw.rows != raw_rows_ || raw.step < raw_row_bytes_)
       throw std::runtime_error("extractRaw: frame does not match setStaging()");
     spfe_result r{};
+    aimMaps();
     const int rc = spfe_extract_staged(h_, raw.data, static_cast<int>(raw.step), &r);
     if (rc == SPFE_EEMPTY) throw std::runtime_error("input image is empty");
     if (rc != SPFE_OK) throw std::runtime_error(std::string("spfe_extract_staged: ") + spfe_last_error());
@@ -144,8 +153,11 @@ class ExtractorCV {
     cv::Mat(hc, wc, CV_32FC1, const_cast<float *>(r.semi_dust)).copyTo(semi_dust_);
     cv::Mat(hc, wc, CV_32FC1, const_cast<float *>(r.dense_dust)).copyTo(dense_dust_);
     cv::Mat(hc, wc, CV_16SC1, const_cast<int16_t *>(r.occ_grid)).copyTo(occ_grid_);
-    if (r.heat && !heat_done) cv::Mat(height_, width_, CV_32FC1, const_cast<float *>(r.heat)).copyTo(heat_);
-    if (r.heat_inv && !heat_inv_done) cv::Mat(height_, width_, CV_32FC1, const_cast<float *>(r.heat_inv)).copyTo(heat_inv_);
+    // (a map the device wrote into the member's own storage — aimMaps() — is in place already)
+    if (r.heat && !heat_done && static_cast<const void *>(r.heat) != heat_.data)
+      cv::Mat(height_, width_, CV_32FC1, const_cast<float *>(r.heat)).copyTo(heat_);
+    if (r.heat_inv && !heat_inv_done && static_cast<const void *>(r.heat_inv) != heat_inv_.data)
+      cv::Mat(height_, width_, CV_32FC1, const_cast<float *>(r.heat_inv)).copyTo(heat_inv_);
     else if (!r.heat_inv) heat_inv_ = cv::Mat();   // (lazy: heatInv() fetches this call's map; a stale one must not be mistaken for it)
     status_ = r.status;
   }
@@ -263,6 +275,35 @@ class ExtractorCV {
     }
     return heat_inv_;
   }
+  // The members' own storage as the destination of the maps' D2H (spfe_set_map_buffers: page-locked by the library while set).
+  // The reference re-fills heat_ / heat_inv_ with every call — `heat_ = (img - min) / (max - min)` evaluates into the member's
+  // existing buffer when size and type match (cv::Mat::create returns early), whoever else shares it — and so does this: the
+  // buffers are created once, re-created (and re-aimed) only when the caller released or replaced a member.  false: the library's
+  // buffers and deep copies, as before (no heat maps, or page-locking refused).
+  bool aimMaps() {
+    if (!with_heat_ || aim_refused_) return false;
+    auto fits = [&](const cv::Mat &m) {
+      return !m.empty() && m.type() == CV_32FC1 && m.rows == height_ && m.cols == width_ && m.step == width_ * sizeof(float);
+    };
+    if (!fits(heat_)) heat_.create(height_, width_, CV_32FC1);
+    if (!lazy_ && !fits(heat_inv_)) heat_inv_.create(height_, width_, CV_32FC1);
+    float *a = reinterpret_cast<float *>(heat_.data), *b = lazy_ ? nullptr : reinterpret_cast<float *>(heat_inv_.data);
+    if (a == aimed_heat_ && b == aimed_inv_) return true;
+    if (spfe_set_map_buffers(h_, a, b) != SPFE_OK) {
+      (void)spfe_set_map_buffers(h_, nullptr, nullptr);
+      aimed_heat_ = aimed_inv_ = nullptr;
+      aim_refused_ = true;
+      return false;
+    }
+    aimed_heat_ = a;
+    aimed_inv_ = b;
+    return true;
+  }
+  // off: the maps through the library's buffers and deep copies into the members (what a refused page-lock falls back to)
+  void setMapsInPlace(bool on) {
+    if (!on && !aim_refused_) { (void)spfe_set_map_buffers(h_, nullptr, nullptr); aimed_heat_ = aimed_inv_ = nullptr; }
+    aim_refused_ = !on;
+  }
   const std::vector<Vec2f> &getCov() const { return cov2_; }
   const std::vector<Vec2f> &getCov2Inv() const { return cov2_inv_; }
   int status() const { return status_; }
@@ -276,6 +317,8 @@ class ExtractorCV {
   std::vector<Vec2f> cov2_, cov2_inv_;
   spfe_handle h_ = nullptr;
   int height_, width_, status_ = 0;
+  bool with_heat_ = true, lazy_ = false, aim_refused_ = false;
+  float *aimed_heat_ = nullptr, *aimed_inv_ = nullptr;   // what spfe_set_map_buffers was last given
   size_t raw_row_bytes_ = 0;
   int raw_rows_ = -1;
 };

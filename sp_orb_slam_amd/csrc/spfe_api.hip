@@ -156,6 +156,8 @@ void spfe_destroy(spfe_handle h) {
     if (ps.ev_done) (void)hipEventDestroy(ps.ev_done);
   }
   if (h->s_heat) { (void)hipStreamSynchronize(h->s_heat); (void)hipStreamDestroy(h->s_heat); }
+  if (h->usr_heat) (void)hipHostUnregister(h->usr_heat);
+  if (h->usr_heat_inv) (void)hipHostUnregister(h->usr_heat_inv);
   if (h->ev_heat) (void)hipEventDestroy(h->ev_heat);
   if (h->ev_heat_copied) (void)hipEventDestroy(h->ev_heat_copied);
   if (h->ev_heat_copied1) (void)hipEventDestroy(h->ev_heat_copied1);
@@ -341,6 +343,28 @@ int spfe_fetch_heat_inv(spfe_handle h, int frame, const float **out) {
   HIP_TRY(hipMemcpyAsync(h->h_heat_inv + (size_t)frame * HW, h->d_heat_inv + (size_t)frame * HW, HW * 4, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   *out = h->h_heat_inv + (size_t)frame * HW;
+  return SPFE_OK;
+}
+
+int spfe_set_map_buffers(spfe_handle h, float *heat, float *heat_inv) {
+  if (!h) return fail(SPFE_EINVAL, "null handle");
+  if (!(h->cfg.flags & SPFE_FLAG_HEAT)) return fail(SPFE_EINVAL, "the handle was created without SPFE_FLAG_HEAT");
+  if (h->open_n) return fail(SPFE_EINVAL, "a call begun by spfe_extract_begin is open: spfe_extract_finish first");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  HIP_TRY(hipStreamSynchronize(h->stream));   // (no copy into the buffers about to be replaced is in flight)
+  if (h->s_heat) HIP_TRY(hipStreamSynchronize(h->s_heat));
+  if (!h->own_heat) { h->own_heat = h->h_heat; h->own_heat_inv = h->h_heat_inv; }
+  const size_t bytes = (size_t)h->B * h->H * h->W * 4;
+  struct Slot { float **cur; float *own; float **usr; float *want; };
+  for (Slot q : {Slot{&h->h_heat, h->own_heat, &h->usr_heat, heat}, Slot{&h->h_heat_inv, h->own_heat_inv, &h->usr_heat_inv, heat_inv}}) {
+    if (*q.usr == q.want) continue;
+    if (*q.usr) { (void)hipHostUnregister(*q.usr); *q.usr = nullptr; *q.cur = q.own; }
+    if (q.want) {
+      HIP_TRY(hipHostRegister(q.want, bytes, hipHostRegisterDefault));
+      *q.usr = *q.cur = q.want;
+    }
+  }
+  h->host_sync_n = 0;   // (spfe_fetch_heat_inv: the last call's frames are no longer what the buffers describe)
   return SPFE_OK;
 }
 

@@ -204,6 +204,8 @@ struct spfe_handle_s {
   // host side
   uint8_t *h_img = nullptr, *h_records = nullptr;
   float *h_heat = nullptr, *h_heat_inv = nullptr;
+  float *own_heat = nullptr, *own_heat_inv = nullptr;   // spfe_set_map_buffers: the library's buffers while h_heat / h_heat_inv
+  float *usr_heat = nullptr, *usr_heat_inv = nullptr;   // point at the caller's (registered) memory
   int last_n = 0;
   int host_sync_n = 0;   // frames of the last synchronous host call (spfe_fetch_heat_inv)
   // Synchronous host calls with SPFE_FLAG_HEAT (the drop-in's operator(): Frame clones heat_, frame.cpp:304): the heat maps are

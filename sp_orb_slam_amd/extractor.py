@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "spfe_comm_stream", "spfe_comm_count", "spfe_submit_batch", "spfe_collect_batch",
     "spfe_align_dust", "spfe_align_dust_record_device", "spfe_align_dust_batch_device", "spfe_match_knn2",
     "spfe_track_dust_record_device", "spfe_fetch_heat_inv",
-    "spfe_extract_begin", "spfe_extract_maps", "spfe_extract_finish",
+    "spfe_extract_begin", "spfe_extract_maps", "spfe_extract_finish", "spfe_set_map_buffers",
 ]
 
 
@@ -142,6 +142,8 @@ def load_library():
     L.spfe_extract_begin.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int]
     L.spfe_extract_maps.restype = C.c_int
     L.spfe_extract_maps.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float))]
+    L.spfe_set_map_buffers.restype = C.c_int
+    L.spfe_set_map_buffers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.spfe_extract_finish.restype = C.c_int
     L.spfe_extract_finish.argtypes = [C.c_void_p, C.POINTER(_Result)]
     L.spfe_get_record_layout.restype = C.c_int
@@ -440,6 +442,17 @@ class SPExtractor:
         out = [FrameResult(res[i], self.height, self.width, self.with_heat) for i in range(n)]
         self._publish(out[-1])
         return out
+
+    def set_map_buffers(self, heat=None, heat_inv=None):
+        """spfe_set_map_buffers: the synchronous calls' H x W maps straight into these float32 arrays ([max_batch, H, W],
+        C-contiguous; the extractor keeps them alive and the library page-locks them while set); None = the library's buffer."""
+        for a in (heat, heat_inv):
+            if a is not None and (a.dtype != np.float32 or not a.flags["C_CONTIGUOUS"] or
+                                  a.size != self.max_batch * self.height * self.width):
+                raise SpfeError("map buffers must be C-contiguous float32 [max_batch, H, W]")
+        _check(self._lib.spfe_set_map_buffers(self._h, heat.ctypes.data if heat is not None else None,
+                                              heat_inv.ctypes.data if heat_inv is not None else None))
+        self._map_buffers = (heat, heat_inv)
 
     # -- direct "dust" alignment (SURVEY.md §8(f) rank 3; optimizer_dust.cpp:170-294) --
     @staticmethod

@@ -76,6 +76,30 @@ int main(int argc, char **argv) {
       if (k2.size() != mvKeys.size()) return 20;
     }
 
+    {   // the members' storage is where the device writes the maps (aimMaps(): spfe_set_map_buffers) — as the reference's
+        // `heat_ = ...` evaluates into the member's existing buffer: the same storage call after call, the same bits as the
+        // copied form, a member the caller released is made (and aimed at) again
+      SPExtractor *sp = dynamic_cast<SPExtractor *>(mpORBextractorLeft);
+      const unsigned char *p_heat = sp->heat_.data, *p_inv = sp->heat_inv_.data;
+      std::vector<cv::KeyPoint> k2;
+      cv::Mat d2;
+      (*mpORBextractorLeft)(im, cv::Mat(), k2, d2);
+      if (sp->heat_.data != p_heat || sp->heat_inv_.data != p_inv) return 21;
+      if (memcmp(sp->heat_.data, heat_.data, (size_t)H * W * 4) || memcmp(sp->heat_inv_.data, heat_inv.data, (size_t)H * W * 4)) return 22;
+      SPExtractor copied(tracking::num_features, H, W, common::model_path);
+      copied.setMapsInPlace(false);
+      copied(im, cv::Mat(), k2, d2);
+      if (memcmp(copied.heat_.data, heat_.data, (size_t)H * W * 4) || memcmp(copied.heat_inv_.data, heat_inv.data, (size_t)H * W * 4)) return 23;
+      if (k2.size() != mvKeys.size() || (k2.size() && memcmp(d2.data, mDescriptors.data, k2.size() * 256 * 4))) return 24;
+      cv::Mat kept = sp->heat_;    // a shallow holder (Frame could be one) ...
+      sp->heat_ = cv::Mat();       // ... and the member released by the caller
+      memset(sp->heat_inv_.data, 0, (size_t)H * W * 4);
+      (*mpORBextractorLeft)(im, cv::Mat(), k2, d2);
+      if (sp->heat_.empty() || sp->heat_.data == kept.data) return 25;
+      if (memcmp(sp->heat_.data, heat_.data, (size_t)H * W * 4) || memcmp(sp->heat_inv_.data, heat_inv.data, (size_t)H * W * 4)) return 26;
+      if (memcmp(kept.data, heat_.data, (size_t)H * W * 4)) return 27;   // (the holder's copy is untouched by the later call)
+    }
+
     // the empty-image error of sp_extractor.cpp:364-365 through the base pointer
     bool threw = false;
     try {

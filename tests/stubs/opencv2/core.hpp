@@ -24,10 +24,13 @@ class Mat {
   Mat() {}
   Mat(int r, int c, int type) { create(r, c, type); }
   Mat(int r, int c, int type, void *ext) : rows(r), cols(c), data((unsigned char *)ext), step((size_t)c * elemSize_(type)), type_(type) {}
+  // cv::Mat::create: "if the current array shape and the type match the new ones, return immediately" (whoever shares the
+  // buffer); else new, UNINITIALISED storage
   void create(int r, int c, int type) {
+    if (data && buf_ && rows == r && cols == c && type_ == type) return;
     rows = r; cols = c; type_ = type; step = (size_t)c * elemSize_(type);
-    buf_ = std::make_shared<std::vector<unsigned char>>((size_t)r * step);
-    data = buf_->data();
+    buf_ = std::shared_ptr<unsigned char[]>(new unsigned char[(size_t)r * step + 1]);
+    data = buf_.get();
   }
   int type() const { return type_; }
   bool empty() const { return rows == 0 || cols == 0 || !data; }
@@ -39,7 +42,7 @@ class Mat {
   template <class T> T &at(int y, int x) { return *reinterpret_cast<T *>(data + y * step + x * sizeof(T)); }
  private:
   int type_ = 0;
-  std::shared_ptr<std::vector<unsigned char>> buf_;
+  std::shared_ptr<unsigned char[]> buf_;
 };
 
 struct Point2f { float x = 0, y = 0; };

@@ -977,3 +977,58 @@ def test_the_call_in_three_parts_is_the_call(monkeypatch):
         ext.close()
         ref.close()
     monkeypatch.delenv("SPFE_EARLY_HEAT_COPY")
+
+
+def test_maps_straight_into_the_callers_memory():
+    """spfe_set_map_buffers (what the drop-in's operator() uses: heat_ / heat_inv_ are cv::Mat members the reference re-fills per
+    call, sp_extractor.cpp:461-474): the maps of the synchronous calls land in the caller's arrays — page-locked by the library,
+    not page-aligned here — bit for bit the maps of a handle without them; batches, single frames, the three-part call, the lazy
+    form's fetch, other arrays, and the library's own buffers again."""
+    H, W, nf, B = 240, 376, 300, 3
+    blob = weights.synthetic(7, "dense")
+    frames = [[synth.make_image(2500 + 5 * r + i, H, W) for i in range(B)] for r in range(3)]
+    same = lambda x, y: np.array_equal(np.ascontiguousarray(x).view(np.uint32), np.ascontiguousarray(y).view(np.uint32))
+    ref = SPExtractor(nf, H, W, blob, max_batch=B)
+    ext = SPExtractor(nf, H, W, blob, max_batch=B)
+    backing = [np.full(B * H * W + 3, np.nan, np.float32) for _ in range(4)]
+    bufs = [b[3:].reshape(B, H, W) for b in backing]          # 12 bytes off whatever alignment numpy gave
+    ext.set_map_buffers(bufs[0], bufs[1])
+    for r in range(3):
+        want = ref.extract_batch(frames[r])
+        got = ext.extract_batch(frames[r])
+        for i in range(B):
+            assert same(bufs[0][i], want[i].heat) and same(bufs[1][i], want[i].heat_inv)
+            assert same(got[i].heat, want[i].heat) and same(got[i].heat_inv, want[i].heat_inv)
+            assert got[i].K == want[i].K and same(got[i].descriptors, want[i].descriptors) and same(got[i].cov2, want[i].cov2)
+    ext.set_map_buffers(bufs[2], bufs[3])                     # other arrays: the first pair is left alone from here on
+    keep = bufs[0].copy()
+    ext.extract_begin(frames[0][:1])
+    with pytest.raises(Exception, match="open"):
+        ext.set_map_buffers(None, None)
+    hm, hi = ext.extract_maps()
+    assert hm is not None and hm.ctypes.data == bufs[2].ctypes.data and hi.ctypes.data == bufs[3].ctypes.data
+    got = ext.extract_finish()
+    want = ref.extract_batch(frames[0][:1])
+    assert same(bufs[2][0], want[0].heat) and same(bufs[3][0], want[0].heat_inv) and same(got[0].heat_inv, want[0].heat_inv)
+    assert same(bufs[0], keep)
+    ext.set_map_buffers(bufs[2], None)                        # one map only; then neither
+    got = ext.extract_batch(frames[1])
+    want = ref.extract_batch(frames[1])
+    assert same(bufs[2][2], want[2].heat) and same(got[2].heat_inv, want[2].heat_inv)
+    ext.set_map_buffers(None, None)
+    snap = bufs[2].copy()
+    got = ext.extract_batch(frames[2])
+    want = ref.extract_batch(frames[2])
+    assert same(got[1].heat, want[1].heat) and same(got[1].heat_inv, want[1].heat_inv) and same(bufs[2], snap)
+    ext.close()
+    lazy = SPExtractor(nf, H, W, blob, max_batch=B, lazy_heat_inv=True)
+    lazy.set_map_buffers(bufs[0], bufs[1])
+    got = lazy.extract_batch(frames[2])
+    assert all(g.heat_inv is None for g in got) and same(bufs[0][1], want[1].heat)
+    assert same(lazy.fetch_heat_inv(1), want[1].heat_inv) and same(bufs[1][1], want[1].heat_inv)
+    lazy.close()
+    nomaps = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=False)
+    with pytest.raises(Exception, match="SPFE_FLAG_HEAT"):
+        nomaps.set_map_buffers(bufs[0], None)
+    nomaps.close()
+    ref.close()

@@ -5,8 +5,9 @@
 // cv::Mat / Eigen out: PCIe inclusive (0.36 MB up; record 1.1 MB + 2 x 1.44 MB of heat maps down at 752x480).
 // Built by __graft_entry__.build() against the interface stand-ins under tests/stubs (the GPU box has neither OpenCV nor the
 // reference tree); bench.py runs it and puts the line into `dropin_operator_call_ms`.
-// usage: dropin_latency <weights.spfw> <image.raw> <H> <W> <nfeatures> <calls> <warmup> [lazy]   -> one JSON line
-// (lazy: the opt-in form whose heat_inv_ stays on the device, orbslam_sp_extractor.hpp; default: the reference's post-call state)
+// usage: dropin_latency <weights.spfw> <image.raw> <H> <W> <nfeatures> <calls> <warmup> [lazy | copy]   -> one JSON line
+// (lazy: the opt-in form whose heat_inv_ stays on the device, orbslam_sp_extractor.hpp; default: the reference's post-call state;
+// copy: the default with the maps through the library's buffers and deep copies into the members, setMapsInPlace(false))
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -42,6 +43,7 @@ int main(int argc, char **argv) {
   try {
     BaseExtractor *mpORBextractorLeft = lazy ? new SPExtractor(tracking::num_features, H, W, common::model_path, 0, true)
                                              : new SPExtractor(tracking::num_features);   // tracker.cpp:131
+    if (argc == 9 && std::string(argv[8]) == "copy") dynamic_cast<SPExtractor *>(mpORBextractorLeft)->setMapsInPlace(false);
     cv::Mat im(H, W, CV_8UC1, pix.data());
     std::vector<double> ms;
     size_t K = 0;
