@@ -161,11 +161,16 @@ SPFE_API int spfe_extract_batch(spfe_handle h, const uint8_t *const *images, int
  *                        for heat alone, copies it, then asks for heat_inv.  NULL results (and SPFE_OK) when the maps do not
  *                        travel ahead of the record in this call (no SPFE_FLAG_HEAT, SPFE_EARLY_HEAT_COPY=0):
  *                        spfe_extract_finish delivers them as spfe_extract_batch does.  Optional, any number of times.
+ *   spfe_extract_rows    blocks until frame `frame`'s descriptor rows are in host memory — final behind the sampling, while
+ *                        the covariance of the call still runs: *K rows of 256 floats at *desc (where spfe_result.desc will
+ *                        point).  *desc = NULL (and SPFE_OK) when the rows travel with the record in this call (batches on
+ *                        the side-stream chain, SPFE_FLAG_DESC_BF16, SPFE_EARLY_HEAT_COPY=0).  Optional.
  *   spfe_extract_finish  the rest of spfe_extract_batch: blocks, fills outs[0 .. n) (same pointers, same lifetime)
  * begin + finish == spfe_extract_batch, bit for bit.  Between the two no other call on the handle (SPFE_EINVAL from begin
  * while a call is open, from maps / finish when none is). */
 SPFE_API int spfe_extract_begin(spfe_handle h, const uint8_t *const *images, int stride, int n);
 SPFE_API int spfe_extract_maps(spfe_handle h, const float **heat, const float **heat_inv);
+SPFE_API int spfe_extract_rows(spfe_handle h, int frame, int *K, const float **desc);
 SPFE_API int spfe_extract_finish(spfe_handle h, spfe_result *outs);
 
 /* Pipelined host path.  spfe_extract_batch is synchronous like the reference's operator() (upload

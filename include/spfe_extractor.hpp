@@ -68,31 +68,33 @@ class ExtractorCV {
     if (image.type() != CV_8UC1) throw std::runtime_error("input image must be CV_8UC1");  // assert :368
     if (image.rows != height_ || image.cols != width_)
       throw std::runtime_error("input image size differs from the configured extractor size");
-    spfe_result r{};
-    if (aimMaps()) {   // heat_ / heat_inv_ are where the device writes the maps: nothing to copy
-      const int rc1 = spfe_extract(h_, image.data, static_cast<int>(image.step), &r);
-      if (rc1 == SPFE_EEMPTY) throw std::runtime_error("input image is empty");
-      if (rc1 != SPFE_OK) throw std::runtime_error(std::string("spfe_extract: ") + spfe_last_error());
-      publish(r, _keypoints, _descriptors);
-      return;
-    }
-    // (the members' storage could not be page-locked.)  The call in three parts (spfe.h): the two H x W maps are in host memory
-    // before selection, sampling and covariance have finished on the device, and their deep copies into the members (:461-474
-    // fills heat_ / heat_inv_) run beside those
+    // The call in parts (spfe.h), so that this side's deep copies run while the device still works on the frame: the H x W maps
+    // are in host memory before selection, sampling and covariance have finished, the descriptor rows before the covariance has.
+    // With the members' storage as the maps' destination (aimMaps()) only the rows are left to copy.
+    const bool in_place = aimMaps();
     const uint8_t *one[1] = {image.data};
     int rc = spfe_extract_begin(h_, one, static_cast<int>(image.step), 1);
     if (rc == SPFE_EEMPTY) throw std::runtime_error("input image is empty");
     if (rc != SPFE_OK) throw std::runtime_error(std::string("spfe_extract: ") + spfe_last_error());
-    const float *heat = nullptr, *heat_inv = nullptr;
-    rc = spfe_extract_maps(h_, &heat, nullptr);          // heat is the first to arrive; heat_inv travels while it is copied
-    if (rc == SPFE_OK && heat) {
-      cv::Mat(height_, width_, CV_32FC1, const_cast<float *>(heat)).copyTo(heat_);
-      rc = spfe_extract_maps(h_, nullptr, &heat_inv);
-      if (rc == SPFE_OK && heat_inv) cv::Mat(height_, width_, CV_32FC1, const_cast<float *>(heat_inv)).copyTo(heat_inv_);
+    const float *heat = nullptr, *heat_inv = nullptr, *rows = nullptr;
+    int K = 0;
+    if (!in_place) {
+      rc = spfe_extract_maps(h_, &heat, nullptr);          // heat is the first to arrive; heat_inv travels while it is copied
+      if (rc == SPFE_OK && heat) {
+        cv::Mat(height_, width_, CV_32FC1, const_cast<float *>(heat)).copyTo(heat_);
+        rc = spfe_extract_maps(h_, nullptr, &heat_inv);
+        if (rc == SPFE_OK && heat_inv) cv::Mat(height_, width_, CV_32FC1, const_cast<float *>(heat_inv)).copyTo(heat_inv_);
+      }
     }
+    if (rc == SPFE_OK) rc = spfe_extract_rows(h_, 0, &K, &rows);
+    if (rc == SPFE_OK && rows) {
+      _descriptors.create(K, SPFE_DESC_DIM, CV_32FC1);  // :512
+      if (K > 0) cv::Mat(K, SPFE_DESC_DIM, CV_32FC1, const_cast<float *>(rows)).copyTo(_descriptors.getMat());
+    }
+    spfe_result r{};
     const int rcf = spfe_extract_finish(h_, &r);   // (always: it closes the call)
     if (rc != SPFE_OK || rcf != SPFE_OK) throw std::runtime_error(std::string("spfe_extract: ") + spfe_last_error());
-    publish(r, _keypoints, _descriptors, heat != nullptr, heat_inv != nullptr);
+    publish(r, _keypoints, _descriptors, heat != nullptr, heat_inv != nullptr, rows != nullptr && K == r.K);
   }
 
   // Input staging on the GPU.  setStaging() once, with the CV_32FC1 maps of
@@ -132,9 +134,9 @@ class ExtractorCV {
   }
 
  protected:
-  // heat_done / heat_inv_done: that map of this call is in its member already (operator() copied it beside the device's work)
+  // heat_done / heat_inv_done / desc_done: that output of this call is in place already (operator() copied it beside the device's work)
   void publish(const spfe_result &r, std::vector<cv::KeyPoint> &_keypoints, cv::OutputArray _descriptors,
-               bool heat_done = false, bool heat_inv_done = false) {
+               bool heat_done = false, bool heat_inv_done = false, bool desc_done = false) {
     const int hc = height_ / 8, wc = width_ / 8;
     _keypoints.resize(r.K);
     cov2_.resize(r.K);
@@ -146,9 +148,10 @@ class ExtractorCV {
       cov2_[i] = {r.cov2[2 * i], r.cov2[2 * i + 1]};
       cov2_inv_[i] = {r.cov2_inv[2 * i], r.cov2_inv[2 * i + 1]};
     }
-    _descriptors.create(r.K, SPFE_DESC_DIM, CV_32FC1);  // :512
-    if (r.K > 0)
-      cv::Mat(r.K, SPFE_DESC_DIM, CV_32FC1, const_cast<float *>(r.desc)).copyTo(_descriptors.getMat());
+    if (!desc_done) {
+      _descriptors.create(r.K, SPFE_DESC_DIM, CV_32FC1);  // :512
+      if (r.K > 0) cv::Mat(r.K, SPFE_DESC_DIM, CV_32FC1, const_cast<float *>(r.desc)).copyTo(_descriptors.getMat());
+    }
     // side outputs: deep copies (the library buffers live until the next call)
     cv::Mat(hc, wc, CV_32FC1, const_cast<float *>(r.semi_dust)).copyTo(semi_dust_);
     cv::Mat(hc, wc, CV_32FC1, const_cast<float *>(r.dense_dust)).copyTo(dense_dust_);

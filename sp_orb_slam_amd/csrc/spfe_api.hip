@@ -278,6 +278,21 @@ int spfe_extract_maps(spfe_handle h, const float **heat, const float **heat_inv)
   return SPFE_OK;
 }
 
+int spfe_extract_rows(spfe_handle h, int frame, int *K, const float **desc) {
+  if (!h || !K || !desc) return fail(SPFE_EINVAL, "null argument");
+  if (!h->open_n) return fail(SPFE_EINVAL, "no open call: spfe_extract_begin first");
+  if (frame < 0 || frame >= h->open_n) return fail(SPFE_EINVAL, "frame %d is not one of the open call's %d", frame, h->open_n);
+  *K = 0;
+  *desc = nullptr;
+  if (!h->desc_early || (h->cfg.flags & SPFE_FLAG_DESC_BF16)) return SPFE_OK;   // the rows come with the record
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  HIP_TRY(hipEventSynchronize(h->ev_desc));   // (side stream: sampling, then the rows' and the headers' D2H)
+  const uint8_t *rec = h->h_records + (size_t)frame * h->rl.bytes;
+  *K = reinterpret_cast<const int *>(rec + h->rl.off_hdr)[0];
+  *desc = reinterpret_cast<const float *>(rec + h->rl.off_desc);
+  return SPFE_OK;
+}
+
 int spfe_extract_finish(spfe_handle h, spfe_result *outs) {
   if (!h || !outs) return fail(SPFE_EINVAL, "null argument");
   if (!h->open_n) return fail(SPFE_EINVAL, "no open call: spfe_extract_begin first");

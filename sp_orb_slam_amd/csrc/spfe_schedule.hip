@@ -650,6 +650,9 @@ int enqueue_post(spfe_handle h, int n, uint8_t *d_records, hipStream_t s, const 
       const size_t seg = h->rl.off_occ - h->rl.off_desc;
       HIP_TRY(hipMemcpy2DAsync(h->h_records + h->rl.off_desc, h->rl.bytes, h->d_records + h->rl.off_desc, h->rl.bytes, seg, (size_t)n,
                                hipMemcpyDeviceToHost, h->side));
+      // ... and the headers, for K (final with the selection; finish_host brings the whole head again): spfe_extract_rows
+      HIP_TRY(hipMemcpy2DAsync(h->h_records + h->rl.off_hdr, h->rl.bytes, h->d_records + h->rl.off_hdr, h->rl.bytes, 16, (size_t)n,
+                               hipMemcpyDeviceToHost, h->side));
       h->desc_early = true;
     }
     HIP_TRY(hipEventRecord(h->ev_desc, h->side));

@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "spfe_comm_stream", "spfe_comm_count", "spfe_submit_batch", "spfe_collect_batch",
     "spfe_align_dust", "spfe_align_dust_record_device", "spfe_align_dust_batch_device", "spfe_match_knn2",
     "spfe_track_dust_record_device", "spfe_fetch_heat_inv",
-    "spfe_extract_begin", "spfe_extract_maps", "spfe_extract_finish", "spfe_set_map_buffers",
+    "spfe_extract_begin", "spfe_extract_maps", "spfe_extract_rows", "spfe_extract_finish", "spfe_set_map_buffers",
 ]
 
 
@@ -144,6 +144,8 @@ def load_library():
     L.spfe_extract_maps.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float))]
     L.spfe_set_map_buffers.restype = C.c_int
     L.spfe_set_map_buffers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.spfe_extract_rows.restype = C.c_int
+    L.spfe_extract_rows.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_float))]
     L.spfe_extract_finish.restype = C.c_int
     L.spfe_extract_finish.argtypes = [C.c_void_p, C.POINTER(_Result)]
     L.spfe_get_record_layout.restype = C.c_int
@@ -432,6 +434,15 @@ class SPExtractor:
         n = getattr(self, "_open_n", 0)
         view = lambda p: np.ctypeslib.as_array(p, shape=(n, self.height, self.width)) if p else None
         return view(ph), view(pi)
+
+    def extract_rows(self, frame=0):
+        """Block until the open call's descriptor rows of `frame` are in host memory: [K, 256] f32 view of the library's
+        buffer, or None when the rows travel with the record in this call."""
+        k, p = C.c_int(0), C.POINTER(C.c_float)()
+        _check(self._lib.spfe_extract_rows(self._h, int(frame), C.byref(k), C.byref(p)))
+        if not p:
+            return None
+        return np.ctypeslib.as_array(p, shape=(max(k.value, 1), 256))[:k.value]
 
     def extract_finish(self):
         """The rest of the call begun by extract_begin(); returns what extract_batch would have."""

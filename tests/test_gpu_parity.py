@@ -943,7 +943,7 @@ def test_the_call_in_three_parts_is_the_call(monkeypatch):
         ref = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=heat, lazy_heat_inv=lazy)
         ext = SPExtractor(nf, H, W, blob, max_batch=B, with_heat=heat, lazy_heat_inv=lazy)
         for r in range(3):
-            batch = frames[r][: 1 + (r % B)] if r else frames[r]
+            batch = frames[r][: (B, 1, 2)[r]]
             want = ref.extract_batch(batch)
             ext.extract_begin(batch)
             with pytest.raises(Exception, match="open"):
@@ -951,6 +951,12 @@ def test_the_call_in_three_parts_is_the_call(monkeypatch):
             with pytest.raises(Exception, match="open"):
                 ext.extract_batch(batch)
             hm, hi = ext.extract_maps()
+            rows = [ext.extract_rows(i) for i in range(len(batch))]
+            assert flag == "1" or all(x is None for x in rows)
+            assert not (flag == "1" and len(batch) == 1) or rows[0] is not None   # (the drop-in's call: a single frame, the inline chain)
+            rows = [x.copy() if x is not None else None for x in rows]
+            with pytest.raises(Exception, match="not one of"):
+                ext.extract_rows(len(batch))
             early = heat and flag == "1"
             assert (hm is not None) == early and (hi is not None) == (early and not lazy)
             hm = hm.copy() if early else None
@@ -962,6 +968,8 @@ def test_the_call_in_three_parts_is_the_call(monkeypatch):
                 for f in ("kp_xy", "response", "descriptors", "cov2", "cov2_inv", "dense_dust", "semi_dust"):
                     assert same(getattr(a, f), getattr(b, f)), f
                 assert np.array_equal(a.occ_grid, b.occ_grid)
+                if rows[i] is not None:
+                    assert rows[i].shape == (b.K, 256) and same(rows[i], b.descriptors)
                 if heat:
                     assert same(a.heat, b.heat)
                     if early:
