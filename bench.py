@@ -413,7 +413,9 @@ def dropin_leg(H, W, nf, blob, frame, lazy=False):
     d = json.loads(r.stdout.strip().splitlines()[-1])
     d["what"] = ("orbslam::SPExtractor::operator() through BaseExtractor* with heat maps on + Frame::ExtractORB's copies "
                  "(frame.cpp:296-311), host frame in -> cv::KeyPoint / cv::Mat / Eigen out, %dx%d f32, PCIe inclusive "
-                 "(record + %s D2H)" % (W, H, "heat_ only: the opt-in lazy form leaves heat_inv_ on the device until heatInv()" if lazy
+                 "(record + %s D2H); the maps land in the members' own (page-locked) storage, the descriptor rows are copied "
+                 "beside the covariance (spfe_set_map_buffers, spfe_extract_begin / _rows / _finish); operator_call_p50 = operator() "
+                 "alone, the rest is Frame's clones" % (W, H, "heat_ only: the opt-in lazy form leaves heat_inv_ on the device until heatInv()" if lazy
                                         else "both heat maps: the reference's post-call state, the drop-in's default"))
     return d
 
