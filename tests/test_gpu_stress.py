@@ -18,3 +18,13 @@ def test_pipeline_stress(cases, seed):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_pipeline.py"), str(cases), str(seed)], env=env,
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "all records bit-identical" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("cases,seed", [(10, 3)])
+def test_sync_parts_stress(cases, seed):
+    """tools/stress_sync_parts.py: the synchronous host calls in every form the drop-in uses them (whole, in parts with early maps
+    and rows, the caller's map buffers swapped between calls, lazy heat_inv, early copies on / off) interleaved on one handle."""
+    env = {k: v for k, v in os.environ.items() if not k.startswith("SPFE_")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_sync_parts.py"), str(cases), str(seed)], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "all records and maps bit-identical" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
