@@ -54,6 +54,12 @@ def test_default_line_is_compact_and_ends_with_configs():
     assert c[c3]["frac_of_sustained"] == leg["roofline"]["frac_of_sustained"]
     assert c[c3]["whole_path_frac_of_peak"] == leg["whole_path_frac_of_peak"] and c[c3]["sclk_avg"] == leg["sclk_mhz"]["avg"]
     assert str(leg["value"]) in tail and str(d["latency_batch1_ms"]["p50"]) in tail
+    # ... and in a 2,000-character tail (what BENCH_r05.json kept of the line): configs[1], configs[3] and the headline close the object
+    short = js[-2000:]
+    assert list(c)[-1] == c1 and list(c)[-2] == c3 and list(c)[-3].startswith("headline")
+    assert c1 in short and c3 in short and list(c)[-3] in short
+    assert '"latency_ms_p50": %s' % json.dumps(d["latency_batch1_ms"]["p50"]) in short and '"value": %s' % json.dumps(leg["value"]) in short
+    assert '"value": %s' % json.dumps(d["value"]) in short
     head = [k for k in c if k.startswith("headline")][0]
     assert c[head]["value"] == d["value"] and c[head]["frac"] == d["roofline"]["frac"]
     for name in ("f32_640x480_b8", "f32_1280x720_b8", "bf16_752x480_b8"):
