@@ -252,7 +252,7 @@ struct spfe_handle_s {
   int conv1b_tile_rows = 8;  // rows per tile of the last call's conv1b launch (f32; spfe_debug_read("conv1b_tile_rows"))
   int tile16x4 = 1;          // SPFE_TILE16X4: conv1b on 16-row tiles of 4 wavefronts x 4 rows (0 never, 1 by the cost model — possibly
                              // cut in a 16-row and an 8-row launch —, 2 always in one launch, 3 cost model without the cut)
-  bool fuse1a = false;  // f32: conv1a computed inside conv1b (opt-in: SPFE_FUSE_CONV1A=1; measured perf-neutral)
+  bool fuse1a = false;  // f32: conv1a computed inside conv1b in every call (SPFE_FUSE_CONV1A=1; perf-neutral on batches); unset: single-frame synchronous calls only
   bool fuse1a_bf16 = true;  // bf16: conv1a computed by the producer waves of the wave-specialised conv1b (SPFE_FUSE_CONV1A=0 to split)
   uint8_t *dust_scratch = nullptr;   // spfe_align_dust: dust map | points | pose | output block (device)
   uint8_t *dust_host = nullptr;      // pinned mirror of the output block

@@ -143,7 +143,10 @@ int enqueue(spfe_handle h, const uint8_t *d_images, int n, uint8_t *d_records, h
     HIP_TRY(hipGetLastError());
   }
   h->tile_ctr_clean = false;   // (until this call's tail has been enqueued)
-  const bool fused = !h->bf16 && h->fuse1a;  // f32: conv1b computes conv1a's outputs itself
+  // f32: conv1b computes conv1a's outputs itself — on request (SPFE_FUSE_CONV1A=1; perf-neutral on batches), and by default in
+  // single-frame synchronous calls, where a launch and its boundary less are worth 5 us (752x480: p50 0.7266 -> 0.7213 ms)
+  const bool fused = !h->bf16 && (h->fuse1a || (h->fuse1a_env < 0 && n == 1 && !((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode) &&
+                                                !(h->timing && h->timing_all)));
   // bf16: when conv1b takes the wave-specialised kernel, its producer waves compute conv1a (no conv1a launch, no act0)
   const int grid_ws0 = std::max(16, (h->num_cus > 0 ? h->num_cus : 256) & ~15);
   const int ws_min = ((h->cfg.flags & SPFE_FLAG_ASYNC_COV) || h->pipe_mode) ? h->ws_min_items : h->ws_min_items_sync;
