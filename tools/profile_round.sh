@@ -20,7 +20,7 @@ SPFE_SPLIT=0 trace f32_sync_nosplit --sync-cov
 # a single frame per call (BASELINE configs[1] as written): per-kernel durations and one call's timeline
 rocprofv3 --kernel-trace --stats -d $out/kt_b1 -o trace -- python tools/latency_stages.py --calls 200 > $out/kt_b1.log 2>&1
 python tools/rocpd_summary.py $out/kt_b1/*.db > $out/kernel_stats_f32_batch1.txt 2>&1
-python tools/rocpd_timeline.py $out/kt_b1/*.db conv1a 60 > $out/timeline_f32_batch1.txt 2>&1
+python tools/rocpd_timeline.py $out/kt_b1/*.db "conv_f32_kernel<2," 60 > $out/timeline_f32_batch1.txt 2>&1
 grep '^{' $out/kt_b1.log | tail -1 > $out/latency_stages_f32_batch1.json
 trace bf16_720p_async --precision bf16 --height 720 --width 1280
 trace bf16_720p_sync --precision bf16 --height 720 --width 1280 --sync-cov
