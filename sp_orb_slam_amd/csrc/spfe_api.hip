@@ -250,8 +250,10 @@ int spfe_extract_begin(spfe_handle h, const uint8_t *const *images, int stride, 
   if (stride < W) return fail(SPFE_EINVAL, "stride %d smaller than width %d", stride, W);
   for (int i = 0; i < n; ++i) {
     if (!images[i]) return fail(SPFE_EEMPTY, "input image is empty");  // sp_extractor.cpp:364-365
-    for (int y = 0; y < H; ++y)
-      memcpy(h->h_img + ((size_t)i * H + y) * W, images[i] + (size_t)y * stride, W);
+    if (stride == W) memcpy(h->h_img + (size_t)i * H * W, images[i], (size_t)H * W);   // (a continuous cv::Mat: one copy)
+    else
+      for (int y = 0; y < H; ++y)
+        memcpy(h->h_img + ((size_t)i * H + y) * W, images[i] + (size_t)y * stride, W);
   }
   HIP_TRY(hipSetDevice(h->cfg.device));
   hipStream_t s = h->stream;
