@@ -68,7 +68,12 @@ const char *spfe_stage_name(int i) { return (i >= 0 && i < NSTAGE) ? kStageNames
 // its own switches (spfe_host.h: blob), never from the caller's pointers.
 static int make_twin(spfe_handle h) {
   if (h->twin || h->is_twin || h->twin_failed) return SPFE_OK;
-  if (!(h->two_chains_env >= 0 ? h->two_chains_env > 0 : (h->bf16 && h->C >= 10000))) { h->blob = std::vector<float>(); return SPFE_OK; }
+  // By workload: where a call's side chain (bounded below by its frame's longest component chain, whatever the batch) outlasts
+  // the next call's convolutions — bf16 frames of >= 10,000 cells in SHORT calls (2+ frames, fewer than 50,000 cells a call:
+  // 1280x720 x 2: +32 %) and frames beyond select_kernel (3840x2160 x 1: +3.7 %).  Longer calls hide one chain completely and a
+  // second set of buffers only costs them cache (round 6: 1280x720 x 4 / 6 / 8: -2.2 / -0.7 / -0.8 %, 1920x1080 x 1: -7 %).
+  const bool by_workload = h->bf16 && h->C >= 10000 && (h->C > 65535 || (h->B >= 2 && (long)h->B * h->C < 50000));
+  if (!(h->two_chains_env >= 0 ? h->two_chains_env > 0 : by_workload)) { h->blob = std::vector<float>(); return SPFE_OK; }
   h->twin = new spfe_handle_s();
   h->twin->is_twin = true;
   // (SPFE_TWO_CHAINS=99, tests: a twin is wanted and its build fails — the failure path without exhausting 288 GB)

@@ -120,7 +120,7 @@ struct spfe_handle_s {
   // between the two (measured first with two handles in one process, tools/microbench/two_chains.py: 7,530 -> 8,115 and
   // 7,745 -> 8,125 frames/s at 1280x720 bf16; 752x480: -3 % bf16, -2 % f32: there the chain is short and a step runs as two
   // half batches).  Tickets stay one sequence: tmap says which of the two ran a ticket, and under which ticket of its own.
-  // SPFE_TWO_CHAINS: -1 by workload (bf16 frames of >= 10,000 cells, SPFE_FLAG_ASYNC_COV handles), 0 never, 1 always.
+  // SPFE_TWO_CHAINS: -1 by workload (bf16 frames of >= 10,000 cells in short calls or beyond select_kernel: make_twin, spfe_api.hip), 0 never, 1 always.
   spfe_handle twin = nullptr;
   bool is_twin = false;
   bool twin_failed = false;                  // the twin could not be built (e.g. out of memory): one side chain, and no second attempt
